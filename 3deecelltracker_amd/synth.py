@@ -1,0 +1,121 @@
+"""Seeded synthetic weights, image stacks and point sets.
+
+There are no trained weights or images in the reference tree (they live on OSF), and no
+network here, so parity tests and the benchmark run on seeded random-init weights of the
+reference architectures and on synthetic stacks / point sets:
+
+* U-Net / FFN weights: Glorot-uniform kernels, small normal biases, BatchNorm statistics drawn
+  away from the identity so that a wrong epilogue order is visible.
+* Point-set pairs follow the reference's own training-pair recipe: centred affine
+  ``I + (U(0,1)-0.5)*0.2`` plus jitter (reference ffn.py:18,23-24,51-53) with a fraction of
+  points replaced (segmentation errors, reference synthesize.py:52-72) and a random permutation.
+* Stacks: Gaussian background + anisotropic Gaussian blobs, then a simple normalisation.
+
+Weight container (plain dict of numpy arrays, Keras layouts):
+    unet: {"arch": name, "convs": [ {"kernel": (3,3,3,Cin,Cout), "bias": (Cout,), "gamma", "beta",
+           "mean", "var": (Cout,)} ... ], "head": {"kernel": (1,1,1,C,1), "bias": (1,)} }
+    ffn:  {"w1": (61,512), "bn1": {gamma,beta,mean,var}, "w2": (1024,512), "bn2": {...},
+           "w3": (512,1), "b3": (1,)}
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .arch import ARCHS, FFN_FEAT, FFN_HID
+
+
+def _glorot(rng, shape, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def _bn(rng, c):
+    return {
+        "gamma": rng.uniform(0.5, 1.5, c).astype(np.float32),
+        "beta": rng.normal(0.0, 0.1, c).astype(np.float32),
+        "mean": rng.normal(0.0, 0.1, c).astype(np.float32),
+        "var": rng.uniform(0.5, 1.5, c).astype(np.float32),
+    }
+
+
+def make_unet_weights(arch_name: str = "unet3_a", seed: int = 0) -> dict:
+    arch = ARCHS[arch_name]
+    rng = np.random.default_rng(seed)
+    convs = []
+    for cin, cout in arch.conv_layers():
+        layer = {
+            "kernel": _glorot(rng, (3, 3, 3, cin, cout), 27 * cin, 27 * cout),
+            "bias": rng.normal(0.0, 0.05, cout).astype(np.float32),
+        }
+        layer.update(_bn(rng, cout))
+        convs.append(layer)
+    c = arch.out[1]
+    head = {"kernel": _glorot(rng, (1, 1, 1, c, 1), c, 1), "bias": rng.normal(0.0, 0.05, 1).astype(np.float32)}
+    return {"arch": arch_name, "convs": convs, "head": head}
+
+
+def make_ffn_weights(seed: int = 0, gain: float = 1.0, shift: float = 0.0) -> dict:
+    """`gain` scales the last layer so that the sigmoid scores spread over (0,1) instead of
+    clustering at 0.5 and `shift` moves the output bias (a trained FFN is strongly bimodal with
+    most pairs near 0; a Glorot-init one is not)."""
+    rng = np.random.default_rng(seed + 1000)
+    return {
+        "w1": _glorot(rng, (FFN_FEAT, FFN_HID), FFN_FEAT, FFN_HID),
+        "bn1": _bn(rng, FFN_HID),
+        "w2": _glorot(rng, (2 * FFN_HID, FFN_HID), 2 * FFN_HID, FFN_HID),
+        "bn2": _bn(rng, FFN_HID),
+        "w3": (_glorot(rng, (FFN_HID, 1), FFN_HID, 1) * gain).astype(np.float32),
+        "b3": (rng.normal(0.0, 0.05, 1) + shift).astype(np.float32),
+    }
+
+
+def make_point_pair(n: int, seed: int = 0, box=(512.0, 512.0, 32.0), voxel_size=(1.0, 1.0, 4.0),
+                    affine_level: float = 0.2, move_level: float = 0.001, replace_ratio: float = 0.15):
+    """Return (X, Y): X uniform in the stack box (real units), Y = affine-perturbed, partly
+    replaced, permuted copy (the reference's synthetic training-pair recipe, ffn.py:18-53)."""
+    rng = np.random.default_rng(seed)
+    ext = np.asarray(box, dtype=np.float64) * np.asarray(voxel_size, dtype=np.float64)
+    x = rng.uniform(0.0, 1.0, (n, 3)) * ext[None, :]
+    mean = x.mean(axis=0)
+    scale = 3.0 * x.std()
+    xc = (x - mean) / scale
+    a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * affine_level
+    y = xc @ a + (rng.uniform(0, 1, xc.shape) - 0.5) * 4 * move_level
+    n_rep = int(round(n * replace_ratio))
+    if n_rep:
+        idx = rng.choice(n, n_rep, replace=False)
+        y[idx] = (rng.uniform(0.0, 1.0, (n_rep, 3)) * ext[None, :] - mean) / scale
+    perm = rng.permutation(n)
+    y = y[perm]
+    return x, y * scale + mean
+
+
+def make_stack(shape=(512, 512, 32), n_cells: int = 600, seed: int = 0):
+    """Synthetic (x, y, z) uint16 stack and its blob centres (voxel coords)."""
+    rng = np.random.default_rng(seed)
+    sx, sy, sz = shape
+    img = rng.normal(100.0, 20.0, shape).astype(np.float32)
+    np.clip(img, 0, None, out=img)
+    lo = np.array([6, 6, 1]); hi = np.array([sx - 6, sy - 6, max(sz - 1, 2)])
+    centres = rng.uniform(lo, hi, (n_cells, 3))
+    amps = rng.uniform(400, 2000, n_cells)
+    sig = np.array([3.0, 3.0, 1.0])
+    rad = np.array([9, 9, 3])
+    for c, a in zip(centres, amps):
+        c0 = np.maximum(np.floor(c - rad).astype(int), 0)
+        c1 = np.minimum(np.ceil(c + rad).astype(int) + 1, shape)
+        gx = np.exp(-0.5 * ((np.arange(c0[0], c1[0]) - c[0]) / sig[0]) ** 2)
+        gy = np.exp(-0.5 * ((np.arange(c0[1], c1[1]) - c[1]) / sig[1]) ** 2)
+        gz = np.exp(-0.5 * ((np.arange(c0[2], c1[2]) - c[2]) / sig[2]) ** 2)
+        img[c0[0]:c1[0], c0[1]:c1[1], c0[2]:c1[2]] += a * gx[:, None, None] * gy[None, :, None] * gz[None, None, :]
+    return np.clip(img, 0, 65535).astype(np.uint16), centres
+
+
+def normalize_stack(img_u16: np.ndarray) -> np.ndarray:
+    """Cheap stand-in for the reference's pre-processing (median subtract, clamp, scale): the
+    LCN step is SURVEY 8(f) 'next' row #1 and not on this path.  Returns fp32 (1,x,y,z,1)."""
+    img = img_u16.astype(np.float32)
+    img -= np.median(img)
+    np.clip(img, 0, None, out=img)
+    img /= (img.std() + 1e-6)
+    return img[None, :, :, :, None]
