@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI declared in include/ctamd.h (libctamd.so, built in-tree by
+csrc/Makefile / __graft_entry__.build()).  There is NO fallback: if the HIP library is missing
+or a call fails, the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libctamd.so"
+
+
+class CtamdError(RuntimeError):
+    pass
+
+
+_lib = None
+MISSING: list = []   # declared in ctamd.h but absent from the built library (tests assert it is empty)
+
+_vp, _i, _sz, _d, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_float
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); must list every symbol of include/ctamd.h
+SIGNATURES = {
+    "ct_version": (_i, []),
+    "ct_error_string": (C.c_char_p, [_i]),
+    "ct_device_info": (_i, [_i, _ip, C.POINTER(_sz), C.c_char_p, _sz]),
+    "ct_unet_create": (_i, [_i, _vp, _sz, _i, C.POINTER(_vp)]),
+    "ct_unet_destroy": (None, [_vp]),
+    "ct_unet_num_weights": (_sz, [_i]),
+    "ct_unet_patch_shape": (_i, [_i, _ip]),
+    "ct_unet_workspace_bytes": (_sz, [_vp, _i]),
+    "ct_unet_predict_patches": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
+    "ct_unet_layer_dump_floats": (_sz, [_i]),
+    "ct_tile_plan": (_i, [_ip, _ip, _ip, _ip, _ip]),
+    "ct_tile_gather_reflect": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),
+    "ct_tile_scatter_center": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),
+    "ct_unet_predict_volume": (_i, [_vp, _vp, _ip, _ip, _i, _i, _vp, _vp, _sz, _vp]),
+    "ct_knn_features": (_i, [_vp, _i, _i, _vp, _vp]),
+    "ct_ffn_create": (_i, [_vp, _sz, _i, C.POINTER(_vp)]),
+    "ct_ffn_destroy": (None, [_vp]),
+    "ct_ffn_num_weights": (_sz, []),
+    "ct_ffn_workspace_bytes": (_sz, [_i, _i]),
+    "ct_ffn_pairgrid": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "ct_ffn_predict": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "ct_ffn_predict_workspace_bytes": (_sz, [_i]),
+    "ct_greedy_workspace_bytes": (_sz, [_i, _i]),
+    "ct_greedy_match": (_i, [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ct_prgls_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ct_prgls_two_ref": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _ip, _vp, _sz, _vp]),
+    "ct_prgls_legacy": (_i, [_vp, _i, _vp, _i, _vp, _d, _i, _d, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ct_gram_apply": (_i, [_vp, _i, _vp, _i, _vp, _d, _vp]),
+    "ct_trim_mean": (_i, [_vp, _i, _i, _d, _vp, _vp]),
+}
+
+
+def lib():
+    """Load libctamd.so (once) and attach the prototypes.  Raises CtamdError if it is absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise CtamdError(
+                f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+                f"or make -C {_HERE / 'csrc'}).  There is no CPU fallback.")
+        try:
+            handle = C.CDLL(str(LIB_PATH))
+        except OSError as e:  # pragma: no cover
+            raise CtamdError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:          # calling it later raises AttributeError: loud, no fallback
+                MISSING.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "ctamd call"):
+    if rc != 0:
+        msg = lib().ct_error_string(rc)
+        raise CtamdError(f"{what} failed: {rc} ({msg.decode() if msg else '?'})")
+
+
+def ivec(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise CtamdError("no ROCm device visible: this package only runs on an MI355X-class GPU (no CPU fallback)")
+    return torch

@@ -1,0 +1,1031 @@
+// ct_match.hip -- FFN initial matching + greedy assignment + PR-GLS for gfx950 (MI355X).
+//
+// What it replaces (reference, numpy / sklearn / Keras):
+//   CellTracker/ffn.py:268-327 (== track.py:117-178)  kNN shape features + all-pairs FFN
+//   CellTracker/ffn.py:225-265                         FFN forward
+//   CellTracker/trackerlite.py:242-259, track.py:58-70 greedy one-to-one assignment / prior
+//   CellTracker/trackerlite.py:262-417                 PR-GLS (TrackerLite dialect)
+//   CellTracker/track.py:11-114                        PR-GLS (legacy dialect)
+//   CellTracker/tracker.py:1269-1289                   Gram + apply of one repetition
+//
+// Compiled with -ffp-contract=off: the fp64 geometry (distances, means, feature division) follows
+// the reference's operation order with separate roundings so that the fp32 feature tables are
+// bit-identical to numpy's; fma() is written explicitly where fusing is wanted.
+//
+// The (m*n) x 122 pair grid of the reference is never materialised: W2 acts linearly on the
+// concatenation, so  concat(h_r, h_t) W2 = h_r W2[:512] + h_t W2[512:]  -- two small GEMMs plus an
+// m x n x 512 element-wise/reduce kernel.
+//
+// The n x n system of the M-step,  (G diag(d) + c I)^T C^T = B^T  with G symmetric PSD, d >= 0,
+// c = lambda sigma^2 > 0, is solved through the symmetric scaling
+//   D^1/2 G D^1/2 + c I  =: M  (SPD),   x = D^1/2 M^-1 D^-1/2 b,
+// i.e. a blocked Cholesky without pivoting (no D^-1 is formed: b_i / sqrt(d_i) is a weighted mean
+// times sqrt(d_i), and rows with d_i = 0 decouple with x_i = 0 = b_i / c).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <new>
+#include <vector>
+
+#include "../../include/ctamd.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+namespace {
+
+constexpr float kLeakyAlpha = 0.3f;
+constexpr float kBnEps = 1e-3f;
+constexpr int FEAT = 61, HID = 512;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------
+// wave-level helpers (64 lanes)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: kNN shape-context features (ffn.py:288-304)
+// one wave per point; distances in LDS; k+1 rounds of wave arg-min on (distance, index)
+// ------------------------------------------------------------------------------------------------
+constexpr int KNN_MAXN = 4096;
+
+__global__ __launch_bounds__(64) void knn_features_kernel(const double* __restrict__ pts, int n, int k,
+                                                          float* __restrict__ feat) {
+    __shared__ double dist[KNN_MAXN];
+    __shared__ double sel_d[32];
+    __shared__ int sel_i[32];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    for (int j = lane; j < n; j += 64) {
+        const double dx = pts[3 * j] - px, dy = pts[3 * j + 1] - py, dz = pts[3 * j + 2] - pz;
+        dist[j] = sqrt(dx * dx + dy * dy + dz * dz);       // separate roundings (no contraction)
+    }
+    __syncthreads();
+    for (int round = 0; round <= k; ++round) {
+        double best = INFINITY; int bi = 0x7fffffff;
+        for (int j = lane; j < n; j += 64) {
+            const double d = dist[j];
+            if (d < best) { best = d; bi = j; }              // ascending j => lowest index on ties
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double od = shfl_xor_d(best, m); const int oi = __shfl_xor(bi, m);
+            if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+        }
+        if (lane == 0) { sel_d[round] = best; sel_i[round] = bi; dist[bi] = INFINITY; }
+        __syncthreads();
+    }
+    // mean of the k+1 distances in numpy's pairwise-sum order (8 partial sums, then the tail)
+    const int cnt = k + 1;
+    double mean;
+    {
+        double res;
+        if (cnt < 8) { res = 0.0; for (int q = 0; q < cnt; ++q) res += sel_d[q]; }
+        else {
+            double r[8];
+            for (int q = 0; q < 8; ++q) r[q] = sel_d[q];
+            int q = 8;
+            for (; q < cnt - (cnt % 8); q += 8)
+                for (int e = 0; e < 8; ++e) r[e] += sel_d[q + e];
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; q < cnt; ++q) res += sel_d[q];
+        }
+        mean = res / (double)cnt;
+    }
+    const int self = sel_i[0];
+    const double sx = pts[3 * self], sy = pts[3 * self + 1], sz = pts[3 * self + 2];
+    float* out = feat + (size_t)i * (3 * k + 1);
+    for (int q = lane; q < k; q += 64) {
+        const int nb = sel_i[q + 1];
+        out[3 * q]     = (float)((pts[3 * nb] - sx) / mean);
+        out[3 * q + 1] = (float)((pts[3 * nb + 1] - sy) / mean);
+        out[3 * q + 2] = (float)((pts[3 * nb + 2] - sz) / mean);
+    }
+    if (lane == 0) out[3 * k] = (float)mean;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small fp32 GEMM  C[M][N] = A[M][K] (row stride lda) * B[K][N], optional BN-affine + LeakyReLU
+// epilogue (Dense(no bias) + BatchNormalization + LeakyReLU, ffn.py:242-254).
+// 64x64 tile, 256 threads, 4x4 outputs per thread, sequential-k fp32 accumulation.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                       float* __restrict__ C, int M, int N, int K,
+                                                       const float* __restrict__ bn /* [4][N] gamma,beta,mean,var or null */) {
+    __shared__ float As[16][64 + 1];
+    __shared__ float Bs[16][64 + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int r = e >> 4, kk = e & 15;
+            const int gm = m0 + r, gk = k0 + kk;
+            As[kk][r] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
+        }
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int kk = e >> 6, c = e & 63;
+            const int gk = k0 + kk, gn = n0 + c;
+            Bs[kk][c] = (gk < K && gn < N) ? B[(size_t)gk * N + gn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + ty * 4 + i;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tx * 4 + j;
+            if (gn >= N) continue;
+            float v = acc[i][j];
+            if (bn) {
+                const float inv = bn[gn] / sqrtf(bn[3 * N + gn] + kBnEps);
+                v = (v - bn[2 * N + gn]) * inv + bn[N + gn];
+                v = v >= 0.f ? v : v * kLeakyAlpha;
+            }
+            C[(size_t)gm * N + gn] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 pair kernel: corr[t][r] = sigmoid( w3 . leaky(BN2(U[r] + V[t])) + b3 )
+// 32 x 32 pairs per block, 256 threads, 2 x 2 pairs per thread, k streamed in chunks of 64.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ffn_pair_kernel(const float* __restrict__ U, int n, const float* __restrict__ V, int m,
+                                                       const float* __restrict__ bn2, const float* __restrict__ w3,
+                                                       float b3, float* __restrict__ corr) {
+    constexpr int KC = 64;
+    __shared__ float Us[32][KC + 1];
+    __shared__ float Vs[32][KC + 1];
+    __shared__ float inv_s[KC], mean_s[KC], beta_s[KC], w3_s[KC];
+    const int tid = threadIdx.x, tr = tid & 15, tt = tid >> 4;
+    const int r0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    float acc[2][2] = {};
+    for (int k0 = 0; k0 < HID; k0 += KC) {
+        for (int e = tid; e < 32 * KC; e += 256) {
+            const int row = e / KC, kk = e - row * KC;
+            Us[row][kk] = (r0 + row < n) ? U[(size_t)(r0 + row) * HID + k0 + kk] : 0.f;
+            Vs[row][kk] = (t0 + row < m) ? V[(size_t)(t0 + row) * HID + k0 + kk] : 0.f;
+        }
+        if (tid < KC) {
+            const int kk = k0 + tid;
+            inv_s[tid] = bn2[kk] / sqrtf(bn2[3 * HID + kk] + kBnEps);
+            mean_s[tid] = bn2[2 * HID + kk]; beta_s[tid] = bn2[HID + kk]; w3_s[tid] = w3[kk];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < KC; ++kk) {
+            const float u0 = Us[tr][kk], u1 = Us[tr + 16][kk];
+            const float v0 = Vs[tt][kk], v1 = Vs[tt + 16][kk];
+            const float inv = inv_s[kk], mu = mean_s[kk], be = beta_s[kk], ww = w3_s[kk];
+            float y;
+            y = ((u0 + v0) - mu) * inv + be; y = y >= 0.f ? y : y * kLeakyAlpha; acc[0][0] = fmaf(y, ww, acc[0][0]);
+            y = ((u1 + v0) - mu) * inv + be; y = y >= 0.f ? y : y * kLeakyAlpha; acc[0][1] = fmaf(y, ww, acc[0][1]);
+            y = ((u0 + v1) - mu) * inv + be; y = y >= 0.f ? y : y * kLeakyAlpha; acc[1][0] = fmaf(y, ww, acc[1][0]);
+            y = ((u1 + v1) - mu) * inv + be; y = y >= 0.f ? y : y * kLeakyAlpha; acc[1][1] = fmaf(y, ww, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = t0 + tt + 16 * i, r = r0 + tr + 16 * j;
+            if (t < m && r < n) corr[(size_t)t * n + r] = 1.f / (1.f + expf(-(acc[i][j] + b3)));
+        }
+}
+
+// rows of explicit 122-feature inputs: out[i] = sigmoid(w3 . leaky(BN2(U[i] + V[i])) + b3)
+__global__ __launch_bounds__(64) void ffn_rows_finish_kernel(const float* __restrict__ U, const float* __restrict__ V, int rows,
+                                                             const float* __restrict__ bn2, const float* __restrict__ w3,
+                                                             float b3, float* __restrict__ out) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int k = lane; k < HID; k += 64) {
+        const float inv = bn2[k] / sqrtf(bn2[3 * HID + k] + kBnEps);
+        float y = ((U[(size_t)i * HID + k] + V[(size_t)i * HID + k]) - bn2[2 * HID + k]) * inv + bn2[HID + k];
+        y = y >= 0.f ? y : y * kLeakyAlpha;
+        acc = fmaf(y, w3[k], acc);
+    }
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) acc += __shfl_xor(acc, mk);
+    if (lane == 0) out[i] = 1.f / (1.f + expf(-(acc + b3)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8 greedy one-to-one assignment (trackerlite.py:242-259 / track.py:58-70)
+// Single workgroup (the loop is inherently sequential): per-row best (value, column) over free
+// columns is cached in LDS; every step = block arg-max over rows (ties -> lowest row, whose cached
+// column is the lowest column) then a re-scan of only those rows whose cached column was taken.
+// Equivalent to the reference's repeated global arg-max with first-occurrence tie-breaking.
+// ------------------------------------------------------------------------------------------------
+constexpr int GR_THREADS = 1024, GR_WAVES = GR_THREADS / 64;
+
+__device__ __forceinline__ void row_scan(const float* __restrict__ row, int n, const unsigned char* col_used, int lane,
+                                         float& best, int& bi) {
+    best = -1.f; bi = 0x7fffffff;
+    for (int c = lane; c < n; c += 64) {
+        if (col_used[c]) continue;
+        const float v = row[c];
+        if (v > best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) {
+        const float ov = __shfl_xor(best, mk); const int oi = __shfl_xor(bi, mk);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+}
+
+__global__ __launch_bounds__(GR_THREADS) void greedy_match_kernel(const float* __restrict__ corr, int m, int n, float thr,
+                                                                  int32_t* __restrict__ pairs, int32_t* __restrict__ n_pairs,
+                                                                  float* __restrict__ row_val, int* __restrict__ row_col,
+                                                                  unsigned char* __restrict__ col_used_g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS: col_used[n] | redv[GR_WAVES] | redi[GR_WAVES] | todo list count
+    unsigned char* col_used = smem;
+    float* redv = reinterpret_cast<float*>(smem + ((n + 15) & ~15));
+    int* redi = reinterpret_cast<int*>(redv + GR_WAVES);
+    int* bc = redi + GR_WAVES;            // bc[0] = chosen row, bc[1] = chosen col, bc[2] = stop flag
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < n; c += GR_THREADS) col_used[c] = 0;
+    __syncthreads();
+    for (int t = wave; t < m; t += GR_WAVES) {
+        float b; int bi; row_scan(corr + (size_t)t * n, n, col_used, lane, b, bi);
+        if (lane == 0) { row_val[t] = b; row_col[t] = bi; }
+    }
+    __syncthreads();
+    int np = 0;
+    for (int it = 0; it < n; ++it) {
+        // block arg-max over rows: (value desc, row asc)
+        float best = -1.f; int bt = 0x7fffffff;
+        for (int t = tid; t < m; t += GR_THREADS) {
+            const float v = row_val[t];
+            if (v > best) { best = v; bt = t; }
+        }
+#pragma unroll
+        for (int mk = 32; mk >= 1; mk >>= 1) {
+            const float ov = __shfl_xor(best, mk); const int oi = __shfl_xor(bt, mk);
+            if (ov > best || (ov == best && oi < bt)) { best = ov; bt = oi; }
+        }
+        if (lane == 0) { redv[wave] = best; redi[wave] = bt; }
+        __syncthreads();
+        if (wave == 0) {
+            float v = lane < GR_WAVES ? redv[lane] : -1.f; int t = lane < GR_WAVES ? redi[lane] : 0x7fffffff;
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) {
+                const float ov = __shfl_xor(v, mk); const int oi = __shfl_xor(t, mk);
+                if (ov > v || (ov == v && oi < t)) { v = ov; t = oi; }
+            }
+            if (lane == 0) {
+                if (!(v >= thr) || t == 0x7fffffff) { bc[2] = 1; }
+                else {
+                    bc[2] = 0; bc[0] = t; bc[1] = row_col[t];
+                    pairs[2 * np] = row_col[t]; pairs[2 * np + 1] = t;      // (ref, tgt)
+                    row_val[t] = -2.f;                                      // row cleared
+                    col_used[row_col[t]] = 1;                               // column cleared
+                }
+            }
+        }
+        __syncthreads();
+        if (bc[2]) break;
+        ++np;
+        const int ccol = bc[1];
+        // re-scan rows whose cached best column was just taken
+        for (int t = wave; t < m; t += GR_WAVES) {
+            if (row_val[t] >= 0.f && row_col[t] == ccol) {      // wave-uniform condition
+                float b; int bi; row_scan(corr + (size_t)t * n, n, col_used, lane, b, bi);
+                if (lane == 0) { row_val[t] = (bi == 0x7fffffff) ? -2.f : b; row_col[t] = bi; }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_pairs = np;
+    (void)col_used_g;
+}
+
+__global__ __launch_bounds__(256) void prior_fill_kernel(double* __restrict__ prior, int m, int n, int mode,
+                                                         const int32_t* __restrict__ pairs, const int32_t* __restrict__ n_pairs,
+                                                         int* __restrict__ row_match /* [m] scratch */) {
+    // pass A (blockIdx.y == 0): row_match[t] = matched ref or -1
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t tot = (size_t)m * n;
+    if (gid >= tot) return;
+    const int t = (int)(gid / n), r = (int)(gid - (size_t)t * n);
+    const int mr = row_match[t];
+    double v;
+    if (mode == 0) {          // np.full_like(float32 matrix, 0.1/(n-1)); prior[tgt, ref] = 0.9   (float32 values)
+        v = (double)(float)(0.1 / (double)(n - 1));
+        if (mr == r) v = (double)0.9f;
+    } else {                  // legacy: ones/n; matched rows 0.1/(n-1) with 0.9 at the pair        (float64 values)
+        v = 1.0 / (double)n;
+        if (mr >= 0) v = (mr == r) ? 0.9 : 0.1 / (double)(n - 1);
+    }
+    prior[gid] = v;
+}
+
+__global__ void row_match_kernel(int* __restrict__ row_match, int m) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < m) row_match[tid] = -1;
+}
+__global__ void row_match_set_kernel(int* __restrict__ row_match, const int32_t* __restrict__ pairs,
+                                     const int32_t* __restrict__ n_pairs) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < *n_pairs) row_match[pairs[2 * tid + 1]] = pairs[2 * tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// PR-GLS kernels (fp64)
+// ------------------------------------------------------------------------------------------------
+// scalars block (device): [0] sigma2  [1] gamma  [2] sumP  [3] move_norm2  [4] c = lambda*sigma2  [5] iteration
+enum { S_SIGMA2 = 0, S_GAMMA = 1, S_SUMP = 2, S_NORM2 = 3, S_C = 4, S_NUM = 8 };
+
+// out[i][j] = exp(-|a_j - b_i|^2 / (2 s2)),  i < nb, j < na      (trackerlite.py:368-372)
+__global__ __launch_bounds__(256) void gauss_kernel(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
+                                                    double two_s2, double* __restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)na * nb) return;
+    const int i = (int)(gid / na), j = (int)(gid - (size_t)i * na);
+    const double dx = a[3 * j] - b[3 * i], dy = a[3 * j + 1] - b[3 * i + 1], dz = a[3 * j + 2] - b[3 * i + 2];
+    out[gid] = exp(-(dx * dx + dy * dy + dz * dz) / two_s2);
+}
+
+// sum over all (t, r) of |ref_r - tgt_t|^2  -> per-row partial sums rowpart[m]
+__global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restrict__ ref, int n, const double* __restrict__ tgt, int m,
+                                                           const double* __restrict__ P /* weights or null */,
+                                                           double* __restrict__ rowpart) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= m) return;
+    const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
+    double acc = 0.0;
+    for (int r = lane; r < n; r += 64) {
+        const double dx = ref[3 * r] - yx, dy = ref[3 * r + 1] - yy, dz = ref[3 * r + 2] - yz;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        acc += P ? d2 * P[(size_t)t * n + r] : d2;
+    }
+    acc = wave_sum_d(acc);
+    if (lane == 0) rowpart[t] = acc;
+}
+
+// finalise scalars from row partials.  mode 0: initial sigma2 = sum / (3 m n)   (both dialects)
+// mode 1 (lite, trackerlite.py:342-350):  gamma = max(1 - sumP/m, 1e-4); sigma2 = sum / (3 sumP)
+// mode 2 (legacy, track.py:103-112):      gamma = 1 - sumP/m;            sigma2 = max(sum / (3 sumP), 1)
+__global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ rowpart, int m, int n, int mode,
+                                                      double* __restrict__ sc) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int t = threadIdx.x; t < m; t += 256) acc += rowpart[t];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s = (red[0] + red[1]) + (red[2] + red[3]);
+        if (mode == 0) { sc[S_SIGMA2] = s / (3.0 * (double)m * (double)n); }
+        else {
+            const double sp = sc[S_SUMP];
+            double g = 1.0 - sp / (double)m;
+            double s2 = s / (3.0 * sp);
+            if (mode == 1) { if (g < 1e-4) g = 1e-4; }
+            else { if (s2 < 1.0) s2 = 1.0; }
+            sc[S_GAMMA] = g; sc[S_SIGMA2] = s2;
+        }
+    }
+}
+
+// E-step: one wave per target row (trackerlite.py:375-382 / track.py:81-88)
+__global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict__ prior, const double* __restrict__ pred,
+                                                        int n, const double* __restrict__ tgt, int m,
+                                                        const double* __restrict__ sc, int legacy, double vol,
+                                                        double* __restrict__ P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= m) return;
+    const double s2 = sc[S_SIGMA2], gamma = sc[S_GAMMA];
+    const double two_s2 = 2.0 * s2;
+    const double norm = pow(2.0 * M_PI * s2, 1.5);
+    const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
+    const double* pr = prior + (size_t)t * n;
+    double* po = P + (size_t)t * n;
+    double acc = 0.0;
+    for (int r = lane; r < n; r += 64) {
+        const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
+        const double k = exp(-(dx * dx + dy * dy + dz * dz) / two_s2);
+        const double num = legacy ? pr[r] * k : (1.0 - gamma) * pr[r] * k / norm;
+        po[r] = num;
+        acc += num;
+    }
+    acc = wave_sum_d(acc);
+    const double den = legacy ? acc + gamma * norm / ((1.0 - gamma) * vol) : acc + gamma / vol;
+    for (int r = lane; r < n; r += 64) po[r] = po[r] / den;
+}
+
+// column statistics, stage 1: block (x: 64 columns, y: row segment) -> part[seg][4][n] = colsum, Y^T P
+constexpr int CS_SEG = 16;
+__global__ __launch_bounds__(64) void colstats_kernel(const double* __restrict__ P, const double* __restrict__ tgt, int m, int n,
+                                                      double* __restrict__ part) {
+    const int r = blockIdx.x * 64 + threadIdx.x, seg = blockIdx.y;
+    if (r >= n) return;
+    const int per = (m + CS_SEG - 1) / CS_SEG;
+    const int t0 = seg * per, t1 = min(m, t0 + per);
+    double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        const double p = P[(size_t)t * n + r];
+        s += p; sx = fma(tgt[3 * t], p, sx); sy = fma(tgt[3 * t + 1], p, sy); sz = fma(tgt[3 * t + 2], p, sz);
+    }
+    double* o = part + (size_t)seg * 4 * n;
+    o[r] = s; o[n + r] = sx; o[2 * n + r] = sy; o[3 * n + r] = sz;
+}
+
+// stage 2: d[r] = colsum, rhs (scaled) and sumP.  xref = points whose X^T D term is subtracted
+// (lite: current prediction, trackerlite.py:414; legacy: the original X, track.py:93)
+__global__ __launch_bounds__(256) void colstats_finish_kernel(const double* __restrict__ part, int n, const double* __restrict__ xref,
+                                                              double lambda, double* __restrict__ sc, double* __restrict__ dvec,
+                                                              double* __restrict__ sqd, double* __restrict__ rhs /* [n][3] */) {
+    __shared__ double red[4];
+    double tot = 0.0;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int seg = 0; seg < CS_SEG; ++seg) {
+            const double* o = part + (size_t)seg * 4 * n;
+            s += o[r]; sx += o[n + r]; sy += o[2 * n + r]; sz += o[3 * n + r];
+        }
+        dvec[r] = s;
+        const double q = sqrt(s);
+        sqd[r] = q;
+        // b_r = Y^T P[:, r] - x_r d_r ;  scaled rhs = b_r / sqrt(d_r)  (0 when d_r == 0: then b_r == 0 too)
+        const double bx = sx - xref[3 * r] * s, by = sy - xref[3 * r + 1] * s, bz = sz - xref[3 * r + 2] * s;
+        const double iq = q > 0.0 ? 1.0 / q : 0.0;
+        rhs[3 * r] = bx * iq; rhs[3 * r + 1] = by * iq; rhs[3 * r + 2] = bz * iq;
+        tot += s;
+    }
+    tot = wave_sum_d(tot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sc[S_SUMP] = (red[0] + red[1]) + (red[2] + red[3]);
+        sc[S_C] = lambda * sc[S_SIGMA2];
+    }
+}
+
+// M = D^1/2 G D^1/2 + c I   (lower triangle is what the factorisation reads; fill everything)
+__global__ __launch_bounds__(256) void assemble_kernel(const double* __restrict__ G, const double* __restrict__ sqd,
+                                                       const double* __restrict__ sc, int n, double* __restrict__ M) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)n * n) return;
+    const int i = (int)(gid / n), j = (int)(gid - (size_t)i * n);
+    double v = sqd[i] * G[gid] * sqd[j];
+    if (i == j) v += sc[S_C];
+    M[gid] = v;
+}
+
+// ---- blocked right-looking Cholesky, NB = 32 ----------------------------------------------------
+constexpr int NB = 32;
+
+// Panel step: every block factors the diagonal block redundantly in LDS (32^3/3 flops), block 0 writes
+// it back; then each block solves its 32 rows of the panel:  L[i, k0:k0+nb] = A[i, k0:k0+nb] L_kk^-T.
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ M, int n, int k0) {
+    __shared__ double Lkk[NB][NB + 1];
+    __shared__ double Arow[NB][NB + 1];
+    const int tid = threadIdx.x;
+    const int nb = min(NB, n - k0);
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        Lkk[i][j] = (i < nb && j < nb) ? M[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {                 // unblocked factorisation of the 32 x 32 block
+        if (tid == 0) Lkk[j][j] = sqrt(Lkk[j][j]);
+        __syncthreads();
+        if (tid > j && tid < nb) Lkk[tid][j] /= Lkk[j][j];
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, c = e % NB;
+            if (c > j && c <= i && i < nb) Lkk[i][c] -= Lkk[i][j] * Lkk[c][j];
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0)
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            if (i < nb && j < nb) M[(size_t)(k0 + i) * n + k0 + j] = (j <= i) ? Lkk[i][j] : 0.0;
+        }
+    const int row0 = k0 + nb + blockIdx.x * NB;
+    if (row0 >= n) return;
+    const int nr = min(NB, n - row0);
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        Arow[i][j] = (i < nr && j < nb) ? M[(size_t)(row0 + i) * n + k0 + j] : 0.0;
+    }
+    __syncthreads();
+    // forward substitution along the row: x_j = (a_j - sum_{p<j} x_p L[j][p]) / L[j][j]; thread = row
+    if (tid < nr) {
+        for (int j = 0; j < nb; ++j) {
+            double s = Arow[tid][j];
+            for (int p = 0; p < j; ++p) s -= Arow[tid][p] * Lkk[j][p];
+            Arow[tid][j] = s / Lkk[j][j];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        if (i < nr && j < nb) M[(size_t)(row0 + i) * n + k0 + j] = Arow[i][j];
+    }
+}
+
+// Trailing update (lower triangle, 32 x 32 tiles): A[i][j] -= sum_p L[i][k0+p] L[j][k0+p]
+__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ M, int n, int k0) {
+    const int nb = min(NB, n - k0);
+    const int base = k0 + nb;
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj > bi) return;
+    const int i0 = base + bi * NB, j0 = base + bj * NB;
+    if (i0 >= n || j0 >= n) return;
+    __shared__ double Li[NB][NB + 1], Lj[NB][NB + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e / NB, p = e % NB;
+        Li[r][p] = (i0 + r < n && p < nb) ? M[(size_t)(i0 + r) * n + k0 + p] : 0.0;
+        Lj[r][p] = (j0 + r < n && p < nb) ? M[(size_t)(j0 + r) * n + k0 + p] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;          // 32 x 8 threads, 4 rows each
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = ty + 8 * q, c = tx;
+        const int gi = i0 + r, gj = j0 + c;
+        if (gi < n && gj < n && gj <= gi) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int p = 0; p < NB; ++p) s = fma(Li[r][p], Lj[c][p], s);
+            M[(size_t)gi * n + gj] -= s;
+        }
+    }
+}
+
+// Triangular solves L w = b, L^T z = w for 3 right-hand sides; one workgroup; then
+// C[d][i] = sqrt(d_i) z[i][d]  (un-scaling).  rhs [n][3] is overwritten with z.
+__global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ L, int n, double* __restrict__ rhs,
+                                                         const double* __restrict__ sqd, double* __restrict__ C) {
+    __shared__ double xb[NB][3];
+    __shared__ double Ld[NB][NB + 1];
+    __shared__ double ps[2][NB][3];
+    const int tid = threadIdx.x;
+    const int nblk = (n + NB - 1) / NB;
+    // ---- forward: for each block row, subtract the contribution of solved unknowns, then solve the diagonal block
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int k0 = kb * NB, nb = min(NB, n - k0);
+        // 96 (row, rhs) dot products of length k0: threads split (row, rhs) x 2 halves?  use 3 x 32 x (k split 2)
+        {
+            const int row = tid & 31, d = (tid >> 5) % 3, part = tid / 96;       // part 0..1 (tid < 192)
+            double s = 0.0;
+            if (tid < 192 && row < nb) {
+                const double* lr = L + (size_t)(k0 + row) * n;
+                for (int p = part; p < k0; p += 2) s = fma(lr[p], rhs[3 * p + d], s);
+            }
+            if (tid < 192) ps[part][row][d] = s;
+            __syncthreads();
+            if (tid < 96 && row < nb) xb[row][d] = rhs[3 * (k0 + row) + d] - (ps[0][row][d] + ps[1][row][d]);
+        }
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            Ld[i][j] = (i < nb && j < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 3) {
+            for (int i = 0; i < nb; ++i) {
+                double s = xb[i][tid];
+                for (int p = 0; p < i; ++p) s -= Ld[i][p] * xb[p][tid];
+                xb[i][tid] = s / Ld[i][i];
+            }
+        }
+        __syncthreads();
+        if (tid < 96) { const int row = tid & 31, d = tid >> 5; if (row < nb) rhs[3 * (k0 + row) + d] = xb[row][d]; }
+        __syncthreads();
+    }
+    // ---- backward with L^T: unknown block kb depends on blocks > kb through L[rows > kb][cols kb]
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int k0 = kb * NB, nb = min(NB, n - k0);
+        const int k1 = k0 + nb;
+        {
+            const int col = tid & 31, d = (tid >> 5) % 3, part = tid / 96;
+            double s = 0.0;
+            if (tid < 192 && col < nb) {
+                for (int p = k1 + part; p < n; p += 2) s = fma(L[(size_t)p * n + k0 + col], rhs[3 * p + d], s);
+            }
+            if (tid < 192) ps[part][col][d] = s;
+            __syncthreads();
+            if (tid < 96 && col < nb) xb[col][d] = rhs[3 * (k0 + col) + d] - (ps[0][col][d] + ps[1][col][d]);
+        }
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            Ld[i][j] = (i < nb && j < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 3) {
+            for (int i = nb - 1; i >= 0; --i) {
+                double s = xb[i][tid];
+                for (int p = i + 1; p < nb; ++p) s -= Ld[p][i] * xb[p][tid];
+                xb[i][tid] = s / Ld[i][i];
+            }
+        }
+        __syncthreads();
+        if (tid < 96) { const int row = tid & 31, d = tid >> 5; if (row < nb) rhs[3 * (k0 + row) + d] = xb[row][d]; }
+        __syncthreads();
+    }
+    for (int e = tid; e < 3 * n; e += 256) {
+        const int i = e / 3, d = e - 3 * i;
+        C[(size_t)d * n + i] = sqd[i] * rhs[e];
+    }
+}
+
+// movement of a point set through the field: mov[j][d] = sum_i C[d][i] G[i][j]; one wave per j.
+// flags: add (pts += mov), replace (pts = base + mov), accumulate |mov|^2 into norm partials
+__global__ __launch_bounds__(256) void apply_field_kernel(const double* __restrict__ C, const double* __restrict__ G, int n, int cols,
+                                                          double* __restrict__ pts, const double* __restrict__ base, int mode,
+                                                          double* __restrict__ norm_part /* [cols] or null */) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= cols) return;
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double g = G[(size_t)i * cols + j];
+        ax = fma(C[i], g, ax); ay = fma(C[n + i], g, ay); az = fma(C[2 * n + i], g, az);
+    }
+    ax = wave_sum_d(ax); ay = wave_sum_d(ay); az = wave_sum_d(az);
+    if (lane == 0) {
+        if (mode == 1) { pts[3 * j] += ax; pts[3 * j + 1] += ay; pts[3 * j + 2] += az; }
+        else if (mode == 2) { pts[3 * j] = base[3 * j] + ax; pts[3 * j + 1] = base[3 * j + 1] + ay; pts[3 * j + 2] = base[3 * j + 2] + az; }
+        if (norm_part) norm_part[j] = ax * ax + ay * ay + az * az;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_to_scalar_kernel(const double* __restrict__ v, int n, double* __restrict__ dst) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// tracker.py:1269-1289: pred[j] += sum_i C[:, i] exp(-|pred_j - inter_i|^2 / 2 beta^2); one wave per j
+__global__ __launch_bounds__(256) void gram_apply_kernel(double* __restrict__ pred, int l, const double* __restrict__ inter, int n,
+                                                         const double* __restrict__ C, double two_b2) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= l) return;
+    const double px = pred[3 * j], py = pred[3 * j + 1], pz = pred[3 * j + 2];
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double dx = px - inter[3 * i], dy = py - inter[3 * i + 1], dz = pz - inter[3 * i + 2];
+        const double g = exp(-(dx * dx + dy * dy + dz * dz) / two_b2);
+        ax = fma(C[i], g, ax); ay = fma(C[n + i], g, ay); az = fma(C[2 * n + i], g, az);
+    }
+    ax = wave_sum_d(ax); ay = wave_sum_d(ay); az = wave_sum_d(az);
+    if (lane == 0) { pred[3 * j] = px + ax; pred[3 * j + 1] = py + ay; pred[3 * j + 2] = pz + az; }
+}
+
+// scipy.stats.trim_mean(stack, cut, axis=0): sort the k values, drop int(cut*k) at both ends
+constexpr int TM_MAXK = 64;
+__global__ __launch_bounds__(256) void trim_mean_kernel(const double* __restrict__ stack, int k, int n3, int lo,
+                                                        double* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n3) return;
+    double v[TM_MAXK];
+    for (int q = 0; q < k; ++q) v[q] = stack[(size_t)q * n3 + e];
+    for (int a = 1; a < k; ++a) {
+        const double x = v[a]; int b = a - 1;
+        while (b >= 0 && v[b] > x) { v[b + 1] = v[b]; --b; }
+        v[b + 1] = x;
+    }
+    double s = 0.0;
+    for (int q = lo; q < k - lo; ++q) s += v[q];
+    out[e] = s / (double)(k - 2 * lo);
+}
+
+}  // namespace
+
+struct ct_ffn {
+    int device;
+    float* d_w;          // arena: w1 | bn1[4][512] | w2 | bn2[4][512] | w3
+    float b3;
+    size_t o_w1, o_bn1, o_w2, o_bn2, o_w3;
+};
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------ kNN
+int ct_knn_features(const double* points, int n, int k, float* feat, ct_stream_t stream) {
+    if (!points || !feat || n <= 0 || k <= 0) return CT_EINVAL;
+    if (n < k + 1 || n > KNN_MAXN || k + 1 > 32) return CT_ESHAPE;     // sklearn raises when n < k+1
+    hipLaunchKernelGGL(knn_features_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, points, n, k, feat);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ FFN
+size_t ct_ffn_num_weights(void) { return (size_t)FEAT * HID + 4 * HID + (size_t)2 * HID * HID + 4 * HID + HID + 1; }
+
+int ct_ffn_create(const float* w, size_t n_floats, int device, ct_ffn_t** out) {
+    if (!w || !out) return CT_EINVAL;
+    if (n_floats != ct_ffn_num_weights()) return CT_ESHAPE;
+    HIPCHK(hipSetDevice(device));
+    ct_ffn* h = new (std::nothrow) ct_ffn();
+    if (!h) return CT_EINVAL;
+    h->device = device;
+    h->o_w1 = 0; h->o_bn1 = h->o_w1 + (size_t)FEAT * HID; h->o_w2 = h->o_bn1 + 4 * HID;
+    h->o_bn2 = h->o_w2 + (size_t)2 * HID * HID; h->o_w3 = h->o_bn2 + 4 * HID;
+    h->b3 = w[n_floats - 1];
+    hipError_t e = hipMalloc((void**)&h->d_w, (n_floats - 1) * sizeof(float));
+    if (e != hipSuccess) { delete h; return (int)e; }
+    e = hipMemcpy(h->d_w, w, (n_floats - 1) * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(h->d_w); delete h; return (int)e; }
+    *out = h;
+    return CT_OK;
+}
+
+void ct_ffn_destroy(ct_ffn_t* h) { if (h) { hipFree(h->d_w); delete h; } }
+
+size_t ct_ffn_workspace_bytes(int n_ref, int n_tgt) {
+    if (n_ref <= 0 || n_tgt <= 0) return 0;
+    return (size_t)2 * (n_ref + n_tgt) * HID * sizeof(float) + 512;     // hidden + projected, both sets
+}
+
+static int gemm(const float* A, int lda, const float* B, float* Cm, int M, int N, int K, const float* bn, hipStream_t st) {
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, lda, B, Cm, M, N, K, bn);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+int ct_ffn_pairgrid(ct_ffn_t* h, const float* feat_ref, int n, const float* feat_tgt, int m, float* corr,
+                    void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (!h || !feat_ref || !feat_tgt || !corr || !workspace || n <= 0 || m <= 0) return CT_EINVAL;
+    if (workspace_bytes < ct_ffn_workspace_bytes(n, m)) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* Hr = ws; float* Ht = Hr + (size_t)n * HID; float* U = Ht + (size_t)m * HID; float* V = U + (size_t)n * HID;
+    int rc;
+    if ((rc = gemm(feat_ref, FEAT, h->d_w + h->o_w1, Hr, n, HID, FEAT, h->d_w + h->o_bn1, st))) return rc;
+    if ((rc = gemm(feat_tgt, FEAT, h->d_w + h->o_w1, Ht, m, HID, FEAT, h->d_w + h->o_bn1, st))) return rc;
+    if ((rc = gemm(Hr, HID, h->d_w + h->o_w2, U, n, HID, HID, nullptr, st))) return rc;                           // ref half: W2[:512]
+    if ((rc = gemm(Ht, HID, h->d_w + h->o_w2 + (size_t)HID * HID, V, m, HID, HID, nullptr, st))) return rc;       // tgt half: W2[512:]
+    hipLaunchKernelGGL(ffn_pair_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, st, U, n, V, m,
+                       h->d_w + h->o_bn2, h->d_w + h->o_w3, h->b3, corr);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+size_t ct_ffn_predict_workspace_bytes(int rows) { return rows <= 0 ? 0 : (size_t)4 * rows * HID * sizeof(float) + 512; }
+
+int ct_ffn_predict(ct_ffn_t* h, const float* x, int rows, float* out, void* workspace, size_t workspace_bytes,
+                   ct_stream_t stream) {
+    if (!h || !x || !out || !workspace || rows <= 0) return CT_EINVAL;
+    if (workspace_bytes < ct_ffn_predict_workspace_bytes(rows)) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* H1 = ws; float* H2 = H1 + (size_t)rows * HID; float* U = H2 + (size_t)rows * HID; float* V = U + (size_t)rows * HID;
+    int rc;
+    if ((rc = gemm(x, 2 * FEAT, h->d_w + h->o_w1, H1, rows, HID, FEAT, h->d_w + h->o_bn1, st))) return rc;
+    if ((rc = gemm(x + FEAT, 2 * FEAT, h->d_w + h->o_w1, H2, rows, HID, FEAT, h->d_w + h->o_bn1, st))) return rc;
+    if ((rc = gemm(H1, HID, h->d_w + h->o_w2, U, rows, HID, HID, nullptr, st))) return rc;
+    if ((rc = gemm(H2, HID, h->d_w + h->o_w2 + (size_t)HID * HID, V, rows, HID, HID, nullptr, st))) return rc;
+    hipLaunchKernelGGL(ffn_rows_finish_kernel, dim3(rows), dim3(64), 0, st, U, V, rows, h->d_w + h->o_bn2,
+                       h->d_w + h->o_w3, h->b3, out);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ greedy
+size_t ct_greedy_workspace_bytes(int m, int n) {
+    if (m <= 0 || n <= 0) return 0;
+    return align_up((size_t)m * 4, 256) * 3 + align_up((size_t)n, 256) + 512;    // row_val, row_col, row_match, col flags
+}
+
+int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, int32_t* pairs, int32_t* n_pairs,
+                    double* prior, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (!corr || !pairs || !n_pairs || !workspace || m <= 0 || n <= 0 || (mode != 0 && mode != 1)) return CT_EINVAL;
+    if (n > 60000) return CT_ESHAPE;
+    if (workspace_bytes < ct_greedy_workspace_bytes(m, n)) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* row_val = (float*)ws; ws += align_up((size_t)m * 4, 256);
+    int* row_col = (int*)ws; ws += align_up((size_t)m * 4, 256);
+    int* row_match = (int*)ws; ws += align_up((size_t)m * 4, 256);
+    unsigned char* colf = ws;
+    const size_t lds = align_up((size_t)n, 16) + GR_WAVES * 8 + 16;
+    hipLaunchKernelGGL(greedy_match_kernel, dim3(1), dim3(GR_THREADS), lds, st, corr, m, n, threshold, pairs, n_pairs,
+                       row_val, row_col, colf);
+    LAUNCH_CHECK();
+    if (prior) {
+        hipLaunchKernelGGL(row_match_kernel, dim3((m + 255) / 256), dim3(256), 0, st, row_match, m);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(row_match_set_kernel, dim3((n + 255) / 256), dim3(256), 0, st, row_match, pairs, n_pairs);
+        LAUNCH_CHECK();
+        const size_t tot = (size_t)m * n;
+        hipLaunchKernelGGL(prior_fill_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, prior, m, n, mode,
+                           pairs, n_pairs, row_match);
+        LAUNCH_CHECK();
+    }
+    return CT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ PR-GLS
+namespace {
+struct PrglsWs {
+    double *G, *Gnl, *M, *P, *part, *dvec, *sqd, *rhs, *C, *predn, *predl, *rowpart, *normpart, *sc;
+};
+size_t prgls_layout(int m, int n, int l, unsigned char* base, PrglsWs* w) {
+    size_t off = 0;
+    auto take = [&](size_t count) { double* p = base ? (double*)(base + off) : nullptr; off += align_up(count * sizeof(double), 256); return p; };
+    double* G = take((size_t)n * n); double* Gnl = take((size_t)n * (l > 0 ? l : 1)); double* M = take((size_t)n * n);
+    double* P = take((size_t)m * n); double* part = take((size_t)CS_SEG * 4 * n); double* dvec = take(n); double* sqd = take(n);
+    double* rhs = take(3 * (size_t)n); double* C = take(3 * (size_t)n); double* predn = take(3 * (size_t)n);
+    double* predl = take(3 * (size_t)(l > 0 ? l : 1)); double* rowpart = take(m); double* normpart = take(n); double* sc = take(S_NUM);
+    if (w) *w = PrglsWs{G, Gnl, M, P, part, dvec, sqd, rhs, C, predn, predl, rowpart, normpart, sc};
+    return off;
+}
+
+int cholesky_solve(const PrglsWs& w, int n, hipStream_t st) {
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int nb = n - k0 < NB ? n - k0 : NB;
+        const int rem = n - k0 - nb;
+        const int nblk = rem > 0 ? (rem + NB - 1) / NB : 1;
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), 0, st, w.M, n, k0);
+        LAUNCH_CHECK();
+        if (rem > 0) {
+            const int t = (rem + NB - 1) / NB;
+            hipLaunchKernelGGL(chol_update_kernel, dim3(t, t), dim3(256), 0, st, w.M, n, k0);
+            LAUNCH_CHECK();
+        }
+    }
+    hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(256), 0, st, w.M, n, w.rhs, w.sqd, w.C);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+// one E-step + M-step solve; leaves C in w.C and sumP in the scalar block
+int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int n, const double* xref, double lambda,
+            int legacy, double vol, hipStream_t st) {
+    hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4), dim3(256), 0, st, prior, w.predn, n, tgt, m, w.sc, legacy, vol, w.P);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(colstats_kernel, dim3((n + 63) / 64, CS_SEG), dim3(64), 0, st, w.P, tgt, m, n, w.part);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(colstats_finish_kernel, dim3(1), dim3(256), 0, st, w.part, n, xref, lambda, w.sc, w.dvec, w.sqd, w.rhs);
+    LAUNCH_CHECK();
+    const size_t nn = (size_t)n * n;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, w.G, w.sqd, w.sc, n, w.M);
+    LAUNCH_CHECK();
+    return cholesky_solve(w, n, st);
+}
+}  // namespace
+
+size_t ct_prgls_workspace_bytes(int m, int n, int l) {
+    if (m <= 0 || n <= 0 || l < 0) return 0;
+    // EM state + (legacy dialect) the prior built inside, its pair list and the greedy scratch
+    return prgls_layout(m, n, l, nullptr, nullptr) + align_up((size_t)m * n * sizeof(double), 256)
+           + align_up((size_t)n * 8 + 4, 256) + ct_greedy_workspace_bytes(m, n) + 1024;
+}
+
+int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double* ref, int n, const double* tracked, int l,
+                     double beta, double lambda, int max_iteration, double* out_tracked, double* out_ref, double* posterior,
+                     int* iters, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (!prior || !tgt || !ref || !workspace || m <= 0 || n <= 0 || l < 0 || (l > 0 && (!tracked || !out_tracked))) return CT_EINVAL;
+    if (workspace_bytes < ct_prgls_workspace_bytes(m, n, l)) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    PrglsWs w;
+    prgls_layout(m, n, l, (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), &w);
+    const size_t nn = (size_t)n * n;
+    // init (trackerlite.py:319-325): gamma 0.05, Gram matrices with beta^2, sigma2 = mean d2 / 3, T(X) = X
+    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ref, n, ref, n, 2.0 * beta * beta, w.G);
+    LAUNCH_CHECK();
+    if (l > 0) {
+        const size_t nl = (size_t)n * l;
+        hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, tracked, l, ref, n, 2.0 * beta * beta, w.Gnl);
+        LAUNCH_CHECK();
+        HIPCHK(hipMemcpyAsync(w.predl, tracked, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(w.predn, ref, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    double init_sc[S_NUM] = {0.0, 0.05, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    HIPCHK(hipMemcpyAsync(w.sc, init_sc, sizeof(init_sc), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, ref, n, tgt, m, (const double*)nullptr, w.rowpart);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 0, w.sc);
+    LAUNCH_CHECK();
+    int it = 0, rc;
+    for (it = 1; it < max_iteration; ++it) {
+        if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, st))) return rc;
+        // movements (skipped on iteration 1: "the first estimation is not reliable", trackerlite.py:339-341)
+        hipLaunchKernelGGL(apply_field_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w.C, w.G, n, n, w.predn, (const double*)nullptr,
+                           it > 1 ? 1 : 0, w.normpart);
+        LAUNCH_CHECK();
+        if (l > 0 && it > 1) {
+            hipLaunchKernelGGL(apply_field_kernel, dim3((l + 3) / 4), dim3(256), 0, st, w.C, w.Gnl, n, l, w.predl, (const double*)nullptr,
+                               1, (double*)nullptr);
+            LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, st, w.normpart, n, w.sc + S_NORM2);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, tgt, m, w.P, w.rowpart);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 1, w.sc);
+        LAUNCH_CHECK();
+        double norm2 = 0.0;
+        HIPCHK(hipMemcpyAsync(&norm2, w.sc + S_NORM2, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (sqrt(norm2) < 1e-3) break;                                  // trackerlite.py:353-356
+    }
+    if (it >= max_iteration) it = max_iteration - 1;
+    if (iters) *iters = it;
+    if (l > 0) HIPCHK(hipMemcpyAsync(out_tracked, w.predl, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (out_ref) HIPCHK(hipMemcpyAsync(out_ref, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (posterior) HIPCHK(hipMemcpyAsync(posterior, w.P, (size_t)m * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return CT_OK;
+}
+
+int ct_prgls_legacy(const double* X, int n, const double* Y, int m, const float* corr, double BETA, int max_iteration,
+                    double LAMBDA, double vol, double* P, double* TX, double* C, void* workspace, size_t workspace_bytes,
+                    ct_stream_t stream) {
+    if (!X || !Y || !corr || !workspace || m <= 0 || n <= 0) return CT_EINVAL;
+    if (workspace_bytes < ct_prgls_workspace_bytes(m, n, 0)) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    PrglsWs w;
+    size_t off = prgls_layout(m, n, 0, base, &w);
+    double* prior = (double*)(base + off); off += align_up((size_t)m * n * sizeof(double), 256);
+    int32_t* pairs = (int32_t*)(base + off); off += align_up((size_t)n * 8 + 4, 256);
+    int32_t* npairs = pairs + 2 * n;
+    void* gws = base + off;
+    // prior built inside with threshold 0.5 (track.py:58-70)
+    int rc = ct_greedy_match(corr, m, n, 0.5f, 1, pairs, npairs, prior, gws, ct_greedy_workspace_bytes(m, n), stream);
+    if (rc) return rc;
+    const size_t nn = (size_t)n * n;
+    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, X, n, X, n, 2.0 * BETA * BETA, w.G);
+    LAUNCH_CHECK();
+    HIPCHK(hipMemcpyAsync(w.predn, X, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    double init_sc[S_NUM] = {0.0, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // gamma0 = 0.1 (track.py:41)
+    HIPCHK(hipMemcpyAsync(w.sc, init_sc, sizeof(init_sc), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(w.C, 0, 3 * (size_t)n * sizeof(double), st));
+    hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, X, n, Y, m, (const double*)nullptr, w.rowpart);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 0, w.sc);
+    LAUNCH_CHECK();
+    for (int it = 1; it < max_iteration; ++it) {
+        if ((rc = em_half(w, prior, Y, m, n, X, LAMBDA, 1, vol, st))) return rc;
+        // T_X = X + (C G)^T recomputed from X (track.py:100)
+        hipLaunchKernelGGL(apply_field_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w.C, w.G, n, n, w.predn, X, 2, (double*)nullptr);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, Y, m, w.P, w.rowpart);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 2, w.sc);
+        LAUNCH_CHECK();
+    }
+    if (P) HIPCHK(hipMemcpyAsync(P, w.P, (size_t)m * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (TX) HIPCHK(hipMemcpyAsync(TX, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (C) HIPCHK(hipMemcpyAsync(C, w.C, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return CT_OK;
+}
+
+int ct_gram_apply(double* pred, int l, const double* inter, int n, const double* C, double beta, ct_stream_t stream) {
+    if (!pred || !inter || !C || l <= 0 || n <= 0) return CT_EINVAL;
+    hipLaunchKernelGGL(gram_apply_kernel, dim3((l + 3) / 4), dim3(256), 0, (hipStream_t)stream, pred, l, inter, n, C, 2.0 * beta * beta);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+int ct_trim_mean(const double* stack, int k, int n3, double cut, double* out, ct_stream_t stream) {
+    if (!stack || !out || k <= 0 || n3 <= 0 || cut < 0.0 || cut >= 0.5) return CT_EINVAL;
+    if (k > TM_MAXK) return CT_ESHAPE;
+    const int lo = (int)(cut * k);
+    hipLaunchKernelGGL(trim_mean_kernel, dim3((n3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, stack, k, n3, lo, out);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+}  // extern "C"

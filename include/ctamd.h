@@ -1,0 +1,163 @@
+/*
+ * ctamd.h -- C ABI of the MI355X-native hot path for 3DeeCellTracker-style tracking.
+ *
+ * The reference (WenChentao/3DeeCellTracker) is pure Python and has NO native / FFI boundary:
+ * its hot path calls tensorflow.keras `model.predict`, numpy/LAPACK and scikit-learn.  The
+ * "binding a maintainer would add" is therefore a ctypes stub at the Python call
+ * sites cited on every entry point below (paths relative to the reference tree).
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch / framework types;
+ *   - pointers marked [dev] are device (HBM) addresses owned by the caller and kept alive by the
+ *     caller until the stream has drained; pointers marked [host] are host addresses;
+ *   - every launch-type function takes a hipStream_t (as void*), is asynchronous w.r.t. the host
+ *     unless stated, returns 0 on success, a negative CT_E* code for argument/shape errors, or a
+ *     positive hipError_t value; nothing throws;
+ *   - no global mutable state: handles own their device-side weights only; all scratch memory is a
+ *     caller-provided workspace whose size the *_workspace_bytes functions report;
+ *   - thread-compatible: one stream per host thread, a handle may be shared for inference.
+ */
+#ifndef CTAMD_H
+#define CTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CT_OK            0
+#define CT_EINVAL       -1   /* bad argument (null pointer, non-positive size, unknown id)      */
+#define CT_ESHAPE       -2   /* shape unsupported by the kernels (e.g. fewer than k+1 points)   */
+#define CT_EWORKSPACE   -3   /* workspace too small                                             */
+#define CT_ENOTCONV     -4   /* iterative routine hit its iteration bound (informational)       */
+
+#define CT_ARCH_UNET3_A  0   /* reference CellTracker/unet3d.py:26-37  (160x160x16, pool 2,2,1) */
+#define CT_ARCH_UNET3_B  1   /* reference CellTracker/unet3d.py:40-67  ( 96x 96x 8, pool 2,2,1) */
+#define CT_ARCH_UNET3_C  2   /* reference CellTracker/unet3d.py:70-81  ( 64x 64x64, pool 2,2,2) */
+
+typedef struct ct_unet ct_unet_t;
+typedef struct ct_ffn  ct_ffn_t;
+typedef void*          ct_stream_t;    /* hipStream_t */
+
+int         ct_version(void);
+const char* ct_error_string(int code);
+/* Device properties the host side reports next to benchmark numbers. */
+int         ct_device_info(int device, int* n_cu, size_t* hbm_bytes, char* name, size_t name_len);
+
+/* ------------------------------------------------------------------------------------------
+ * 3D U-Net  (replaces keras Model construction + `model.predict`, unet3d.py:26-98, :253)
+ * ------------------------------------------------------------------------------------------
+ * weights [host]: flat fp32 array in Keras layouts, in execution order:
+ *   for every 3x3x3 conv block: kernel (3,3,3,Cin,Cout) | bias (Cout) | gamma | beta | moving_mean |
+ *   moving_var (Cout each);  then the 1x1x1 head: kernel (C,1) | bias (1).
+ * The handle keeps a device copy re-packed for the MFMA kernels with BatchNorm folded into a
+ * per-channel (scale, shift) epilogue (BN follows the activation, so it cannot be folded into
+ * the conv itself: unet3d.py:117-119).                                                        */
+int    ct_unet_create(int arch_id, const float* weights, size_t n_floats, int device, ct_unet_t** out);
+void   ct_unet_destroy(ct_unet_t* h);
+size_t ct_unet_num_weights(int arch_id);
+int    ct_unet_patch_shape(int arch_id, int shape_xyz[3]);
+size_t ct_unet_workspace_bytes(const ct_unet_t* h, int n_patches);
+
+/* model.predict on a batch of patches (unet3d.py:253).
+ * patches_in [dev]  fp32 [n_patches][X][Y][Z]   (channel dim of size 1 elided)
+ * prob_out   [dev]  fp32 [n_patches][X][Y][Z]
+ * If layer_dump [dev] is non-null the outputs of every conv block of patch 0 are additionally
+ * copied there in Keras NDHWC order, back to back (parity tests only; sizes via
+ * ct_unet_layer_dump_floats).                                                                  */
+int    ct_unet_predict_patches(ct_unet_t* h, const float* patches_in, int n_patches, float* prob_out,
+                               void* workspace, size_t workspace_bytes, float* layer_dump, ct_stream_t stream);
+size_t ct_unet_layer_dump_floats(int arch_id);
+
+/* Sliding-window tiler (replaces np.pad(..., 'reflect') + the patch loop + centre-crop stitch of
+ * unet3_prediction, unet3d.py:221-255).  Patch p in [p_begin, p_begin+n) enumerates
+ * itertools.product(range(gx), range(gy), range(gz)).
+ * vol [dev] fp32 [x][y][z];  patches [dev] fp32 [n][nx][ny][nz];  out_vol [dev] fp32 [x][y][z].    */
+int ct_tile_plan(const int vol_xyz[3], const int net_xyz[3], const int shrink[3],
+                 int centre[3], int grid[3]);                       /* _get_sizes_padded_im :259-279 */
+int ct_tile_gather_reflect(const float* vol, const int vol_xyz[3], const int net_xyz[3], const int shrink[3],
+                           int p_begin, int n, float* patches, ct_stream_t stream);
+int ct_tile_scatter_center(const float* pred, const int vol_xyz[3], const int net_xyz[3], const int shrink[3],
+                           int p_begin, int n, float* out_vol, ct_stream_t stream);
+
+/* Whole unet3_prediction(img, model, shrink) for the patch range [p_begin, p_begin+n) of one
+ * volume (unet3d.py:203-256): gather -> network -> scatter, processed in batches that fit the
+ * workspace.  Voxels of out_vol not covered by the given patch range are left untouched, so R
+ * ranks can each fill their share and exchange centre crops afterwards.                        */
+int ct_unet_predict_volume(ct_unet_t* h, const float* vol, const int vol_xyz[3], const int shrink[3],
+                           int p_begin, int n, float* out_vol,
+                           void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FFN initial matching  (ffn.py:225-327, track.py:117-178)
+ * ------------------------------------------------------------------------------------------ */
+/* kNN shape-context features (ffn.py:288-304): points [dev] fp64 [n][3] -> feat [dev] fp32 [n][3k+1].
+ * Needs n >= k+1 (sklearn raises otherwise) -> CT_ESHAPE.                                        */
+int ct_knn_features(const double* points, int n, int k, float* feat, ct_stream_t stream);
+
+/* weights [host] flat fp32: w1 (61,512) | bn1 gamma,beta,mean,var (512 each) | w2 (1024,512) |
+ * bn2 gamma,beta,mean,var | w3 (512) | b3 (1).                                                   */
+int    ct_ffn_create(const float* weights, size_t n_floats, int device, ct_ffn_t** out);
+void   ct_ffn_destroy(ct_ffn_t* h);
+size_t ct_ffn_num_weights(void);
+size_t ct_ffn_workspace_bytes(int n_ref, int n_tgt);
+
+/* All n_tgt x n_ref pairs through the FFN without materialising the (m*n) x 122 grid
+ * (ffn.py:306-326): corr [dev] fp32 [m][n], corr[t][r] = FFN([feat_ref[r] | feat_tgt[t]]).          */
+int ct_ffn_pairgrid(ct_ffn_t* h, const float* feat_ref, int n, const float* feat_tgt, int m, float* corr,
+                    void* workspace, size_t workspace_bytes, ct_stream_t stream);
+/* Generic `ffn_model.predict(x)` on explicit rows: x [dev] fp32 [rows][122] -> out [dev] fp32 [rows]. */
+int ct_ffn_predict(ct_ffn_t* h, const float* x, int rows, float* out,
+                   void* workspace, size_t workspace_bytes, ct_stream_t stream);
+size_t ct_ffn_predict_workspace_bytes(int rows);
+
+/* ------------------------------------------------------------------------------------------
+ * Greedy one-to-one assignment  (trackerlite.py:242-259; legacy prior track.py:58-70)
+ * ------------------------------------------------------------------------------------------
+ * corr [dev] fp32 [m][n] (not modified).  Repeats: global max (first in row-major order on ties)
+ * -> pair -> clear row and column; stops below `threshold` or after n pairs.
+ * pairs [dev] int32 [n][2] = (ref, tgt);  n_pairs [dev] int32[1];
+ * prior [dev] fp64 [m][n]: mode 0 (TrackerLite): float32(0.1/(n-1)) everywhere, 0.9 at pairs;
+ *                          mode 1 (legacy):  1/n, matched rows 0.1/(n-1) with 0.9 at the pair.   */
+size_t ct_greedy_workspace_bytes(int m, int n);
+int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode,
+                    int32_t* pairs, int32_t* n_pairs, double* prior,
+                    void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PR-GLS  (TrackerLite dialect trackerlite.py:262-417; legacy dialect track.py:11-114)
+ * ------------------------------------------------------------------------------------------ */
+size_t ct_prgls_workspace_bytes(int m, int n, int l);
+
+/* prgls_with_two_ref (trackerlite.py:309-358); prgls_quick is the case tracked == ref.
+ * prior [dev] fp64 [m][n]; tgt [dev] fp64 [m][3]; ref [dev] fp64 [n][3]; tracked [dev] fp64 [l][3]
+ * out_tracked [dev] fp64 [l][3]; out_ref [dev] fp64 [n][3] (may be null); posterior [dev] fp64 [m][n]
+ * (may be null); iters [host] receives the number of EM iterations run.
+ * Synchronous: the convergence test (|movement|_2 < 1e-3) is read back by the host.               */
+int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double* ref, int n,
+                     const double* tracked, int l, double beta, double lambda, int max_iteration,
+                     double* out_tracked, double* out_ref, double* posterior, int* iters,
+                     void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
+/* pr_gls_quick (track.py:11-114): X [dev] fp64 [n][3], Y [dev] fp64 [m][3], corr [dev] fp32 [m][n].
+ * Runs max_iteration-1 EM iterations.  P [dev] fp64 [m][n], TX [dev] fp64 [n][3], C [dev] fp64 [3][n]. */
+int ct_prgls_legacy(const double* X, int n, const double* Y, int m, const float* corr,
+                    double BETA, int max_iteration, double LAMBDA, double vol,
+                    double* P, double* TX, double* C,
+                    void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
+/* Tracker._predict_one_rep (tracker.py:1269-1289): pred [dev] fp64 [l][3] (in/out),
+ * inter [dev] fp64 [n][3], C [dev] fp64 [3][n]:  pred += (C . exp(-|pred - inter|^2 / 2 beta^2))^T.  */
+int ct_gram_apply(double* pred, int l, const double* inter, int n, const double* C, double beta,
+                  ct_stream_t stream);
+
+/* trim_mean(stack, 0.1, axis=0) of k predictions (trackerlite.py:123, tracker.py:1508):
+ * stack [dev] fp64 [k][n3] -> out [dev] fp64 [n3].                                               */
+int ct_trim_mean(const double* stack, int k, int n3, double cut, double* out, ct_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTAMD_H */
