@@ -1,0 +1,117 @@
+"""Device plumbing shared by the host-side mirrors: numpy <-> HBM (torch as allocator), the current
+HIP stream, and thin typed wrappers over the C ABI for the matching kernels."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def torch():
+    return _lib.require_gpu()
+
+
+def stream(device=None):
+    t = torch()
+    return t.cuda.current_stream(device).cuda_stream
+
+
+def to_dev(a, dtype, device=None):
+    t = torch()
+    if isinstance(a, t.Tensor):
+        return a.to(device=device or "cuda", dtype=dtype).contiguous()
+    arr = np.ascontiguousarray(np.asarray(a), dtype={t.float64: np.float64, t.float32: np.float32, t.int32: np.int32}[dtype])
+    return t.from_numpy(arr).to(device or "cuda")
+
+
+def points_dev(p, device=None):
+    p = np.asarray(p) if not hasattr(p, "is_cuda") else p
+    if p.ndim != 2 or p.shape[1] != 3:
+        raise ValueError(f"expected an (n, 3) array of points, got {tuple(p.shape)}")
+    return to_dev(p, torch().float64, device)
+
+
+def empty(shape, dtype, device=None):
+    t = torch()
+    return t.empty(shape, dtype=dtype, device=device or "cuda")
+
+
+def workspace(nbytes, device=None):
+    return empty((int(nbytes),), torch().uint8, device)
+
+
+# ----------------------------------------------------------------------------------------- wrappers
+def knn_features(points_d, k):
+    t = torch(); L = _lib.lib()
+    n = points_d.shape[0]
+    if n < k + 1:
+        raise ValueError(f"Expected n_neighbors <= n_samples,  but n_samples = {n}, n_neighbors = {k + 1}")
+    feat = empty((n, 3 * k + 1), t.float32, points_d.device)
+    _lib.check(L.ct_knn_features(points_d.data_ptr(), n, k, feat.data_ptr(), stream(points_d.device)), "ct_knn_features")
+    return feat
+
+
+def greedy_match(corr_d, threshold, mode, want_prior=True):
+    """corr_d fp32 [m][n] -> (pairs int32 [n][2] (ref, tgt), n_pairs tensor, prior fp64 [m][n] or None)."""
+    t = torch(); L = _lib.lib()
+    m, n = corr_d.shape
+    pairs = empty((n, 2), t.int32, corr_d.device)
+    npairs = empty((1,), t.int32, corr_d.device)
+    prior = empty((m, n), t.float64, corr_d.device) if want_prior else None
+    ws = workspace(L.ct_greedy_workspace_bytes(m, n), corr_d.device)
+    _lib.check(L.ct_greedy_match(corr_d.data_ptr(), m, n, float(threshold), int(mode), pairs.data_ptr(), npairs.data_ptr(),
+                                 prior.data_ptr() if prior is not None else None, ws.data_ptr(), ws.numel(),
+                                 stream(corr_d.device)), "ct_greedy_match")
+    return pairs, npairs, prior
+
+
+def prgls_two_ref(prior_d, tgt_d, ref_d, tracked_d, beta, lambda_, max_iteration, want_posterior=True, want_ref=False):
+    t = torch(); L = _lib.lib()
+    m, n = prior_d.shape
+    l = 0 if tracked_d is None else tracked_d.shape[0]
+    dev = prior_d.device
+    out_l = empty((l, 3), t.float64, dev) if l else None
+    out_n = empty((n, 3), t.float64, dev) if want_ref else None
+    post = empty((m, n), t.float64, dev) if want_posterior else None
+    ws = workspace(L.ct_prgls_workspace_bytes(m, n, l), dev)
+    iters = C.c_int(0)
+    _lib.check(L.ct_prgls_two_ref(prior_d.data_ptr(), tgt_d.data_ptr(), m, ref_d.data_ptr(), n,
+                                  tracked_d.data_ptr() if l else None, l, float(beta), float(lambda_), int(max_iteration),
+                                  out_l.data_ptr() if l else None, out_n.data_ptr() if want_ref else None,
+                                  post.data_ptr() if want_posterior else None, C.byref(iters), ws.data_ptr(), ws.numel(),
+                                  stream(dev)), "ct_prgls_two_ref")
+    return out_l, out_n, post, iters.value
+
+
+def prgls_legacy(X_d, Y_d, corr_d, BETA, max_iteration, LAMBDA, vol, want_P=True):
+    t = torch(); L = _lib.lib()
+    n, m = X_d.shape[0], Y_d.shape[0]
+    dev = X_d.device
+    P = empty((m, n), t.float64, dev) if want_P else None
+    TX = empty((n, 3), t.float64, dev)
+    Cm = empty((3, n), t.float64, dev)
+    ws = workspace(L.ct_prgls_workspace_bytes(m, n, 0), dev)
+    _lib.check(L.ct_prgls_legacy(X_d.data_ptr(), n, Y_d.data_ptr(), m, corr_d.data_ptr(), float(BETA), int(max_iteration),
+                                 float(LAMBDA), float(vol), P.data_ptr() if want_P else None, TX.data_ptr(), Cm.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), stream(dev)), "ct_prgls_legacy")
+    return P, TX, Cm
+
+
+def gram_apply(pred_d, inter_d, C_d, beta):
+    L = _lib.lib()
+    _lib.check(L.ct_gram_apply(pred_d.data_ptr(), pred_d.shape[0], inter_d.data_ptr(), inter_d.shape[0], C_d.data_ptr(),
+                               float(beta), stream(pred_d.device)), "ct_gram_apply")
+    return pred_d
+
+
+def trim_mean(stack_d, cut=0.1):
+    """stack_d fp64 [k][n][3] -> [n][3]  (scipy.stats.trim_mean(..., cut, axis=0))"""
+    t = torch(); L = _lib.lib()
+    k = stack_d.shape[0]
+    n3 = int(stack_d[0].numel())
+    out = empty(tuple(stack_d.shape[1:]), t.float64, stack_d.device)
+    _lib.check(L.ct_trim_mean(stack_d.contiguous().data_ptr(), k, n3, float(cut), out.data_ptr(), stream(stack_d.device)),
+               "ct_trim_mean")
+    return out

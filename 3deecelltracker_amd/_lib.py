@@ -50,6 +50,10 @@ SIGNATURES = {
     "ct_prgls_workspace_bytes": (_sz, [_i, _i, _i]),
     "ct_prgls_two_ref": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _ip, _vp, _sz, _vp]),
     "ct_prgls_legacy": (_i, [_vp, _i, _vp, _i, _vp, _d, _i, _d, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ct_dist_squares": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "ct_gaussian_kernel": (_i, [_vp, _i, _vp, _i, _d, _vp, _vp]),
+    "ct_estimate_posterior": (_i, [_vp, _d, _vp, _i, _vp, _i, _d, _d, _vp, _vp]),
+    "ct_solve_movements": (_i, [_d, _d, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "ct_gram_apply": (_i, [_vp, _i, _vp, _i, _vp, _d, _vp]),
     "ct_trim_mean": (_i, [_vp, _i, _i, _d, _vp, _vp]),
 }

@@ -367,12 +367,13 @@ enum { S_SIGMA2 = 0, S_GAMMA = 1, S_SUMP = 2, S_NORM2 = 3, S_C = 4, S_NUM = 8 };
 
 // out[i][j] = exp(-|a_j - b_i|^2 / (2 s2)),  i < nb, j < na      (trackerlite.py:368-372)
 __global__ __launch_bounds__(256) void gauss_kernel(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
-                                                    double two_s2, double* __restrict__ out) {
+                                                    double two_s2, double* __restrict__ out, int raw = 0) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)na * nb) return;
     const int i = (int)(gid / na), j = (int)(gid - (size_t)i * na);
     const double dx = a[3 * j] - b[3 * i], dy = a[3 * j + 1] - b[3 * i + 1], dz = a[3 * j + 2] - b[3 * i + 2];
-    out[gid] = exp(-(dx * dx + dy * dy + dz * dz) / two_s2);
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    out[gid] = raw ? d2 : exp(-d2 / two_s2);
 }
 
 // sum over all (t, r) of |ref_r - tgt_t|^2  -> per-row partial sums rowpart[m]
@@ -422,11 +423,11 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
 __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict__ prior, const double* __restrict__ pred,
                                                         int n, const double* __restrict__ tgt, int m,
                                                         const double* __restrict__ sc, int legacy, double vol,
-                                                        double* __restrict__ P) {
+                                                        double* __restrict__ P, double s2v = 0.0, double gammav = 0.0) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wave;
     if (t >= m) return;
-    const double s2 = sc[S_SIGMA2], gamma = sc[S_GAMMA];
+    const double s2 = sc ? sc[S_SIGMA2] : s2v, gamma = sc ? sc[S_GAMMA] : gammav;
     const double two_s2 = 2.0 * s2;
     const double norm = pow(2.0 * M_PI * s2, 1.5);
     const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
@@ -1009,6 +1010,54 @@ int ct_prgls_legacy(const double* X, int n, const double* Y, int m, const float*
     if (P) HIPCHK(hipMemcpyAsync(P, w.P, (size_t)m * n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (TX) HIPCHK(hipMemcpyAsync(TX, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (C) HIPCHK(hipMemcpyAsync(C, w.C, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return CT_OK;
+}
+
+int ct_dist_squares(const double* ref, int n, const double* tgt, int m, double* out, ct_stream_t stream) {
+    if (!ref || !tgt || !out || n <= 0 || m <= 0) return CT_EINVAL;
+    const size_t tot = (size_t)m * n;
+    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ref, n, tgt, m, 1.0, out, 1);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+int ct_gaussian_kernel(const double* ref, int n, const double* tgt, int m, double sigma_square, double* out, ct_stream_t stream) {
+    if (!ref || !tgt || !out || n <= 0 || m <= 0) return CT_EINVAL;
+    const size_t tot = (size_t)m * n;
+    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ref, n, tgt, m,
+                       2.0 * sigma_square, out, 0);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+int ct_estimate_posterior(const double* prior, double sigma_square, const double* pred, int n, const double* tgt, int m,
+                          double ratio_outliers, double vol, double* P, ct_stream_t stream) {
+    if (!prior || !pred || !tgt || !P || n <= 0 || m <= 0) return CT_EINVAL;
+    hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, prior, pred, n, tgt, m,
+                       (const double*)nullptr, 0, vol, P, sigma_square, ratio_outliers);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+int ct_solve_movements(double sigma_square, double lambda, const double* P, const double* ref, int n, const double* tgt, int m,
+                       const double* G, double* C, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (!P || !ref || !tgt || !G || !C || !workspace || n <= 0 || m <= 0) return CT_EINVAL;
+    if (workspace_bytes < ct_prgls_workspace_bytes(m, n, 0)) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    PrglsWs w;
+    prgls_layout(m, n, 0, (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), &w);
+    double init_sc[S_NUM] = {sigma_square, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    HIPCHK(hipMemcpyAsync(w.sc, init_sc, sizeof(init_sc), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(colstats_kernel, dim3((n + 63) / 64, CS_SEG), dim3(64), 0, st, P, tgt, m, n, w.part);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(colstats_finish_kernel, dim3(1), dim3(256), 0, st, w.part, n, ref, lambda, w.sc, w.dvec, w.sqd, w.rhs);
+    LAUNCH_CHECK();
+    const size_t nn = (size_t)n * n;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, G, w.sqd, w.sc, n, w.M);
+    LAUNCH_CHECK();
+    int rc = cholesky_solve(w, n, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(C, w.C, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return CT_OK;
 }
 

@@ -148,6 +148,20 @@ int ct_prgls_legacy(const double* X, int n, const double* Y, int m, const float*
                     double* P, double* TX, double* C,
                     void* workspace, size_t workspace_bytes, ct_stream_t stream);
 
+/* Fine-grained numpy helpers of trackerlite.py kept callable one by one (fp64, [dev]):
+ *   dist_squares     :361-365  out[m][n] = |ref_r - tgt_t|^2
+ *   gaussian_kernel  :368-372  out[m][n] = exp(-|ref_r - tgt_t|^2 / (2 sigma_square))
+ *   estimate_posterior :375-382
+ *   solve_movements_ref :409-417  C [3][n]; G [n][n] is the Gram matrix (symmetric)            */
+int ct_dist_squares(const double* ref, int n, const double* tgt, int m, double* out, ct_stream_t stream);
+int ct_gaussian_kernel(const double* ref, int n, const double* tgt, int m, double sigma_square, double* out,
+                       ct_stream_t stream);
+int ct_estimate_posterior(const double* prior, double sigma_square, const double* pred, int n, const double* tgt, int m,
+                          double ratio_outliers, double vol, double* P, ct_stream_t stream);
+int ct_solve_movements(double sigma_square, double lambda, const double* P, const double* ref, int n,
+                       const double* tgt, int m, const double* G, double* C,
+                       void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
 /* Tracker._predict_one_rep (tracker.py:1269-1289): pred [dev] fp64 [l][3] (in/out),
  * inter [dev] fp64 [n][3], C [dev] fp64 [3][n]:  pred += (C . exp(-|pred - inter|^2 / 2 beta^2))^T.  */
 int ct_gram_apply(double* pred, int l, const double* inter, int n, const double* C, double beta,

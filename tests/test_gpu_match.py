@@ -1,0 +1,286 @@
+"""GPU parity: FFN matching + greedy assignment + PR-GLS (HIP, through the C ABI) vs the golden
+vectors produced by the reference itself and vs the numpy oracle."""
+import importlib
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import match_ref as mr
+
+synth = importlib.import_module("3deecelltracker_amd.synth")
+ffn_mod = importlib.import_module("3deecelltracker_amd.ffn")
+track = importlib.import_module("3deecelltracker_amd.track")
+tl = importlib.import_module("3deecelltracker_amd.trackerlite")
+tracker_mod = importlib.import_module("3deecelltracker_amd.tracker")
+cit = importlib.import_module("3deecelltracker_amd.coord_image_transformer")
+dev = importlib.import_module("3deecelltracker_amd._dev")
+
+NS = (21, 50, 113, 180)
+COORD_TOL = 1e-6      # north-star: transformed coordinates within 1e-4; we hold 1e-6
+SCORE_TOL = 2e-5      # fp32 sigmoid scores: accumulation-order differences only
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(golden_dir / "match.npz")
+
+
+@pytest.fixture(scope="module")
+def meta(golden_dir):
+    return json.loads((golden_dir / "match.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def ffn_w():
+    return synth.make_ffn_weights(seed=0, gain=6.0, shift=-3.0)
+
+
+@pytest.fixture(scope="module")
+def ffn(ffn_w):
+    return ffn_mod.FFN().set_weights_dict(ffn_w)
+
+
+# ------------------------------------------------------------------------------------ features / FFN
+@pytest.mark.parametrize("n", NS)
+def test_knn_features_vs_reference(g, n):
+    import torch
+    fr = dev.knn_features(dev.points_dev(g[f"ref_pts_{n}"]), 20).cpu().numpy()
+    ft = dev.knn_features(dev.points_dev(g[f"tgt_pts_{n}"]), 20).cpu().numpy()
+    assert fr.dtype == np.float32 and fr.shape == (n, 61)
+    if n >= 50:      # sklearn kd-tree path: exact euclidean distances -> bit-exact fp32 tables
+        assert np.array_equal(fr, g[f"feat_ref_{n}"]) and np.array_equal(ft, g[f"feat_tgt_{n}"])
+    else:            # sklearn brute path (dot-product distances): last-ulp differences
+        np.testing.assert_allclose(fr, g[f"feat_ref_{n}"], rtol=0, atol=2e-6)
+    assert np.array_equal(fr, mr.knn_features(g[f"ref_pts_{n}"], 20))      # and bit-exact vs the oracle
+    assert np.array_equal(ft, mr.knn_features(g[f"tgt_pts_{n}"], 20))
+
+
+def test_knn_needs_k_plus_1_points():
+    with pytest.raises(ValueError):
+        dev.knn_features(dev.points_dev(np.random.default_rng(0).normal(size=(20, 3))), 20)
+
+
+@pytest.mark.parametrize("n", NS)
+def test_initial_matching_vs_reference(g, ffn, n):
+    corr = ffn_mod.initial_matching_ffn(ffn, g[f"ref_pts_{n}"], g[f"tgt_pts_{n}"], 20)
+    assert corr.shape == (n, n) and corr.dtype == np.float32
+    np.testing.assert_allclose(corr, g[f"corr_{n}"], rtol=0, atol=SCORE_TOL)
+    corr2 = track.initial_matching_quick(ffn, g[f"ref_pts_{n}"], g[f"tgt_pts_{n}"], 20)
+    assert np.array_equal(corr, corr2)
+
+
+def test_ffn_predict_both_call_forms(ffn, ffn_w):
+    x = np.random.default_rng(0).normal(size=(700, 122)).astype(np.float32)
+    a = ffn.predict(x)
+    b = ffn.predict([x[:, :61], x[:, 61:]], batch_size=1024)
+    assert a.shape == (700, 1) and a.dtype == np.float32 and np.array_equal(a, b)
+    np.testing.assert_allclose(a, mr.ffn_forward(ffn_w, x), rtol=0, atol=SCORE_TOL)
+    assert np.array_equal(ffn(x[:3]), a[:3])
+
+
+def test_foreign_model_gets_reference_pair_grid(g, ffn_w):
+    """a non-FFN object with .predict receives exactly the reference's (m*n) x 122 grid / two-input list"""
+    seen = {}
+
+    class Foreign:
+        def predict(self, x, batch_size=None):
+            seen["x"] = x
+            return mr.ffn_forward(ffn_w, x)
+    n = 50
+    corr = ffn_mod.initial_matching_ffn(Foreign(), g[f"ref_pts_{n}"], g[f"tgt_pts_{n}"], 20)
+    assert np.array_equal(seen["x"], mr.pair_grid(g[f"feat_ref_{n}"], g[f"feat_tgt_{n}"]))
+    np.testing.assert_allclose(corr, g[f"corr_{n}"], rtol=0, atol=1e-6)
+    track.initial_matching_quick(Foreign(), g[f"ref_pts_{n}"], g[f"tgt_pts_{n}"], 20)
+    assert isinstance(seen["x"], list) and len(seen["x"]) == 2 and seen["x"][0].shape == (n * n, 61)
+
+
+# ------------------------------------------------------------------------------------ greedy
+@pytest.mark.parametrize("n", NS)
+def test_simple_match_vs_reference(g, n):
+    prior, pairs = tl.simple_match(g[f"corr_{n}"])
+    assert np.array_equal(pairs, g[f"sm_pairs_{n}"])          # integer correspondence: bit-exact
+    assert prior.dtype == np.float32 and np.array_equal(prior, g[f"sm_prior_{n}"])
+
+
+def test_simple_match_crafted_cases(g, meta):
+    for i, npairs in enumerate(meta["simple_match_cases"]):
+        prior, pairs = tl.simple_match(g[f"smc_in_{i}"])
+        assert np.asarray(pairs).reshape(-1, 2).shape[0] == npairs
+        assert np.array_equal(np.asarray(pairs).reshape(-1, 2), g[f"smc_pairs_{i}"])
+        assert np.array_equal(prior, g[f"smc_prior_{i}"])
+
+
+def test_end_to_end_indices_with_gap_guard(g, ffn):
+    """pairs from GPU scores == pairs from reference scores whenever every greedy decision of the
+    reference has a margin above the fp32 score tolerance (reported otherwise)."""
+    for n in NS:
+        corr_gpu = ffn_mod.initial_matching_ffn(ffn, g[f"ref_pts_{n}"], g[f"tgt_pts_{n}"], 20)
+        _, pairs_gpu = tl.simple_match(corr_gpu)
+        _, pairs_ref_on_gpu_scores = mr.simple_match(corr_gpu)
+        assert np.array_equal(pairs_gpu, pairs_ref_on_gpu_scores)
+        # decision margin of the reference run
+        work = g[f"corr_{n}"].copy(); margin = np.inf
+        for r, t in g[f"sm_pairs_{n}"]:
+            top2 = np.partition(work.ravel(), -2)[-2:]
+            margin = min(margin, float(top2[1] - top2[0]), float(top2[1] - 0.1))
+            work[t, :] = 0; work[:, r] = 0
+        if margin > 2 * SCORE_TOL:
+            assert np.array_equal(pairs_gpu, g[f"sm_pairs_{n}"]), (n, margin)
+
+
+# ------------------------------------------------------------------------------------ PR-GLS pieces
+@pytest.mark.parametrize("n", NS)
+def test_fine_grained_helpers(g, n):
+    xn, yn, prior = g[f"ref_pts_{n}"], g[f"tgt_pts_{n}"], g[f"sm_prior_{n}"]
+    np.testing.assert_allclose(tl.dist_squares(xn, yn), mr.dist_squares(xn, yn), rtol=0, atol=1e-14)
+    np.testing.assert_allclose(tl.gaussian_kernel(xn, yn, 0.7), mr.gaussian_kernel(xn, yn, 0.7), rtol=1e-13, atol=1e-15)
+    s2 = float(g[f"ep_s2_{n}"])
+    post = tl.estimate_posterior(prior, s2, xn, yn, 0.05)
+    # the reference multiplies (1-gamma) * prior in float32 when the prior is a float32 array and gamma a
+    # Python float (numpy scalar promotion; iteration 1 only under numpy 2.x, every iteration under 1.x);
+    # the device path keeps fp64 throughout -> differences <= float32 eps, 4 orders below the 1e-4 budget
+    np.testing.assert_allclose(post, g[f"ep_post_{n}"], rtol=2e-7, atol=1e-14)
+    post64 = tl.estimate_posterior(prior.astype(np.float64), s2, xn, yn, 0.05)
+    np.testing.assert_allclose(post64, mr.estimate_posterior(prior.astype(np.float64), s2, xn, yn, 0.05), rtol=1e-11, atol=1e-15)
+    c = tl.solve_movements_ref(s2, 3, g[f"ep_post_{n}"], xn, yn, mr.gaussian_kernel(xn, xn, 9.0))
+    np.testing.assert_allclose(c, g[f"ep_c_{n}"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("n", NS)
+def test_prgls_trackerlite_dialect_vs_reference(g, n):
+    xn, yn, prior = g[f"ref_pts_{n}"], g[f"tgt_pts_{n}"], g[f"sm_prior_{n}"]
+    pred_l, post = tl.prgls_with_two_ref(prior, yn, xn, g[f"p2_tracked_{n}"], beta=3, lambda_=3)
+    np.testing.assert_allclose(pred_l, g[f"p2_pred_{n}"], rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post, g[f"p2_post_{n}"], rtol=0, atol=COORD_TOL)
+    pred_n, post_q = tl.prgls_quick(prior, yn, xn, beta=3, lambda_=3)
+    np.testing.assert_allclose(pred_n, g[f"pq_pred_{n}"], rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post_q, g[f"pq_post_{n}"], rtol=0, atol=COORD_TOL)
+    pred_b, post_b = tl.prgls_with_two_ref(prior, yn, xn, g[f"p2_tracked_{n}"], beta=1.5, lambda_=0.5, max_iteration=4)
+    np.testing.assert_allclose(pred_b, g[f"p2b_pred_{n}"], rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post_b, g[f"p2b_post_{n}"], rtol=0, atol=COORD_TOL)
+
+
+@pytest.mark.parametrize("n", (50, 113, 180))
+def test_prgls_legacy_dialect_vs_reference(g, n):
+    X, Y, corr = g[f"lg_X_{n}"], g[f"lg_Y_{n}"], g[f"lg_corr_{n}"]
+    for tag, (beta, lam, mi) in {"a": (300, 0.1, 20), "b": (1000 * 0.8 ** 2, 1e-5, 10)}.items():
+        P, TX, C = track.pr_gls_quick(X.copy(), Y, corr, BETA=beta, max_iteration=mi, LAMBDA=lam)
+        assert C.shape == (3, n) and P.shape == (n, n)
+        np.testing.assert_allclose(P, g[f"lg_{tag}_P_{n}"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(TX, g[f"lg_{tag}_TX_{n}"], rtol=0, atol=1e-4)     # voxel units, |X| ~ 1e2..1e3
+
+
+@pytest.mark.parametrize("n", (50, 113, 180))
+def test_tracker_predict_pos_once_vs_reference(g, ffn, n):
+    trk = tracker_mod.Tracker(ffn, beta_tk=1000.0, lambda_tk=1e-5, max_iteration=10)
+    trk.set_volume1(g[f"lg_X_{n}"], g[f"trk_tracked0_{n}"])
+    trk.set_segmentation(g[f"lg_Y_{n}"])
+    pred, _ = trk._predict_pos_once(source_volume=1, draw=False)
+    np.testing.assert_allclose(pred, g[f"trk_pred_{n}"], rtol=0, atol=1e-4)
+    anim, (bd, vol, _, pred2) = trk.match(7, g[f"lg_Y_{n}"])
+    assert vol == 7 and np.array_equal(pred, pred2)
+    trk.miss_frame = [9]
+    with pytest.raises(ValueError):
+        trk.match(9)
+
+
+def test_trim_mean_device():
+    from scipy.stats import trim_mean
+    import torch
+    a = np.random.default_rng(0).normal(size=(20, 37, 3))
+    for k in (20, 7, 3):
+        got = dev.trim_mean(torch.from_numpy(a[:k]).cuda()).cpu().numpy()
+        np.testing.assert_allclose(got, trim_mean(a[:k], 0.1, axis=0), rtol=0, atol=1e-14)
+
+
+# ------------------------------------------------------------------------------------ TrackerLite boundary
+def _write_case(tmp_path, ffn_w, n=113, frames=(1, 2, 3, 4, 5)):
+    vs = np.array([1.0, 1.0, 4.0])
+    (tmp_path / "seg").mkdir()
+    (tmp_path / "ffn_models").mkdir()
+    f = ffn_mod.FFN().set_weights_dict(ffn_w)
+    f.save_weights(tmp_path / "ffn_models" / "synthetic.npz")
+    rng = np.random.default_rng(3)
+    base = rng.uniform(0, 1, (n, 3)) * np.array([168, 401, 32])
+    coords = {}
+    for t in frames:
+        a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.05
+        c = (base - base.mean(0)) @ a + base.mean(0) + rng.normal(0, 0.3, base.shape)
+        coords[t] = c[rng.permutation(n)].astype(np.float32)
+        np.save(tmp_path / "seg" / f"coords{str(t).zfill(6)}.npy", coords[t])
+    return vs, coords
+
+
+def test_trackerlite_end_to_end(tmp_path, ffn_w):
+    vs, coords = _write_case(tmp_path, ffn_w)
+    proof = cit.Coordinates(coords[1], interpolation_factor=4, voxel_size=vs, dtype="raw")
+    with pytest.raises(TypeError):
+        tl.TrackerLite(str(tmp_path), "synthetic", proof, miss_frame=(3,), basedir=str(tmp_path / "ffn_models"))
+    with pytest.raises(ValueError):
+        tl.TrackerLite(str(tmp_path), "does_not_exist", proof, basedir=str(tmp_path / "ffn_models"))
+    trk = tl.TrackerLite(str(tmp_path), "synthetic", proof, miss_frame=[4], basedir=str(tmp_path / "ffn_models"))
+    for sub in ("figure", "coords_real", "labels"):
+        assert (tmp_path / "track_results" / sub).is_dir()
+    out = trk.predict_cell_positions(1, 2)
+    assert isinstance(out, cit.Coordinates) and out.cell_num == coords[1].shape[0]
+    with pytest.raises(AssertionError):
+        trk.predict_cell_positions(1, 4)
+    # oracle pipeline (reference formulation) on the same files
+    c1 = cit.Coordinates(coords[1], 4, vs, "raw"); c2 = cit.Coordinates(coords[2], 4, vs, "raw")
+    conf_n, (mean, scale) = mr.normalize_points(c1.real, return_para=True)
+    s2 = (c2.real - mean) / scale; s1 = (c1.real - mean) / scale
+    corr = mr.initial_matching(lambda x: mr.ffn_forward(ffn_w, x), s1, s2, 20)
+    prior, pairs = mr.simple_match(corr)
+    want_n, _ = mr.prgls_with_two_ref(prior, s2, s1, conf_n, beta=3, lambda_=3)
+    want = cit.Coordinates(want_n * scale + mean, 4, vs, "real")
+    got_pairs = trk.match_by_ffn(1, 2)
+    if np.array_equal(got_pairs, pairs):          # identical correspondences -> coordinates within 1e-4
+        np.testing.assert_allclose(out.real, want.real, rtol=0, atol=1e-4)
+    # ensemble: frames 1..3 tracked, predict 5 skipping the missing frame 4
+    for t in (1, 2, 3):
+        np.save(tmp_path / "track_results" / "coords_real" / f"coords{str(t).zfill(6)}.npy",
+                cit.Coordinates(coords[t], 4, vs, "raw").real)
+    ens = trk.predict_cell_positions_ensemble([4], 5, proof, beta=3, lambda_=3, sampling_number=20)
+    singles = [trk.predict_cell_positions(t1, 5, cit.Coordinates(np.load(tmp_path / "track_results" / "coords_real" / f"coords{str(t1).zfill(6)}.npy"), 4, vs, "real")).real
+               for t1 in tl.get_volumes_list(5, [4])]
+    from scipy.stats import trim_mean
+    np.testing.assert_allclose(ens.real, cit.Coordinates(trim_mean(singles, 0.1, axis=0), 4, vs, "real").real, rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ BASELINE sizes
+def test_match_600_cells_against_oracle(ffn, ffn_w):
+    """BASELINE metric size: ~600 cells.  Scores vs oracle, greedy exact on identical scores, PR-GLS
+    coordinates within 1e-6 given the same prior."""
+    x, y = synth.make_point_pair(600, seed=1)
+    xn, (mean, scale) = mr.normalize_points(x, return_para=True); yn = (y - mean) / scale
+    corr = ffn_mod.initial_matching_ffn(ffn, xn, yn, 20)
+    want = mr.initial_matching(lambda q: mr.ffn_forward(ffn_w, q), xn, yn, 20)
+    np.testing.assert_allclose(corr, want, rtol=0, atol=SCORE_TOL)
+    prior, pairs = tl.simple_match(corr)
+    prior_o, pairs_o = mr.simple_match(corr)
+    assert np.array_equal(pairs, pairs_o) and np.array_equal(prior, prior_o)
+    got, post = tl.prgls_with_two_ref(prior, yn, xn, xn, beta=3, lambda_=3)
+    ref, post_o, iters = mr.prgls_with_two_ref(prior_o, yn, xn, xn, beta=3, lambda_=3, return_iters=True)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post, post_o, rtol=0, atol=COORD_TOL)
+
+
+def test_match_2000_cells_properties(ffn):
+    """config 5 size (N = 2000): size-independent properties instead of a multi-minute oracle run."""
+    x, y = synth.make_point_pair(2000, seed=2, box=(512, 1024, 21))
+    xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True); yn = (y - mean) / scale
+    corr = ffn_mod.initial_matching_ffn(ffn, xn, yn, 20)
+    assert corr.shape == (2000, 2000) and np.all((corr > 0) & (corr < 1))
+    prior, pairs = tl.simple_match(corr)
+    assert len(set(pairs[:, 0])) == len(pairs) and len(set(pairs[:, 1])) == len(pairs)      # one-to-one
+    vals = corr[pairs[:, 1], pairs[:, 0]]
+    assert np.all(np.diff(vals) <= 0) and vals.min() >= 0.1                                    # greedy order, threshold
+    assert np.count_nonzero(prior == np.float32(0.9)) == len(pairs)
+    got, post = tl.prgls_with_two_ref(prior, yn, xn, xn, beta=3, lambda_=3)
+    assert np.all(np.isfinite(got)) and np.all(post >= 0) and np.all(post.sum(1) <= 1 + 1e-12)
+    # a pure translation of the target set moves the prediction by the same translation
+    got_shift, _ = tl.prgls_with_two_ref(prior, yn + 1e-3, xn, xn, beta=3, lambda_=3)
+    assert float(np.abs((got_shift - got) - 1e-3).max()) < 5e-4
