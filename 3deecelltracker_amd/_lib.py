@@ -33,6 +33,10 @@ SIGNATURES = {
     "ct_unet_workspace_bytes": (_sz, [_vp, _i]),
     "ct_unet_predict_patches": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
     "ct_unet_layer_dump_floats": (_sz, [_i]),
+    "ct_unet_num_conv_layers": (_i, [_vp]),
+    "ct_unet_layer_info": (_i, [_vp, _i, _ip, _ip, _ip, _ip]),
+    "ct_unet_set_timing": (_i, [_vp, _i]),
+    "ct_unet_get_timing": (_i, [_vp, C.POINTER(C.c_float), _ip, _i]),
     "ct_tile_plan": (_i, [_ip, _ip, _ip, _ip, _ip]),
     "ct_tile_gather_reflect": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),
     "ct_tile_scatter_center": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <new>
 #include <vector>
 
@@ -245,14 +247,16 @@ __global__ __launch_bounds__(64) void ffn_rows_finish_kernel(const float* __rest
 // column is the lowest column) then a re-scan of only those rows whose cached column was taken.
 // Equivalent to the reference's repeated global arg-max with first-occurrence tie-breaking.
 // ------------------------------------------------------------------------------------------------
-constexpr int GR_THREADS = 1024, GR_WAVES = GR_THREADS / 64;
+constexpr int GR_THREADS = 256, GR_WAVES = GR_THREADS / 64, GR_K = 8;
 
+// (value desc, column asc) arg-max of one row over columns not in `col_used` and "after" (pv, pc) in that order
 __device__ __forceinline__ void row_scan(const float* __restrict__ row, int n, const unsigned char* col_used, int lane,
-                                         float& best, int& bi) {
+                                         float pv, int pc, float& best, int& bi) {
     best = -1.f; bi = 0x7fffffff;
     for (int c = lane; c < n; c += 64) {
-        if (col_used[c]) continue;
+        if (col_used && col_used[c]) continue;
         const float v = row[c];
+        if (!(v < pv || (v == pv && c > pc))) continue;          // strictly after the previous candidate
         if (v > best) { best = v; bi = c; }
     }
 #pragma unroll
@@ -262,30 +266,50 @@ __device__ __forceinline__ void row_scan(const float* __restrict__ row, int n, c
     }
 }
 
+// stage 1 (whole GPU): the GR_K best (value, column) candidates of every row, in the order the reference's
+// repeated arg-max would visit them (value descending, first occurrence = lowest column on ties).
+__global__ __launch_bounds__(256) void greedy_topk_kernel(const float* __restrict__ corr, int m, int n,
+                                                          float* __restrict__ cand_val, int* __restrict__ cand_col) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= m) return;
+    float pv = INFINITY; int pc = -1;
+    for (int k = 0; k < GR_K; ++k) {
+        float b; int bi;
+        row_scan(corr + (size_t)t * n, n, nullptr, lane, pv, pc, b, bi);
+        if (lane == 0) { cand_val[(size_t)t * GR_K + k] = (bi == 0x7fffffff) ? -2.f : b; cand_col[(size_t)t * GR_K + k] = bi; }
+        if (bi == 0x7fffffff) { for (int q = k + 1; q < GR_K && lane == 0; ++q) { cand_val[(size_t)t * GR_K + q] = -2.f; cand_col[(size_t)t * GR_K + q] = 0x7fffffff; } break; }
+        pv = b; pc = bi;
+    }
+}
+
+// stage 2 (single workgroup; the loop is inherently sequential): every step = block arg-max over the rows'
+// current candidates (ties -> lowest row, whose candidate is its lowest free column) -> pair -> rows whose
+// candidate column was taken advance along their list; an exhausted list is refilled by a wave re-scan.
+// Equivalent to the reference's repeated global arg-max with first-occurrence tie-breaking.
 __global__ __launch_bounds__(GR_THREADS) void greedy_match_kernel(const float* __restrict__ corr, int m, int n, float thr,
                                                                   int32_t* __restrict__ pairs, int32_t* __restrict__ n_pairs,
-                                                                  float* __restrict__ row_val, int* __restrict__ row_col,
-                                                                  unsigned char* __restrict__ col_used_g) {
+                                                                  float* __restrict__ cand_val, int* __restrict__ cand_col) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: col_used[n] | redv[GR_WAVES] | redi[GR_WAVES] | todo list count
-    unsigned char* col_used = smem;
-    float* redv = reinterpret_cast<float*>(smem + ((n + 15) & ~15));
+    // LDS: cur_val[m] | cur_col[m] | ptr[m] | redv | redi | bc[4] | todo[m] | col_used[n]
+    float* cur_val = reinterpret_cast<float*>(smem);
+    int* cur_col = reinterpret_cast<int*>(cur_val + m);
+    int* ptr = cur_col + m;
+    float* redv = reinterpret_cast<float*>(ptr + m);
     int* redi = reinterpret_cast<int*>(redv + GR_WAVES);
-    int* bc = redi + GR_WAVES;            // bc[0] = chosen row, bc[1] = chosen col, bc[2] = stop flag
+    int* bc = redi + GR_WAVES;            // bc[0] = chosen row, bc[1] = chosen col, bc[2] = stop flag, bc[3] = todo count
+    int* todo = bc + 4;
+    unsigned char* col_used = reinterpret_cast<unsigned char*>(todo + m);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c < n; c += GR_THREADS) col_used[c] = 0;
-    __syncthreads();
-    for (int t = wave; t < m; t += GR_WAVES) {
-        float b; int bi; row_scan(corr + (size_t)t * n, n, col_used, lane, b, bi);
-        if (lane == 0) { row_val[t] = b; row_col[t] = bi; }
-    }
+    for (int t = tid; t < m; t += GR_THREADS) { cur_val[t] = cand_val[(size_t)t * GR_K]; cur_col[t] = cand_col[(size_t)t * GR_K]; ptr[t] = 0; }
+    if (tid == 0) bc[3] = 0;
     __syncthreads();
     int np = 0;
     for (int it = 0; it < n; ++it) {
-        // block arg-max over rows: (value desc, row asc)
         float best = -1.f; int bt = 0x7fffffff;
         for (int t = tid; t < m; t += GR_THREADS) {
-            const float v = row_val[t];
+            const float v = cur_val[t];
             if (v > best) { best = v; bt = t; }
         }
 #pragma unroll
@@ -295,38 +319,49 @@ __global__ __launch_bounds__(GR_THREADS) void greedy_match_kernel(const float* _
         }
         if (lane == 0) { redv[wave] = best; redi[wave] = bt; }
         __syncthreads();
-        if (wave == 0) {
-            float v = lane < GR_WAVES ? redv[lane] : -1.f; int t = lane < GR_WAVES ? redi[lane] : 0x7fffffff;
-#pragma unroll
-            for (int mk = 32; mk >= 1; mk >>= 1) {
-                const float ov = __shfl_xor(v, mk); const int oi = __shfl_xor(t, mk);
-                if (ov > v || (ov == v && oi < t)) { v = ov; t = oi; }
+        if (tid == 0) {
+            float v = redv[0]; int t = redi[0];
+            for (int w2 = 1; w2 < GR_WAVES; ++w2) if (redv[w2] > v || (redv[w2] == v && redi[w2] < t)) { v = redv[w2]; t = redi[w2]; }
+            if (!(v >= thr) || t == 0x7fffffff) { bc[2] = 1; }
+            else {
+                bc[2] = 0; bc[0] = t; bc[1] = cur_col[t];
+                pairs[2 * np] = cur_col[t]; pairs[2 * np + 1] = t;        // (ref, tgt)
+                cur_val[t] = -2.f;                                        // row cleared
+                col_used[cur_col[t]] = 1;                                 // column cleared
             }
-            if (lane == 0) {
-                if (!(v >= thr) || t == 0x7fffffff) { bc[2] = 1; }
-                else {
-                    bc[2] = 0; bc[0] = t; bc[1] = row_col[t];
-                    pairs[2 * np] = row_col[t]; pairs[2 * np + 1] = t;      // (ref, tgt)
-                    row_val[t] = -2.f;                                      // row cleared
-                    col_used[row_col[t]] = 1;                               // column cleared
-                }
-            }
+            bc[3] = 0;
         }
         __syncthreads();
         if (bc[2]) break;
         ++np;
         const int ccol = bc[1];
-        // re-scan rows whose cached best column was just taken
-        for (int t = wave; t < m; t += GR_WAVES) {
-            if (row_val[t] >= 0.f && row_col[t] == ccol) {      // wave-uniform condition
-                float b; int bi; row_scan(corr + (size_t)t * n, n, col_used, lane, b, bi);
-                if (lane == 0) { row_val[t] = (bi == 0x7fffffff) ? -2.f : b; row_col[t] = bi; }
+        // rows whose candidate column was just taken advance to their next free candidate
+        for (int t = tid; t < m; t += GR_THREADS) {
+            if (cur_val[t] >= 0.f && cur_col[t] == ccol) {
+                int k = ptr[t] >= GR_K ? GR_K : ptr[t] + 1;           // a refilled row has no list left: re-scan again
+                while (k < GR_K) {
+                    const int cc = cand_col[(size_t)t * GR_K + k];
+                    if (cc == 0x7fffffff) { k = GR_K + 1; break; }            // row has no further entries at all
+                    if (!col_used[cc]) break;
+                    ++k;
+                }
+                if (k < GR_K) { ptr[t] = k; cur_val[t] = cand_val[(size_t)t * GR_K + k]; cur_col[t] = cand_col[(size_t)t * GR_K + k]; }
+                else if (k == GR_K) { todo[atomicAdd(&bc[3], 1)] = t; }       // list exhausted: full re-scan
+                else { cur_val[t] = -2.f; }
             }
         }
         __syncthreads();
+        const int ntodo = bc[3];
+        if (ntodo) {
+            for (int q = wave; q < ntodo; q += GR_WAVES) {
+                const int t = todo[q];
+                float b; int bi; row_scan(corr + (size_t)t * n, n, col_used, lane, INFINITY, -1, b, bi);
+                if (lane == 0) { cur_val[t] = (bi == 0x7fffffff) ? -2.f : b; cur_col[t] = bi; ptr[t] = GR_K; }
+            }
+            __syncthreads();
+        }
     }
     if (tid == 0) *n_pairs = np;
-    (void)col_used_g;
 }
 
 __global__ __launch_bounds__(256) void prior_fill_kernel(double* __restrict__ prior, int m, int n, int mode,
@@ -363,7 +398,7 @@ __global__ void row_match_set_kernel(int* __restrict__ row_match, const int32_t*
 // PR-GLS kernels (fp64)
 // ------------------------------------------------------------------------------------------------
 // scalars block (device): [0] sigma2  [1] gamma  [2] sumP  [3] move_norm2  [4] c = lambda*sigma2  [5] iteration
-enum { S_SIGMA2 = 0, S_GAMMA = 1, S_SUMP = 2, S_NORM2 = 3, S_C = 4, S_NUM = 8 };
+enum { S_SIGMA2 = 0, S_GAMMA = 1, S_SUMP = 2, S_NORM2 = 3, S_C = 4, S_IT = 5, S_DONE = 6, S_RES = 7, S_NUM = 8 };
 
 // out[i][j] = exp(-|a_j - b_i|^2 / (2 s2)),  i < nb, j < na      (trackerlite.py:368-372)
 __global__ __launch_bounds__(256) void gauss_kernel(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
@@ -379,7 +414,8 @@ __global__ __launch_bounds__(256) void gauss_kernel(const double* __restrict__ a
 // sum over all (t, r) of |ref_r - tgt_t|^2  -> per-row partial sums rowpart[m]
 __global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restrict__ ref, int n, const double* __restrict__ tgt, int m,
                                                            const double* __restrict__ P /* weights or null */,
-                                                           double* __restrict__ rowpart) {
+                                                           double* __restrict__ rowpart, const double* __restrict__ sc = nullptr) {
+    if (sc && sc[S_DONE] != 0.0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wave;
     if (t >= m) return;
@@ -398,8 +434,25 @@ __global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restr
 // mode 1 (lite, trackerlite.py:342-350):  gamma = max(1 - sumP/m, 1e-4); sigma2 = sum / (3 sumP)
 // mode 2 (legacy, track.py:103-112):      gamma = 1 - sumP/m;            sigma2 = max(sum / (3 sumP), 1)
 __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ rowpart, int m, int n, int mode,
-                                                      double* __restrict__ sc) {
+                                                      double* __restrict__ sc, const double* __restrict__ normpart = nullptr,
+                                                      const double* __restrict__ respart = nullptr) {
     __shared__ double red[4];
+    __shared__ double red2[4];
+    __shared__ double red3[4], red4[4];
+    if (mode != 0 && sc[S_DONE] != 0.0) return;
+    if (respart) {
+        double r1 = 0.0, r2 = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) { r1 = fmax(r1, respart[i]); r2 = fmax(r2, respart[n + i]); }
+#pragma unroll
+        for (int mk = 32; mk >= 1; mk >>= 1) { r1 = fmax(r1, shfl_xor_d(r1, mk)); r2 = fmax(r2, shfl_xor_d(r2, mk)); }
+        if ((threadIdx.x & 63) == 0) { red3[threadIdx.x >> 6] = r1; red4[threadIdx.x >> 6] = r2; }
+    }
+    double nacc = 0.0;
+    if (normpart) {
+        for (int i = threadIdx.x; i < n; i += 256) nacc += normpart[i];
+        nacc = wave_sum_d(nacc);
+        if ((threadIdx.x & 63) == 0) red2[threadIdx.x >> 6] = nacc;
+    }
     double acc = 0.0;
     for (int t = threadIdx.x; t < m; t += 256) acc += rowpart[t];
     acc = wave_sum_d(acc);
@@ -415,6 +468,18 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
             if (mode == 1) { if (g < 1e-4) g = 1e-4; }
             else { if (s2 < 1.0) s2 = 1.0; }
             sc[S_GAMMA] = g; sc[S_SIGMA2] = s2;
+            sc[S_IT] = sc[S_IT] + 1.0;
+            if (normpart) {
+                const double n2 = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+                sc[S_NORM2] = n2;
+                if (mode == 1 && sqrt(n2) < 1e-3) sc[S_DONE] = 1.0;           // trackerlite.py:353-356
+            }
+            if (respart) {
+                const double r1 = fmax(fmax(red3[0], red3[1]), fmax(red3[2], red3[3]));
+                const double r2 = fmax(fmax(red4[0], red4[1]), fmax(red4[2], red4[3]));
+                const double rel = r2 > 0.0 ? r1 / r2 : 0.0;
+                if (rel > sc[S_RES]) sc[S_RES] = rel;
+            }
         }
     }
 }
@@ -424,6 +489,7 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
                                                         int n, const double* __restrict__ tgt, int m,
                                                         const double* __restrict__ sc, int legacy, double vol,
                                                         double* __restrict__ P, double s2v = 0.0, double gammav = 0.0) {
+    if (sc && sc[S_DONE] != 0.0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wave;
     if (t >= m) return;
@@ -447,20 +513,28 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
 }
 
 // column statistics, stage 1: block (x: 64 columns, y: row segment) -> part[seg][4][n] = colsum, Y^T P
-constexpr int CS_SEG = 16;
-__global__ __launch_bounds__(64) void colstats_kernel(const double* __restrict__ P, const double* __restrict__ tgt, int m, int n,
-                                                      double* __restrict__ part) {
-    const int r = blockIdx.x * 64 + threadIdx.x, seg = blockIdx.y;
-    if (r >= n) return;
+constexpr int CS_SEG = 32;
+__global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict__ P, const double* __restrict__ tgt, int m, int n,
+                                                       double* __restrict__ part, const double* __restrict__ sc = nullptr) {
+    if (sc && sc[S_DONE] != 0.0) return;
+    __shared__ double red[4][64][4];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + cl, seg = blockIdx.y;
     const int per = (m + CS_SEG - 1) / CS_SEG;
     const int t0 = seg * per, t1 = min(m, t0 + per);
     double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int t = t0; t < t1; ++t) {
-        const double p = P[(size_t)t * n + r];
-        s += p; sx = fma(tgt[3 * t], p, sx); sy = fma(tgt[3 * t + 1], p, sy); sz = fma(tgt[3 * t + 2], p, sz);
+    if (r < n)
+        for (int t = t0 + rl; t < t1; t += 4) {
+            const double p = P[(size_t)t * n + r];
+            s += p; sx = fma(tgt[3 * t], p, sx); sy = fma(tgt[3 * t + 1], p, sy); sz = fma(tgt[3 * t + 2], p, sz);
+        }
+    red[rl][cl][0] = s; red[rl][cl][1] = sx; red[rl][cl][2] = sy; red[rl][cl][3] = sz;
+    __syncthreads();
+    if (rl == 0 && r < n) {
+        double* o = part + (size_t)seg * 4 * n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q * n + r] = (red[0][cl][q] + red[1][cl][q]) + (red[2][cl][q] + red[3][cl][q]);
     }
-    double* o = part + (size_t)seg * 4 * n;
-    o[r] = s; o[n + r] = sx; o[2 * n + r] = sy; o[3 * n + r] = sz;
 }
 
 // stage 2: d[r] = colsum, rhs (scaled) and sumP.  xref = points whose X^T D term is subtracted
@@ -667,15 +741,22 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restric
 
 // movement of a point set through the field: mov[j][d] = sum_i C[d][i] G[i][j]; one wave per j.
 // flags: add (pts += mov), replace (pts = base + mov), accumulate |mov|^2 into norm partials
-__global__ __launch_bounds__(256) void apply_field_kernel(const double* __restrict__ C, const double* __restrict__ G, int n, int cols,
+// Gt is stored [cols][n] (row j contiguous over i): the symmetric n x n Gram matrix as is, and the
+// tracked-set kernel computed transposed.  mode 3 = "add unless this is EM iteration 1" (device counter).
+__global__ __launch_bounds__(256) void apply_field_kernel(const double* __restrict__ C, const double* __restrict__ Gt, int n, int cols,
                                                           double* __restrict__ pts, const double* __restrict__ base, int mode,
-                                                          double* __restrict__ norm_part /* [cols] or null */) {
+                                                          double* __restrict__ norm_part /* [cols] or null */,
+                                                          const double* __restrict__ sc = nullptr,
+                                                          const double* __restrict__ dvec = nullptr, const double* __restrict__ sqd = nullptr,
+                                                          const double* __restrict__ rhs = nullptr, double* __restrict__ res_part = nullptr) {
+    if (sc && sc[S_DONE] != 0.0) return;
+    if (mode == 3) mode = (sc[S_IT] >= 1.0) ? 1 : 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
     if (j >= cols) return;
     double ax = 0.0, ay = 0.0, az = 0.0;
     for (int i = lane; i < n; i += 64) {
-        const double g = G[(size_t)i * cols + j];
+        const double g = Gt[(size_t)j * n + i];
         ax = fma(C[i], g, ax); ay = fma(C[n + i], g, ay); az = fma(C[2 * n + i], g, az);
     }
     ax = wave_sum_d(ax); ay = wave_sum_d(ay); az = wave_sum_d(az);
@@ -683,6 +764,50 @@ __global__ __launch_bounds__(256) void apply_field_kernel(const double* __restri
         if (mode == 1) { pts[3 * j] += ax; pts[3 * j + 1] += ay; pts[3 * j + 2] += az; }
         else if (mode == 2) { pts[3 * j] = base[3 * j] + ax; pts[3 * j + 1] = base[3 * j + 1] + ay; pts[3 * j + 2] = base[3 * j + 2] + az; }
         if (norm_part) norm_part[j] = ax * ax + ay * ay + az * az;
+        if (res_part) {   // residual of the ORIGINAL system with the exact Gram matrix: d_j (G C^T)_j + c C_j - b_j
+            const double c = sc[S_C], d = dvec[j], q = sqd[j];
+            const double bx = q * rhs[3 * j], by = q * rhs[3 * j + 1], bz = q * rhs[3 * j + 2];
+            const double rx = d * ax + c * C[j] - bx, ry = d * ay + c * C[n + j] - by, rz = d * az + c * C[2 * n + j] - bz;
+            res_part[j] = fmax(fabs(rx), fmax(fabs(ry), fabs(rz)));
+            res_part[cols + j] = fmax(fabs(bx), fmax(fabs(by), fabs(bz)));
+        }
+    }
+}
+
+// TrackerLite-dialect field application for both point sets in one launch: waves [0, n) move the ref set
+// (symmetric Gram matrix G, |movement|^2 partials, exact-system residual monitor), waves [n, n+l) the tracked
+// set (kernel stored [l][n]).  Movements are added only from EM iteration 2 on (trackerlite.py:339-341).
+__global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restrict__ C, const double* __restrict__ G, int n,
+                                                         double* __restrict__ predn, const double* __restrict__ Gln, int l,
+                                                         double* __restrict__ predl, double* __restrict__ norm_part,
+                                                         const double* __restrict__ sc, const double* __restrict__ dvec,
+                                                         const double* __restrict__ sqd, const double* __restrict__ rhs,
+                                                         double* __restrict__ res_part) {
+    if (sc[S_DONE] != 0.0) return;
+    const bool add = sc[S_IT] >= 1.0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int j = blockIdx.x * 4 + wave;
+    if (j >= n + l) return;
+    const bool second = j >= n;
+    if (second) j -= n;
+    const double* row = second ? Gln + (size_t)j * n : G + (size_t)j * n;
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double g = row[i];
+        ax = fma(C[i], g, ax); ay = fma(C[n + i], g, ay); az = fma(C[2 * n + i], g, az);
+    }
+    ax = wave_sum_d(ax); ay = wave_sum_d(ay); az = wave_sum_d(az);
+    if (lane != 0) return;
+    double* pts = second ? predl : predn;
+    if (add) { pts[3 * j] += ax; pts[3 * j + 1] += ay; pts[3 * j + 2] += az; }
+    if (second) return;
+    norm_part[j] = ax * ax + ay * ay + az * az;
+    if (res_part) {
+        const double c = sc[S_C], d = dvec[j], q = sqd[j];
+        const double bx = q * rhs[3 * j], by = q * rhs[3 * j + 1], bz = q * rhs[3 * j + 2];
+        const double rx = d * ax + c * C[j] - bx, ry = d * ay + c * C[n + j] - by, rz = d * az + c * C[2 * n + j] - bz;
+        res_part[j] = fmax(fabs(rx), fmax(fabs(ry), fabs(rz)));
+        res_part[n + j] = fmax(fabs(bx), fmax(fabs(by), fabs(bz)));
     }
 }
 
@@ -694,6 +819,279 @@ __global__ __launch_bounds__(256) void sum_to_scalar_kernel(const double* __rest
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) *dst = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Low-rank fast path of the M-step.  A wide Gaussian Gram matrix is numerically low-rank (rank ~60-90
+// for beta = 3 in normalised units, independent of n), so G = U^T U (U: r x n) from a pivoted Cholesky
+// computed ONCE per match, and every EM iteration solves only an r x r SPD system:
+//   (c I + W W^T)^-1 = (1/c) [ I - W (c I_r + W^T W)^-1 W^T ],   W = D^1/2 U^T  (n x r)
+// (Woodbury on the symmetrically scaled system; its cancellation error is cond * eps, the same as a
+// direct factorisation's).  The truncation |G - U^T U| <= tol perturbs the solution by ~ tol/c.
+// ------------------------------------------------------------------------------------------------
+constexpr int LR_RMAX = 128;
+
+// pivoted Cholesky of the symmetric PSD matrix G (n x n); single workgroup.
+// U [LR_RMAX][n] (row k contiguous), *rank_out = r, or -1 if tol was not reached within LR_RMAX steps.
+__global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __restrict__ G, int n, double tol,
+                                                              double* __restrict__ U, double* __restrict__ resid,
+                                                              int* __restrict__ rank_out) {
+    __shared__ double redv[16];
+    __shared__ int redi[16];
+    __shared__ double pivv; __shared__ int pivi;
+    __shared__ double urow[LR_RMAX];            // U[0..k-1][p]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n; i += 1024) resid[i] = G[(size_t)i * n + i];
+    __syncthreads();
+    int k = 0;
+    for (; k < LR_RMAX; ++k) {
+        double best = -1.0; int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 1024) { const double d = resid[i]; if (d > best) { best = d; bi = i; } }
+#pragma unroll
+        for (int mk = 32; mk >= 1; mk >>= 1) {
+            const double od = shfl_xor_d(best, mk); const int oi = __shfl_xor(bi, mk);
+            if (od > best || (od == best && oi < bi)) { best = od; bi = oi; }
+        }
+        if (lane == 0) { redv[wave] = best; redi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double b = redv[0]; int ix = redi[0];
+            for (int w = 1; w < 16; ++w) if (redv[w] > b || (redv[w] == b && redi[w] < ix)) { b = redv[w]; ix = redi[w]; }
+            pivv = b; pivi = ix;
+        }
+        __syncthreads();
+        if (!(pivv > tol)) break;
+        const int p = pivi; const double piv = sqrt(pivv);
+        if (tid < k) urow[tid] = U[(size_t)tid * n + p];
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            double u = G[(size_t)i * n + p];
+            for (int j = 0; j < k; ++j) u -= U[(size_t)j * n + i] * urow[j];
+            u /= piv;
+            U[(size_t)k * n + i] = u;
+            resid[i] = (i == p) ? 0.0 : resid[i] - u * u;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *rank_out = (k == LR_RMAX && pivv > tol) ? -1 : k;
+}
+
+// column statistics, stage 2 (parallel): 64 columns per block, the CS_SEG segment partials split over
+// 4 waves; writes d_i, sqrt d_i and the scaled right-hand side b~_i = (Y^T P[:, i] - x_i d_i) / sqrt d_i.
+__global__ __launch_bounds__(256) void colstats_finish_par_kernel(const double* __restrict__ part, int n, const double* __restrict__ xref,
+                                                                  const double* __restrict__ sc, double* __restrict__ dvec,
+                                                                  double* __restrict__ sqd, double* __restrict__ rhs) {
+    if (sc[S_DONE] != 0.0) return;
+    __shared__ double red[4][64][4];
+    const int cl = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;
+    double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+    if (i < n)
+        for (int seg = wv; seg < CS_SEG; seg += 4) {
+            const double* o = part + (size_t)seg * 4 * n;
+            s += o[i]; sx += o[n + i]; sy += o[2 * n + i]; sz += o[3 * n + i];
+        }
+    red[wv][cl][0] = s; red[wv][cl][1] = sx; red[wv][cl][2] = sy; red[wv][cl][3] = sz;
+    __syncthreads();
+    if (wv == 0 && i < n) {
+        s = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+        sx = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+        sy = (red[0][cl][2] + red[1][cl][2]) + (red[2][cl][2] + red[3][cl][2]);
+        sz = (red[0][cl][3] + red[1][cl][3]) + (red[2][cl][3] + red[3][cl][3]);
+        const double q = sqrt(s);
+        const double iq = q > 0.0 ? 1.0 / q : 0.0;
+        dvec[i] = s; sqd[i] = q;
+        rhs[3 * i] = (sx - xref[3 * i] * s) * iq; rhs[3 * i + 1] = (sy - xref[3 * i + 1] * s) * iq;
+        rhs[3 * i + 2] = (sz - xref[3 * i + 2] * s) * iq;
+    }
+}
+
+// S = U D U^T (r x r, lower triangle) and y = U D^1/2 b~ (r x 3): one wave per entry, lanes stride the n rows
+// (coalesced reads of the rows of U, which stay L2-resident); deterministic butterfly reduction.
+__global__ __launch_bounds__(256) void lr_gram_kernel(int n, const double* __restrict__ U, const int* __restrict__ rank_p,
+                                                      const double* __restrict__ sc, const double* __restrict__ dvec,
+                                                      const double* __restrict__ sqd, const double* __restrict__ rhs,
+                                                      double* __restrict__ Sout /* [LR_RMAX][LR_RMAX] */, double* __restrict__ yout /* [LR_RMAX][3] */) {
+    if (sc[S_DONE] != 0.0) return;
+    const int r = *rank_p;
+    const int ntri = r * (r + 1) / 2;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= ntri + 3 * r) return;
+    double acc = 0.0;
+    if (e < ntri) {
+        int a2 = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((a2 + 1) * (a2 + 2) / 2 <= e) ++a2;
+        while (a2 * (a2 + 1) / 2 > e) --a2;
+        const int b2 = e - a2 * (a2 + 1) / 2;
+        const double* ua = U + (size_t)a2 * n; const double* ub = U + (size_t)b2 * n;
+        for (int i = lane; i < n; i += 64) acc = fma(ua[i] * dvec[i], ub[i], acc);
+        acc = wave_sum_d(acc);
+        if (lane == 0) Sout[a2 * LR_RMAX + b2] = acc;
+    } else {
+        const int q = e - ntri, a2 = q / 3, d = q - a2 * 3;
+        const double* ua = U + (size_t)a2 * n;
+        for (int i = lane; i < n; i += 64) acc = fma(ua[i] * sqd[i], rhs[3 * i + d], acc);
+        acc = wave_sum_d(acc);
+        if (lane == 0) yout[a2 * 3 + d] = acc;
+    }
+}
+
+// single workgroup: q = (c I + S)^-1 y for 3 right-hand sides, S given by lr_gram_kernel.
+// The right-hand sides ride along as 3 extra rows of the matrix being factorised
+// ([[S, y], [y^T, .]] = L_aug L_aug^T puts w = L^-1 y into those rows), so the forward substitution is
+// free.  Blocked right-looking factorisation, 8 columns per step, 2 barriers per step: (1) every thread
+// factors the 8 x 8 diagonal block redundantly in registers and solves its own rows of the panel,
+// (2) rank-8 update of the trailing block.  Then a back-substitution, one unknown per thread.
+constexpr int LS_B = 8;
+__global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict__ Sin, const double* __restrict__ yin,
+                                                       int n, const int* __restrict__ rank_p, double lambda,
+                                                       const double* __restrict__ dvec, double* __restrict__ sc,
+                                                       double* __restrict__ qout) {
+    if (sc[S_DONE] != 0.0) return;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int r = *rank_p;
+    const int ld = r | 1;                  // odd leading dimension (doubles): spreads rows over the LDS banks
+    const int ra = r + 3;                  // augmented row count
+    double* S = sm;                        // [ra][ld]
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const double c = lambda * sc[S_SIGMA2];
+    for (int e = tid; e < r * r; e += 256) {
+        const int a = e / r, b = e - a * r;
+        if (b <= a) S[a * ld + b] = Sin[a * LR_RMAX + b] + (a == b ? c : 0.0);
+    }
+    for (int e = tid; e < r * 3; e += 256) { const int a = e / 3, d = e - a * 3; S[(r + d) * ld + a] = yin[e]; }
+    {   // sumP = sum_i d_i
+        double acc = 0.0;
+        for (int i = tid; i < n; i += 256) acc += dvec[i];
+        acc = wave_sum_d(acc);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) { sc[S_SUMP] = (red[0] + red[1]) + (red[2] + red[3]); sc[S_C] = c; }
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int j0 = 0; j0 < r; j0 += LS_B) {
+        const int nb = min(LS_B, r - j0);
+        // ---- (1) diagonal block factor in registers (every thread), then this thread's panel rows
+        double Ld[LS_B][LS_B];
+#pragma unroll
+        for (int i = 0; i < LS_B; ++i)
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k)
+                Ld[i][k] = (k <= i) ? ((i < nb) ? S[(j0 + i) * ld + j0 + k] : (i == k ? 1.0 : 0.0)) : 0.0;
+#pragma unroll
+        for (int k = 0; k < LS_B; ++k) {
+            const double dk = sqrt(Ld[k][k]);
+            Ld[k][k] = dk;
+            const double ik = 1.0 / dk;
+#pragma unroll
+            for (int i = k + 1; i < LS_B; ++i) Ld[i][k] *= ik;
+#pragma unroll
+            for (int i = k + 1; i < LS_B; ++i)
+#pragma unroll
+                for (int q = k + 1; q <= i; ++q) Ld[i][q] -= Ld[i][k] * Ld[q][k];
+        }
+        for (int a2 = j0 + nb + tid; a2 < ra; a2 += 256) {
+            double x[LS_B];
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) x[k] = (k < nb) ? S[a2 * ld + j0 + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) {
+                double t = x[k];
+#pragma unroll
+                for (int q = 0; q < k; ++q) t -= x[q] * Ld[k][q];
+                x[k] = t / Ld[k][k];
+            }
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) if (k < nb) S[a2 * ld + j0 + k] = x[k];
+        }
+        __syncthreads();
+        // ---- (2) trailing rank-nb update; thread 0 also stores the factored diagonal block
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < LS_B; ++i)
+#pragma unroll
+                for (int k = 0; k < LS_B; ++k) if (i < nb && k <= i) S[(j0 + i) * ld + j0 + k] = Ld[i][k];
+        }
+        const int base = j0 + nb;
+        for (int a2 = base + ty; a2 < ra; a2 += 16) {
+            double La[LS_B];
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) La[k] = (k < nb) ? S[a2 * ld + j0 + k] : 0.0;
+            const int bmax = a2 < r ? a2 : r - 1;
+            for (int b2 = base + tx; b2 <= bmax; b2 += 16) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < LS_B; ++k) t = fma(La[k], (k < nb) ? S[b2 * ld + j0 + k] : 0.0, t);
+                S[a2 * ld + b2] -= t;
+            }
+        }
+        __syncthreads();
+    }
+    // blocked backward substitution L^T q = w (w_d lives in row r+d): 8 unknowns per step; every thread solves the
+    // 8 x 8 triangle redundantly in registers, then thread p < j0 removes their contribution from unknown p.
+    for (int j0 = ((r - 1) / LS_B) * LS_B; j0 >= 0; j0 -= LS_B) {
+        const int nb = min(LS_B, r - j0);
+        double qv[LS_B][3];
+#pragma unroll
+        for (int k = LS_B - 1; k >= 0; --k) {
+            if (k < nb) {
+                double t0 = S[(r + 0) * ld + j0 + k], t1 = S[(r + 1) * ld + j0 + k], t2 = S[(r + 2) * ld + j0 + k];
+#pragma unroll
+                for (int p2 = k + 1; p2 < LS_B; ++p2)
+                    if (p2 < nb) { const double lpk = S[(j0 + p2) * ld + j0 + k]; t0 -= lpk * qv[p2][0]; t1 -= lpk * qv[p2][1]; t2 -= lpk * qv[p2][2]; }
+                const double idk = 1.0 / S[(j0 + k) * ld + j0 + k];
+                qv[k][0] = t0 * idk; qv[k][1] = t1 * idk; qv[k][2] = t2 * idk;
+            } else { qv[k][0] = qv[k][1] = qv[k][2] = 0.0; }
+        }
+        __syncthreads();                                   // every thread has read this step's inputs
+        if (tid < j0) {
+            double u0 = S[(r + 0) * ld + tid], u1 = S[(r + 1) * ld + tid], u2 = S[(r + 2) * ld + tid];
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k)
+                if (k < nb) { const double l = S[(j0 + k) * ld + tid]; u0 -= l * qv[k][0]; u1 -= l * qv[k][1]; u2 -= l * qv[k][2]; }
+            S[(r + 0) * ld + tid] = u0; S[(r + 1) * ld + tid] = u1; S[(r + 2) * ld + tid] = u2;
+        } else if (tid == j0) {
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k)
+                if (k < nb) { S[(r + 0) * ld + j0 + k] = qv[k][0]; S[(r + 1) * ld + j0 + k] = qv[k][1]; S[(r + 2) * ld + j0 + k] = qv[k][2]; }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < r * 3; e += 256) { const int a2 = e / 3, d = e - a2 * 3; qout[e] = S[(r + d) * ld + a2]; }
+}
+
+// C[d][i] = sqrt(d_i) (b~_i - sqrt(d_i) sum_a U[a][i] q[a]) / c ; 64 rows i per block, the rank split over 4 waves
+__global__ __launch_bounds__(256) void lr_coeff_kernel(const double* __restrict__ U, int n, const int* __restrict__ rank_p,
+                                                       const double* __restrict__ q, const double* __restrict__ sqd,
+                                                       const double* __restrict__ rhs, const double* __restrict__ sc,
+                                                       double* __restrict__ C) {
+    if (sc[S_DONE] != 0.0) return;
+    __shared__ double ps[4][64][3];
+    __shared__ double qs[LR_RMAX * 3];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const int r = *rank_p;
+    for (int e = threadIdx.x; e < 3 * r; e += 256) qs[e] = q[e];
+    __syncthreads();
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (i < n)
+        for (int a = wv; a < r; a += 4) {
+            const double u = U[(size_t)a * n + i];
+            ax = fma(u, qs[3 * a], ax); ay = fma(u, qs[3 * a + 1], ay); az = fma(u, qs[3 * a + 2], az);
+        }
+    ps[wv][lane][0] = ax; ps[wv][lane][1] = ay; ps[wv][lane][2] = az;
+    __syncthreads();
+    if (wv == 0 && i < n) {
+        const double c = sc[S_C], s = sqd[i];
+        ax = (ps[0][lane][0] + ps[1][lane][0]) + (ps[2][lane][0] + ps[3][lane][0]);
+        ay = (ps[0][lane][1] + ps[1][lane][1]) + (ps[2][lane][1] + ps[3][lane][1]);
+        az = (ps[0][lane][2] + ps[1][lane][2]) + (ps[2][lane][2] + ps[3][lane][2]);
+        C[i] = s * (rhs[3 * i] - s * ax) / c;
+        C[n + i] = s * (rhs[3 * i + 1] - s * ay) / c;
+        C[2 * n + i] = s * (rhs[3 * i + 2] - s * az) / c;
+    }
 }
 
 // tracker.py:1269-1289: pred[j] += sum_i C[:, i] exp(-|pred_j - inter_i|^2 / 2 beta^2); one wave per j
@@ -767,12 +1165,12 @@ int ct_ffn_create(const float* w, size_t n_floats, int device, ct_ffn_t** out) {
     hipError_t e = hipMalloc((void**)&h->d_w, (n_floats - 1) * sizeof(float));
     if (e != hipSuccess) { delete h; return (int)e; }
     e = hipMemcpy(h->d_w, w, (n_floats - 1) * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(h->d_w); delete h; return (int)e; }
+    if (e != hipSuccess) { (void)hipFree(h->d_w); delete h; return (int)e; }
     *out = h;
     return CT_OK;
 }
 
-void ct_ffn_destroy(ct_ffn_t* h) { if (h) { hipFree(h->d_w); delete h; } }
+void ct_ffn_destroy(ct_ffn_t* h) { if (h) { (void)hipFree(h->d_w); delete h; } }
 
 size_t ct_ffn_workspace_bytes(int n_ref, int n_tgt) {
     if (n_ref <= 0 || n_tgt <= 0) return 0;
@@ -826,23 +1224,29 @@ int ct_ffn_predict(ct_ffn_t* h, const float* x, int rows, float* out, void* work
 // ------------------------------------------------------------------------------------------------ greedy
 size_t ct_greedy_workspace_bytes(int m, int n) {
     if (m <= 0 || n <= 0) return 0;
-    return align_up((size_t)m * 4, 256) * 3 + align_up((size_t)n, 256) + 512;    // row_val, row_col, row_match, col flags
+    return align_up((size_t)m * GR_K * 4, 256) * 2 + align_up((size_t)m * 4, 256) + 512;    // candidate lists + row_match
 }
 
 int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, int32_t* pairs, int32_t* n_pairs,
                     double* prior, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
     if (!corr || !pairs || !n_pairs || !workspace || m <= 0 || n <= 0 || (mode != 0 && mode != 1)) return CT_EINVAL;
-    if (n > 60000) return CT_ESHAPE;
     if (workspace_bytes < ct_greedy_workspace_bytes(m, n)) return CT_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    float* row_val = (float*)ws; ws += align_up((size_t)m * 4, 256);
-    int* row_col = (int*)ws; ws += align_up((size_t)m * 4, 256);
-    int* row_match = (int*)ws; ws += align_up((size_t)m * 4, 256);
-    unsigned char* colf = ws;
-    const size_t lds = align_up((size_t)n, 16) + GR_WAVES * 8 + 16;
+    float* cand_val = (float*)ws; ws += align_up((size_t)m * GR_K * 4, 256);
+    int* cand_col = (int*)ws; ws += align_up((size_t)m * GR_K * 4, 256);
+    int* row_match = (int*)ws;
+    const size_t lds = (size_t)m * 16 + GR_WAVES * 8 + 16 + align_up((size_t)n, 16);
+    if (lds > 150 * 1024) return CT_ESHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)greedy_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(greedy_topk_kernel, dim3((m + 3) / 4), dim3(256), 0, st, corr, m, n, cand_val, cand_col);
+    LAUNCH_CHECK();
     hipLaunchKernelGGL(greedy_match_kernel, dim3(1), dim3(GR_THREADS), lds, st, corr, m, n, threshold, pairs, n_pairs,
-                       row_val, row_col, colf);
+                       cand_val, cand_col);
     LAUNCH_CHECK();
     if (prior) {
         hipLaunchKernelGGL(row_match_kernel, dim3((m + 255) / 256), dim3(256), 0, st, row_match, m);
@@ -860,16 +1264,21 @@ int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, 
 // ------------------------------------------------------------------------------------------------ PR-GLS
 namespace {
 struct PrglsWs {
-    double *G, *Gnl, *M, *P, *part, *dvec, *sqd, *rhs, *C, *predn, *predl, *rowpart, *normpart, *sc;
+    double *G, *Gln, *M, *P, *part, *dvec, *sqd, *rhs, *C, *predn, *predl, *rowpart, *rowpart0, *normpart, *sc;
+    double *U, *Spart, *ypart, *q, *resid, *respart; int* rank;
 };
 size_t prgls_layout(int m, int n, int l, unsigned char* base, PrglsWs* w) {
     size_t off = 0;
     auto take = [&](size_t count) { double* p = base ? (double*)(base + off) : nullptr; off += align_up(count * sizeof(double), 256); return p; };
-    double* G = take((size_t)n * n); double* Gnl = take((size_t)n * (l > 0 ? l : 1)); double* M = take((size_t)n * n);
-    double* P = take((size_t)m * n); double* part = take((size_t)CS_SEG * 4 * n); double* dvec = take(n); double* sqd = take(n);
-    double* rhs = take(3 * (size_t)n); double* C = take(3 * (size_t)n); double* predn = take(3 * (size_t)n);
-    double* predl = take(3 * (size_t)(l > 0 ? l : 1)); double* rowpart = take(m); double* normpart = take(n); double* sc = take(S_NUM);
-    if (w) *w = PrglsWs{G, Gnl, M, P, part, dvec, sqd, rhs, C, predn, predl, rowpart, normpart, sc};
+    const int nblk = (n + 31) / 32;
+    PrglsWs t{};
+    t.G = take((size_t)n * n); t.Gln = take((size_t)n * (l > 0 ? l : 1)); t.M = take((size_t)n * n);
+    t.P = take((size_t)m * n); t.part = take((size_t)CS_SEG * 4 * n); t.dvec = take(n); t.sqd = take(n);
+    t.rhs = take(3 * (size_t)n); t.C = take(3 * (size_t)n); t.predn = take(3 * (size_t)n);
+    t.predl = take(3 * (size_t)(l > 0 ? l : 1)); t.rowpart = take(m); t.rowpart0 = take(m); t.normpart = take(n); t.sc = take(S_NUM);
+    t.U = take((size_t)LR_RMAX * n); t.Spart = take((size_t)LR_RMAX * LR_RMAX); t.ypart = take((size_t)LR_RMAX * 3); (void)nblk;
+    t.q = take(LR_RMAX * 3); t.resid = take(n); t.respart = take(2 * (size_t)n); t.rank = (int*)take(8);
+    if (w) *w = t;
     return off;
 }
 
@@ -891,13 +1300,27 @@ int cholesky_solve(const PrglsWs& w, int n, hipStream_t st) {
     return CT_OK;
 }
 
-// one E-step + M-step solve; leaves C in w.C and sumP in the scalar block
+// one E-step + M-step solve; leaves C in w.C and sumP in the scalar block.
+// rank > 0: low-rank Woodbury M-step (4 launches); rank <= 0: dense blocked Cholesky.
 int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int n, const double* xref, double lambda,
-            int legacy, double vol, hipStream_t st) {
-    hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4), dim3(256), 0, st, prior, w.predn, n, tgt, m, w.sc, legacy, vol, w.P);
+            int legacy, double vol, int rank, hipStream_t st) {
+    hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4), dim3(256), 0, st, prior, w.predn, n, tgt, m, w.sc, legacy, vol, w.P, 0.0, 0.0);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(colstats_kernel, dim3((n + 63) / 64, CS_SEG), dim3(64), 0, st, w.P, tgt, m, n, w.part);
+    hipLaunchKernelGGL(colstats_kernel, dim3((n + 63) / 64, CS_SEG), dim3(256), 0, st, w.P, tgt, m, n, w.part, w.sc);
     LAUNCH_CHECK();
+    if (rank > 0) {
+        hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((n + 63) / 64), dim3(256), 0, st, w.part, n, xref, w.sc, w.dvec, w.sqd, w.rhs);
+        LAUNCH_CHECK();
+        const int nent = rank * (rank + 1) / 2 + 3 * rank;
+        hipLaunchKernelGGL(lr_gram_kernel, dim3((nent + 3) / 4), dim3(256), 0, st, n, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs, w.Spart, w.ypart);
+        LAUNCH_CHECK();
+        const size_t lds = (size_t)(rank + 3) * (rank | 1) * sizeof(double);
+        hipLaunchKernelGGL(lr_solve_kernel, dim3(1), dim3(256), lds, st, w.Spart, w.ypart, n, w.rank, lambda, w.dvec, w.sc, w.q);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(lr_coeff_kernel, dim3((n + 63) / 64), dim3(256), 0, st, w.U, n, w.rank, w.q, w.sqd, w.rhs, w.sc, w.C);
+        LAUNCH_CHECK();
+        return CT_OK;
+    }
     hipLaunchKernelGGL(colstats_finish_kernel, dim3(1), dim3(256), 0, st, w.part, n, xref, lambda, w.sc, w.dvec, w.sqd, w.rhs);
     LAUNCH_CHECK();
     const size_t nn = (size_t)n * n;
@@ -905,6 +1328,24 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
     LAUNCH_CHECK();
     return cholesky_solve(w, n, st);
 }
+
+// pivoted Cholesky of w.G -> w.U; returns the rank (host value; one stream sync), <= 0 => use the dense path
+int lowrank_prepare(const PrglsWs& w, int n, double tol, hipStream_t st, int* rank_out) {
+    static bool attr_set = false;      // r x r system (r <= 128) lives in LDS: needs more than the 64 KiB default
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)lr_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1), dim3(1024), 0, st, w.G, n, tol, w.U, w.resid, w.rank);
+    LAUNCH_CHECK();
+    int r = 0;
+    HIPCHK(hipMemcpyAsync(&r, w.rank, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *rank_out = r;
+    return CT_OK;
+}
+constexpr double kLowRankTol = 1e-10;     // |G - U^T U|_max; diag(G) = 1
+constexpr double kLowRankMaxResidual = 1e-6;   // accepted relative residual of the exact system (monitored every iteration)
 }  // namespace
 
 size_t ct_prgls_workspace_bytes(int m, int n, int l) {
@@ -924,46 +1365,66 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
     prgls_layout(m, n, l, (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), &w);
     const size_t nn = (size_t)n * n;
     // init (trackerlite.py:319-325): gamma 0.05, Gram matrices with beta^2, sigma2 = mean d2 / 3, T(X) = X
-    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ref, n, ref, n, 2.0 * beta * beta, w.G);
+    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ref, n, ref, n, 2.0 * beta * beta, w.G, 0);
     LAUNCH_CHECK();
-    if (l > 0) {
+    if (l > 0) {   // tracked-set kernel stored transposed [l][n] so that the field application reads rows
         const size_t nl = (size_t)n * l;
-        hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, tracked, l, ref, n, 2.0 * beta * beta, w.Gnl);
+        hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, ref, n, tracked, l, 2.0 * beta * beta, w.Gln, 0);
         LAUNCH_CHECK();
         HIPCHK(hipMemcpyAsync(w.predl, tracked, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
     HIPCHK(hipMemcpyAsync(w.predn, ref, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     double init_sc[S_NUM] = {0.0, 0.05, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     HIPCHK(hipMemcpyAsync(w.sc, init_sc, sizeof(init_sc), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, ref, n, tgt, m, (const double*)nullptr, w.rowpart);
+    hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, ref, n, tgt, m, (const double*)nullptr, w.rowpart0,
+                       (const double*)nullptr);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 0, w.sc);
+    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart0, m, n, 0, w.sc, (const double*)nullptr, (const double*)nullptr);
     LAUNCH_CHECK();
-    int it = 0, rc;
-    for (it = 1; it < max_iteration; ++it) {
-        if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, st))) return rc;
-        // movements (skipped on iteration 1: "the first estimation is not reliable", trackerlite.py:339-341)
-        hipLaunchKernelGGL(apply_field_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w.C, w.G, n, n, w.predn, (const double*)nullptr,
-                           it > 1 ? 1 : 0, w.normpart);
-        LAUNCH_CHECK();
-        if (l > 0 && it > 1) {
-            hipLaunchKernelGGL(apply_field_kernel, dim3((l + 3) / 4), dim3(256), 0, st, w.C, w.Gnl, n, l, w.predl, (const double*)nullptr,
-                               1, (double*)nullptr);
+    int rank = 0, rc;
+    if ((rc = lowrank_prepare(w, n, kLowRankTol, st, &rank))) return rc;
+    if (getenv("CT_PRGLS_DENSE")) rank = 0;
+    // EM iterations are enqueued in chunks; every kernel returns immediately once the device-side
+    // convergence flag is set, the host looks at the flag once per chunk (trackerlite.py:353-356).
+    // The low-rank M-step is verified on the fly against the exact Gram matrix (S_RES); if its residual
+    // is not negligible the whole loop is redone with the dense Cholesky M-step.
+    const int total = max_iteration - 1;
+    int done_iters = 0;
+    double hsc[S_NUM] = {0};
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt == 1) {      // restart from the initial state with the dense path
+            rank = 0;
+            HIPCHK(hipMemcpyAsync(w.predn, ref, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (l > 0) HIPCHK(hipMemcpyAsync(w.predl, tracked, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(w.sc, init_sc, sizeof(init_sc), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart0, m, n, 0, w.sc, (const double*)nullptr, (const double*)nullptr);
             LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, st, w.normpart, n, w.sc + S_NORM2);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, tgt, m, w.P, w.rowpart);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 1, w.sc);
-        LAUNCH_CHECK();
-        double norm2 = 0.0;
-        HIPCHK(hipMemcpyAsync(&norm2, w.sc + S_NORM2, sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (sqrt(norm2) < 1e-3) break;                                  // trackerlite.py:353-356
+        for (int enq = 0; enq < total;) {
+            const int chunk = (total - enq) < 16 ? (total - enq) : 16;
+            for (int k = 0; k < chunk; ++k) {
+                if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, rank, st))) return rc;
+                hipLaunchKernelGGL(apply_dual_kernel, dim3((n + l + 3) / 4), dim3(256), 0, st, w.C, w.G, n, w.predn, w.Gln, l, w.predl,
+                                   w.normpart, w.sc, w.dvec, w.sqd, w.rhs, rank > 0 ? w.respart : (double*)nullptr);
+                LAUNCH_CHECK();
+                hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, tgt, m, w.P, w.rowpart, w.sc);
+                LAUNCH_CHECK();
+                hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 1, w.sc, w.normpart,
+                                   rank > 0 ? w.respart : (const double*)nullptr);
+                LAUNCH_CHECK();
+            }
+            enq += chunk;
+            HIPCHK(hipMemcpyAsync(hsc, w.sc, sizeof(hsc), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            done_iters = (int)hsc[S_IT];
+            if (hsc[S_DONE] != 0.0 || (rank > 0 && hsc[S_RES] > kLowRankMaxResidual)) break;
+        }
+        if (getenv("CT_DEBUG"))
+            fprintf(stderr, "[ct_prgls_two_ref] attempt %d rank %d iterations %d done %g residual %.3e sigma2 %.6e norm2 %.3e\n",
+                    attempt, rank, done_iters, hsc[S_DONE], hsc[S_RES], hsc[S_SIGMA2], hsc[S_NORM2]);
+        if (!(rank > 0 && hsc[S_RES] > kLowRankMaxResidual)) break;
     }
-    if (it >= max_iteration) it = max_iteration - 1;
-    if (iters) *iters = it;
+    if (iters) *iters = done_iters;
     if (l > 0) HIPCHK(hipMemcpyAsync(out_tracked, w.predl, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (out_ref) HIPCHK(hipMemcpyAsync(out_ref, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (posterior) HIPCHK(hipMemcpyAsync(posterior, w.P, (size_t)m * n * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -987,24 +1448,29 @@ int ct_prgls_legacy(const double* X, int n, const double* Y, int m, const float*
     int rc = ct_greedy_match(corr, m, n, 0.5f, 1, pairs, npairs, prior, gws, ct_greedy_workspace_bytes(m, n), stream);
     if (rc) return rc;
     const size_t nn = (size_t)n * n;
-    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, X, n, X, n, 2.0 * BETA * BETA, w.G);
+    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, X, n, X, n, 2.0 * BETA * BETA, w.G, 0);
     LAUNCH_CHECK();
     HIPCHK(hipMemcpyAsync(w.predn, X, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     double init_sc[S_NUM] = {0.0, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // gamma0 = 0.1 (track.py:41)
     HIPCHK(hipMemcpyAsync(w.sc, init_sc, sizeof(init_sc), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(w.C, 0, 3 * (size_t)n * sizeof(double), st));
-    hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, X, n, Y, m, (const double*)nullptr, w.rowpart);
+    hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, X, n, Y, m, (const double*)nullptr, w.rowpart,
+                       (const double*)nullptr);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 0, w.sc);
+    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 0, w.sc, (const double*)nullptr, (const double*)nullptr);
     LAUNCH_CHECK();
+    // dense M-step only: with LAMBDA ~ 1e-5 the coefficients C reach ~1e5 with massive cancellation in C.G,
+    // which amplifies any truncation of the Gram matrix beyond the parity budget
+    const int rank = 0;
     for (int it = 1; it < max_iteration; ++it) {
-        if ((rc = em_half(w, prior, Y, m, n, X, LAMBDA, 1, vol, st))) return rc;
+        if ((rc = em_half(w, prior, Y, m, n, X, LAMBDA, 1, vol, rank, st))) return rc;
         // T_X = X + (C G)^T recomputed from X (track.py:100)
-        hipLaunchKernelGGL(apply_field_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w.C, w.G, n, n, w.predn, X, 2, (double*)nullptr);
+        hipLaunchKernelGGL(apply_field_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w.C, w.G, n, n, w.predn, X, 2, (double*)nullptr,
+                           (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, Y, m, w.P, w.rowpart);
+        hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, Y, m, w.P, w.rowpart, (const double*)nullptr);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 2, w.sc);
+        hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 2, w.sc, (const double*)nullptr, (const double*)nullptr);
         LAUNCH_CHECK();
     }
     if (P) HIPCHK(hipMemcpyAsync(P, w.P, (size_t)m * n * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1048,7 +1514,7 @@ int ct_solve_movements(double sigma_square, double lambda, const double* P, cons
     prgls_layout(m, n, 0, (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), &w);
     double init_sc[S_NUM] = {sigma_square, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     HIPCHK(hipMemcpyAsync(w.sc, init_sc, sizeof(init_sc), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(colstats_kernel, dim3((n + 63) / 64, CS_SEG), dim3(64), 0, st, P, tgt, m, n, w.part);
+    hipLaunchKernelGGL(colstats_kernel, dim3((n + 63) / 64, CS_SEG), dim3(256), 0, st, P, tgt, m, n, w.part, (const double*)nullptr);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(colstats_finish_kernel, dim3(1), dim3(256), 0, st, w.part, n, ref, lambda, w.sc, w.dvec, w.sqd, w.rhs);
     LAUNCH_CHECK();

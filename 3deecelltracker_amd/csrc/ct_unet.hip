@@ -394,6 +394,10 @@ struct ct_unet {
     float* d_weights;                // device arena
     size_t first_w_off, head_off;    // float offsets
     size_t arena_floats;
+    // optional per-launch HIP-event timing (bench.py roofline): pairs recorded on the launch stream
+    bool timing;
+    std::vector<hipEvent_t> ev_pool;          // 2 events per timed launch
+    std::vector<int> ev_layer;                // conv index of each timed launch
 };
 
 namespace {
@@ -438,9 +442,58 @@ int launch_conv(const ConvArgs& a, int P, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+struct TimedScope {     // records an event pair around one launch when the handle has timing enabled
+    ct_unet* h; hipStream_t st; hipEvent_t e1 = nullptr;
+    TimedScope(ct_unet* h_, int layer, hipStream_t st_);
+    ~TimedScope() { if (e1) (void)hipEventRecord(e1, st); }
+};
+
 }  // namespace
 
+TimedScope::TimedScope(ct_unet* h_, int layer, hipStream_t st_) : h(h_), st(st_) {
+    if (!h->timing || h->ev_layer.size() >= 200000) return;
+    hipEvent_t e0;
+    if (hipEventCreate(&e0) != hipSuccess) return;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); e1 = nullptr; return; }
+    h->ev_pool.push_back(e0); h->ev_pool.push_back(e1); h->ev_layer.push_back(layer);
+    (void)hipEventRecord(e0, st);
+}
+
 extern "C" {
+
+int ct_unet_num_conv_layers(const ct_unet_t* h) { return h ? (int)h->convs.size() : 0; }
+
+int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int dims_xyz[3], int* nt) {
+    if (!h || layer < 0 || layer >= (int)h->convs.size()) return CT_EINVAL;
+    const ConvPlan& c = h->convs[layer];
+    if (cin) *cin = c.cin;
+    if (cout) *cout = c.cout;
+    if (nt) *nt = layer == 0 ? 0 : c.NT;
+    if (dims_xyz) for (int i = 0; i < 3; ++i) dims_xyz[i] = h->dims[c.level][i];
+    return CT_OK;
+}
+
+int ct_unet_set_timing(ct_unet_t* h, int enable) {
+    if (!h) return CT_EINVAL;
+    h->timing = enable != 0;
+    return CT_OK;
+}
+
+// Synchronises the device, sums the elapsed time of every timed launch per conv layer, clears the log.
+int ct_unet_get_timing(ct_unet_t* h, float* ms_per_layer, int* launches_per_layer, int n_layers) {
+    if (!h || !ms_per_layer || !launches_per_layer || n_layers < (int)h->convs.size()) return CT_EINVAL;
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i < n_layers; ++i) { ms_per_layer[i] = 0.f; launches_per_layer[i] = 0; }
+    for (size_t k = 0; k < h->ev_layer.size(); ++k) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[2 * k], h->ev_pool[2 * k + 1]) == hipSuccess) {
+            ms_per_layer[h->ev_layer[k]] += ms; launches_per_layer[h->ev_layer[k]] += 1;
+        }
+        (void)hipEventDestroy(h->ev_pool[2 * k]); (void)hipEventDestroy(h->ev_pool[2 * k + 1]);
+    }
+    h->ev_pool.clear(); h->ev_layer.clear();
+    return CT_OK;
+}
 
 size_t ct_unet_num_weights(int arch_id) {
     if (arch_id < 0 || arch_id > 2) return 0;
@@ -477,6 +530,7 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
     HIPCHK(hipSetDevice(device));
     ct_unet* h = new (std::nothrow) ct_unet();
     if (!h) return CT_EINVAL;
+    h->timing = false;
     h->arch_id = arch_id; h->device = device; h->ad = kArch[arch_id];
     const ArchDesc& ad = h->ad;
     h->nlevels = ad.ndown + 1;
@@ -577,14 +631,15 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
     hipError_t e = hipMalloc((void**)&h->d_weights, arena.size() * sizeof(float));
     if (e != hipSuccess) { delete h; return (int)e; }
     e = hipMemcpy(h->d_weights, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(h->d_weights); delete h; return (int)e; }
+    if (e != hipSuccess) { (void)hipFree(h->d_weights); delete h; return (int)e; }
     *out = h;
     return CT_OK;
 }
 
 void ct_unet_destroy(ct_unet_t* h) {
     if (!h) return;
-    hipFree(h->d_weights);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    (void)hipFree(h->d_weights);
     delete h;
 }
 
@@ -603,6 +658,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
     for (size_t i = 0; i < h->convs.size(); ++i) {
         const ConvPlan& c = h->convs[i];
         const int* d = h->dims[c.level];
+        TimedScope timed(h, (int)i, st);
         if (i == 0) {
             const size_t nvox = (size_t)P * d[0] * d[1] * d[2];
             const unsigned nblk = (unsigned)((nvox + 255) / 256);

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: volumes/s, segment + match, 512x512x32 stack, ~600 cells.
+
+One "step" = one frame: 3D U-Net sliding-window inference of a synthetic 512x512x32 stack (75
+patches of unet3_a, reflect pad + stitch on device) AND one TrackerLite-style match of two ~600-point
+sets (kNN features -> FFN all pairs -> greedy prior -> PR-GLS), inputs resident in HBM.
+N GPUs: frames are independent units -> every rank processes its own frame per step (weak scaling),
+followed by the all-gather of the tracked centroid sets (RCCL).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events recorded on the launch
+stream around every launch of the dominant kernel (conv3_mfma_kernel instantiation with the largest
+share of time); `cpu_baseline` times the numpy oracle (reference formulation) on the host cores on a
+bounded sample at N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+PKG = "3deecelltracker_amd"
+FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 = fp32 vector peak
+HBM_PEAK_TBS = 8.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shape", type=int, nargs=3, default=(512, 512, 32))
+    ap.add_argument("--cells", type=int, default=600)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-patches", type=int, default=2, help="U-Net patches timed by the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+
+    arch = importlib.import_module(f"{PKG}.arch").UNET3_A
+    synth = importlib.import_module(f"{PKG}.synth")
+    unet3d = importlib.import_module(f"{PKG}.unet3d")
+    ffn_mod = importlib.import_module(f"{PKG}.ffn")
+    tl = importlib.import_module(f"{PKG}.trackerlite")
+    _dev = importlib.import_module(f"{PKG}._dev")
+    _lib = importlib.import_module(f"{PKG}._lib")
+    L = _lib.lib()
+
+    # ---- synthetic, seeded inputs (different frame per rank), resident in HBM before timing
+    shape = tuple(args.shape)
+    unet_w = synth.make_unet_weights("unet3_a", seed=0)
+    ffn_w = synth.make_ffn_weights(seed=0)
+    model = unet3d.unet3_a(device=local).set_weights_dict(unet_w)
+    ffn = ffn_mod.FFN(device=local).set_weights_dict(ffn_w)
+    stack, _ = synth.make_stack(shape, n_cells=args.cells, seed=rank)
+    vol = torch.from_numpy(np.ascontiguousarray(synth.normalize_stack(stack)[0, :, :, :, 0])).to(dev)
+    prob = torch.zeros_like(vol)
+    x, y = synth.make_point_pair(args.cells, seed=100 + rank, box=shape, voxel_size=(1.0, 1.0, 4.0))
+    xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True)
+    yn = (y - mean) / scale
+    seg1, seg2, conf = _dev.points_dev(xn, dev), _dev.points_dev(yn, dev), _dev.points_dev(xn, dev)
+    centre, grid = unet3d.tile_plan(shape, arch.input_shape, (24, 24, 2))
+    n_patches = grid[0] * grid[1] * grid[2]
+
+    s_seg, s_match = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    gather_buf = [torch.empty((args.cells, 3), dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+    iters_log = []
+
+    def step():
+        with torch.cuda.stream(s_seg):
+            model.predict_volume_device(vol, out=prob)
+        with torch.cuda.stream(s_match):
+            tracked, iters = tl.match_device(ffn, seg1, seg2, conf, beta=3, lambda_=3)
+            if world > 1:
+                dist.all_gather(gather_buf, tracked)           # "gather of centroid sets" (14 KB / rank)
+        iters_log.append(iters)
+        return tracked
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    L.ct_unet_set_timing(model._handle, 1)
+    iters_log.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    L.ct_unet_set_timing(model._handle, 0)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- roofline of the dominant kernel from the live HIP-event log
+    nl = L.ct_unet_num_conv_layers(model._handle)
+    ms = (C.c_float * nl)(); cnt = (C.c_int * nl)()
+    _lib.check(L.ct_unet_get_timing(model._handle, ms, cnt, nl), "ct_unet_get_timing")
+    by_kernel = {}
+    layers = []
+    for i in range(nl):
+        cin, cout, nt = C.c_int(), C.c_int(), C.c_int(); d = (C.c_int * 3)()
+        L.ct_unet_layer_info(model._handle, i, C.byref(cin), C.byref(cout), d, C.byref(nt))
+        flops = 2.0 * d[0] * d[1] * d[2] * 27 * cin.value * cout.value * n_patches       # per launch (one volume)
+        abytes = 4.0 * d[0] * d[1] * d[2] * (cin.value + cout.value) * n_patches
+        name = "conv_first_kernel" if i == 0 else f"conv3_mfma_kernel<{nt.value}>"
+        k = by_kernel.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+        k["ms"] += ms[i]; k["launches"] += cnt[i]; k["flops"] += flops * cnt[i]; k["bytes"] += abytes * cnt[i]
+        layers.append({"layer": i, "cin": cin.value, "cout": cout.value, "dims": [d[0], d[1], d[2]], "kernel": name,
+                       "ms": round(ms[i] / max(cnt[i], 1), 4),
+                       "tflops": round(flops * cnt[i] / max(ms[i], 1e-9) / 1e9, 2),
+                       "gbps": round(abytes * cnt[i] / max(ms[i], 1e-9) / 1e6, 1)})
+    dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
+    dom = by_kernel[dom_name]
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    conv_ms_total = sum(k["ms"] for k in by_kernel.values()) / max(args.steps, 1)
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": None, "kernel": dom_name,
+                "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4), "launches": dom["launches"],
+                "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
+                "conv_stack_ms_per_volume": round(conv_ms_total, 3),
+                "conv_stack_tflops": round(n_patches * arch.flops_per_patch() / (conv_ms_total * 1e-3) / 1e12, 2) if conv_ms_total else None,
+                "conv_stack_hbm_frac": round(n_patches * arch.algorithmic_bytes_per_patch() / (conv_ms_total * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if conv_ms_total else None}
+
+    # ---- CPU baseline: the numpy oracle (reference formulation) on the host cores, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import match_ref as mr
+        from oracle import unet_ref as ur
+        rng = np.random.default_rng(0)
+        plan = ur.tile_plan(shape, arch.input_shape, arch.input_shape, (24, 24, 2))
+        vol_h = vol.cpu().numpy()
+        patches = ur.gather_patches(vol_h, plan)[:args.cpu_patches]
+        tp = time.perf_counter()
+        for p in patches:
+            ur.unet_forward(p, unet_w, arch)
+        t_patch = (time.perf_counter() - tp) / len(patches)
+        tm = time.perf_counter()
+        corr = mr.initial_matching(lambda q: mr.ffn_forward(ffn_w, q), xn, yn, 20)
+        prior, _ = mr.simple_match(corr)
+        _, _, it_cpu = mr.prgls_with_two_ref(prior, yn, xn, xn, beta=3, lambda_=3, return_iters=True)
+        t_match = time.perf_counter() - tm
+        t_vol = n_patches * t_patch + t_match
+        cpu = {"value": round(1.0 / t_vol, 6), "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"{len(patches)} of {n_patches} unet3_a patches ({t_patch:.2f} s/patch, numpy fp32 shifted-matmul conv) "
+                         f"+ one full {args.cells}-cell match ({t_match:.2f} s, {it_cpu} PR-GLS iterations); "
+                         f"volume time extrapolated as {n_patches} x patch + match"}
+
+    if rank == 0:
+        value = world * args.steps / dt
+        out = {
+            "metric": "volumes/s segment+match, 512x512x32 stack ~600 cells",
+            "value": round(value, 3), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (U-Net, FFN) / f64 (PR-GLS)", "data": "synthetic",
+            "config": {"workload": f"{shape[0]}x{shape[1]}x{shape[2]} synthetic stack, unet3_a sliding window "
+                                   f"({n_patches} patches, shrink 24,24,2) + {args.cells}-cell TrackerLite match "
+                                   f"(FFN all pairs, greedy prior, PR-GLS beta=lambda=3), seeded random-init weights",
+                       "patches_per_volume": n_patches, "cells": args.cells,
+                       "prgls_iterations": int(np.median(iters_log)) if iters_log else None,
+                       "parallelism": f"frames sharded, {world} rank(s), all-gather of tracked centroids"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "layers": layers,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,6 +71,15 @@ int    ct_unet_predict_patches(ct_unet_t* h, const float* patches_in, int n_patc
                                void* workspace, size_t workspace_bytes, float* layer_dump, ct_stream_t stream);
 size_t ct_unet_layer_dump_floats(int arch_id);
 
+/* Introspection + optional per-launch timing used by bench.py's roofline measurement: when enabled,
+ * every conv launch is bracketed by a hipEvent pair recorded on the launch stream; ct_unet_get_timing
+ * synchronises, returns the summed milliseconds and launch counts per conv layer (layer 0 is the
+ * Cin=1 VALU conv, layers >= 1 the MFMA conv with `nt` cout tiles per block) and clears the log.     */
+int ct_unet_num_conv_layers(const ct_unet_t* h);
+int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int dims_xyz[3], int* nt);
+int ct_unet_set_timing(ct_unet_t* h, int enable);
+int ct_unet_get_timing(ct_unet_t* h, float* ms_per_layer, int* launches_per_layer, int n_layers);
+
 /* Sliding-window tiler (replaces np.pad(..., 'reflect') + the patch loop + centre-crop stitch of
  * unet3_prediction, unet3d.py:221-255).  Patch p in [p_begin, p_begin+n) enumerates
  * itertools.product(range(gx), range(gy), range(gz)).

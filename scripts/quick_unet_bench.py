@@ -1,7 +1,7 @@
 """Quick timing of the U-Net volume path (dev helper, not the contract bench)."""
 import importlib, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 synth = importlib.import_module("3deecelltracker_amd.synth")
 unet3d = importlib.import_module("3deecelltracker_amd.unet3d")
 arch = importlib.import_module("3deecelltracker_amd.arch").UNET3_A
