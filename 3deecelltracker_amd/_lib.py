@@ -26,6 +26,8 @@ SIGNATURES = {
     "ct_version": (_i, []),
     "ct_error_string": (C.c_char_p, [_i]),
     "ct_device_info": (_i, [_i, _ip, C.POINTER(_sz), C.c_char_p, _sz]),
+    "ct_stream_create_cu_range": (_i, [_i, _i, _i, C.POINTER(_vp)]),
+    "ct_stream_destroy": (_i, [_vp]),
     "ct_unet_create": (_i, [_i, _vp, _sz, _i, C.POINTER(_vp)]),
     "ct_unet_destroy": (None, [_vp]),
     "ct_unet_num_weights": (_sz, [_i]),

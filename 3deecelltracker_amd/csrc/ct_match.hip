@@ -247,121 +247,114 @@ __global__ __launch_bounds__(64) void ffn_rows_finish_kernel(const float* __rest
 // column is the lowest column) then a re-scan of only those rows whose cached column was taken.
 // Equivalent to the reference's repeated global arg-max with first-occurrence tie-breaking.
 // ------------------------------------------------------------------------------------------------
-constexpr int GR_THREADS = 256, GR_WAVES = GR_THREADS / 64, GR_K = 8;
+// The reference repeats "global arg-max (first occurrence on ties) -> record -> clear its row and column" up to n
+// times: inherently sequential.  With the strict total order  e1 > e2  <=>  (value1 > value2) or (equal values and
+// flat index1 < flat index2)  the greedy matching is exactly the set obtained by repeatedly accepting every
+// LOCALLY DOMINANT edge (best of its row AND best of its column among the still-free rows/columns): the current
+// global maximum is always locally dominant, and accepting another dominant edge first never changes what the
+// sequential loop would pick.  Each round is three data-parallel kernels; the number of rounds is O(log n) for
+// generic inputs.  The threshold test of the reference (stop at the first maximum below it) == never accept an
+// edge below it.  A final sort by the same order recovers the reference's pick sequence.
+constexpr int GD_ROWLANES = 16;
+enum { GD_COUNT = 0, GD_NEW = 1, GD_DONE = 2 };
 
-// (value desc, column asc) arg-max of one row over columns not in `col_used` and "after" (pv, pc) in that order
-__device__ __forceinline__ void row_scan(const float* __restrict__ row, int n, const unsigned char* col_used, int lane,
-                                         float pv, int pc, float& best, int& bi) {
-    best = -1.f; bi = 0x7fffffff;
+__global__ __launch_bounds__(256) void gd_rowbest_kernel(const float* __restrict__ corr, int m, int n,
+                                                         const unsigned char* __restrict__ row_used,
+                                                         const unsigned char* __restrict__ col_used,
+                                                         float* __restrict__ rowval, int* __restrict__ rowcol,
+                                                         int* __restrict__ ctr) {
+    if (ctr[GD_DONE]) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= m) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr[GD_NEW] = 0;      // reset for this round's accept kernel
+    if (row_used[t]) { if (lane == 0) rowcol[t] = -1; return; }
+    const float* row = corr + (size_t)t * n;
+    float best = -1.f; int bi = 0x7fffffff;
     for (int c = lane; c < n; c += 64) {
-        if (col_used && col_used[c]) continue;
+        if (col_used[c]) continue;
         const float v = row[c];
-        if (!(v < pv || (v == pv && c > pc))) continue;          // strictly after the previous candidate
-        if (v > best) { best = v; bi = c; }
+        if (v > best) { best = v; bi = c; }                           // ascending c => lowest column on ties
     }
 #pragma unroll
     for (int mk = 32; mk >= 1; mk >>= 1) {
         const float ov = __shfl_xor(best, mk); const int oi = __shfl_xor(bi, mk);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
+    if (lane == 0) { rowval[t] = best; rowcol[t] = (bi == 0x7fffffff) ? -1 : bi; }
 }
 
-// stage 1 (whole GPU): the GR_K best (value, column) candidates of every row, in the order the reference's
-// repeated arg-max would visit them (value descending, first occurrence = lowest column on ties).
-__global__ __launch_bounds__(256) void greedy_topk_kernel(const float* __restrict__ corr, int m, int n,
-                                                          float* __restrict__ cand_val, int* __restrict__ cand_col) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wave;
-    if (t >= m) return;
-    float pv = INFINITY; int pc = -1;
-    for (int k = 0; k < GR_K; ++k) {
-        float b; int bi;
-        row_scan(corr + (size_t)t * n, n, nullptr, lane, pv, pc, b, bi);
-        if (lane == 0) { cand_val[(size_t)t * GR_K + k] = (bi == 0x7fffffff) ? -2.f : b; cand_col[(size_t)t * GR_K + k] = bi; }
-        if (bi == 0x7fffffff) { for (int q = k + 1; q < GR_K && lane == 0; ++q) { cand_val[(size_t)t * GR_K + q] = -2.f; cand_col[(size_t)t * GR_K + q] = 0x7fffffff; } break; }
-        pv = b; pc = bi;
+__global__ __launch_bounds__(64 * GD_ROWLANES) void gd_colbest_kernel(const float* __restrict__ corr, int m, int n,
+                                                                      const unsigned char* __restrict__ row_used,
+                                                                      const unsigned char* __restrict__ col_used,
+                                                                      int* __restrict__ colrow, const int* __restrict__ ctr) {
+    if (ctr[GD_DONE]) return;
+    __shared__ float sv[GD_ROWLANES][64];
+    __shared__ int si[GD_ROWLANES][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + cl;
+    float best = -1.f; int bt = 0x7fffffff;
+    if (r < n && !col_used[r])
+        for (int t = rl; t < m; t += GD_ROWLANES) {
+            if (row_used[t]) continue;
+            const float v = corr[(size_t)t * n + r];
+            if (v > best) { best = v; bt = t; }                       // ascending t => lowest row on ties
+        }
+    sv[rl][cl] = best; si[rl][cl] = bt;
+    __syncthreads();
+    if (rl == 0 && r < n) {
+        for (int q = 1; q < GD_ROWLANES; ++q) {
+            const float ov = sv[q][cl]; const int oi = si[q][cl];
+            if (ov > best || (ov == best && oi < bt)) { best = ov; bt = oi; }
+        }
+        colrow[r] = (bt == 0x7fffffff) ? -1 : bt;
     }
 }
 
-// stage 2 (single workgroup; the loop is inherently sequential): every step = block arg-max over the rows'
-// current candidates (ties -> lowest row, whose candidate is its lowest free column) -> pair -> rows whose
-// candidate column was taken advance along their list; an exhausted list is refilled by a wave re-scan.
-// Equivalent to the reference's repeated global arg-max with first-occurrence tie-breaking.
-__global__ __launch_bounds__(GR_THREADS) void greedy_match_kernel(const float* __restrict__ corr, int m, int n, float thr,
-                                                                  int32_t* __restrict__ pairs, int32_t* __restrict__ n_pairs,
-                                                                  float* __restrict__ cand_val, int* __restrict__ cand_col) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: cur_val[m] | cur_col[m] | ptr[m] | redv | redi | bc[4] | todo[m] | col_used[n]
-    float* cur_val = reinterpret_cast<float*>(smem);
-    int* cur_col = reinterpret_cast<int*>(cur_val + m);
-    int* ptr = cur_col + m;
-    float* redv = reinterpret_cast<float*>(ptr + m);
-    int* redi = reinterpret_cast<int*>(redv + GR_WAVES);
-    int* bc = redi + GR_WAVES;            // bc[0] = chosen row, bc[1] = chosen col, bc[2] = stop flag, bc[3] = todo count
-    int* todo = bc + 4;
-    unsigned char* col_used = reinterpret_cast<unsigned char*>(todo + m);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < n; c += GR_THREADS) col_used[c] = 0;
-    for (int t = tid; t < m; t += GR_THREADS) { cur_val[t] = cand_val[(size_t)t * GR_K]; cur_col[t] = cand_col[(size_t)t * GR_K]; ptr[t] = 0; }
-    if (tid == 0) bc[3] = 0;
+__global__ __launch_bounds__(256) void gd_accept_kernel(int m, int n, float thr, const float* __restrict__ rowval,
+                                                        const int* __restrict__ rowcol, const int* __restrict__ colrow,
+                                                        unsigned char* __restrict__ row_used, unsigned char* __restrict__ col_used,
+                                                        unsigned long long* __restrict__ keys, int* __restrict__ ctr) {
+    if (ctr[GD_DONE]) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= m || row_used[t]) return;
+    const int r = rowcol[t];
+    const float v = rowval[t];
+    if (r < 0 || !(v >= thr) || colrow[r] != t) return;
+    row_used[t] = 1; col_used[r] = 1;
+    const int k = atomicAdd(&ctr[GD_COUNT], 1);
+    atomicAdd(&ctr[GD_NEW], 1);
+    const unsigned flat = (unsigned)t * (unsigned)n + (unsigned)r;
+    keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
+}
+
+__global__ void gd_round_end_kernel(int* __restrict__ ctr) { if (ctr[GD_NEW] == 0) ctr[GD_DONE] = 1; }
+
+// single workgroup: bitonic sort of the accepted keys (descending) -> pairs in the reference's pick order
+__global__ __launch_bounds__(1024) void gd_finalize_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ ctr,
+                                                           int n, int32_t* __restrict__ pairs, int32_t* __restrict__ n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
+    const int cnt = ctr[GD_COUNT];
+    int p2 = 1; while (p2 < cnt) p2 <<= 1;
+    for (int i = threadIdx.x; i < p2; i += 1024) sk[i] = i < cnt ? keys[i] : 0ull;
     __syncthreads();
-    int np = 0;
-    for (int it = 0; it < n; ++it) {
-        float best = -1.f; int bt = 0x7fffffff;
-        for (int t = tid; t < m; t += GR_THREADS) {
-            const float v = cur_val[t];
-            if (v > best) { best = v; bt = t; }
-        }
-#pragma unroll
-        for (int mk = 32; mk >= 1; mk >>= 1) {
-            const float ov = __shfl_xor(best, mk); const int oi = __shfl_xor(bt, mk);
-            if (ov > best || (ov == best && oi < bt)) { best = ov; bt = oi; }
-        }
-        if (lane == 0) { redv[wave] = best; redi[wave] = bt; }
-        __syncthreads();
-        if (tid == 0) {
-            float v = redv[0]; int t = redi[0];
-            for (int w2 = 1; w2 < GR_WAVES; ++w2) if (redv[w2] > v || (redv[w2] == v && redi[w2] < t)) { v = redv[w2]; t = redi[w2]; }
-            if (!(v >= thr) || t == 0x7fffffff) { bc[2] = 1; }
-            else {
-                bc[2] = 0; bc[0] = t; bc[1] = cur_col[t];
-                pairs[2 * np] = cur_col[t]; pairs[2 * np + 1] = t;        // (ref, tgt)
-                cur_val[t] = -2.f;                                        // row cleared
-                col_used[cur_col[t]] = 1;                                 // column cleared
-            }
-            bc[3] = 0;
-        }
-        __syncthreads();
-        if (bc[2]) break;
-        ++np;
-        const int ccol = bc[1];
-        // rows whose candidate column was just taken advance to their next free candidate
-        for (int t = tid; t < m; t += GR_THREADS) {
-            if (cur_val[t] >= 0.f && cur_col[t] == ccol) {
-                int k = ptr[t] >= GR_K ? GR_K : ptr[t] + 1;           // a refilled row has no list left: re-scan again
-                while (k < GR_K) {
-                    const int cc = cand_col[(size_t)t * GR_K + k];
-                    if (cc == 0x7fffffff) { k = GR_K + 1; break; }            // row has no further entries at all
-                    if (!col_used[cc]) break;
-                    ++k;
+    for (int k = 2; k <= p2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < p2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool desc = (i & k) == 0;
+                    const unsigned long long x = sk[i], y = sk[ixj];
+                    if (desc ? (x < y) : (x > y)) { sk[i] = y; sk[ixj] = x; }
                 }
-                if (k < GR_K) { ptr[t] = k; cur_val[t] = cand_val[(size_t)t * GR_K + k]; cur_col[t] = cand_col[(size_t)t * GR_K + k]; }
-                else if (k == GR_K) { todo[atomicAdd(&bc[3], 1)] = t; }       // list exhausted: full re-scan
-                else { cur_val[t] = -2.f; }
-            }
-        }
-        __syncthreads();
-        const int ntodo = bc[3];
-        if (ntodo) {
-            for (int q = wave; q < ntodo; q += GR_WAVES) {
-                const int t = todo[q];
-                float b; int bi; row_scan(corr + (size_t)t * n, n, col_used, lane, INFINITY, -1, b, bi);
-                if (lane == 0) { cur_val[t] = (bi == 0x7fffffff) ? -2.f : b; cur_col[t] = bi; ptr[t] = GR_K; }
             }
             __syncthreads();
         }
+    for (int i = threadIdx.x; i < cnt; i += 1024) {
+        const unsigned flat = 0xFFFFFFFFu - (unsigned)(sk[i] & 0xFFFFFFFFull);
+        pairs[2 * i] = (int)(flat % (unsigned)n); pairs[2 * i + 1] = (int)(flat / (unsigned)n);      // (ref, tgt)
     }
-    if (tid == 0) *n_pairs = np;
+    if (threadIdx.x == 0) *n_pairs = cnt;
 }
 
 __global__ __launch_bounds__(256) void prior_fill_kernel(double* __restrict__ prior, int m, int n, int mode,
@@ -1224,30 +1217,58 @@ int ct_ffn_predict(ct_ffn_t* h, const float* x, int rows, float* out, void* work
 // ------------------------------------------------------------------------------------------------ greedy
 size_t ct_greedy_workspace_bytes(int m, int n) {
     if (m <= 0 || n <= 0) return 0;
-    return align_up((size_t)m * GR_K * 4, 256) * 2 + align_up((size_t)m * 4, 256) + 512;    // candidate lists + row_match
+    const size_t mx = (size_t)(m > n ? m : n);
+    return align_up((size_t)m, 256) + align_up((size_t)n, 256) + 3 * align_up((size_t)m * 4, 256) + align_up((size_t)n * 4, 256)
+           + align_up(mx * 8, 256) + 256 + 512;
 }
 
 int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, int32_t* pairs, int32_t* n_pairs,
                     double* prior, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
     if (!corr || !pairs || !n_pairs || !workspace || m <= 0 || n <= 0 || (mode != 0 && mode != 1)) return CT_EINVAL;
+    if ((double)m * (double)n >= 4294967295.0 || (m < n ? m : n) > 16384) return CT_ESHAPE;
     if (workspace_bytes < ct_greedy_workspace_bytes(m, n)) return CT_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    float* cand_val = (float*)ws; ws += align_up((size_t)m * GR_K * 4, 256);
-    int* cand_col = (int*)ws; ws += align_up((size_t)m * GR_K * 4, 256);
-    int* row_match = (int*)ws;
-    const size_t lds = (size_t)m * 16 + GR_WAVES * 8 + 16 + align_up((size_t)n, 16);
-    if (lds > 150 * 1024) return CT_ESHAPE;
+    unsigned char* row_used = ws; ws += align_up((size_t)m, 256);
+    unsigned char* col_used = ws; ws += align_up((size_t)n, 256);
+    float* rowval = (float*)ws; ws += align_up((size_t)m * 4, 256);
+    int* rowcol = (int*)ws; ws += align_up((size_t)m * 4, 256);
+    int* row_match = (int*)ws; ws += align_up((size_t)m * 4, 256);
+    int* colrow = (int*)ws; ws += align_up((size_t)n * 4, 256);
+    unsigned long long* keys = (unsigned long long*)ws; ws += align_up((size_t)(m > n ? m : n) * 8, 256);
+    int* ctr = (int*)ws;
+    HIPCHK(hipMemsetAsync(row_used, 0, (size_t)(ws - row_used) + 256, st));     // flags, tables and counters
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)greedy_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)gd_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(greedy_topk_kernel, dim3((m + 3) / 4), dim3(256), 0, st, corr, m, n, cand_val, cand_col);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(greedy_match_kernel, dim3(1), dim3(GR_THREADS), lds, st, corr, m, n, threshold, pairs, n_pairs,
-                       cand_val, cand_col);
-    LAUNCH_CHECK();
+    const int max_rounds = (m < n ? m : n) + 1;
+    int hctr[4] = {0, 0, 0, 0};
+    for (int done_rounds = 0; done_rounds < max_rounds;) {
+        const int chunk = done_rounds == 0 ? 12 : 8;
+        for (int k = 0; k < chunk; ++k) {
+            hipLaunchKernelGGL(gd_rowbest_kernel, dim3((m + 3) / 4), dim3(256), 0, st, corr, m, n, row_used, col_used, rowval, rowcol, ctr);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(gd_colbest_kernel, dim3((n + 63) / 64), dim3(64 * GD_ROWLANES), 0, st, corr, m, n, row_used, col_used, colrow, ctr);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(gd_accept_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, n, threshold, rowval, rowcol, colrow,
+                               row_used, col_used, keys, ctr);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(gd_round_end_kernel, dim3(1), dim3(1), 0, st, ctr);
+            LAUNCH_CHECK();
+        }
+        done_rounds += chunk;
+        HIPCHK(hipMemcpyAsync(hctr, ctr, sizeof(hctr), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hctr[GD_DONE]) break;
+    }
+    if (getenv("CT_DEBUG")) fprintf(stderr, "[ct_greedy_match] m %d n %d pairs %d\n", m, n, hctr[GD_COUNT]);
+    {
+        int p2 = 1; while (p2 < hctr[GD_COUNT]) p2 <<= 1;
+        hipLaunchKernelGGL(gd_finalize_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, st, keys, ctr, n, pairs, n_pairs);
+        LAUNCH_CHECK();
+    }
     if (prior) {
         hipLaunchKernelGGL(row_match_kernel, dim3((m + 255) / 256), dim3(256), 0, st, row_match, m);
         LAUNCH_CHECK();

@@ -46,6 +46,12 @@ const char* ct_error_string(int code);
 /* Device properties the host side reports next to benchmark numbers. */
 int         ct_device_info(int device, int* n_cu, size_t* hbm_bytes, char* name, size_t name_len);
 
+/* HIP streams limited to the CU range [first_cu, first_cu + n_cu) (hipExtStreamCreateWithCUMask): lets the
+ * latency-bound matching chain and the throughput-bound U-Net of different frames share a GPU without the
+ * tiny kernels queueing behind resident conv workgroups.  Destroy with ct_stream_destroy.                  */
+int ct_stream_create_cu_range(int device, int first_cu, int n_cu, ct_stream_t* out);
+int ct_stream_destroy(ct_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * 3D U-Net  (replaces keras Model construction + `model.predict`, unet3d.py:26-98, :253)
  * ------------------------------------------------------------------------------------------

@@ -1,0 +1,81 @@
+"""CPU-only: the C-ABI library builds/loads, exports every symbol include/ctamd.h declares, and its
+host-only entry points (no kernel launches) behave."""
+import ctypes as C
+import importlib
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+_lib = importlib.import_module("3deecelltracker_amd._lib")
+arch_mod = importlib.import_module("3deecelltracker_amd.arch")
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not _lib.LIB_PATH.exists():
+        importlib.import_module("__graft_entry__").build()
+    return _lib.lib()
+
+
+def _declared_symbols():
+    text = (REPO / "include" / "ctamd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ct_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    names = _declared_symbols()
+    assert len(names) >= 35
+    assert _lib.MISSING == []
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ctamd.h but not exported by libctamd.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in _lib.SIGNATURES"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_host_only_entry_points(L):
+    assert L.ct_version() >= 100
+    assert L.ct_error_string(0) == b"ok" and L.ct_error_string(-3) == b"workspace too small"
+    for a in arch_mod.ARCHS.values():
+        convs = a.conv_layers()
+        want = sum(27 * ci * co + 5 * co for ci, co in convs) + a.out[1] + 1
+        assert L.ct_unet_num_weights(a.arch_id) == want
+        s = (C.c_int * 3)()
+        assert L.ct_unet_patch_shape(a.arch_id, s) == 0 and tuple(s) == a.input_shape
+    assert L.ct_unet_num_weights(7) == 0
+    assert L.ct_unet_num_weights(0) == 510393 + 1632          # conv params + BN params
+    assert L.ct_ffn_num_weights() == 61 * 512 + 1024 * 512 + 513 + 2 * 4 * 512
+
+
+def test_tile_plan_matches_reference_counts(L):
+    centre, grid = (C.c_int * 3)(), (C.c_int * 3)()
+    for vol, want in (((64, 64, 16), 2), ((256, 256, 24), 18), ((512, 512, 32), 75), ((168, 401, 128), 88)):
+        rc = L.ct_tile_plan(_lib.ivec(vol), _lib.ivec((160, 160, 16)), _lib.ivec((24, 24, 2)), centre, grid)
+        assert rc == 0 and tuple(centre) == (112, 112, 12) and int(np.prod(tuple(grid))) == want
+    assert L.ct_tile_plan(_lib.ivec((64, 64, 16)), _lib.ivec((40, 40, 16)), _lib.ivec((24, 24, 2)), centre, grid) == -2
+    assert L.ct_tile_plan(_lib.ivec((0, 64, 16)), _lib.ivec((160, 160, 16)), _lib.ivec((24, 24, 2)), centre, grid) == -1
+
+
+def test_argument_validation_without_a_gpu(L):
+    assert L.ct_knn_features(None, 10, 20, None, None) == -1
+    assert L.ct_greedy_workspace_bytes(0, 5) == 0 and L.ct_greedy_workspace_bytes(600, 600) > 0
+    assert L.ct_prgls_workspace_bytes(600, 600, 600) > 3 * 600 * 600 * 8
+    assert L.ct_ffn_workspace_bytes(600, 600) >= 2 * 1200 * 512 * 4
+    assert L.ct_unet_workspace_bytes(None, 3) == 0
+
+
+def test_product_raises_without_library_or_gpu(monkeypatch):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    unet3d = importlib.import_module("3deecelltracker_amd.unet3d")
+    synth = importlib.import_module("3deecelltracker_amd.synth")
+    with pytest.raises(_lib.CtamdError):            # no silent CPU fallback
+        unet3d.unet3_c().set_weights_dict(synth.make_unet_weights("unet3_c", 0))
+    monkeypatch.setattr(_lib, "LIB_PATH", Path("/nonexistent/libctamd.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.CtamdError):
+        _lib.lib()

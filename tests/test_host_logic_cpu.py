@@ -1,0 +1,99 @@
+"""CPU-only: host-side mirrors (no kernels) against the golden vectors produced by the reference."""
+import importlib
+import json
+
+import numpy as np
+import pytest
+
+cit = importlib.import_module("3deecelltracker_amd.coord_image_transformer")
+ffn_mod = importlib.import_module("3deecelltracker_amd.ffn")
+track = importlib.import_module("3deecelltracker_amd.track")
+tl = importlib.import_module("3deecelltracker_amd.trackerlite")
+unet3d = importlib.import_module("3deecelltracker_amd.unet3d")
+synth = importlib.import_module("3deecelltracker_amd.synth")
+arch_mod = importlib.import_module("3deecelltracker_amd.arch")
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(golden_dir / "match.npz")
+
+
+@pytest.fixture(scope="module")
+def meta(golden_dir):
+    return json.loads((golden_dir / "match.json").read_text())
+
+
+def test_coordinates_against_reference(g):
+    cr, vs = g["coords_in"], g["coords_vs"]
+    views = {"raw": cit.Coordinates(cr, 5, vs, "raw"), "real": cit.Coordinates(cr, 5, vs, "real"),
+             "interp": cit.Coordinates(cr, 5, vs, "interp")}
+    for tag, c in views.items():
+        assert c._raw.dtype == np.float32 and c.cell_num == 9
+        assert np.array_equal(c.real, g[f"coords_{tag}_real"])
+        assert np.array_equal(c.interp, g[f"coords_{tag}_interp"]) and c.interp.dtype == np.int32
+        assert np.array_equal(c.raw, g[f"coords_{tag}_raw"])
+    assert np.array_equal((views["raw"] + views["real"]).real, g["coords_add_real"])
+    assert np.array_equal((views["raw"] - views["interp"]).real, g["coords_sub_real"])
+    with pytest.raises(ValueError):
+        cit.Coordinates(cr, 5, vs, "voxels")
+
+
+@pytest.mark.parametrize("n", (21, 50, 113, 180))
+def test_normalize_points_against_reference(g, n):
+    norm, (mean, scale) = ffn_mod.normalize_points(g[f"norm_in_{n}"], return_para=True)
+    np.testing.assert_allclose(mean, g[f"norm_mean_{n}"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(scale, g[f"norm_scale_{n}"], rtol=1e-12)
+    np.testing.assert_allclose(norm, g[f"norm_out_{n}"], rtol=0, atol=1e-12)
+    assert np.array_equal(ffn_mod.normalize_points(g[f"norm_in_{n}"]), norm)
+    with pytest.raises(ValueError):
+        ffn_mod.normalize_points(np.zeros(5))
+    with pytest.raises(ValueError):
+        ffn_mod.normalize_points(np.zeros((5, 2)))
+
+
+def test_ensemble_schedules_against_reference(meta):
+    for c in meta["get_volumes_list"]:
+        assert tl.get_volumes_list(c["cur"], c["skip"], c["samp"], c["adj"], c["start"]) == c["out"], c
+    for c in meta["get_reference_vols"]:
+        assert track.get_reference_vols(c["ens"], c["vol"], c["adj"]) == c["out"], c
+    with pytest.raises(AssertionError):
+        tl.get_volumes_list(1, [], 20, False, 1)
+    assert tl.get_volumes_list(80, [79], 20) == list(range(20, 78, 3))        # SURVEY 8a a13 example
+
+
+def test_get_sizes_padded_im():
+    assert unet3d._get_sizes_padded_im(512, 112) == (560, 5)
+    assert unet3d._get_sizes_padded_im(112, 112) == (112, 1)
+    assert unet3d._get_sizes_padded_im(113, 112) == (224, 2)
+
+
+def test_weight_flattening_layout():
+    w = synth.make_unet_weights("unet3_a", 0)
+    flat = unet3d.flatten_unet_weights(w)
+    assert flat.dtype == np.float32 and flat.size == 512025
+    k0 = w["convs"][0]["kernel"].ravel()
+    assert np.array_equal(flat[:k0.size], k0) and np.array_equal(flat[k0.size:k0.size + 8], w["convs"][0]["bias"])
+    assert np.array_equal(flat[-1:], w["head"]["bias"]) and np.array_equal(flat[-9:-1], w["head"]["kernel"].ravel())
+    fw = synth.make_ffn_weights(0)
+    ff = ffn_mod.flatten_ffn_weights(fw)
+    assert ff.size == 61 * 512 + 4 * 512 + 1024 * 512 + 4 * 512 + 512 + 1
+    assert np.array_equal(ff[:61 * 512], fw["w1"].ravel()) and ff[-1] == fw["b3"][0]
+
+
+def test_model_objects_expose_keras_surface_without_gpu():
+    m = unet3d.unet3_a()
+    assert m.input_shape == (None, 160, 160, 16, 1) and m.output_shape == (None, 160, 160, 16, 1)
+    assert unet3d.unet3_b().input_shape == (None, 96, 96, 8, 1)
+    assert unet3d.unet3_c().input_shape == (None, 64, 64, 64, 1)
+    with pytest.raises(NotImplementedError):
+        m.fit_generator()
+
+
+def test_trackerlite_constructor_errors(tmp_path, g):
+    proof = cit.Coordinates(g["coords_in"], 5, g["coords_vs"], "raw")
+    with pytest.raises(TypeError):
+        tl.TrackerLite(str(tmp_path), "x", proof, miss_frame=(1, 2))
+    with pytest.raises(ValueError):                  # missing weight file -> ValueError wrapping OSError
+        tl.TrackerLite(str(tmp_path), "missing_model", proof, basedir=str(tmp_path))
+    assert (tmp_path / "track_results" / "coords_real").is_dir()

@@ -1,0 +1,76 @@
+"""CPU-only, world_size 2 over gloo: the sharding / gather layer used for patches, frames and ensemble
+matches (parallel.py).  The same code runs over RCCL ("nccl") on the GPUs."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+par = importlib.import_module("3deecelltracker_amd.parallel")
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 20, 75, 88):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [par.shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    assert [par.shard_range(75, r, 8)[1] - par.shard_range(75, r, 8)[0] for r in range(8)] == [10, 10, 10, 9, 9, 9, 9, 9]
+    assert [len(par.shard_list(list(range(20)), r, 8)) for r in range(8)] == [3, 3, 3, 3, 2, 2, 2, 2]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert par.dist_info() == (rank, world)
+        items = list(range(5))                                   # 5 ensemble matches over 2 ranks: 3 + 2
+
+        def fn(i):
+            return torch.full((4, 3), float(i), dtype=torch.float64) + torch.arange(3, dtype=torch.float64)
+        stack = par.sharded_map_gather(fn, items)
+        assert tuple(stack.shape) == (5, 4, 3)
+        for i in items:
+            assert torch.equal(stack[i], fn(i))
+        # rank with an empty shard
+        one = par.sharded_map_gather(fn, [7], tail_shape=(4, 3), dtype=torch.float64, device="cpu")
+        assert tuple(one.shape) == (1, 4, 3) and torch.equal(one[0], fn(7))
+        # variable-size centroid sets
+        local = torch.arange((rank + 2) * 3, dtype=torch.float64).reshape(-1, 3) + 100 * rank
+        sets = par.gather_centroids(local, cap=16)
+        assert [s.shape[0] for s in sets] == [2, 3] and torch.equal(sets[rank], local)
+        assert torch.equal(sets[1 - rank], torch.arange((1 - rank + 2) * 3, dtype=torch.float64).reshape(-1, 3) + 100 * (1 - rank))
+        # disjoint-support sum == gather (what predict_volume_sharded does with the partial volumes)
+        vol = torch.zeros(10, dtype=torch.float32)
+        b, e = par.shard_range(10, rank, world)
+        vol[b:e] = torch.arange(b, e, dtype=torch.float32) + 1
+        dist.all_reduce(vol)
+        assert torch.equal(vol, torch.arange(10, dtype=torch.float32) + 1)
+        q.put((rank, "ok"))
+    except Exception as ex:   # pragma: no cover
+        q.put((rank, repr(ex)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
