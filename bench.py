@@ -156,8 +156,21 @@ def main():
     dom = by_kernel[dom_name]
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     conv_ms_total = sum(k["ms"] for k in by_kernel.values()) / max(args.steps, 1)
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed
+    # measurement (profiles/, scripts/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 fetch
+    # correction) is attached when it exists for this kernel
+    traffic = None
+    for cand in sorted((ROOT / "profiles").glob("r*_unet_hbm_traffic.json"), reverse=True):
+        try:
+            kk = json.loads(cand.read_text())["kernels"].get(dom_name)
+            if kk:
+                traffic = {"hbm_bytes_per_launch": round(kk["hbm_bytes_per_launch"]), "source": f"profiles/{cand.name}",
+                           "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1))}
+                break
+        except Exception:
+            pass
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": None, "kernel": dom_name,
+                "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": traffic, "kernel": dom_name,
                 "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4), "launches": dom["launches"],
                 "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                 "conv_stack_ms_per_volume": round(conv_ms_total, 3),
