@@ -243,6 +243,116 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Cout = 8 variant.  With only 8 output channels half of the 16 MFMA rows would be padding, so the rows are
+// (x-select, cout): ONE MFMA column now produces the 8 channels of TWO x-adjacent voxels.  Both share a
+// 4 x 3 x 3 input footprint (36 taps instead of 2 x 27): 288 k-values = 18 slabs per 8-channel chunk versus
+// 2 x 14, i.e. 36 % fewer MFMAs (75 % useful rows instead of 50 %).  The weight tile of row (xs, co) at tap
+// (dx', dy, dz) is K[dx' - xs][dy][dz][ci][co] when 0 <= dx' - xs <= 2, else 0 (packed on the host).
+// ------------------------------------------------------------------------------------------------
+constexpr int NSLAB8 = 18;
+__host__ __device__ constexpr int tap_off4(int tap) {   // tap = (dx' * 3 + dy) * 3 + dz, dx' in 0..3
+    return (((tap / 9) * HY + (tap / 3) % 3) * HZ + tap % 3) * 8;
+}
+
+__global__ __launch_bounds__(256, 2) void conv3_mfma_c8_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[NF4 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b = blockIdx.x;
+    const int zb = b % a.zblocks; b /= a.zblocks;
+    const int ty = b % a.tilesY;  b /= a.tilesY;
+    const int tx = b % a.tilesX;
+    const int p = b / a.tilesX;
+    const int x0 = tx * TX, y0 = ty * TY, z0 = zb * 16;
+    const int g = lane >> 4, zl = lane & 15;
+    const int wx0 = 2 * (wave >> 1), wy0 = 4 * (wave & 1);
+    const int lbase = ((wx0 * HY + wy0) * HZ + zl) * 8 + 4 * (g & 1);
+    const bool hi = (g >> 1) != 0;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
+        {
+            const int c0 = chunk * 8;
+            if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
+                             sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
+            else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
+                             sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
+        }
+        f32x4 v[NSTAGE];
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int f = tid + 256 * i;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (f < NF4) {
+                const int col = f / (HZ * 2), w = f - col * (HZ * 2);
+                const int hz = w >> 1, half = w & 1;
+                const int hx = col / HY, hy = col - hx * HY;
+                const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+                if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
+                    const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
+                                        + (gz >> suz)) * 8 + half * 4;
+                    v[i] = *reinterpret_cast<const f32x4*>(src + idx);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int f = tid + 256 * i;
+            if (f < NF4) *reinterpret_cast<f32x4*>(&lds[f * 4]) = v[i];
+        }
+        __syncthreads();
+
+        const f32x4* wp = a.wpack + (size_t)chunk * NSLAB8 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NSLAB8; ++s) {
+            const int off = lbase + (hi ? tap_off4(2 * s + 1) : tap_off4(2 * s));
+            const f32x4 wv = wp[s * 64];
+            f32x4 av[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt * HZ * 8]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], av[mt][t], acc[mt], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx0 + (g>>1), y = y0 + wy0 + mt
+    const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
+    const int cb = 4 * (g & 1);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + 16 + cb);
+    const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 32 + cb);
+    const int x = x0 + wx0 + (g >> 1), z = z0 + zl;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        f32x4 r = acc[mt] + bias;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = r[e];
+            r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+        }
+        const int y = y0 + wy0 + mt;
+        const bool ok = x < a.X && y < a.Y && z < a.Z;
+        if (a.out && ok)
+            *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
+        if (a.head) {
+            const f32x4 hw = *reinterpret_cast<const f32x4*>(a.head + cb);
+            float part = r[0] * hw[0] + r[1] * hw[1] + r[2] * hw[2] + r[3] * hw[3];
+            part += __shfl_xor(part, 16);                    // the other channel half of the same voxel
+            if ((g & 1) == 0 && ok)
+                a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + a.head[16])));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // first conv (Cin = 1): HBM-bound (AI ~ 12 flop/B), plain VALU, one voxel per thread.
 // in [P][X][Y][Z]; w [27][COUT] (scalar loads); out blocked.
@@ -376,6 +486,7 @@ struct ConvPlan {
     int dst;              // tensor id or -1 (head layer)
     int pool_dst;         // tensor id or -1
     bool head;
+    bool c8;              // Cout == 8: paired-column kernel
     size_t wpack_off;     // float4 offset into the device weight arena
     size_t epi_off;       // float offset
 };
@@ -433,6 +544,25 @@ void pack_conv_weights(const float* k, int cin, int cout, int NT, float* dst) {
                     }
 }
 
+// Cout = 8 packing (conv3_mfma_c8_kernel): rows n = xs * 8 + co, taps dx' in 0..3:
+//   wpack8[chunk][slab][lane = g*16 + n][t] = K[dx' - xs][dy][dz][8*chunk + 4*(g&1) + t][co], tap' = 2*slab + (g>>1)
+void pack_conv_weights_c8(const float* k, int cin, float* dst) {
+    const int nchunks = cin / 8;
+    for (int ch = 0; ch < nchunks; ++ch)
+        for (int s = 0; s < NSLAB8; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 4; ++t) {
+                    const int g = lane >> 4, n = lane & 15;
+                    const int tapp = 2 * s + (g >> 1), ci = 8 * ch + 4 * (g & 1) + t;
+                    const int xs = n >> 3, co = n & 7;
+                    const int dxp = tapp / 9, dy = (tapp / 3) % 3, dz = tapp % 3;
+                    const int dx = dxp - xs;
+                    float v = 0.f;
+                    if (dx >= 0 && dx <= 2) v = k[((size_t)((dx * 3 + dy) * 3 + dz) * cin + ci) * 8 + co];
+                    dst[(((size_t)ch * NSLAB8 + s) * 64 + lane) * 4 + t] = v;
+                }
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <int NT>
@@ -468,7 +598,7 @@ int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int d
     const ConvPlan& c = h->convs[layer];
     if (cin) *cin = c.cin;
     if (cout) *cout = c.cout;
-    if (nt) *nt = layer == 0 ? 0 : c.NT;
+    if (nt) *nt = layer == 0 ? 0 : (c.c8 ? -8 : c.NT);      // 0: conv_first_kernel, -8: conv3_mfma_c8_kernel, else conv3_mfma_kernel<nt>
     if (dims_xyz) for (int i = 0; i < 3; ++i) dims_xyz[i] = h->dims[c.level][i];
     return CT_OK;
 }
@@ -614,8 +744,14 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
             arena.resize(align_up(arena.size(), 4), 0.f);
         } else {
             c.wpack_off = arena.size();
-            arena.resize(arena.size() + (size_t)(c.cin / 8) * NSLAB * c.nt_total * 64 * 4);
-            pack_conv_weights(kern, c.cin, c.cout, c.nt_total, arena.data() + c.wpack_off);
+            if (c.cout == 8 && c.pool_dst < 0) {          // paired-column kernel
+                c.c8 = true;
+                arena.resize(arena.size() + (size_t)(c.cin / 8) * NSLAB8 * 64 * 4);
+                pack_conv_weights_c8(kern, c.cin, arena.data() + c.wpack_off);
+            } else {
+                arena.resize(arena.size() + (size_t)(c.cin / 8) * NSLAB * c.nt_total * 64 * 4);
+                pack_conv_weights(kern, c.cin, c.cout, c.nt_total, arena.data() + c.wpack_off);
+            }
             c.epi_off = push_epi(bias, gamma, beta, mean, var, c.cout, c.nt_total * 16);
         }
     }
@@ -692,6 +828,11 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             a.act = ad.act;
             a.tilesX = (d[0] + TX - 1) / TX; a.tilesY = (d[1] + TY - 1) / TY; a.zblocks = (d[2] + 15) / 16;
             int rc;
+            if (c.c8) {
+                const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
+                hipLaunchKernelGGL(conv3_mfma_c8_kernel, dim3(nblk), dim3(256), 0, st, a);
+                rc = (int)hipGetLastError();
+            } else
             switch (c.NT) {
                 case 1: rc = launch_conv<1>(a, P, st); break;
                 case 2: rc = launch_conv<2>(a, P, st); break;

@@ -108,3 +108,75 @@ def gather_centroids(local_coords, cap: int = 4096):
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
     return [o[:int(o[cap, 0].item())] for o in out]
+
+
+class FramePipeline:
+    """Intra-GPU overlap of the two halves of the path across frames.
+
+    One PR-GLS match is a chain of ~10^3 dependent tiny kernels (latency-bound, ~5 us dispatch floor each), the
+    U-Net a stream of chip-filling kernels.  On this GPU plain streams do not interleave them (the dispatcher
+    drains the conv workgroups first), so the device is split with CU-masked streams: the U-Net gets
+    `n_cu - match_cus` CUs, and `workers` host threads each drive the match chain of a *different* frame on their
+    own stream inside the remaining `match_cus` CUs (ctypes releases the GIL while a chain runs).  Frames are
+    independent units, so results are identical to processing them one after another.
+    """
+
+    def __init__(self, device: int = 0, match_cus: int = 32, workers: int = 3):
+        import ctypes as C
+        from concurrent.futures import ThreadPoolExecutor
+        import threading
+        import torch
+        from . import _lib
+        L = _lib.lib()
+        n_cu = C.c_int(0)
+        _lib.check(L.ct_device_info(device, C.byref(n_cu), None, None, 0), "ct_device_info")
+        self.device = device
+        self.n_cu = n_cu.value
+        self.match_cus = max(4, min(int(match_cus), self.n_cu // 2))
+        self.workers = max(1, int(workers))
+        self._handles = []
+
+        def cu_stream(first, count):
+            h = C.c_void_p()
+            _lib.check(L.ct_stream_create_cu_range(device, first, count, C.byref(h)), "ct_stream_create_cu_range")
+            self._handles.append(h)
+            return torch.cuda.ExternalStream(h.value, device=f"cuda:{device}")
+        self.seg_stream = cu_stream(self.match_cus, self.n_cu - self.match_cus)
+        self._match_streams = [cu_stream(0, self.match_cus) for _ in range(self.workers)]
+        self._tls = threading.local()
+        self._free = list(range(self.workers))
+        self._lock = threading.Lock()
+        self._pool = ThreadPoolExecutor(max_workers=self.workers)
+        self._inflight = []
+
+    def _run(self, fn, args):
+        import torch
+        with self._lock:
+            idx = self._free.pop()
+        try:
+            torch.cuda.set_device(self.device)
+            s = self._match_streams[idx]
+            with torch.cuda.stream(s):
+                out = fn(*args)
+            s.synchronize()
+            return out
+        finally:
+            with self._lock:
+                self._free.append(idx)
+
+    def submit_match(self, fn, *args):
+        """Run `fn(*args)` (a device match, e.g. trackerlite.match_device) on a worker; at most `workers` in flight."""
+        while len(self._inflight) >= self.workers:
+            self._inflight.pop(0).result()
+        fut = self._pool.submit(self._run, fn, args)
+        self._inflight.append(fut)
+        return fut
+
+    def drain(self):
+        for f in self._inflight:
+            f.result()
+        self._inflight.clear()
+
+    def close(self):
+        self.drain()
+        self._pool.shutdown(wait=True)

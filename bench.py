@@ -45,7 +45,8 @@ def main():
     ap.add_argument("--shape", type=int, nargs=3, default=(512, 512, 32))
     ap.add_argument("--cells", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--match-cus", type=int, default=64, help="CUs reserved for the matching chain (rest: U-Net)")
+    ap.add_argument("--match-cus", type=int, default=32, help="CUs reserved for the matching chains (rest: U-Net)")
+    ap.add_argument("--match-workers", type=int, default=3, help="frames whose match chains are in flight concurrently")
     ap.add_argument("--cpu-patches", type=int, default=2, help="U-Net patches timed by the CPU baseline sample")
     args = ap.parse_args()
 
@@ -87,30 +88,38 @@ def main():
     n_patches = grid[0] * grid[1] * grid[2]
 
     # Two plain streams do not interleave on this GPU (the dispatcher drains the conv kernel's workgroups first, so the
-    # dependent chain of tiny matching kernels only advances between conv launches: measured step = sum, not max).
-    # CU-partitioned streams do overlap: the matching chain gets its own CUs, the U-Net the rest.
-    n_cu = C.c_int(0)
-    _lib.check(L.ct_device_info(local, C.byref(n_cu), None, None, 0), "ct_device_info")
-    k_match = max(8, min(args.match_cus, n_cu.value // 2))
-
-    def cu_stream(first, count):
-        h = C.c_void_p()
-        _lib.check(L.ct_stream_create_cu_range(local, first, count, C.byref(h)), "ct_stream_create_cu_range")
-        return torch.cuda.ExternalStream(h.value, device=dev)
-    s_match = cu_stream(0, k_match)
-    s_seg = cu_stream(k_match, n_cu.value - k_match)
+    # dependent chain of tiny matching kernels only advances between conv launches: measured step = sum, not max), and one
+    # PR-GLS chain is latency-bound (~31 ms of dependent ~5 us kernels).  FramePipeline splits the CUs with masked streams
+    # and lets `--match-workers` host threads each drive the match of a different frame (frames are independent units).
+    par = importlib.import_module(f"{PKG}.parallel")
+    pipe = par.FramePipeline(device=local, match_cus=args.match_cus, workers=args.match_workers)
+    s_seg = pipe.seg_stream
+    n_cu, k_match = pipe.n_cu, pipe.match_cus
     gather_buf = [torch.empty((args.cells, 3), dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
     iters_log = []
+    pending = []
+
+    def match_job():
+        tracked, iters = tl.match_device(ffn, seg1, seg2, conf, beta=3, lambda_=3)
+        iters_log.append(iters)
+        return tracked
+
+    def collect(fut):
+        tracked = fut.result()
+        if world > 1:
+            dist.all_gather(gather_buf, tracked)           # "gather of centroid sets" (14 KB / rank), main thread only
+        return tracked
 
     def step():
         with torch.cuda.stream(s_seg):
             model.predict_volume_device(vol, out=prob)
-        with torch.cuda.stream(s_match):
-            tracked, iters = tl.match_device(ffn, seg1, seg2, conf, beta=3, lambda_=3)
-            if world > 1:
-                dist.all_gather(gather_buf, tracked)           # "gather of centroid sets" (14 KB / rank)
-        iters_log.append(iters)
-        return tracked
+        pending.append(pipe.submit_match(match_job))
+        while len(pending) > args.match_workers:
+            collect(pending.pop(0))
+
+    def finish():
+        while pending:
+            collect(pending.pop(0))
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -120,12 +129,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    finish()
     sync_all()
     L.ct_unet_set_timing(model._handle, 1)
     iters_log.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    finish()                                   # every frame's match (and gather) has completed
     sync_all()
     dt = time.perf_counter() - t0
     L.ct_unet_set_timing(model._handle, 0)
@@ -145,7 +156,7 @@ def main():
         L.ct_unet_layer_info(model._handle, i, C.byref(cin), C.byref(cout), d, C.byref(nt))
         flops = 2.0 * d[0] * d[1] * d[2] * 27 * cin.value * cout.value * n_patches       # per launch (one volume)
         abytes = 4.0 * d[0] * d[1] * d[2] * (cin.value + cout.value) * n_patches
-        name = "conv_first_kernel" if i == 0 else f"conv3_mfma_kernel<{nt.value}>"
+        name = "conv_first_kernel" if nt.value == 0 else ("conv3_mfma_c8_kernel" if nt.value == -8 else f"conv3_mfma_kernel<{nt.value}>")
         k = by_kernel.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
         k["ms"] += ms[i]; k["launches"] += cnt[i]; k["flops"] += flops * cnt[i]; k["bytes"] += abytes * cnt[i]
         layers.append({"layer": i, "cin": cin.value, "cout": cout.value, "dims": [d[0], d[1], d[2]], "kernel": name,
@@ -213,13 +224,14 @@ def main():
                                    f"(FFN all pairs, greedy prior, PR-GLS beta=lambda=3), seeded random-init weights",
                        "patches_per_volume": n_patches, "cells": args.cells,
                        "prgls_iterations": int(np.median(iters_log)) if iters_log else None,
-                       "cu_partition": {"unet": n_cu.value - k_match, "match": k_match},
+                       "cu_partition": {"unet": n_cu - k_match, "match": k_match}, "match_chains_in_flight": args.match_workers,
                        "parallelism": f"frames sharded, {world} rank(s), all-gather of tracked centroids"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "layers": layers,
         }
         print(json.dumps(out))
+    pipe.close()
     if world > 1:
         dist.destroy_process_group()
 
