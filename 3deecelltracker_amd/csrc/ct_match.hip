@@ -470,8 +470,8 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
             if (respart) {
                 const double r1 = fmax(fmax(red3[0], red3[1]), fmax(red3[2], red3[3]));
                 const double r2 = fmax(fmax(red4[0], red4[1]), fmax(red4[2], red4[3]));
-                const double rel = r2 > 0.0 ? r1 / r2 : 0.0;
-                if (rel > sc[S_RES]) sc[S_RES] = rel;
+                const double rel = r2 > 0.0 ? r1 / r2 : (r1 > 0.0 ? INFINITY : 0.0);
+                if (!(rel <= sc[S_RES])) sc[S_RES] = rel;
             }
         }
     }
@@ -761,7 +761,8 @@ __global__ __launch_bounds__(256) void apply_field_kernel(const double* __restri
             const double c = sc[S_C], d = dvec[j], q = sqd[j];
             const double bx = q * rhs[3 * j], by = q * rhs[3 * j + 1], bz = q * rhs[3 * j + 2];
             const double rx = d * ax + c * C[j] - bx, ry = d * ay + c * C[n + j] - by, rz = d * az + c * C[2 * n + j] - bz;
-            res_part[j] = fmax(fabs(rx), fmax(fabs(ry), fabs(rz)));
+            const double rr = fabs(rx) + fabs(ry) + fabs(rz);
+            res_part[j] = isfinite(rr) ? fmax(fabs(rx), fmax(fabs(ry), fabs(rz))) : INFINITY;
             res_part[cols + j] = fmax(fabs(bx), fmax(fabs(by), fabs(bz)));
         }
     }
@@ -799,7 +800,8 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
         const double c = sc[S_C], d = dvec[j], q = sqd[j];
         const double bx = q * rhs[3 * j], by = q * rhs[3 * j + 1], bz = q * rhs[3 * j + 2];
         const double rx = d * ax + c * C[j] - bx, ry = d * ay + c * C[n + j] - by, rz = d * az + c * C[2 * n + j] - bz;
-        res_part[j] = fmax(fabs(rx), fmax(fabs(ry), fabs(rz)));
+        const double rr = fabs(rx) + fabs(ry) + fabs(rz);                 // NaN/Inf must not be swallowed by fmax
+        res_part[j] = isfinite(rr) ? fmax(fabs(rx), fmax(fabs(ry), fabs(rz))) : INFINITY;
         res_part[n + j] = fmax(fabs(bx), fmax(fabs(by), fabs(bz)));
     }
 }
@@ -1412,39 +1414,58 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
     const int total = max_iteration - 1;
     int done_iters = 0;
     double hsc[S_NUM] = {0};
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (attempt == 1) {      // restart from the initial state with the dense path
-            rank = 0;
-            HIPCHK(hipMemcpyAsync(w.predn, ref, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-            if (l > 0) HIPCHK(hipMemcpyAsync(w.predl, tracked, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
-            HIPCHK(hipMemcpyAsync(w.sc, init_sc, sizeof(init_sc), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart0, m, n, 0, w.sc, (const double*)nullptr, (const double*)nullptr);
+    // state checkpoint (ref set, tracked set, scalars) taken at every chunk start: if the monitor rejects the
+    // low-rank M-step inside a chunk, that chunk is redone with the dense M-step from the last verified state
+    double* ck_n = w.M;                                   // the dense-path matrix is idle while the low-rank path runs
+    double* ck_l = w.M + 3 * (size_t)n;
+    double* ck_sc = w.M + 3 * (size_t)(n + (l > 0 ? l : 1));
+    const bool ck_fits = (size_t)3 * (n + (l > 0 ? l : 1)) + S_NUM <= (size_t)n * n;
+    for (int enq = 0; enq < total;) {
+        const int chunk = (total - enq) < 16 ? (total - enq) : 16;
+        if (rank > 0 && ck_fits) {
+            HIPCHK(hipMemcpyAsync(ck_n, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (l > 0) HIPCHK(hipMemcpyAsync(ck_l, w.predl, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(ck_sc, w.sc, S_NUM * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        for (int k = 0; k < chunk; ++k) {
+            if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, rank, st))) return rc;
+            hipLaunchKernelGGL(apply_dual_kernel, dim3((n + l + 3) / 4), dim3(256), 0, st, w.C, w.G, n, w.predn, w.Gln, l, w.predl,
+                               w.normpart, w.sc, w.dvec, w.sqd, w.rhs, rank > 0 ? w.respart : (double*)nullptr);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, tgt, m, w.P, w.rowpart, w.sc);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 1, w.sc, w.normpart,
+                               rank > 0 ? w.respart : (const double*)nullptr);
             LAUNCH_CHECK();
         }
-        for (int enq = 0; enq < total;) {
-            const int chunk = (total - enq) < 16 ? (total - enq) : 16;
-            for (int k = 0; k < chunk; ++k) {
-                if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, rank, st))) return rc;
-                hipLaunchKernelGGL(apply_dual_kernel, dim3((n + l + 3) / 4), dim3(256), 0, st, w.C, w.G, n, w.predn, w.Gln, l, w.predl,
-                                   w.normpart, w.sc, w.dvec, w.sqd, w.rhs, rank > 0 ? w.respart : (double*)nullptr);
+        HIPCHK(hipMemcpyAsync(hsc, w.sc, sizeof(hsc), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (rank > 0 && !(hsc[S_RES] <= kLowRankMaxResidual)) {
+            if (getenv("CT_DEBUG"))
+                fprintf(stderr, "[ct_prgls_two_ref] low-rank M-step rejected after %d iterations (rank %d, residual %.3e, sigma2 %.3e): dense from the last checkpoint\n",
+                        (int)hsc[S_IT], rank, hsc[S_RES], hsc[S_SIGMA2]);
+            rank = 0;
+            if (ck_fits) {           // restore the last verified state and redo this chunk
+                HIPCHK(hipMemcpyAsync(w.predn, ck_n, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (l > 0) HIPCHK(hipMemcpyAsync(w.predl, ck_l, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(w.sc, ck_sc, S_NUM * sizeof(double), hipMemcpyDeviceToDevice, st));
+            } else {                 // no room for a checkpoint: restart from the initial state
+                HIPCHK(hipMemcpyAsync(w.predn, ref, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (l > 0) HIPCHK(hipMemcpyAsync(w.predl, tracked, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(w.sc, init_sc, sizeof(init_sc), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart0, m, n, 0, w.sc, (const double*)nullptr, (const double*)nullptr);
                 LAUNCH_CHECK();
-                hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, tgt, m, w.P, w.rowpart, w.sc);
-                LAUNCH_CHECK();
-                hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 1, w.sc, w.normpart,
-                                   rank > 0 ? w.respart : (const double*)nullptr);
-                LAUNCH_CHECK();
+                enq = 0;
             }
-            enq += chunk;
-            HIPCHK(hipMemcpyAsync(hsc, w.sc, sizeof(hsc), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            done_iters = (int)hsc[S_IT];
-            if (hsc[S_DONE] != 0.0 || (rank > 0 && hsc[S_RES] > kLowRankMaxResidual)) break;
+            continue;
         }
-        if (getenv("CT_DEBUG"))
-            fprintf(stderr, "[ct_prgls_two_ref] attempt %d rank %d iterations %d done %g residual %.3e sigma2 %.6e norm2 %.3e\n",
-                    attempt, rank, done_iters, hsc[S_DONE], hsc[S_RES], hsc[S_SIGMA2], hsc[S_NORM2]);
-        if (!(rank > 0 && hsc[S_RES] > kLowRankMaxResidual)) break;
+        enq += chunk;
+        done_iters = (int)hsc[S_IT];
+        if (hsc[S_DONE] != 0.0) break;
     }
+    if (getenv("CT_DEBUG"))
+        fprintf(stderr, "[ct_prgls_two_ref] rank %d iterations %d done %g residual %.3e sigma2 %.6e norm2 %.3e\n",
+                rank, done_iters, hsc[S_DONE], hsc[S_RES], hsc[S_SIGMA2], hsc[S_NORM2]);
     if (iters) *iters = done_iters;
     if (l > 0) HIPCHK(hipMemcpyAsync(out_tracked, w.predl, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (out_ref) HIPCHK(hipMemcpyAsync(out_ref, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
