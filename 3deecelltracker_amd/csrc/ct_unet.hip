@@ -68,6 +68,9 @@ constexpr int HX = TX + 2, HY = TY + 2, HZ = 18;  // halo tile (columns, z rows)
 constexpr int NF4 = HX * HY * HZ * 2;             // float4 slots of one 8-channel halo tile
 constexpr int NSTAGE = (NF4 + 255) / 256;
 constexpr int NSLAB = 14;                         // ceil(27 taps * 8 cin / 16 k per slab)
+// Two-plane staging (no tap padding, half the barriers) measured 24.7 vs 24.4 ms/volume: the 3.6 % fewer MFMAs are
+// eaten by the occupancy drop (69 KB LDS, +60 VGPRs).  Kept as a validated variant, switched off.
+constexpr bool kUsePairStaging = false;
 
 __host__ __device__ constexpr int tap_off(int tap) {   // float offset of tap (dx,dy,dz) in the LDS tile
     return (((tap / 9) * HY + (tap / 3) % 3) * HZ + tap % 3) * 8;
@@ -76,9 +79,14 @@ __host__ __device__ constexpr int mt_off(int mt) {      // float offset of the w
     return (((mt >> 2) * HY + (mt & 3)) * HZ) * 8;
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[NF4 * 4];
+// PAIR = true: two 8-channel planes are staged per stage (LDS 2 x 34.5 KB) so that K = 27 taps x 16 cin is exactly
+// 27 slabs of 16 (slab = one tap; lane group g reads plane g>>1, channels 4(g&1)..+3): no tap padding and half as
+// many barriers.  PAIR = false (Cin == 8): one plane, 27 x 8 = 216 k-values padded to 14 slabs of 2 taps.
+template <int NT, bool PAIR>
+__global__ __launch_bounds__(256, (NT == 2 && !PAIR) ? 3 : 2) void conv3_mfma_kernel(ConvArgs a) {
+    constexpr int PLANES = PAIR ? 2 : 1;
+    constexpr int PLANE_F = NF4 * 4;                 // floats per plane
+    __shared__ __attribute__((aligned(16))) float lds[PLANES * PLANE_F];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int b = blockIdx.x;
     const int cg = b % a.ngroups; b /= a.ngroups;
@@ -91,8 +99,8 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
 
     const int g = lane >> 4, zl = lane & 15;
     const int wx0 = 2 * (wave >> 1), wy0 = 4 * (wave & 1);
-    const int lbase = ((wx0 * HY + wy0) * HZ + zl) * 8 + 4 * (g & 1);
     const bool hi = (g >> 1) != 0;
+    const int lbase = ((wx0 * HY + wy0) * HZ + zl) * 8 + 4 * (g & 1) + (PAIR && hi ? PLANE_F : 0);
 
     f32x4 acc[8][NT];
 #pragma unroll
@@ -100,60 +108,94 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        // ---- stage the 8-channel halo tile: global -> registers -> LDS (zero 'same' padding)
-        const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
-        {
-            const int c0 = chunk * 8;
-            if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
-                             sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
-            else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
-                             sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
-        }
-        f32x4 v[NSTAGE];
+    const int nstages = a.nchunks / PLANES;
+    for (int stage = 0; stage < nstages; ++stage) {
+        // ---- stage the halo tile(s): global -> registers -> LDS (zero 'same' padding).
+        // NT < 4: both planes are in flight together; NT == 4 (128 accumulator registers): one plane at a time.
+        constexpr int GROUP = (NT >= 4) ? 1 : PLANES;          // planes loaded per round
 #pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
-            const int f = tid + 256 * i;
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (f < NF4) {
-                const int col = f / (HZ * 2), w = f - col * (HZ * 2);
-                const int hz = w >> 1, half = w & 1;
-                const int hx = col / HY, hy = col - hx * HY;
-                const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-                if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
-                    const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
-                                        + (gz >> suz)) * 8 + half * 4;
-                    v[i] = *reinterpret_cast<const f32x4*>(src + idx);
+        for (int round = 0; round < PLANES / GROUP; ++round) {
+            f32x4 v[GROUP][NSTAGE];
+#pragma unroll
+            for (int q = 0; q < GROUP; ++q) {
+                const int pl = round * GROUP + q;
+                const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
+                {
+                    const int c0 = (stage * PLANES + pl) * 8;
+                    if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
+                                     sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
+                    else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
+                                     sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
+                }
+#pragma unroll
+                for (int i = 0; i < NSTAGE; ++i) {
+                    const int f = tid + 256 * i;
+                    v[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (f < NF4) {
+                        const int col = f / (HZ * 2), w = f - col * (HZ * 2);
+                        const int hz = w >> 1, half = w & 1;
+                        const int hx = col / HY, hy = col - hx * HY;
+                        const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+                        if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
+                            const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
+                                                + (gz >> suz)) * 8 + half * 4;
+                            v[q][i] = *reinterpret_cast<const f32x4*>(src + idx);
+                        }
+                    }
                 }
             }
-        }
-        __syncthreads();                      // every wave is done reading the previous tile
+            if (round == 0) __syncthreads();                  // every wave is done reading the previous tile
 #pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
-            const int f = tid + 256 * i;
-            if (f < NF4) *reinterpret_cast<f32x4*>(&lds[f * 4]) = v[i];
+            for (int q = 0; q < GROUP; ++q)
+#pragma unroll
+                for (int i = 0; i < NSTAGE; ++i) {
+                    const int f = tid + 256 * i;
+                    if (f < NF4) *reinterpret_cast<f32x4*>(&lds[(round * GROUP + q) * PLANE_F + f * 4]) = v[q][i];
+                }
         }
         __syncthreads();
 
-        // ---- 14 slabs of 16 k-values (2 taps x 8 cin); lane group g owns tap 2s+(g>>1), cin 4(g&1)..+3
-        const f32x4* wp = a.wpack + ((size_t)chunk * NSLAB * a.nt_total + ntb) * 64 + lane;
+        if constexpr (PAIR) {
+            // ---- 27 slabs = 27 taps x 16 cin
+            const f32x4* wp = a.wpack + ((size_t)stage * 27 * a.nt_total + ntb) * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < NSLAB; ++s) {
-            const int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;   // tap 27 is padding (zero weights)
-            const int off = lbase + (hi ? tap_off(t1) : tap_off(t0));
-            f32x4 wv[NT];
+            for (int s = 0; s < 27; ++s) {
+                const int off = lbase + tap_off(s);
+                f32x4 wv[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
-            f32x4 av[8];
+                for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
+                f32x4 av[8];
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt_off(mt)]);
+                for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt_off(mt)]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt)
+                    for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
+            }
+        } else {
+            // ---- 14 slabs of 16 k-values (2 taps x 8 cin); lane group g owns tap 2s+(g>>1), cin 4(g&1)..+3
+            const f32x4* wp = a.wpack + ((size_t)stage * NSLAB * a.nt_total + ntb) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < NSLAB; ++s) {
+                const int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;   // tap 27 is padding (zero weights)
+                const int off = lbase + (hi ? tap_off(t1) : tap_off(t0));
+                f32x4 wv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
+                f32x4 av[8];
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt_off(mt)]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
+            }
         }
     }
 
@@ -487,6 +529,7 @@ struct ConvPlan {
     int pool_dst;         // tensor id or -1
     bool head;
     bool c8;              // Cout == 8: paired-column kernel
+    bool pair;            // Cin % 16 == 0: two planes per stage
     size_t wpack_off;     // float4 offset into the device weight arena
     size_t epi_off;       // float offset
 };
@@ -544,6 +587,23 @@ void pack_conv_weights(const float* k, int cin, int cout, int NT, float* dst) {
                     }
 }
 
+// PAIR packing (Cin multiple of 16): slab = tap, lane group g -> plane g>>1, channels 4(g&1)..+3 of that plane:
+//   wpack[pair][tap][nt][lane = g*16 + n][t] = K[tap][cin = 16*pair + 8*(g>>1) + 4*(g&1) + t][cout = 16*nt + n]
+void pack_conv_weights_pair(const float* k, int cin, int cout, int NT, float* dst) {
+    const int npairs = cin / 16;
+    for (int pr = 0; pr < npairs; ++pr)
+        for (int s = 0; s < 27; ++s)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int t = 0; t < 4; ++t) {
+                        const int g = lane >> 4, n = lane & 15;
+                        const int ci = 16 * pr + 8 * (g >> 1) + 4 * (g & 1) + t, co = 16 * nt + n;
+                        float v = 0.f;
+                        if (co < cout) v = k[((size_t)s * cin + ci) * cout + co];
+                        dst[((((size_t)pr * 27 + s) * NT + nt) * 64 + lane) * 4 + t] = v;
+                    }
+}
+
 // Cout = 8 packing (conv3_mfma_c8_kernel): rows n = xs * 8 + co, taps dx' in 0..3:
 //   wpack8[chunk][slab][lane = g*16 + n][t] = K[dx' - xs][dy][dz][8*chunk + 4*(g&1) + t][co], tap' = 2*slab + (g>>1)
 void pack_conv_weights_c8(const float* k, int cin, float* dst) {
@@ -566,9 +626,10 @@ void pack_conv_weights_c8(const float* k, int cin, float* dst) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <int NT>
-int launch_conv(const ConvArgs& a, int P, hipStream_t st) {
+int launch_conv(const ConvArgs& a, int P, bool pair, hipStream_t st) {
     const int nblk = P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
-    hipLaunchKernelGGL(conv3_mfma_kernel<NT>, dim3(nblk), dim3(256), 0, st, a);
+    if (pair) hipLaunchKernelGGL((conv3_mfma_kernel<NT, true>), dim3(nblk), dim3(256), 0, st, a);
+    else      hipLaunchKernelGGL((conv3_mfma_kernel<NT, false>), dim3(nblk), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -748,6 +809,10 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
                 c.c8 = true;
                 arena.resize(arena.size() + (size_t)(c.cin / 8) * NSLAB8 * 64 * 4);
                 pack_conv_weights_c8(kern, c.cin, arena.data() + c.wpack_off);
+            } else if (kUsePairStaging && c.cin % 16 == 0 && c.NT < 4) {   // two planes per stage, 27 exact slabs (NT = 4 would spill)
+                c.pair = true;
+                arena.resize(arena.size() + (size_t)(c.cin / 16) * 27 * c.nt_total * 64 * 4);
+                pack_conv_weights_pair(kern, c.cin, c.cout, c.nt_total, arena.data() + c.wpack_off);
             } else {
                 arena.resize(arena.size() + (size_t)(c.cin / 8) * NSLAB * c.nt_total * 64 * 4);
                 pack_conv_weights(kern, c.cin, c.cout, c.nt_total, arena.data() + c.wpack_off);
@@ -834,9 +899,9 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 rc = (int)hipGetLastError();
             } else
             switch (c.NT) {
-                case 1: rc = launch_conv<1>(a, P, st); break;
-                case 2: rc = launch_conv<2>(a, P, st); break;
-                case 4: rc = launch_conv<4>(a, P, st); break;
+                case 1: rc = launch_conv<1>(a, P, c.pair, st); break;
+                case 2: rc = launch_conv<2>(a, P, c.pair, st); break;
+                case 4: rc = launch_conv<4>(a, P, c.pair, st); break;
                 default: return CT_ESHAPE;
             }
             if (rc) return rc;

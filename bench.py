@@ -45,7 +45,9 @@ def main():
     ap.add_argument("--shape", type=int, nargs=3, default=(512, 512, 32))
     ap.add_argument("--cells", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--match-cus", type=int, default=32, help="CUs reserved for the matching chains (rest: U-Net)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--same-device", action="store_true", help="dry run: all ranks on cuda:0 (needs --backend gloo)")
+    ap.add_argument("--match-cus", type=int, default=24, help="CUs reserved for the matching chains (rest: U-Net)")
     ap.add_argument("--match-workers", type=int, default=3, help="frames whose match chains are in flight concurrently")
     ap.add_argument("--cpu-patches", type=int, default=2, help="U-Net patches timed by the CPU baseline sample")
     args = ap.parse_args()
@@ -57,8 +59,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 
