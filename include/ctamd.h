@@ -186,6 +186,21 @@ int ct_gram_apply(double* pred, int l, const double* inter, int n, const double*
  * stack [dev] fp64 [k][n3] -> out [dev] fp64 [n3].                                               */
 int ct_trim_mean(const double* stack, int k, int n3, double cut, double* out, ct_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Pre-processing: local contrast normalisation  (preprocess.py:85-188)
+ * ------------------------------------------------------------------------------------------
+ * dtype: 0 = uint16, 1 = float32.  img/data [dev], [x][y][z].
+ * ct_median: np.median (mean of the two middle order statistics) by radix select; median_out [dev] fp64.
+ * ct_normalize_image: subtract_median = 1 -> _normalize_image (:170-188: x = max(img - median, 0), then LCN);
+ *   mode 0 = zero padding (lcn_gpu :136-167, the Keras ones-kernel Conv3D), mode 1 = scipy 'reflect' (lcn_cpu :85-114);
+ *   filter: odd window sizes (reference default 27, 27, 1); out [dev] fp32 [x][y][z].                       */
+size_t ct_normalize_workspace_bytes(const int dims_xyz[3]);
+int ct_median(const void* data, int dtype, size_t n, double* median_out, void* workspace, size_t workspace_bytes,
+              ct_stream_t stream);
+int ct_normalize_image(const void* img, int dtype, const int dims_xyz[3], double noise_level, const int filter_xyz[3],
+                       int mode, int subtract_median, float* out, void* workspace, size_t workspace_bytes,
+                       ct_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,9 +263,23 @@ def gen_match():
     (HERE / "match.json").write_text(json.dumps(meta))
 
 
+def gen_preprocess():
+    """reference lcn_cpu (scipy, reflect) -- the runnable twin of lcn_gpu (preprocess.py:85-114)"""
+    ref_pre = importlib.import_module("CellTracker.preprocess")
+    out = {}
+    rng = np.random.default_rng(21)
+    for i, (shape, fs, nl) in enumerate((((40, 52, 6), (27, 27, 1), 20.0), ((31, 33, 4), (5, 7, 3), 5.0), ((64, 64, 16), (27, 27, 1), 100.0))):
+        img = rng.integers(0, 3000, size=shape).astype(np.float64)
+        out[f"lcn_in_{i}"] = img; out[f"lcn_fs_{i}"] = np.array(fs); out[f"lcn_nl_{i}"] = np.float64(nl)
+        out[f"lcn_out_{i}"] = ref_pre.lcn_cpu(img, nl, filter_size=fs)
+    np.savez_compressed(HERE / "preprocess.npz", **out)
+    print("preprocess goldens written")
+
+
 if __name__ == "__main__":
     gen_tiler()
     gen_match()
+    gen_preprocess()
     leftovers = [p for p in Path("/root/reference").rglob("__pycache__")]
     assert not leftovers, leftovers
     print("golden vectors written to", HERE)

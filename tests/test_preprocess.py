@@ -1,0 +1,82 @@
+"""Local contrast normalisation: oracle vs the reference's lcn_cpu (golden), HIP vs oracle."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import preprocess_ref as pr
+
+pre = importlib.import_module("3deecelltracker_amd.preprocess")
+synth = importlib.import_module("3deecelltracker_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(golden_dir / "preprocess.npz")
+
+
+def test_oracle_reflect_variant_against_reference_lcn_cpu(g):
+    for i in range(3):
+        got = pr.lcn(g[f"lcn_in_{i}"], float(g[f"lcn_nl_{i}"]), tuple(int(v) for v in g[f"lcn_fs_{i}"]), mode="reflect")
+        np.testing.assert_allclose(got, g[f"lcn_out_{i}"], rtol=0, atol=1e-12)
+
+
+def test_oracle_zero_variant_matches_direct_window_sums():
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0, 100, (9, 11, 3))
+    s = pr.box_sum(x, (5, 3, 1), "constant")
+    want = np.zeros_like(x)
+    for i in range(9):
+        for j in range(11):
+            want[i, j] = x[max(0, i - 2):i + 3, max(0, j - 1):j + 2].sum(axis=(0, 1))
+    np.testing.assert_allclose(s, want, rtol=0, atol=1e-10)
+    img = rng.integers(0, 500, (20, 20, 4)).astype(np.uint16)
+    out = pr.normalize_image(img, 20.0)
+    assert out.shape == img.shape and np.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_device_lcn_reflect_against_reference_golden(g):
+    for i in range(3):
+        got = pre.lcn_cpu(g[f"lcn_in_{i}"], float(g[f"lcn_nl_{i}"]), tuple(int(v) for v in g[f"lcn_fs_{i}"]))
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, g[f"lcn_out_{i}"], rtol=0, atol=2e-4)         # fp32 storage of sums ~1e6..1e8
+
+
+@pytest.mark.gpu
+def test_device_median_is_exact():
+    import torch
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 7, 1000, 1001, 65536 * 3 + 5):
+        a = rng.integers(0, 5000, n).astype(np.uint16)
+        assert pre.median_device(torch.from_numpy(a).cuda()) == float(np.median(a))
+        f = rng.normal(0, 100, n).astype(np.float32)
+        assert pre.median_device(torch.from_numpy(f).cuda()) == float(np.median(f.astype(np.float64)))
+    z = np.zeros(100, np.uint16); z[:50] = 7
+    assert pre.median_device(torch.from_numpy(z).cuda()) == float(np.median(z)) == 3.5
+
+
+@pytest.mark.gpu
+def test_device_normalize_image_against_oracle():
+    stack, _ = synth.make_stack((128, 96, 12), 40, seed=3)
+    got = pre._normalize_image(stack, 100.0)
+    want = pr.normalize_image(stack, 100.0)
+    assert got.shape == stack.shape and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)
+    got2 = pre.lcn_gpu(stack.astype(np.float64), noise_level=5, filter_size=(27, 27, 1))
+    np.testing.assert_allclose(got2, pr.lcn(stack.astype(np.float64), 5, (27, 27, 1), "constant"), rtol=0, atol=3e-4)
+
+
+@pytest.mark.gpu
+def test_device_normalize_full_size_properties():
+    """512x512x32 uint16: linearity-type properties instead of a slow CPU run: adding a constant to the image leaves the
+    result unchanged (median subtraction) wherever nothing is clamped; output is finite."""
+    import torch
+    stack, _ = synth.make_stack((512, 512, 32), 600, seed=0)
+    d = torch.from_numpy(stack).cuda()
+    a = pre.normalize_image_device(d, 100.0)
+    b = pre.normalize_image_device((d.to(torch.int32) + 1000).to(torch.uint16), 100.0)
+    assert bool(torch.isfinite(a).all()) and tuple(a.shape) == (512, 512, 32)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        pre.normalize_image_device(d, 100.0, filter_size=(26, 27, 1))
