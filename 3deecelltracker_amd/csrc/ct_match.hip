@@ -563,173 +563,15 @@ __global__ __launch_bounds__(256) void colstats_finish_kernel(const double* __re
 
 // M = D^1/2 G D^1/2 + c I   (lower triangle is what the factorisation reads; fill everything)
 __global__ __launch_bounds__(256) void assemble_kernel(const double* __restrict__ G, const double* __restrict__ sqd,
-                                                       const double* __restrict__ sc, int n, double* __restrict__ M) {
+                                                       const double* __restrict__ sc, int n, double* __restrict__ M,
+                                                       const double* __restrict__ rhs = nullptr, double* __restrict__ W = nullptr) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (W && gid < 3 * (size_t)n) { const int d = (int)(gid / n), i = (int)(gid - (size_t)d * n); W[gid] = rhs[3 * i + d]; }
     if (gid >= (size_t)n * n) return;
     const int i = (int)(gid / n), j = (int)(gid - (size_t)i * n);
     double v = sqd[i] * G[gid] * sqd[j];
     if (i == j) v += sc[S_C];
     M[gid] = v;
-}
-
-// ---- blocked right-looking Cholesky, NB = 32 ----------------------------------------------------
-constexpr int NB = 32;
-
-// Panel step: every block factors the diagonal block redundantly in LDS (32^3/3 flops), block 0 writes
-// it back; then each block solves its 32 rows of the panel:  L[i, k0:k0+nb] = A[i, k0:k0+nb] L_kk^-T.
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ M, int n, int k0) {
-    __shared__ double Lkk[NB][NB + 1];
-    __shared__ double Arow[NB][NB + 1];
-    const int tid = threadIdx.x;
-    const int nb = min(NB, n - k0);
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e % NB;
-        Lkk[i][j] = (i < nb && j < nb) ? M[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {                 // unblocked factorisation of the 32 x 32 block
-        if (tid == 0) Lkk[j][j] = sqrt(Lkk[j][j]);
-        __syncthreads();
-        if (tid > j && tid < nb) Lkk[tid][j] /= Lkk[j][j];
-        __syncthreads();
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int i = e / NB, c = e % NB;
-            if (c > j && c <= i && i < nb) Lkk[i][c] -= Lkk[i][j] * Lkk[c][j];
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x == 0)
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int i = e / NB, j = e % NB;
-            if (i < nb && j < nb) M[(size_t)(k0 + i) * n + k0 + j] = (j <= i) ? Lkk[i][j] : 0.0;
-        }
-    const int row0 = k0 + nb + blockIdx.x * NB;
-    if (row0 >= n) return;
-    const int nr = min(NB, n - row0);
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e % NB;
-        Arow[i][j] = (i < nr && j < nb) ? M[(size_t)(row0 + i) * n + k0 + j] : 0.0;
-    }
-    __syncthreads();
-    // forward substitution along the row: x_j = (a_j - sum_{p<j} x_p L[j][p]) / L[j][j]; thread = row
-    if (tid < nr) {
-        for (int j = 0; j < nb; ++j) {
-            double s = Arow[tid][j];
-            for (int p = 0; p < j; ++p) s -= Arow[tid][p] * Lkk[j][p];
-            Arow[tid][j] = s / Lkk[j][j];
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e % NB;
-        if (i < nr && j < nb) M[(size_t)(row0 + i) * n + k0 + j] = Arow[i][j];
-    }
-}
-
-// Trailing update (lower triangle, 32 x 32 tiles): A[i][j] -= sum_p L[i][k0+p] L[j][k0+p]
-__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ M, int n, int k0) {
-    const int nb = min(NB, n - k0);
-    const int base = k0 + nb;
-    const int bi = blockIdx.y, bj = blockIdx.x;
-    if (bj > bi) return;
-    const int i0 = base + bi * NB, j0 = base + bj * NB;
-    if (i0 >= n || j0 >= n) return;
-    __shared__ double Li[NB][NB + 1], Lj[NB][NB + 1];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e / NB, p = e % NB;
-        Li[r][p] = (i0 + r < n && p < nb) ? M[(size_t)(i0 + r) * n + k0 + p] : 0.0;
-        Lj[r][p] = (j0 + r < n && p < nb) ? M[(size_t)(j0 + r) * n + k0 + p] : 0.0;
-    }
-    __syncthreads();
-    const int tx = tid & 31, ty = tid >> 5;          // 32 x 8 threads, 4 rows each
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = ty + 8 * q, c = tx;
-        const int gi = i0 + r, gj = j0 + c;
-        if (gi < n && gj < n && gj <= gi) {
-            double s = 0.0;
-#pragma unroll 8
-            for (int p = 0; p < NB; ++p) s = fma(Li[r][p], Lj[c][p], s);
-            M[(size_t)gi * n + gj] -= s;
-        }
-    }
-}
-
-// Triangular solves L w = b, L^T z = w for 3 right-hand sides; one workgroup; then
-// C[d][i] = sqrt(d_i) z[i][d]  (un-scaling).  rhs [n][3] is overwritten with z.
-__global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ L, int n, double* __restrict__ rhs,
-                                                         const double* __restrict__ sqd, double* __restrict__ C) {
-    __shared__ double xb[NB][3];
-    __shared__ double Ld[NB][NB + 1];
-    __shared__ double ps[2][NB][3];
-    const int tid = threadIdx.x;
-    const int nblk = (n + NB - 1) / NB;
-    // ---- forward: for each block row, subtract the contribution of solved unknowns, then solve the diagonal block
-    for (int kb = 0; kb < nblk; ++kb) {
-        const int k0 = kb * NB, nb = min(NB, n - k0);
-        // 96 (row, rhs) dot products of length k0: threads split (row, rhs) x 2 halves?  use 3 x 32 x (k split 2)
-        {
-            const int row = tid & 31, d = (tid >> 5) % 3, part = tid / 96;       // part 0..1 (tid < 192)
-            double s = 0.0;
-            if (tid < 192 && row < nb) {
-                const double* lr = L + (size_t)(k0 + row) * n;
-                for (int p = part; p < k0; p += 2) s = fma(lr[p], rhs[3 * p + d], s);
-            }
-            if (tid < 192) ps[part][row][d] = s;
-            __syncthreads();
-            if (tid < 96 && row < nb) xb[row][d] = rhs[3 * (k0 + row) + d] - (ps[0][row][d] + ps[1][row][d]);
-        }
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int i = e / NB, j = e % NB;
-            Ld[i][j] = (i < nb && j < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-        }
-        __syncthreads();
-        if (tid < 3) {
-            for (int i = 0; i < nb; ++i) {
-                double s = xb[i][tid];
-                for (int p = 0; p < i; ++p) s -= Ld[i][p] * xb[p][tid];
-                xb[i][tid] = s / Ld[i][i];
-            }
-        }
-        __syncthreads();
-        if (tid < 96) { const int row = tid & 31, d = tid >> 5; if (row < nb) rhs[3 * (k0 + row) + d] = xb[row][d]; }
-        __syncthreads();
-    }
-    // ---- backward with L^T: unknown block kb depends on blocks > kb through L[rows > kb][cols kb]
-    for (int kb = nblk - 1; kb >= 0; --kb) {
-        const int k0 = kb * NB, nb = min(NB, n - k0);
-        const int k1 = k0 + nb;
-        {
-            const int col = tid & 31, d = (tid >> 5) % 3, part = tid / 96;
-            double s = 0.0;
-            if (tid < 192 && col < nb) {
-                for (int p = k1 + part; p < n; p += 2) s = fma(L[(size_t)p * n + k0 + col], rhs[3 * p + d], s);
-            }
-            if (tid < 192) ps[part][col][d] = s;
-            __syncthreads();
-            if (tid < 96 && col < nb) xb[col][d] = rhs[3 * (k0 + col) + d] - (ps[0][col][d] + ps[1][col][d]);
-        }
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int i = e / NB, j = e % NB;
-            Ld[i][j] = (i < nb && j < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : 0.0;
-        }
-        __syncthreads();
-        if (tid < 3) {
-            for (int i = nb - 1; i >= 0; --i) {
-                double s = xb[i][tid];
-                for (int p = i + 1; p < nb; ++p) s -= Ld[p][i] * xb[p][tid];
-                xb[i][tid] = s / Ld[i][i];
-            }
-        }
-        __syncthreads();
-        if (tid < 96) { const int row = tid & 31, d = tid >> 5; if (row < nb) rhs[3 * (k0 + row) + d] = xb[row][d]; }
-        __syncthreads();
-    }
-    for (int e = tid; e < 3 * n; e += 256) {
-        const int i = e / 3, d = e - 3 * i;
-        C[(size_t)d * n + i] = sqd[i] * rhs[e];
-    }
 }
 
 // movement of a point set through the field: mov[j][d] = sum_i C[d][i] G[i][j]; one wave per j.
@@ -932,39 +774,11 @@ __global__ __launch_bounds__(256) void lr_gram_kernel(int n, const double* __res
     }
 }
 
-// single workgroup: q = (c I + S)^-1 y for 3 right-hand sides, S given by lr_gram_kernel.
-// The right-hand sides ride along as 3 extra rows of the matrix being factorised
-// ([[S, y], [y^T, .]] = L_aug L_aug^T puts w = L^-1 y into those rows), so the forward substitution is
-// free.  Blocked right-looking factorisation, 8 columns per step, 2 barriers per step: (1) every thread
-// factors the 8 x 8 diagonal block redundantly in registers and solves its own rows of the panel,
-// (2) rank-8 update of the trailing block.  Then a back-substitution, one unknown per thread.
 constexpr int LS_B = 8;
-__global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict__ Sin, const double* __restrict__ yin,
-                                                       int n, const int* __restrict__ rank_p, double lambda,
-                                                       const double* __restrict__ dvec, double* __restrict__ sc,
-                                                       double* __restrict__ qout) {
-    if (sc[S_DONE] != 0.0) return;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int r = *rank_p;
-    const int ld = r | 1;                  // odd leading dimension (doubles): spreads rows over the LDS banks
-    const int ra = r + 3;                  // augmented row count
-    double* S = sm;                        // [ra][ld]
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    const double c = lambda * sc[S_SIGMA2];
-    for (int e = tid; e < r * r; e += 256) {
-        const int a = e / r, b = e - a * r;
-        if (b <= a) S[a * ld + b] = Sin[a * LR_RMAX + b] + (a == b ? c : 0.0);
-    }
-    for (int e = tid; e < r * 3; e += 256) { const int a = e / 3, d = e - a * 3; S[(r + d) * ld + a] = yin[e]; }
-    {   // sumP = sum_i d_i
-        double acc = 0.0;
-        for (int i = tid; i < n; i += 256) acc += dvec[i];
-        acc = wave_sum_d(acc);
-        if ((tid & 63) == 0) red[tid >> 6] = acc;
-    }
-    __syncthreads();
-    if (tid == 0) { sc[S_SUMP] = (red[0] + red[1]) + (red[2] + red[3]); sc[S_C] = c; }
+// In-LDS solve of the SPD system S q = y for 3 right-hand sides stored as rows r..r+2 of S (augmented Cholesky,
+// 8-column blocks, 2 barriers per block; then a blocked back-substitution).  256 threads.  On return rows r..r+2 hold q.
+__device__ void chol_factor_aug_lds(double* S, int ld, int r, int naug, int tid) {
+    const int ra = r + naug;
     const int ty = tid >> 4, tx = tid & 15;
     for (int j0 = 0; j0 < r; j0 += LS_B) {
         const int nb = min(LS_B, r - j0);
@@ -1024,8 +838,11 @@ __global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict_
         }
         __syncthreads();
     }
-    // blocked backward substitution L^T q = w (w_d lives in row r+d): 8 unknowns per step; every thread solves the
-    // 8 x 8 triangle redundantly in registers, then thread p < j0 removes their contribution from unknown p.
+}
+
+// blocked backward substitution L^T q = w (w_d lives in row r+d): 8 unknowns per step; every thread solves the
+// 8 x 8 triangle redundantly in registers, then thread p < j0 removes their contribution from unknown p.
+__device__ void chol_backsub3_lds(double* S, int ld, int r, int tid) {
     for (int j0 = ((r - 1) / LS_B) * LS_B; j0 >= 0; j0 -= LS_B) {
         const int nb = min(LS_B, r - j0);
         double qv[LS_B][3];
@@ -1054,7 +871,221 @@ __global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict_
         }
         __syncthreads();
     }
+}
+
+// ---- dense path for n > DS_MAXN: blocked right-looking Cholesky of M = D^1/2 G D^1/2 + c I (NB = 32) --------------
+// The 3 right-hand sides W [3][n] ride through the factorisation as extra rows (forward substitution for free);
+// per panel: (1) every block factors the 32 x 32 diagonal block in LDS with the register-blocked routine above and
+// solves its 32 panel rows (the last block: the rhs rows), (2) trailing rank-32 update incl. the rhs rows; then one
+// blocked backward substitution kernel.
+constexpr int NB = 32;
+
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ M, double* __restrict__ W, int n, int k0) {
+    __shared__ double Lkk[NB * (NB + 1)];
+    __shared__ double Arow[NB][NB + 1];
+    const int tid = threadIdx.x;
+    const int nb = min(NB, n - k0);
+    constexpr int ld = NB + 1;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        Lkk[i * ld + j] = (i < nb && j < nb) ? M[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    chol_factor_aug_lds(Lkk, ld, nb, 0, tid);
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            if (i < nb && j < nb) M[(size_t)(k0 + i) * n + k0 + j] = (j <= i) ? Lkk[i * ld + j] : 0.0;
+        }
+    const bool rhs_block = blockIdx.x == gridDim.x - 1;
+    const int row0 = k0 + nb + blockIdx.x * NB;
+    const int nr = rhs_block ? 3 : min(NB, n - row0);
+    if (!rhs_block && row0 >= n) return;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        double v = 0.0;
+        if (i < nr && j < nb) v = rhs_block ? W[(size_t)i * n + k0 + j] : M[(size_t)(row0 + i) * n + k0 + j];
+        Arow[i][j] = v;
+    }
+    __syncthreads();
+    if (tid < nr) {       // x L_kk^T = a : forward substitution with the row in registers, L broadcast from LDS
+        double x[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) x[j] = Arow[tid][j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double t = x[j];
+#pragma unroll
+            for (int p2 = 0; p2 < j; ++p2) t = fma(-x[p2], Lkk[j * ld + p2], t);
+            x[j] = t / Lkk[j * ld + j];                 // rows/cols >= nb are identity padding
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Arow[tid][j] = x[j];
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        if (i < nr && j < nb) {
+            if (rhs_block) W[(size_t)i * n + k0 + j] = Arow[i][j];
+            else M[(size_t)(row0 + i) * n + k0 + j] = Arow[i][j];
+        }
+    }
+}
+
+// trailing update: A[i][j] -= sum_p L[i][k0+p] L[j][k0+p] (lower tiles), rhs rows: W[d][j] -= sum_p W[d][k0+p] L[j][k0+p]
+__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ M, double* __restrict__ W, int n, int k0) {
+    const int nb = min(NB, n - k0);
+    const int base = k0 + nb;
+    const int ntile = (n - base + NB - 1) / NB;
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    const bool rhs_tile = bi == ntile;
+    if (!rhs_tile && bj > bi) return;
+    const int i0 = base + bi * NB, j0 = base + bj * NB;
+    if (j0 >= n || (!rhs_tile && i0 >= n)) return;
+    __shared__ double Li[NB][NB + 1], Lj[NB][NB + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e / NB, p2 = e % NB;
+        double vi = 0.0;
+        if (p2 < nb) {
+            if (rhs_tile) { if (r < 3) vi = W[(size_t)r * n + k0 + p2]; }
+            else if (i0 + r < n) vi = M[(size_t)(i0 + r) * n + k0 + p2];
+        }
+        Li[r][p2] = vi;
+        Lj[r][p2] = (j0 + r < n && p2 < nb) ? M[(size_t)(j0 + r) * n + k0 + p2] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = ty + 8 * q, c = tx;
+        const int gj = j0 + c;
+        if (gj >= n) continue;
+        if (rhs_tile) {
+            if (r >= 3) continue;
+        } else if (i0 + r >= n || gj > i0 + r) continue;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int p2 = 0; p2 < NB; ++p2) acc = fma(Li[r][p2], Lj[c][p2], acc);
+        if (rhs_tile) W[(size_t)r * n + gj] -= acc;
+        else M[(size_t)(i0 + r) * n + gj] -= acc;
+    }
+}
+
+// backward substitution L^T z = w for the 3 right-hand sides in W [3][n] (in place), one workgroup, right-looking:
+// solve the 32 unknowns of block kb (in-LDS blocked triangle), then every earlier unknown p < k0 subtracts the 32
+// terms L[k0+i][p] z_i (rows of L: coalesced over p, no reduction).  Finally C[d][i] = sqrt(d_i) z[d][i].
+__global__ __launch_bounds__(256) void chol_backward_kernel(const double* __restrict__ L, int n, double* __restrict__ W,
+                                                             const double* __restrict__ sqd, double* __restrict__ C) {
+    __shared__ double T[(NB + 3) * (NB + 1)];
+    constexpr int ld = NB + 1;
+    const int tid = threadIdx.x;
+    const int nblk = (n + NB - 1) / NB;
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int k0 = kb * NB, nb = min(NB, n - k0);
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            T[i * ld + j] = (i < nb && j < nb) ? L[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+        }
+        if (tid < 96) { const int c = tid & 31, d = tid >> 5; T[(nb + d) * ld + c] = (c < nb) ? W[(size_t)d * n + k0 + c] : 0.0; }
+        __syncthreads();
+        chol_backsub3_lds(T, ld, nb, tid);
+        if (tid < 96) { const int c = tid & 31, d = tid >> 5; if (c < nb) W[(size_t)d * n + k0 + c] = T[(nb + d) * ld + c]; }
+        for (int p2 = tid; p2 < k0; p2 += 256) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll 8
+            for (int i = 0; i < NB; ++i) {
+                if (i < nb) {
+                    const double l = L[(size_t)(k0 + i) * n + p2];
+                    a0 = fma(l, T[(nb + 0) * ld + i], a0); a1 = fma(l, T[(nb + 1) * ld + i], a1); a2 = fma(l, T[(nb + 2) * ld + i], a2);
+                }
+            }
+            W[p2] -= a0; W[(size_t)n + p2] -= a1; W[2 * (size_t)n + p2] -= a2;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 3 * n; e += 256) { const int i = e % n; C[e] = sqd[i] * W[e]; }
+}
+
+// single workgroup: q = (c I + S)^-1 y for 3 right-hand sides, S given by lr_gram_kernel.
+// The right-hand sides ride along as 3 extra rows of the matrix being factorised
+// ([[S, y], [y^T, .]] = L_aug L_aug^T puts w = L^-1 y into those rows), so the forward substitution is
+// free.  Blocked right-looking factorisation, 8 columns per step, 2 barriers per step: (1) every thread
+// factors the 8 x 8 diagonal block redundantly in registers and solves its own rows of the panel,
+// (2) rank-8 update of the trailing block.  Then a back-substitution, one unknown per thread.
+__global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict__ Sin, const double* __restrict__ yin,
+                                                       int n, const int* __restrict__ rank_p, double lambda,
+                                                       const double* __restrict__ dvec, double* __restrict__ sc,
+                                                       double* __restrict__ qout) {
+    if (sc[S_DONE] != 0.0) return;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int r = *rank_p;
+    const int ld = r | 1;                  // odd leading dimension (doubles): spreads rows over the LDS banks
+    const int ra = r + 3;                  // augmented row count
+    double* S = sm;                        // [ra][ld]
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const double c = lambda * sc[S_SIGMA2];
+    for (int e = tid; e < r * r; e += 256) {
+        const int a = e / r, b = e - a * r;
+        if (b <= a) S[a * ld + b] = Sin[a * LR_RMAX + b] + (a == b ? c : 0.0);
+    }
+    for (int e = tid; e < r * 3; e += 256) { const int a = e / 3, d = e - a * 3; S[(r + d) * ld + a] = yin[e]; }
+    {   // sumP = sum_i d_i
+        double acc = 0.0;
+        for (int i = tid; i < n; i += 256) acc += dvec[i];
+        acc = wave_sum_d(acc);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) { sc[S_SUMP] = (red[0] + red[1]) + (red[2] + red[3]); sc[S_C] = c; }
+    chol_factor_aug_lds(S, ld, r, 3, tid);
+    chol_backsub3_lds(S, ld, r, tid);
     for (int e = tid; e < r * 3; e += 256) { const int a2 = e / 3, d = e - a2 * 3; qout[e] = S[(r + d) * ld + a2]; }
+}
+
+// Dense M-step for small n (n + 3 rows of n|1 doubles fit the LDS: n <= DS_MAXN): one workgroup finishes the column
+// statistics, assembles M = D^1/2 G D^1/2 + c I in LDS, solves it with the augmented Cholesky and writes
+// C[d][i] = sqrt(d_i) z_i[d].  Replaces finish + assemble + 2 n/32 panel/update launches + the triangular solves.
+constexpr int DS_MAXN = 132;
+__global__ __launch_bounds__(256) void dense_small_solve_kernel(const double* __restrict__ part, int n, const double* __restrict__ xref,
+                                                                const double* __restrict__ G, double lambda, double* __restrict__ sc,
+                                                                double* __restrict__ dvec, double* __restrict__ sqd_g,
+                                                                double* __restrict__ rhs_g, double* __restrict__ C) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double sq[DS_MAXN];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int ld = n | 1;
+    double* S = sm;                         // [n + 3][ld]
+    const double c = lambda * sc[S_SIGMA2];
+    double tot = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        double s0 = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int seg = 0; seg < CS_SEG; ++seg) {
+            const double* o = part + (size_t)seg * 4 * n;
+            s0 += o[i]; sx += o[n + i]; sy += o[2 * n + i]; sz += o[3 * n + i];
+        }
+        const double q = sqrt(s0), iq = q > 0.0 ? 1.0 / q : 0.0;
+        const double bx = (sx - xref[3 * i] * s0) * iq, by = (sy - xref[3 * i + 1] * s0) * iq, bz = (sz - xref[3 * i + 2] * s0) * iq;
+        sq[i] = q; dvec[i] = s0; sqd_g[i] = q;
+        rhs_g[3 * i] = bx; rhs_g[3 * i + 1] = by; rhs_g[3 * i + 2] = bz;
+        S[(n + 0) * ld + i] = bx; S[(n + 1) * ld + i] = by; S[(n + 2) * ld + i] = bz;
+        tot += s0;
+    }
+    tot = wave_sum_d(tot);
+    if ((tid & 63) == 0) red[tid >> 6] = tot;
+    __syncthreads();
+    if (tid == 0) { sc[S_SUMP] = (red[0] + red[1]) + (red[2] + red[3]); sc[S_C] = c; }
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        if (j <= i) S[i * ld + j] = sq[i] * G[e] * sq[j] + (i == j ? c : 0.0);
+    }
+    __syncthreads();
+    chol_factor_aug_lds(S, ld, n, 3, tid);
+    chol_backsub3_lds(S, ld, n, tid);
+    for (int e = tid; e < 3 * n; e += 256) { const int d = e / n, i = e - d * n; C[e] = sq[i] * S[(n + d) * ld + i]; }
 }
 
 // C[d][i] = sqrt(d_i) (b~_i - sqrt(d_i) sum_a U[a][i] q[a]) / c ; 64 rows i per block, the rank split over 4 waves
@@ -1306,19 +1337,19 @@ size_t prgls_layout(int m, int n, int l, unsigned char* base, PrglsWs* w) {
 }
 
 int cholesky_solve(const PrglsWs& w, int n, hipStream_t st) {
+    double* W = w.Spart;                       // [3][n]: idle low-rank buffer (>= 128 * 128 doubles >= 3 n for n <= 5461)
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int nb = n - k0 < NB ? n - k0 : NB;
         const int rem = n - k0 - nb;
-        const int nblk = rem > 0 ? (rem + NB - 1) / NB : 1;
-        hipLaunchKernelGGL(chol_panel_kernel, dim3(nblk), dim3(256), 0, st, w.M, n, k0);
+        const int nrow = rem > 0 ? (rem + NB - 1) / NB : 0;
+        hipLaunchKernelGGL(chol_panel_kernel, dim3(nrow + 1), dim3(256), 0, st, w.M, W, n, k0);
         LAUNCH_CHECK();
         if (rem > 0) {
-            const int t = (rem + NB - 1) / NB;
-            hipLaunchKernelGGL(chol_update_kernel, dim3(t, t), dim3(256), 0, st, w.M, n, k0);
+            hipLaunchKernelGGL(chol_update_kernel, dim3(nrow, nrow + 1), dim3(256), 0, st, w.M, W, n, k0);
             LAUNCH_CHECK();
         }
     }
-    hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(256), 0, st, w.M, n, w.rhs, w.sqd, w.C);
+    hipLaunchKernelGGL(chol_backward_kernel, dim3(1), dim3(256), 0, st, w.M, n, W, w.sqd, w.C);
     LAUNCH_CHECK();
     return CT_OK;
 }
@@ -1344,10 +1375,22 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
         LAUNCH_CHECK();
         return CT_OK;
     }
+    if (n <= DS_MAXN) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute((const void*)dense_small_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+        const size_t lds = (size_t)(n + 3) * (n | 1) * sizeof(double);
+        hipLaunchKernelGGL(dense_small_solve_kernel, dim3(1), dim3(256), lds, st, w.part, n, xref, w.G, lambda, w.sc, w.dvec, w.sqd, w.rhs, w.C);
+        LAUNCH_CHECK();
+        return CT_OK;
+    }
     hipLaunchKernelGGL(colstats_finish_kernel, dim3(1), dim3(256), 0, st, w.part, n, xref, lambda, w.sc, w.dvec, w.sqd, w.rhs);
     LAUNCH_CHECK();
     const size_t nn = (size_t)n * n;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, w.G, w.sqd, w.sc, n, w.M);
+    if (3 * (size_t)n > (size_t)LR_RMAX * LR_RMAX) return CT_ESHAPE;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, w.G, w.sqd, w.sc, n, w.M, w.rhs, w.Spart);
     LAUNCH_CHECK();
     return cholesky_solve(w, n, st);
 }
@@ -1561,7 +1604,7 @@ int ct_solve_movements(double sigma_square, double lambda, const double* P, cons
     hipLaunchKernelGGL(colstats_finish_kernel, dim3(1), dim3(256), 0, st, w.part, n, ref, lambda, w.sc, w.dvec, w.sqd, w.rhs);
     LAUNCH_CHECK();
     const size_t nn = (size_t)n * n;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, G, w.sqd, w.sc, n, w.M);
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, G, w.sqd, w.sc, n, w.M, w.rhs, w.Spart);
     LAUNCH_CHECK();
     int rc = cholesky_solve(w, n, st);
     if (rc) return rc;
