@@ -40,8 +40,8 @@ HBM_PEAK_TBS = 8.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shape", type=int, nargs=3, default=(512, 512, 32))
     ap.add_argument("--cells", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -160,7 +160,7 @@ def main():
         L.ct_unet_layer_info(model._handle, i, C.byref(cin), C.byref(cout), d, C.byref(nt))
         flops = 2.0 * d[0] * d[1] * d[2] * 27 * cin.value * cout.value * n_patches       # per launch (one volume)
         abytes = 4.0 * d[0] * d[1] * d[2] * (cin.value + cout.value) * n_patches
-        name = "conv_first_kernel" if nt.value == 0 else ("conv3_mfma_c8_kernel" if nt.value == -8 else f"conv3_mfma_kernel<{nt.value}>")
+        name = "conv_first_kernel" if nt.value == 0 else ("conv3_mfma_c8_kernel" if nt.value == -8 else f"conv3_mfma_kernel<{nt.value}, false>")
         k = by_kernel.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
         k["ms"] += ms[i]; k["launches"] += cnt[i]; k["flops"] += flops * cnt[i]; k["bytes"] += abytes * cnt[i]
         layers.append({"layer": i, "cin": cin.value, "cout": cout.value, "dims": [d[0], d[1], d[2]], "kernel": name,
