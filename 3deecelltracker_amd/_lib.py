@@ -64,6 +64,8 @@ SIGNATURES = {
     "ct_normalize_workspace_bytes": (_sz, [_ip]),
     "ct_median": (_i, [_vp, _i, _sz, _vp, _vp, _sz, _vp]),
     "ct_normalize_image": (_i, [_vp, _i, _ip, _d, _ip, _i, _i, _vp, _vp, _sz, _vp]),
+    "ct_correction_workspace_bytes": (_sz, [_ip, _i]),
+    "ct_accurate_correction": (_i, [_vp, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ip, _vp, _sz, _vp]),
     "ct_trim_mean": (_i, [_vp, _i, _i, _d, _vp, _vp]),
 }
 

@@ -48,3 +48,87 @@ class Coordinates:
     @property
     def cell_num(self) -> int:
         return self._raw.shape[0]
+
+
+class CoordsToImageTransformer:
+    """The accurate-correction part of the reference's CoordsToImageTransformer (coord_image_transformer.py:143-489).
+
+    Only what the correction loop needs is kept: the per-cell sub-regions on the z-interpolated grid (the reference builds
+    them with skimage in `interpolate`; here they are supplied as (bbox slices, mask) pairs), the volume-1 centres and the
+    image geometry.  `accurate_correction` returns the corrected Coordinates; the corrected *label image* of the reference
+    goes through skimage's watershed and is outside this path."""
+
+    def __init__(self, proofed_shape, voxel_size, interpolation_factor, subregions, coord_vol1: Coordinates):
+        self.proofed_shape = tuple(int(v) for v in proofed_shape)
+        self.voxel_size = np.asarray(voxel_size)
+        self.interpolation_factor = int(interpolation_factor)
+        self.subregions = list(subregions)
+        self.coord_vol1 = coord_vol1
+        self.z_slice_original_labels = slice(self.interpolation_factor // 2,
+                                             self.interpolation_factor * self.proofed_shape[2], self.interpolation_factor)
+        self._dev = None
+
+    def get_cells_on_boundary(self, coordinates_real_nx3, ensemble: bool, boundary_xy: int = 6):
+        """reference :371-404"""
+        if ensemble:
+            boundary_xy = 0
+        x_siz, y_siz, z_siz = self.proofed_shape
+        x, y, z = np.asarray(coordinates_real_nx3).T
+        near = ((x < boundary_xy) | (y < boundary_xy) | (x > (x_siz - boundary_xy) * self.voxel_size[0]) |
+                (y > (y_siz - boundary_xy) * self.voxel_size[1]) | (z < 0) | (z > z_siz * self.voxel_size[2]))
+        return np.where(near)[0] + 1
+
+    def _upload(self):
+        from . import _dev
+        t = _dev.torch()
+        n = len(self.subregions)
+        bbox = np.zeros((n, 6), dtype=np.int32)
+        offs = np.zeros(n, dtype=np.int64)
+        chunks = []
+        pos = 0
+        for i, (bb, sub) in enumerate(self.subregions):
+            sub = np.ascontiguousarray(np.asarray(sub) != 0, dtype=np.uint8)
+            bbox[i, :3] = [s.start for s in bb]
+            bbox[i, 3:] = sub.shape
+            if tuple(s.stop - s.start for s in bb) != sub.shape:
+                raise ValueError("sub-image shape does not match its bounding box")
+            offs[i] = pos; pos += sub.size
+            chunks.append(sub.ravel())
+        self._dev = (t.from_numpy(bbox).cuda(), t.from_numpy(np.concatenate(chunks)).cuda(), t.from_numpy(offs).cuda(),
+                     t.from_numpy(np.ascontiguousarray(self.coord_vol1._raw, dtype=np.float32)).cuda())
+
+    def accurate_correction(self, prob_map, coords: Coordinates, ensemble: bool, max_repetition: int = 20, grid=(1, 1, 1)):
+        """reference :406-447 (coordinates only).  prob_map: numpy / cuda tensor (x, y, z); `grid` repeats it like the reference."""
+        import ctypes as C
+        from . import _dev, _lib
+        t = _dev.torch(); L = _lib.lib()
+        if self._dev is None:
+            self._upload()
+        if not hasattr(prob_map, "is_cuda"):
+            pm = np.asarray(prob_map)
+            if tuple(grid) != (1, 1, 1):
+                pm = np.repeat(np.repeat(np.repeat(pm, grid[1], axis=0), grid[2], axis=1), grid[0], axis=2)
+            if pm.shape != self.proofed_shape:
+                pm = pm[:self.proofed_shape[0], :self.proofed_shape[1], :self.proofed_shape[2]]
+            prob_d = t.from_numpy(np.ascontiguousarray(pm, dtype=np.float32)).cuda()
+        else:
+            prob_d = prob_map.to(t.float32).contiguous()
+        if tuple(prob_d.shape) != self.proofed_shape:
+            raise ValueError(f"probability map shape {tuple(prob_d.shape)} != segmentation shape {self.proofed_shape}")
+        n = len(self.subregions)
+        boundary_ids = set(self.get_cells_on_boundary(coords.real, ensemble=ensemble).tolist())
+        missed = np.zeros(n, dtype=np.uint8)
+        for b in boundary_ids:
+            missed[b - 1] = 1
+        bbox, subs, offs, vol1 = self._dev
+        cur = t.from_numpy(np.ascontiguousarray(coords._raw, dtype=np.float32)).cuda()
+        ws = _dev.workspace(L.ct_correction_workspace_bytes(_lib.ivec(self.proofed_shape), n), cur.device)
+        iters = C.c_int(0)
+        rc = L.ct_accurate_correction(prob_d.data_ptr(), _lib.ivec(self.proofed_shape), self.interpolation_factor, n, bbox.data_ptr(),
+                                      subs.data_ptr(), offs.data_ptr(), t.from_numpy(missed).cuda().data_ptr(), vol1.data_ptr(),
+                                      cur.data_ptr(), int(max_repetition), C.byref(iters), ws.data_ptr(), ws.numel(), _dev.stream(cur.device))
+        if rc == -2:
+            raise ValueError(f"Slices are out of range for image of size {self.proofed_shape}")
+        _lib.check(rc, "ct_accurate_correction")
+        self.last_iterations = iters.value
+        return Coordinates(cur.cpu().numpy(), self.interpolation_factor, self.voxel_size, dtype="raw")

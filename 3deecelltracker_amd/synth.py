@@ -119,3 +119,32 @@ def normalize_stack(img_u16: np.ndarray) -> np.ndarray:
     np.clip(img, 0, None, out=img)
     img /= (img.std() + 1e-6)
     return img[None, :, :, :, None]
+
+
+def make_correction_case(seed=0, shape=(64, 56, 8), factor=5, n_cells=18, margin=8):
+    """Hand-built state for the accurate correction: ellipsoidal sub-regions on the z-interpolated grid, a
+    probability map whose blobs sit a few voxels away from the current positions (the reference builds its sub-regions with
+    skimage, which is not available; the correction itself only needs (bbox, mask) pairs)."""
+    rng = np.random.default_rng(seed)
+    sx, sy, sz = shape
+    cen = np.stack([rng.uniform(margin, sx - margin, n_cells), rng.uniform(margin, sy - margin, n_cells), rng.uniform(1.5, sz - 1.5, n_cells)], 1)
+    subregions = []
+    for c in cen:
+        r = np.array([rng.integers(3, 6), rng.integers(3, 6), rng.integers(4, 9)])          # radii on the interp grid
+        ci = np.array([c[0], c[1], c[2] * factor + factor // 2])
+        lo = np.maximum(np.floor(ci - r).astype(int), 0); hi = np.minimum(np.ceil(ci + r).astype(int) + 1, (sx, sy, sz * factor))
+        g = np.meshgrid(*(np.arange(lo[a], hi[a]) for a in range(3)), indexing="ij")
+        sub = sum(((g[a] - ci[a]) / r[a]) ** 2 for a in range(3)) <= 1.0
+        subregions.append((tuple(slice(int(lo[a]), int(hi[a])) for a in range(3)), sub))
+    vol1 = cen.astype(np.float32)
+    shift = np.stack([rng.uniform(-3, 3, n_cells), rng.uniform(-3, 3, n_cells), rng.uniform(-0.6, 0.6, n_cells)], 1)
+    gx, gy, gz = np.meshgrid(np.arange(sx), np.arange(sy), np.arange(sz), indexing="ij")
+    prob = np.zeros(shape, dtype=np.float64)
+    for c in cen + shift:
+        prob += np.exp(-0.5 * (((gx - c[0]) / 2.5) ** 2 + ((gy - c[1]) / 2.5) ** 2 + ((gz - c[2]) / 0.8) ** 2))
+    prob = np.clip(prob, 0, 1).astype(np.float32)
+    coords0 = (cen + 0.35 * shift + rng.normal(0, 0.2, cen.shape)).astype(np.float32)
+    return {"shape": shape, "factor": factor, "subregions": subregions, "vol1": vol1, "prob": prob, "coords0": coords0,
+            "voxel_size": np.array([1.0, 1.0, 4.0])}
+
+

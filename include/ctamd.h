@@ -201,6 +201,21 @@ int ct_normalize_image(const void* img, int dtype, const int dims_xyz[3], double
                        int mode, int subtract_median, float* out, void* workspace, size_t workspace_bytes,
                        ct_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Accurate correction of cell centres  (coord_image_transformer.py:292-369, :406-489)
+ * ------------------------------------------------------------------------------------------
+ * prob [dev] fp32 [x][y][z] on the original grid; the per-cell sub-regions live on the z-interpolated grid
+ * (z * factor): bbox [dev] int32 [n][6] = start xyz, size xyz; subimages [dev] uint8 masks packed back to back
+ * (C order x, y, z), sub_offsets [dev] int64 [n]; missed [dev] uint8 [n] (1 = cell skipped, e.g. on the boundary);
+ * coord_vol1_raw / coords_raw [dev] fp32 [n][3] raw voxel coordinates (coords_raw is updated in place).
+ * Repeats _correction_once until np.max(delta.interp) < 0.5 or max_repetition; iterations [host] receives the count.
+ * Returns CT_ESHAPE where the reference raises "Slices are out of range".  Synchronises the stream every iteration.  */
+size_t ct_correction_workspace_bytes(const int dims_xyz[3], int n_cells);
+int ct_accurate_correction(const float* prob, const int dims_xyz[3], int factor, int n_cells, const int32_t* bbox,
+                           const uint8_t* subimages, const long long* sub_offsets, const uint8_t* missed,
+                           const float* coord_vol1_raw, float* coords_raw, int max_repetition, int* iterations,
+                           void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -276,10 +276,43 @@ def gen_preprocess():
     print("preprocess goldens written")
 
 
+def gen_correction():
+    """reference CoordsToImageTransformer.accurate_correction / _correction_once (coord_image_transformer.py:406-489)"""
+    import tempfile
+    out = {}
+    for ci, (seed, shape, factor, n_cells, ens, margin) in enumerate(((0, (64, 56, 8), 5, 18, True, 8), (1, (48, 48, 6), 3, 14, False, 3))):
+        case = ct_synth.make_correction_case(seed, shape, factor, n_cells, margin)
+        tr = object.__new__(ref_cit.CoordsToImageTransformer)
+        tmp = tempfile.mkdtemp()
+        tr.results_folder = Path(tmp); (Path(tmp) / "seg").mkdir()
+        tr.voxel_size = case["voxel_size"]
+        tr.proofed_segmentation = np.zeros(shape, dtype=np.int32)
+        tr.interpolation_factor = factor
+        tr.z_slice_original_labels = slice(factor // 2, factor * shape[2], factor)
+        tr.subregions = case["subregions"]
+        tr.auto_corrected_segmentation = np.array([n_cells])
+        tr.coord_vol1 = ref_cit.Coordinates(case["vol1"], factor, case["voxel_size"], dtype="raw")
+        tr.move_cells_in_3d_image = lambda *a, **k: None     # final label image needs skimage's watershed (absent, out of scope)
+        np.save(Path(tmp) / "seg" / "prob000007.npy", case["prob"])
+        coords = ref_cit.Coordinates(case["coords0"], factor, case["voxel_size"], dtype="raw")
+        bd = tr.get_cells_on_boundary(coords.real, ensemble=ens)
+        one, delta = tr._correction_once(case["prob"], coords, set(bd.tolist()))
+        final, _ = tr.accurate_correction(7, (1, 1, 1), coords, ensemble=ens, max_repetition=20)
+        out[f"corr_seed_{ci}"] = np.array([seed, *shape, factor, n_cells, int(ens), margin])
+        out[f"corr_boundary_{ci}"] = bd
+        out[f"corr_once_{ci}"] = one._raw; out[f"corr_delta_{ci}"] = delta._raw
+        out[f"corr_final_{ci}"] = final._raw
+        lab, msk = tr.move_cells(coords.__sub__(tr.coord_vol1).interp, set(bd.tolist()))
+        out[f"corr_mask_sum_{ci}"] = np.array([int(msk.sum()), int((msk > 1).sum()), int(lab.sum())])
+        print("correction case", ci, "boundary", bd.tolist(), "max move", float(np.abs(final._raw - case["coords0"]).max()))
+    np.savez_compressed(HERE / "correction.npz", **out)
+
+
 if __name__ == "__main__":
     gen_tiler()
     gen_match()
     gen_preprocess()
+    gen_correction()
     leftovers = [p for p in Path("/root/reference").rglob("__pycache__")]
     assert not leftovers, leftovers
     print("golden vectors written to", HERE)

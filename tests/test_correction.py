@@ -1,0 +1,82 @@
+"""Accurate correction of cell centres: oracle vs the reference's own accurate_correction
+(golden), HIP vs golden."""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import correction_ref as cr
+
+synth = importlib.import_module("3deecelltracker_amd.synth")
+cit = importlib.import_module("3deecelltracker_amd.coord_image_transformer")
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(golden_dir / "correction.npz")
+
+
+def _case(g, ci):
+    seed, sx, sy, sz, f, n, ens, margin = [int(v) for v in g[f"corr_seed_{ci}"]]
+    return synth.make_correction_case(seed, (sx, sy, sz), f, n, margin), (sx, sy, sz), f, n, bool(ens)
+
+
+@pytest.mark.parametrize("ci", (0, 1))
+def test_oracle_against_reference(g, ci):
+    case, shape, f, n, ens = _case(g, ci)
+    real = case["coords0"] * case["voxel_size"][None, :]
+    bd = cr.get_cells_on_boundary(real, shape, case["voxel_size"], ens)
+    assert np.array_equal(bd, g[f"corr_boundary_{ci}"])
+    mov = cr.raw_to_interp(case["coords0"] - case["vol1"], f)
+    lab, msk = cr.move_cells(shape, f, case["subregions"], mov, set(bd.tolist()))
+    assert [int(msk.sum()), int((msk > 1).sum()), int(lab.sum())] == g[f"corr_mask_sum_{ci}"].tolist()
+    one, delta = cr.correction_once(case["prob"], shape, f, slice(f // 2, f * shape[2], f), case["subregions"], n, case["vol1"],
+                                    case["coords0"], set(bd.tolist()))
+    assert np.array_equal(one, g[f"corr_once_{ci}"]) and np.array_equal(delta, g[f"corr_delta_{ci}"])
+    fin, it = cr.accurate_correction(case["prob"], shape, f, case["subregions"], n, case["vol1"], case["coords0"], set(bd.tolist()))
+    assert np.array_equal(fin, g[f"corr_final_{ci}"])
+
+
+def test_oracle_out_of_range_raises():
+    case = synth.make_correction_case(0, (64, 56, 8), 5, 18, 8)
+    far = case["coords0"].copy(); far[0, 0] += 500
+    with pytest.raises(ValueError):
+        cr.accurate_correction(case["prob"], (64, 56, 8), 5, case["subregions"], 18, case["vol1"], far, set())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", (0, 1))
+def test_device_against_reference_golden(g, ci):
+    case, shape, f, n, ens = _case(g, ci)
+    vol1 = cit.Coordinates(case["vol1"], f, case["voxel_size"], "raw")
+    tr = cit.CoordsToImageTransformer(shape, case["voxel_size"], f, case["subregions"], vol1)
+    coords = cit.Coordinates(case["coords0"], f, case["voxel_size"], "raw")
+    assert np.array_equal(tr.get_cells_on_boundary(coords.real, ens), g[f"corr_boundary_{ci}"])
+    one = tr.accurate_correction(case["prob"], coords, ensemble=ens, max_repetition=1)
+    np.testing.assert_allclose(one._raw, g[f"corr_once_{ci}"], rtol=0, atol=2e-6)       # fp64 sums in a different order
+    fin = tr.accurate_correction(case["prob"], coords, ensemble=ens, max_repetition=20)
+    np.testing.assert_allclose(fin._raw, g[f"corr_final_{ci}"], rtol=0, atol=1e-5)
+    assert tr.last_iterations == 4
+    assert np.array_equal(fin.interp, cit.Coordinates(g[f"corr_final_{ci}"], f, case["voxel_size"], "raw").interp)   # integer views exact
+
+
+@pytest.mark.gpu
+def test_device_out_of_range_and_larger_case():
+    case = synth.make_correction_case(3, (256, 256, 24), 5, 150, 12)
+    vol1 = cit.Coordinates(case["vol1"], 5, case["voxel_size"], "raw")
+    tr = cit.CoordsToImageTransformer((256, 256, 24), case["voxel_size"], 5, case["subregions"], vol1)
+    coords = cit.Coordinates(case["coords0"], 5, case["voxel_size"], "raw")
+    fin = tr.accurate_correction(case["prob"], coords, ensemble=True)
+    want, it = cr.accurate_correction(case["prob"], (256, 256, 24), 5, case["subregions"], 150, case["vol1"], case["coords0"], set())
+    np.testing.assert_allclose(fin._raw, want, rtol=0, atol=1e-5)
+    assert tr.last_iterations == it
+    # a cell whose centre left the image is flagged by get_cells_on_boundary and skipped (it keeps its rounded position),
+    # exactly like the reference: the "Slices are out of range" error cannot be reached through accurate_correction
+    far = case["coords0"].copy(); far[0, 0] += 5000.3
+    cf = cit.Coordinates(far, 5, case["voxel_size"], "raw")
+    bd = set(tr.get_cells_on_boundary(cf.real, True).tolist())
+    assert 1 in bd
+    got = tr.accurate_correction(case["prob"], cf, ensemble=True)
+    want2, _ = cr.accurate_correction(case["prob"], (256, 256, 24), 5, case["subregions"], 150, case["vol1"], far, bd)
+    np.testing.assert_allclose(got._raw, want2, rtol=0, atol=1e-5)
+    assert got._raw[0, 0] == np.float32(np.round(np.float32(far[0, 0])))
