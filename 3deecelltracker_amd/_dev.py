@@ -115,3 +115,23 @@ def trim_mean(stack_d, cut=0.1):
     _lib.check(L.ct_trim_mean(stack_d.contiguous().data_ptr(), k, n3, float(cut), out.data_ptr(), stream(stack_d.device)),
                "ct_trim_mean")
     return out
+
+
+def normalize_points(points_d, apply_para=None):
+    """points_d fp64 [n][3] device -> (normalised points, para [4] = mean xyz, scale) all on the device."""
+    t = torch(); L = _lib.lib()
+    n = points_d.shape[0]
+    out = empty((n, 3), t.float64, points_d.device)
+    para = apply_para if apply_para is not None else empty((4,), t.float64, points_d.device)
+    _lib.check(L.ct_normalize_points(points_d.data_ptr(), n, apply_para.data_ptr() if apply_para is not None else None,
+                                     out.data_ptr(), None if apply_para is not None else para.data_ptr(), stream(points_d.device)),
+               "ct_normalize_points")
+    return out, para
+
+
+def denormalize_points(points_d, para):
+    t = torch(); L = _lib.lib()
+    out = empty(tuple(points_d.shape), t.float64, points_d.device)
+    _lib.check(L.ct_denormalize_points(points_d.data_ptr(), points_d.shape[0], para.data_ptr(), out.data_ptr(), stream(points_d.device)),
+               "ct_denormalize_points")
+    return out

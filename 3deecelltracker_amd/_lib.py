@@ -43,6 +43,8 @@ SIGNATURES = {
     "ct_tile_gather_reflect": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),
     "ct_tile_scatter_center": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),
     "ct_unet_predict_volume": (_i, [_vp, _vp, _ip, _ip, _i, _i, _vp, _vp, _sz, _vp]),
+    "ct_normalize_points": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "ct_denormalize_points": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ct_knn_features": (_i, [_vp, _i, _i, _vp, _vp]),
     "ct_ffn_create": (_i, [_vp, _sz, _i, C.POINTER(_vp)]),
     "ct_ffn_destroy": (None, [_vp]),

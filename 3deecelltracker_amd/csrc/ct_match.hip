@@ -118,6 +118,77 @@ __global__ __launch_bounds__(64) void knn_features_kernel(const double* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// K14 normalize_points (ffn.py:330-374): centre; divide by 3 x std (ddof 0) of the projection on the first principal
+// axis.  That std is sqrt(lambda_max(Xc^T Xc) / n), so no projection is needed: one workgroup computes the mean, the
+// 3 x 3 scatter matrix (fp64, two-pass) and its largest eigenvalue by cyclic Jacobi rotations.
+// para [dev] = mean[3], scale.  If `apply_para` is non-null the given (mean, scale) are used instead (normalising a
+// second point set with the first one's parameters, trackerlite.py:91-93).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normalize_points_kernel(const double* __restrict__ pts, int n, const double* __restrict__ apply_para,
+                                                               double* __restrict__ out, double* __restrict__ para) {
+    __shared__ double red[4][6];
+    __shared__ double sh[4];
+    const int tid = threadIdx.x;
+    if (!apply_para) {
+        double s[3] = {0.0, 0.0, 0.0};
+        for (int i = tid; i < n; i += 256) { s[0] += pts[3 * i]; s[1] += pts[3 * i + 1]; s[2] += pts[3 * i + 2]; }
+        for (int d = 0; d < 3; ++d) s[d] = wave_sum_d(s[d]);
+        if ((tid & 63) == 0) for (int d = 0; d < 3; ++d) red[tid >> 6][d] = s[d];
+        __syncthreads();
+        if (tid == 0) for (int d = 0; d < 3; ++d) sh[d] = ((red[0][d] + red[1][d]) + (red[2][d] + red[3][d])) / (double)n;
+        __syncthreads();
+        const double mx = sh[0], my = sh[1], mz = sh[2];
+        double c[6] = {0, 0, 0, 0, 0, 0};                  // xx xy xz yy yz zz
+        for (int i = tid; i < n; i += 256) {
+            const double x = pts[3 * i] - mx, y = pts[3 * i + 1] - my, z = pts[3 * i + 2] - mz;
+            c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
+        }
+        for (int q = 0; q < 6; ++q) c[q] = wave_sum_d(c[q]);
+        __syncthreads();
+        if ((tid & 63) == 0) for (int q = 0; q < 6; ++q) red[tid >> 6][q] = c[q];
+        __syncthreads();
+        if (tid == 0) {
+            double a[3][3];
+            double t6[6];
+            for (int q = 0; q < 6; ++q) t6[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+            a[0][0] = t6[0]; a[0][1] = a[1][0] = t6[1]; a[0][2] = a[2][0] = t6[2]; a[1][1] = t6[3]; a[1][2] = a[2][1] = t6[4]; a[2][2] = t6[5];
+            for (int sweep = 0; sweep < 30; ++sweep) {
+                const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+                if (off == 0.0) break;
+                for (int p2 = 0; p2 < 2; ++p2)
+                    for (int q2 = p2 + 1; q2 < 3; ++q2) {
+                        if (a[p2][q2] == 0.0) continue;
+                        const double theta = (a[q2][q2] - a[p2][p2]) / (2.0 * a[p2][q2]);
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                        for (int k = 0; k < 3; ++k) { const double akp = a[k][p2], akq = a[k][q2]; a[k][p2] = cs * akp - sn * akq; a[k][q2] = sn * akp + cs * akq; }
+                        for (int k = 0; k < 3; ++k) { const double apk = a[p2][k], aqk = a[q2][k]; a[p2][k] = cs * apk - sn * aqk; a[q2][k] = sn * apk + cs * aqk; }
+                    }
+            }
+            const double lmax = fmax(a[0][0], fmax(a[1][1], a[2][2]));
+            sh[3] = 3.0 * sqrt(lmax / (double)n);
+            para[0] = sh[0]; para[1] = sh[1]; para[2] = sh[2]; para[3] = sh[3];
+        }
+        __syncthreads();
+    } else {
+        if (tid < 4) sh[tid] = apply_para[tid];
+        __syncthreads();
+    }
+    if (out) {
+        const double mx = sh[0], my = sh[1], mz = sh[2], sc = sh[3];
+        for (int i = tid; i < n; i += 256) {
+            out[3 * i] = (pts[3 * i] - mx) / sc; out[3 * i + 1] = (pts[3 * i + 1] - my) / sc; out[3 * i + 2] = (pts[3 * i + 2] - mz) / sc;
+        }
+    }
+}
+
+// x * scale + mean  (trackerlite.py:101)
+__global__ void denormalize_points_kernel(const double* __restrict__ pts, int n, const double* __restrict__ para, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * n) out[i] = pts[i] * para[3] + para[i % 3];
+}
+
+// ------------------------------------------------------------------------------------------------
 // small fp32 GEMM  C[M][N] = A[M][K] (row stride lda) * B[K][N], optional BN-affine + LeakyReLU
 // epilogue (Dense(no bias) + BatchNormalization + LeakyReLU, ffn.py:242-254).
 // 64x64 tile, 256 threads, 4x4 outputs per thread, sequential-k fp32 accumulation.
@@ -1167,6 +1238,20 @@ struct ct_ffn {
 extern "C" {
 
 // ------------------------------------------------------------------------------------------------ kNN
+int ct_normalize_points(const double* points, int n, const double* apply_para, double* out_points, double* para, ct_stream_t stream) {
+    if (!points || n <= 0 || (!apply_para && !para)) return CT_EINVAL;
+    hipLaunchKernelGGL(normalize_points_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, points, n, apply_para, out_points, para);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+int ct_denormalize_points(const double* points, int n, const double* para, double* out_points, ct_stream_t stream) {
+    if (!points || !para || !out_points || n <= 0) return CT_EINVAL;
+    hipLaunchKernelGGL(denormalize_points_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, points, n, para, out_points);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
 int ct_knn_features(const double* points, int n, int k, float* feat, ct_stream_t stream) {
     if (!points || !feat || n <= 0 || k <= 0) return CT_EINVAL;
     if (n < k + 1 || n > KNN_MAXN || k + 1 > 32) return CT_ESHAPE;     // sklearn raises when n < k+1

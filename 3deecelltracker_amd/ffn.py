@@ -153,16 +153,14 @@ def initial_matching_ffn(ffn_model, ref: np.ndarray, tgt: np.ndarray, k_ptrs: in
 
 
 def normalize_points(points: np.ndarray, return_para: bool = False) -> Union[np.ndarray, Tuple[np.ndarray, Tuple]]:
-    """reference ffn.py:330-374: centre, divide by 3 x std (ddof 0) of the projection on the first
-    principal axis.  N x 3 -> two scalars: host arithmetic (3x3 symmetric eigen-problem)."""
+    """reference ffn.py:330-374: centre, divide by 3 x std (ddof 0) of the projection on the first principal axis
+    (device kernel: mean, 3x3 scatter matrix, largest eigenvalue by Jacobi rotations)."""
     points = np.asarray(points)
     if points.ndim != 2:
         raise ValueError(f"Points should be a 2D table, but get {points.ndim}D")
     if points.shape[1] != 3:
         raise ValueError(f"Points should have 3D coordinates, but get {points.shape[1]}D")
-    mean = np.mean(points, axis=0)
-    xc = points - mean
-    evals, evecs = np.linalg.eigh(xc.T @ xc)
-    std = np.std(xc @ evecs[:, -1])
-    norm_points = (points - mean) / (3 * std)
-    return (norm_points, (mean, 3 * std)) if return_para else norm_points
+    out_d, para_d = _dev.normalize_points(_dev.points_dev(points))
+    para = para_d.cpu().numpy()
+    norm_points = out_d.cpu().numpy()
+    return (norm_points, (para[:3].copy(), float(para[3]))) if return_para else norm_points

@@ -181,13 +181,12 @@ class TrackerLite:
         if confirmed_coord_t1 is None:
             confirmed_coord_t1 = segmented_pos_t1
 
-        confirmed_norm_t1, (mean_t1, scale_t1) = normalize_points(confirmed_coord_t1.real, return_para=True)
-        seg_norm_t2 = (segmented_pos_t2.real - mean_t1) / scale_t1
-        seg_norm_t1 = (segmented_pos_t1.real - mean_t1) / scale_t1
-
-        tracked_norm_d, _ = match_device(self.ffn_model, _dev.points_dev(seg_norm_t1), _dev.points_dev(seg_norm_t2),
-                                         _dev.points_dev(confirmed_norm_t1), beta, lambda_)
-        tracked_coords_t2 = tracked_norm_d.cpu().numpy() * scale_t1 + mean_t1
+        # normalise the three point sets with the confirmed set's (mean, scale), match, de-normalise: all on the device
+        confirmed_norm_d, para_d = _dev.normalize_points(_dev.points_dev(confirmed_coord_t1.real))
+        seg_norm_t2_d, _ = _dev.normalize_points(_dev.points_dev(segmented_pos_t2.real), apply_para=para_d)
+        seg_norm_t1_d, _ = _dev.normalize_points(_dev.points_dev(segmented_pos_t1.real), apply_para=para_d)
+        tracked_norm_d, _ = match_device(self.ffn_model, seg_norm_t1_d, seg_norm_t2_d, confirmed_norm_d, beta, lambda_)
+        tracked_coords_t2 = _dev.denormalize_points(tracked_norm_d, para_d).cpu().numpy()
         if draw_fig:
             raise NotImplementedError("figure drawing is outside the accelerated path")
         return Coordinates(tracked_coords_t2, interpolation_factor=self.proofed_coords_vol1.interpolation_factor,

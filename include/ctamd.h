@@ -108,6 +108,13 @@ int ct_unet_predict_volume(ct_unet_t* h, const float* vol, const int vol_xyz[3],
 /* ------------------------------------------------------------------------------------------
  * FFN initial matching  (ffn.py:225-327, track.py:117-178)
  * ------------------------------------------------------------------------------------------ */
+/* normalize_points (ffn.py:330-374): centre, divide by 3 x std of the projection on the first principal axis
+ * (= 3 sqrt(lambda_max(Xc^T Xc) / n)).  points/out_points [dev] fp64 [n][3]; para [dev] fp64 [4] = mean xyz, scale.
+ * apply_para != NULL: normalise with the given parameters instead (trackerlite.py:91-93); out_points may be NULL.    */
+int ct_normalize_points(const double* points, int n, const double* apply_para, double* out_points, double* para,
+                        ct_stream_t stream);
+int ct_denormalize_points(const double* points, int n, const double* para, double* out_points, ct_stream_t stream);
+
 /* kNN shape-context features (ffn.py:288-304): points [dev] fp64 [n][3] -> feat [dev] fp32 [n][3k+1].
  * Needs n >= k+1 (sklearn raises otherwise) -> CT_ESHAPE.                                        */
 int ct_knn_features(const double* points, int n, int k, float* feat, ct_stream_t stream);

@@ -43,6 +43,23 @@ def ffn(ffn_w):
     return ffn_mod.FFN().set_weights_dict(ffn_w)
 
 
+# ------------------------------------------------------------------------------------ normalisation
+@pytest.mark.parametrize("n", NS)
+def test_normalize_points_against_reference(g, n):
+    norm, (mean, scale) = ffn_mod.normalize_points(g[f"norm_in_{n}"], return_para=True)
+    np.testing.assert_allclose(mean, g[f"norm_mean_{n}"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(scale, g[f"norm_scale_{n}"], rtol=1e-12)
+    np.testing.assert_allclose(norm, g[f"norm_out_{n}"], rtol=0, atol=1e-12)
+    assert np.array_equal(ffn_mod.normalize_points(g[f"norm_in_{n}"]), norm)
+    import torch
+    d = dev.points_dev(g[f"norm_in_{n}"])
+    nd, para = dev.normalize_points(d)
+    other, _ = dev.normalize_points(d + 1.0, apply_para=para)          # second set with the first one's parameters
+    np.testing.assert_allclose(other.cpu().numpy(), (g[f"norm_in_{n}"] + 1.0 - mean) / scale, rtol=0, atol=1e-12)
+    back = dev.denormalize_points(nd, para).cpu().numpy()
+    np.testing.assert_allclose(back, g[f"norm_in_{n}"], rtol=0, atol=1e-9)
+
+
 # ------------------------------------------------------------------------------------ features / FFN
 @pytest.mark.parametrize("n", NS)
 def test_knn_features_vs_reference(g, n):
