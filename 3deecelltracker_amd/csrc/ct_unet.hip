@@ -29,6 +29,7 @@
 #include "../../include/ctamd.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -176,12 +177,12 @@ __global__ __launch_bounds__(256, (NT == 2 && !PAIR) ? 3 : 2) void conv3_mfma_ke
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
             }
         } else {
-            // ---- 14 slabs of 16 k-values (2 taps x 8 cin); lane group g owns tap 2s+(g>>1), cin 4(g&1)..+3
+            // ---- 13 full slabs of 16 k-values (2 taps x 8 cin; lane group g owns tap 2s+(g>>1), cin 4(g&1)..+3) and a
+            //      half slab for tap 26 (lane group g owns cin 2g, 2g+1 -> two K=4 MFMAs): 27 x 8 = 216 k-values, no padding
             const f32x4* wp = a.wpack + ((size_t)stage * NSLAB * a.nt_total + ntb) * 64 + lane;
 #pragma unroll
-            for (int s = 0; s < NSLAB; ++s) {
-                const int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;   // tap 27 is padding (zero weights)
-                const int off = lbase + (hi ? tap_off(t1) : tap_off(t0));
+            for (int s = 0; s < NSLAB - 1; ++s) {
+                const int off = lbase + (hi ? tap_off(2 * s + 1) : tap_off(2 * s));
                 f32x4 wv[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
@@ -190,6 +191,22 @@ __global__ __launch_bounds__(256, (NT == 2 && !PAIR) ? 3 : 2) void conv3_mfma_ke
                 for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt_off(mt)]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
+            }
+            {
+                const int off = ((wx0 * HY + wy0) * HZ + zl) * 8 + 2 * g + tap_off(26);
+                f32x4 wv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)((NSLAB - 1) * a.nt_total + nt) * 64];
+                f32x2 av[8];
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x2*>(&lds[off + mt_off(mt)]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
@@ -571,7 +588,7 @@ void conv_layer_list(const ArchDesc& ad, std::vector<std::pair<int, int>>& layer
 
 // Pack Keras kernel (3,3,3,Cin,Cout) into MFMA operand order:
 //   wpack[chunk][slab][nt][lane = g*16 + n][t] = K[tap = 2*slab + (g>>1)][cin = 8*chunk + 4*(g&1) + t][cout = 16*nt + n]
-// (0 for the padding tap 27 and for cout >= Cout).
+// for slabs 0..12; slab 13 is a half slab: [t < 2] = K[tap 26][cin = 8*chunk + 2*g + t][cout] (0 for cout >= Cout).
 void pack_conv_weights(const float* k, int cin, int cout, int NT, float* dst) {
     const int nchunks = cin / 8;
     for (int ch = 0; ch < nchunks; ++ch)
@@ -580,7 +597,9 @@ void pack_conv_weights(const float* k, int cin, int cout, int NT, float* dst) {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int t = 0; t < 4; ++t) {
                         const int g = lane >> 4, n = lane & 15;
-                        const int tap = 2 * s + (g >> 1), ci = 8 * ch + 4 * (g & 1) + t, co = 16 * nt + n;
+                        int tap = 2 * s + (g >> 1), ci = 8 * ch + 4 * (g & 1) + t;
+                        const int co = 16 * nt + n;
+                        if (s == NSLAB - 1) { tap = (t < 2) ? 26 : 27; ci = 8 * ch + 2 * g + t; }      // half slab: cin 2g + t of tap 26
                         float v = 0.f;
                         if (tap < 27 && co < cout) v = k[((size_t)tap * cin + ci) * cout + co];
                         dst[((((size_t)ch * NSLAB + s) * NT + nt) * 64 + lane) * 4 + t] = v;
