@@ -60,6 +60,7 @@ struct ConvArgs {
     int cout;
     int nt_total;           // cout tiles of 16 in the packed weights (a block computes NT of them)
     int ngroups;            // nt_total / NT  (blocks along the cout dimension; 1 unless Cout > 64)
+    int xcd_remap;          // 1: XCD-aware block order
 };
 
 namespace {
@@ -83,13 +84,21 @@ __host__ __device__ constexpr int mt_off(int mt) {      // float offset of the w
 // PAIR = true: two 8-channel planes are staged per stage (LDS 2 x 34.5 KB) so that K = 27 taps x 16 cin is exactly
 // 27 slabs of 16 (slab = one tap; lane group g reads plane g>>1, channels 4(g&1)..+3): no tap padding and half as
 // many barriers.  PAIR = false (Cin == 8): one plane, 27 x 8 = 216 k-values padded to 14 slabs of 2 taps.
+
+// XCD-aware workgroup order: the dispatcher places block b on XCD b % 8 (observed, used for speed only), so a
+// contiguous run of the tile grid is handed to each XCD and neighbouring tiles (which share halos) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;      // bijective for any nblk
+}
+
 template <int NT, bool PAIR>
 __global__ __launch_bounds__(256, (NT == 2 && !PAIR) ? 3 : 2) void conv3_mfma_kernel(ConvArgs a) {
     constexpr int PLANES = PAIR ? 2 : 1;
     constexpr int PLANE_F = NF4 * 4;                 // floats per plane
     __shared__ __attribute__((aligned(16))) float lds[PLANES * PLANE_F];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.x;
+    int b = a.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int cg = b % a.ngroups; b /= a.ngroups;
     const int ntb = cg * NT;                       // first cout tile of this block
     const int zb = b % a.zblocks; b /= a.zblocks;
@@ -318,7 +327,7 @@ __host__ __device__ constexpr int tap_off4(int tap) {   // tap = (dx' * 3 + dy) 
 __global__ __launch_bounds__(256, 2) void conv3_mfma_c8_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[NF4 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = blockIdx.x;
+    int b = a.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int zb = b % a.zblocks; b /= a.zblocks;
     const int ty = b % a.tilesY;  b /= a.tilesY;
     const int tx = b % a.tilesX;
@@ -910,6 +919,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             }
             if (c.head) { a.head = h->d_weights + h->head_off; a.head_out = prob_out; }
             a.act = ad.act;
+            a.xcd_remap = getenv("CT_XCD_REMAP") ? 1 : 0;      // measured: 24.0 vs 23.9 ms/volume -> off (kernel is MFMA-bound)
             a.tilesX = (d[0] + TX - 1) / TX; a.tilesY = (d[1] + TY - 1) / TY; a.zblocks = (d[2] + 15) / 16;
             int rc;
             if (c.c8) {
