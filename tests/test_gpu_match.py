@@ -301,3 +301,51 @@ def test_match_2000_cells_properties(ffn):
     # a pure translation of the target set moves the prediction by the same translation
     got_shift, _ = tl.prgls_with_two_ref(prior, yn + 1e-3, xn, xn, beta=3, lambda_=3)
     assert float(np.abs((got_shift - got) - 1e-3).max()) < 5e-4
+
+
+# ------------------------------------------------------------------------------------ rectangular / degenerate shapes
+@pytest.mark.parametrize("n_ref,n_tgt,n_trk", [(113, 90, 113), (70, 131, 40), (600, 540, 600), (25, 21, 25)])
+def test_rectangular_point_sets_against_oracle(ffn, ffn_w, n_ref, n_tgt, n_trk):
+    """m != n != l: the golden cases are all square; the oracle (pinned on the square cases) arbitrates here."""
+    rng = np.random.default_rng(n_ref + n_tgt)
+    x, y = synth.make_point_pair(max(n_ref, n_tgt), seed=n_ref, box=(168, 401, 32))
+    xn, (mean, scale) = mr.normalize_points(x, return_para=True)
+    ref = xn[:n_ref]; tgt = ((y - mean) / scale)[:n_tgt]
+    trk = ref[:n_trk] + rng.normal(0, 0.003, (n_trk, 3)) if n_trk <= n_ref else None
+    corr = ffn_mod.initial_matching_ffn(ffn, ref, tgt, 20)
+    assert corr.shape == (n_tgt, n_ref)
+    np.testing.assert_allclose(corr, mr.initial_matching(lambda q: mr.ffn_forward(ffn_w, q), ref, tgt, 20), rtol=0, atol=SCORE_TOL)
+    prior, pairs = tl.simple_match(corr)
+    prior_o, pairs_o = mr.simple_match(corr)
+    assert np.array_equal(pairs, pairs_o) and np.array_equal(prior, prior_o)
+    got, post = tl.prgls_with_two_ref(prior, tgt, ref, trk, beta=3, lambda_=3)
+    want, post_o = mr.prgls_with_two_ref(prior_o, tgt, ref, trk, beta=3, lambda_=3)
+    np.testing.assert_allclose(got, want, rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post, post_o, rtol=0, atol=COORD_TOL)
+    # legacy dialect with a rectangular score matrix
+    X = ref * scale + mean; Y = tgt * scale + mean
+    P, TX, C = track.pr_gls_quick(X.copy(), Y, corr, BETA=300, max_iteration=8, LAMBDA=0.1)
+    Po, TXo, Co = mr.pr_gls_quick(X.copy(), Y, corr, BETA=300, max_iteration=8, LAMBDA=0.1)
+    assert P.shape == (n_tgt, n_ref)
+    np.testing.assert_allclose(P, Po, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(TX, TXo, rtol=0, atol=1e-4)
+
+
+def test_small_beta_forces_dense_path(ffn):
+    """beta = 0.05 makes the Gram matrix full rank: the low-rank factorisation gives up and the dense M-step must agree."""
+    x, y = synth.make_point_pair(150, seed=9, box=(168, 401, 32))
+    xn, (mean, scale) = mr.normalize_points(x, return_para=True); yn = (y - mean) / scale
+    corr = ffn_mod.initial_matching_ffn(ffn, xn, yn, 20)
+    prior, _ = tl.simple_match(corr)
+    for beta in (0.05, 0.3):
+        got, post = tl.prgls_with_two_ref(prior, yn, xn, xn, beta=beta, lambda_=3, max_iteration=40)
+        want, post_o = mr.prgls_with_two_ref(prior, yn, xn, xn, beta=beta, lambda_=3, max_iteration=40)
+        np.testing.assert_allclose(got, want, rtol=0, atol=COORD_TOL)
+
+
+def test_no_pair_above_threshold():
+    """all scores below the threshold: no pairs, uniform prior (reference loop breaks immediately)."""
+    corr = np.full((30, 40), 0.05, dtype=np.float32)
+    prior, pairs = tl.simple_match(corr)
+    prior_o, pairs_o = mr.simple_match(corr)
+    assert len(pairs) == 0 and len(pairs_o) == 0 and np.array_equal(prior, prior_o)
