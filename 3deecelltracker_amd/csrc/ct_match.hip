@@ -719,15 +719,6 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void sum_to_scalar_kernel(const double* __restrict__ v, int n, double* __restrict__ dst) {
-    __shared__ double red[4];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
-    acc = wave_sum_d(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) *dst = (red[0] + red[1]) + (red[2] + red[3]);
-}
 
 
 // ------------------------------------------------------------------------------------------------
@@ -1093,7 +1084,6 @@ __global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict_
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int r = *rank_p;
     const int ld = r | 1;                  // odd leading dimension (doubles): spreads rows over the LDS banks
-    const int ra = r + 3;                  // augmented row count
     double* S = sm;                        // [ra][ld]
     __shared__ double red[4];
     const int tid = threadIdx.x;

@@ -73,6 +73,7 @@ constexpr int NSLAB = 14;                         // ceil(27 taps * 8 cin / 16 k
 // Two-plane staging (no tap padding, half the barriers) measured 24.7 vs 24.4 ms/volume: the 3.6 % fewer MFMAs are
 // eaten by the occupancy drop (69 KB LDS, +60 VGPRs).  Kept as a validated variant, switched off.
 constexpr bool kUsePairStaging = false;
+constexpr int kConvDmaDefaultMask = 0;          // LDS-DMA staged variant per NT (bit 0: NT=1, bit 1: NT=2, bit 2: NT=4)
 
 __host__ __device__ constexpr int tap_off(int tap) {   // float offset of tap (dx,dy,dz) in the LDS tile
     return (((tap / 9) * HY + (tap / 3) % 3) * HZ + tap % 3) * 8;
@@ -310,6 +311,210 @@ __global__ __launch_bounds__(256, (NT == 2 && !PAIR) ? 3 : 2) void conv3_mfma_ke
         }
     }
 }
+
+
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the main conv kernel.  The LDS halo tile is a linear copy of global memory (blocked layout), so
+// the staging is done by `global_load_lds` (16 B per lane, wave-uniform LDS base + lane * 16): no staging VGPRs, no
+// register -> LDS pass.  Two LDS buffers: the DMA of chunk c+1 is issued while the last MFMAs of chunk c run, one
+// barrier per chunk.  Out-of-image halo voxels (zero 'same' padding) are the SAME lanes for every chunk of a workgroup:
+// both buffers are zeroed once and those lanes are simply masked (a masked lane leaves LDS untouched -- probed in
+// scripts/probe/glds_masked.hip).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_dma_kernel(ConvArgs a) {
+    constexpr bool PAIR = false;
+    constexpr int PLANE_F = NF4 * 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * PLANE_F];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int b = blockIdx.x;
+    const int cg = b % a.ngroups; b /= a.ngroups;
+    const int ntb = cg * NT;
+    const int zb = b % a.zblocks; b /= a.zblocks;
+    const int ty = b % a.tilesY;  b /= a.tilesY;
+    const int tx = b % a.tilesX;
+    const int p = b / a.tilesX;
+    const int x0 = tx * TX, y0 = ty * TY, z0 = zb * 16;
+
+    const int g = lane >> 4, zl = lane & 15;
+    const int wx0 = 2 * (wave >> 1), wy0 = 4 * (wave & 1);
+    const bool hi = (g >> 1) != 0;
+    const int lbase = ((wx0 * HY + wy0) * HZ + zl) * 8 + 4 * (g & 1);
+
+    for (int i = tid; i < 2 * NF4; i += 256) *reinterpret_cast<f32x4*>(&lds[i * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-thread halo coordinates of its NSTAGE float4 slots (identical for every chunk)
+    auto issue = [&](int chunk, int buf) {
+        const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
+        {
+            const int c0 = chunk * 8;
+            if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
+                             sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
+            else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
+                             sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
+        }
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int f = tid + 256 * i;
+            if (f < NF4) {
+                const int col = f / (HZ * 2), w = f - col * (HZ * 2);
+                const int hz = w >> 1, half = w & 1;
+                const int hx = col / HY, hy = col - hx * HY;
+                const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+                if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
+                    const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
+                                        + (gz >> suz)) * 8 + half * 4;
+                    float* dstw = &lds[buf * PLANE_F + (wave_u * 64 + 256 * i) * 4];       // wave-uniform base
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx),
+                                                     (__attribute__((address_space(3))) void*)dstw, 16, 0, 0);
+                }
+            }
+        }
+    };
+
+    __syncthreads();                           // zero fill complete before any DMA lands
+    issue(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    const int nstages = a.nchunks;
+    for (int stage = 0; stage < nstages; ++stage) {
+        const float* cur = &lds[(stage & 1) * PLANE_F];
+        const f32x4* wp = a.wpack + ((size_t)stage * NSLAB * a.nt_total + ntb) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NSLAB - 1; ++s) {
+            const int off = lbase + (hi ? tap_off(2 * s + 1) : tap_off(2 * s));
+            f32x4 wv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
+            f32x4 av[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&cur[off + mt_off(mt)]);
+            if (s == NSLAB - 3) {              // weights of this slab are in flight/landed: the DMA queues behind them
+                if (stage + 1 < nstages) issue(stage + 1, (stage + 1) & 1);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
+        }
+        {
+            const int off = ((wx0 * HY + wy0) * HZ + zl) * 8 + 2 * g + tap_off(26);
+            f32x4 wv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)((NSLAB - 1) * a.nt_total + nt) * 64];
+            f32x2 av[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x2*>(&cur[off + mt_off(mt)]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0);         // next tile landed (DMA is tracked by vmcnt)
+        __syncthreads();
+    }
+    (void)PAIR;
+
+    // ---- epilogue: bias -> activation -> BatchNorm affine (BN follows the activation)
+    // lane (zl, g) holds, for column mt and n-tile nt, couts 16nt+4g .. +3 of voxel z0+zl
+    const int CP = a.nt_total * 16;
+    const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cb = 16 * (ntb + nt) + 4 * g;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
+        const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + CP + cb);
+        const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 2 * CP + cb);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            f32x4 r = acc[mt][nt] + bias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = r[e];
+                r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+            }
+            acc[mt][nt] = r;
+        }
+    }
+    const int z = z0 + zl;
+    const int OQ = a.cout >> 3;
+    if (a.out) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int x = x0 + wx0 + (mt >> 2), y = y0 + wy0 + (mt & 3);
+            if (x < a.X && y < a.Y && z < a.Z) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int cb = 16 * (ntb + nt) + 4 * g;
+                    if (cb < a.cout) {
+                        const size_t idx = ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7);
+                        *reinterpret_cast<f32x4*>(a.out + idx) = acc[mt][nt];
+                    }
+                }
+            }
+        }
+    }
+    if (a.pool) {      // MaxPooling3D (2,2,pz): the wave's 2x4 columns are two 2x2 blocks
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int x = x0 + wx0, y = y0 + wy0 + 2 * blk;
+            const bool ok = (x + 1 < a.X) && (y + 1 < a.Y) && (z < a.Z);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = fmaxf(fmaxf(acc[2 * blk][nt][e], acc[2 * blk + 1][nt][e]),
+                                    fmaxf(acc[4 + 2 * blk][nt][e], acc[5 + 2 * blk][nt][e]));
+                    if (a.pz == 2) t = fmaxf(t, __shfl_xor(t, 1));
+                    m[e] = t;
+                }
+                const int cb = 16 * (ntb + nt) + 4 * g;
+                const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
+                if (ok && zok && cb < a.cout) {
+                    const int pzc = a.pz == 2 ? (z >> 1) : z;
+                    const size_t idx = ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7);
+                    *reinterpret_cast<f32x4*>(a.pool + idx) = m;
+                }
+            }
+        }
+    }
+    if (a.head) {      // Conv3D(1, 1, activation='sigmoid') fused: dot over channels, then sigmoid
+        const float hb = a.head[CP];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            float part = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 hw = *reinterpret_cast<const f32x4*>(a.head + 16 * (ntb + nt) + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += acc[mt][nt][e] * hw[e];
+            }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            const int x = x0 + wx0 + (mt >> 2), y = y0 + wy0 + (mt & 3);
+            if (g == 0 && x < a.X && y < a.Y && z < a.Z) {
+                const float logit = part + hb;
+                a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-logit));
+            }
+        }
+    }
+}
+
 
 
 // ------------------------------------------------------------------------------------------------
@@ -653,9 +858,20 @@ void pack_conv_weights_c8(const float* k, int cin, float* dst) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+int conv_dma_mask() {      // which NT instantiations use the LDS-DMA kernel: bit 0 NT=1, bit 1 NT=2, bit 2 NT=4
+    static int mask = -1;
+    if (mask < 0) { const char* e = getenv("CT_CONV_DMA"); mask = e ? atoi(e) : kConvDmaDefaultMask; }
+    return mask;
+}
+
 template <int NT>
 int launch_conv(const ConvArgs& a, int P, bool pair, hipStream_t st) {
     const int nblk = P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
+    const int bit = NT == 1 ? 1 : (NT == 2 ? 2 : 4);
+    if (!pair && (conv_dma_mask() & bit)) {
+        hipLaunchKernelGGL((conv3_mfma_dma_kernel<NT>), dim3(nblk), dim3(256), 0, st, a);
+        return (int)hipGetLastError();
+    }
     if (pair) hipLaunchKernelGGL((conv3_mfma_kernel<NT, true>), dim3(nblk), dim3(256), 0, st, a);
     else      hipLaunchKernelGGL((conv3_mfma_kernel<NT, false>), dim3(nblk), dim3(256), 0, st, a);
     return (int)hipGetLastError();
