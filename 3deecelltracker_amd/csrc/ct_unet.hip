@@ -1137,13 +1137,21 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             a.act = ad.act;
             a.xcd_remap = getenv("CT_XCD_REMAP") ? 1 : 0;      // measured: 24.0 vs 23.9 ms/volume -> off (kernel is MFMA-bound)
             a.tilesX = (d[0] + TX - 1) / TX; a.tilesY = (d[1] + TY - 1) / TY; a.zblocks = (d[2] + 15) / 16;
+            // small grids: a wide layer whose NT = 4 grid is only a few "waves" of workgroups loses up to a third to the
+            // tail; NT = 2 with two cout groups doubles the workgroups (and fits 3 per CU) at the price of staging twice
+            int NTsel = c.NT;
+            {
+                const long nblk4 = (long)P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
+                static const int thr = getenv("CT_CONV_SPLIT_THR") ? atoi(getenv("CT_CONV_SPLIT_THR")) : 4096;
+                if (!c.c8 && !c.pair && !c.head && c.NT == 4 && nblk4 < thr) { NTsel = 2; a.ngroups = c.nt_total / 2; }   // (the fused head needs all channels in one block)
+            }
             int rc;
             if (c.c8) {
                 const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
                 hipLaunchKernelGGL(conv3_mfma_c8_kernel, dim3(nblk), dim3(256), 0, st, a);
                 rc = (int)hipGetLastError();
             } else
-            switch (c.NT) {
+            switch (NTsel) {
                 case 1: rc = launch_conv<1>(a, P, c.pair, st); break;
                 case 2: rc = launch_conv<2>(a, P, c.pair, st); break;
                 case 4: rc = launch_conv<4>(a, P, c.pair, st); break;
