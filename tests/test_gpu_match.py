@@ -349,3 +349,28 @@ def test_no_pair_above_threshold():
     prior, pairs = tl.simple_match(corr)
     prior_o, pairs_o = mr.simple_match(corr)
     assert len(pairs) == 0 and len(pairs_o) == 0 and np.array_equal(prior, prior_o)
+
+
+def test_tracker_ensemble_prediction_against_oracle(ffn, ffn_w):
+    """legacy ensemble step of track_one_vol (tracker.py:1499-1506): one FFN+PR-GLS prediction per source volume chosen by
+    get_reference_vols, then trim_mean(0.1) -- BASELINE config 3 pattern at a small size."""
+    n, vols = 60, 9
+    rng = np.random.default_rng(12)
+    base = rng.uniform(0, 1, (n, 3)) * np.array([168, 401, 120])
+    segs, trks = [], []
+    for t in range(vols):
+        a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.04
+        pts = (base - base.mean(0)) @ a + base.mean(0) + rng.normal(0, 0.5, base.shape)
+        segs.append(pts[rng.permutation(n)]); trks.append(pts + rng.normal(0, 0.3, base.shape))
+    target_seg = segs[-1]
+    trk = tracker_mod.Tracker(ffn, beta_tk=1000.0, lambda_tk=1e-5, max_iteration=6, ensemble=5, adjacent=False)
+    trk.history.r_segmented_coordinates = segs[:-1]; trk.history.r_tracked_coordinates = trks[:-1]
+    trk.cell_num_t0 = n
+    trk.set_segmentation(target_seg)
+    vol = vols                                             # predicting volume 9 from volumes chosen among 1..8
+    got = trk.predict_ensemble(vol)
+    src = mr.get_reference_vols(5, vol, False)
+    assert src == track.get_reference_vols(5, vol, False) and len(src) >= 5
+    preds = [mr.predict_pos_once(lambda q: mr.ffn_forward(ffn_w, q), segs[v - 1], trks[v - 1], target_seg, 1000.0, 1e-5, 6)
+             for v in src]
+    np.testing.assert_allclose(got, mr.trim_mean(np.stack(preds), 0.1), rtol=0, atol=1e-4)
