@@ -121,7 +121,7 @@ class FramePipeline:
     independent units, so results are identical to processing them one after another.
     """
 
-    def __init__(self, device: int = 0, match_cus: int = 32, workers: int = 3):
+    def __init__(self, device: int = 0, match_cus: int = 32, workers: int = 3, disjoint: bool = False):
         import ctypes as C
         from concurrent.futures import ThreadPoolExecutor
         import threading
@@ -142,7 +142,14 @@ class FramePipeline:
             self._handles.append(h)
             return torch.cuda.ExternalStream(h.value, device=f"cuda:{device}")
         self.seg_stream = cu_stream(self.match_cus, self.n_cu - self.match_cus)
-        self._match_streams = [cu_stream(0, self.match_cus) for _ in range(self.workers)]
+        if disjoint and self.match_cus >= 2 * self.workers:
+            # every chain gets its own slice of the match partition (streams sharing one CU mask were observed to
+            # advance in lock-step, i.e. serialised)
+            per = self.match_cus // self.workers
+            self._match_streams = [cu_stream(i * per, per if i < self.workers - 1 else self.match_cus - i * per)
+                                   for i in range(self.workers)]
+        else:
+            self._match_streams = [cu_stream(0, self.match_cus) for _ in range(self.workers)]
         self._tls = threading.local()
         self._free = list(range(self.workers))
         self._lock = threading.Lock()

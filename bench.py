@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run: all ranks on cuda:0 (needs --backend gloo)")
     ap.add_argument("--match-cus", type=int, default=24, help="CUs reserved for the matching chains (rest: U-Net)")
+    ap.add_argument("--disjoint-match-cus", action="store_true", help="give every match chain its own CU slice (measured: worse)")
     ap.add_argument("--match-workers", type=int, default=3, help="frames whose match chains are in flight concurrently")
     ap.add_argument("--cpu-patches", type=int, default=2, help="U-Net patches timed by the CPU baseline sample")
     args = ap.parse_args()
@@ -96,7 +97,7 @@ def main():
     # PR-GLS chain is latency-bound (~31 ms of dependent ~5 us kernels).  FramePipeline splits the CUs with masked streams
     # and lets `--match-workers` host threads each drive the match of a different frame (frames are independent units).
     par = importlib.import_module(f"{PKG}.parallel")
-    pipe = par.FramePipeline(device=local, match_cus=args.match_cus, workers=args.match_workers)
+    pipe = par.FramePipeline(device=local, match_cus=args.match_cus, workers=args.match_workers, disjoint=args.disjoint_match_cus)
     s_seg = pipe.seg_stream
     n_cu, k_match = pipe.n_cu, pipe.match_cus
     gather_buf = [torch.empty((args.cells, 3), dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
