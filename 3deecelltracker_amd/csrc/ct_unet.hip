@@ -761,6 +761,7 @@ struct ConvPlan {
     bool head;
     bool c8;              // Cout == 8: paired-column kernel
     bool pair;            // Cin % 16 == 0: two planes per stage
+    int nt_used;          // instantiation launched by the last run (small grids split NT = 4 into 2 x NT = 2)
     size_t wpack_off;     // float4 offset into the device weight arena
     size_t epi_off;       // float offset
 };
@@ -903,7 +904,7 @@ int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int d
     const ConvPlan& c = h->convs[layer];
     if (cin) *cin = c.cin;
     if (cout) *cout = c.cout;
-    if (nt) *nt = layer == 0 ? 0 : (c.c8 ? -8 : c.NT);      // 0: conv_first_kernel, -8: conv3_mfma_c8_kernel, else conv3_mfma_kernel<nt>
+    if (nt) *nt = layer == 0 ? 0 : (c.c8 ? -8 : (c.nt_used ? c.nt_used : c.NT));      // 0: conv_first_kernel, -8: conv3_mfma_c8_kernel, else conv3_mfma_kernel<nt>
     if (dims_xyz) for (int i = 0; i < 3; ++i) dims_xyz[i] = h->dims[c.level][i];
     return CT_OK;
 }
@@ -1101,7 +1102,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
     const ArchDesc& ad = h->ad;
     size_t dump_off = 0;
     for (size_t i = 0; i < h->convs.size(); ++i) {
-        const ConvPlan& c = h->convs[i];
+        ConvPlan& c = h->convs[i];
         const int* d = h->dims[c.level];
         TimedScope timed(h, (int)i, st);
         if (i == 0) {
@@ -1145,6 +1146,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 static const int thr = getenv("CT_CONV_SPLIT_THR") ? atoi(getenv("CT_CONV_SPLIT_THR")) : 4096;
                 if (!c.c8 && !c.pair && !c.head && c.NT == 4 && nblk4 < thr) { NTsel = 2; a.ngroups = c.nt_total / 2; }   // (the fused head needs all channels in one block)
             }
+            c.nt_used = NTsel;
             int rc;
             if (c.c8) {
                 const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
