@@ -144,7 +144,7 @@ class UNet3Model:
             out = torch.zeros_like(vol)
         if n <= 0:
             return out
-        nb = n if max_batch is None else min(n, max_batch)
+        nb = min(n, 128 if max_batch is None else max_batch)        # 119 MB of workspace per patch: cap the batch
         ws = self._workspace(lib.ct_unet_workspace_bytes(self._handle, nb))
         st = torch.cuda.current_stream(vol.device).cuda_stream
         _lib.check(lib.ct_unet_predict_volume(self._handle, vol.data_ptr(), _lib.ivec(vol.shape), _lib.ivec(shrink),
