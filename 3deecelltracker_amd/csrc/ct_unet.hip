@@ -726,6 +726,160 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const float* __restri
             pred[(((size_t)lp * q.nx + q.bx + x) * q.ny + q.by + y) * q.nz + q.bz + z];
 }
 
+// ------------------------------------------------------------------------------------------------
+// first conv fused with the sliding-window gather (volume path): reads the reflect-padded volume directly (the patch
+// tensor is never materialised), stages the 1-channel halo tile of an 8 x 8 x 16 output block in LDS, 4 voxels x 8
+// channels per thread.  Zero 'same' padding applies at the PATCH border (patch-local coordinate outside [0, n)),
+// reflect padding at the VOLUME border -- exactly np.pad(..., 'reflect') followed by Conv3D(padding='same').
+// ------------------------------------------------------------------------------------------------
+constexpr int F1X = 8, F1Y = 8, F1Z = 16;
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_first_vol_kernel(const float* __restrict__ vol, TileGeom q, int p_begin,
+                                                             const float* __restrict__ w, const float* __restrict__ epi,
+                                                             float* __restrict__ out, int act) {
+    __shared__ float tile[(F1X + 2) * (F1Y + 2) * (F1Z + 2)];
+    __shared__ int mapx[F1X + 2], mapy[F1Y + 2], mapz[F1Z + 2];       // volume index per halo coordinate, -1 = zero padding
+    const int tid = threadIdx.x;
+    const int tilesX = (q.nx + F1X - 1) / F1X, tilesY = (q.ny + F1Y - 1) / F1Y, tilesZ = (q.nz + F1Z - 1) / F1Z;
+    int b = blockIdx.x;
+    const int tz = b % tilesZ; b /= tilesZ;
+    const int ty = b % tilesY; b /= tilesY;
+    const int tx = b % tilesX; const int lp = b / tilesX;
+    const int pg = p_begin + lp;
+    const int pk = pg % q.gz, pj = (pg / q.gz) % q.gy, pi = pg / (q.gz * q.gy);
+    const int x0 = tx * F1X, y0 = ty * F1Y, z0 = tz * F1Z;
+    constexpr int HX1 = F1X + 2, HY1 = F1Y + 2, HZ1 = F1Z + 2;
+    if (tid < HX1) { const int l = x0 - 1 + tid; mapx[tid] = (l >= 0 && l < q.nx) ? reflect_idx(pi * q.cx + l - q.bx, q.vx) : -1; }
+    else if (tid >= 64 && tid < 64 + HY1) { const int t = tid - 64, l = y0 - 1 + t; mapy[t] = (l >= 0 && l < q.ny) ? reflect_idx(pj * q.cy + l - q.by, q.vy) : -1; }
+    else if (tid >= 128 && tid < 128 + HZ1) { const int t = tid - 128, l = z0 - 1 + t; mapz[t] = (l >= 0 && l < q.nz) ? reflect_idx(pk * q.cz + l - q.bz, q.vz) : -1; }
+    __syncthreads();
+    for (int e = tid; e < HX1 * HY1 * HZ1; e += 256) {
+        const int hz = e % HZ1, hy = (e / HZ1) % HY1, hx = e / (HZ1 * HY1);
+        const int sx = mapx[hx], sy = mapy[hy], sz = mapz[hz];
+        tile[e] = (sx >= 0 && sy >= 0 && sz >= 0) ? vol[((size_t)sx * q.vy + sy) * q.vz + sz] : 0.f;
+    }
+    __syncthreads();
+    // thread -> (column c in 0..63, z quarter): 4 consecutive z per thread
+    const int zq = tid & 3, col = tid >> 2;
+    const int cx = col >> 3, cy = col & 7;
+    float acc[4][COUT];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[v][c] = 0.f;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            float in[6];
+            const int base = ((cx + dx) * HY1 + (cy + dy)) * HZ1 + zq * 4;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) in[k] = tile[base + k];
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const float* wt = w + ((dx * 3 + dy) * 3 + dz) * COUT;          // uniform address -> scalar loads
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c) acc[v][c] = fmaf(in[v + dz], wt[c], acc[v][c]);
+            }
+        }
+    const float alpha = act == 0 ? kLeakyAlpha : 0.f;
+    const float* ep = epi;
+    const int x = x0 + cx, y = y0 + cy;
+    if (x >= q.nx || y >= q.ny) return;
+    constexpr int OQ = COUT / 8;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int z = z0 + zq * 4 + v;
+        if (z >= q.nz) continue;
+#pragma unroll
+        for (int qq = 0; qq < OQ; ++qq) {
+            f32x4 o[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = qq * 8 + e;
+                const float t = acc[v][c] + ep[c];
+                o[e >> 2][e & 3] = (t >= 0.f ? t : t * alpha) * ep[COUT + c] + ep[2 * COUT + c];
+            }
+            float* dst = out + ((((size_t)(lp * q.nx + x) * q.ny + y) * OQ + qq) * q.nz + z) * 8;
+            *reinterpret_cast<f32x4*>(dst) = o[0];
+            *reinterpret_cast<f32x4*>(dst + 4) = o[1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First conv (Cin = 1, Cout = 8) on the matrix cores, fused with the sliding-window gather.  This layer is HBM-bound
+// (AI 12 flop/B: it writes 8 channels per input voxel), but a VALU version is issue-bound at 1.3 TB/s.  MFMA rows are
+// (x-select, cout) as in conv3_mfma_c8_kernel: one MFMA column = 16 z of TWO x-adjacent voxels sharing a 4 x 3 x 3
+// footprint: K = 36 taps = 9 MFMAs (lane group g owns tap 4t + g), the 9 weight values per lane stay in registers,
+// the B operand is one ds_read_b32 per MFMA from the 1-channel halo tile.  8 x 8 x 16 outputs per workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ vol, TileGeom q, int p_begin,
+                                                              const float* __restrict__ wfirst /* [9][64] */,
+                                                              const float* __restrict__ epi /* [3][8] */,
+                                                              float* __restrict__ out, int act) {
+    constexpr int HX1 = F1X + 2, HY1 = F1Y + 2, HZ1 = F1Z + 2;
+    __shared__ float tile[HX1 * HY1 * HZ1];
+    __shared__ int mapx[HX1], mapy[HY1], mapz[HZ1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tilesX = (q.nx + F1X - 1) / F1X, tilesY = (q.ny + F1Y - 1) / F1Y, tilesZ = (q.nz + F1Z - 1) / F1Z;
+    int b = blockIdx.x;
+    const int tz = b % tilesZ; b /= tilesZ;
+    const int ty = b % tilesY; b /= tilesY;
+    const int tx = b % tilesX; const int lp = b / tilesX;
+    const int pg = p_begin + lp;
+    const int pk = pg % q.gz, pj = (pg / q.gz) % q.gy, pi = pg / (q.gz * q.gy);
+    const int x0 = tx * F1X, y0 = ty * F1Y, z0 = tz * F1Z;
+    if (tid < HX1) { const int l = x0 - 1 + tid; mapx[tid] = (l >= 0 && l < q.nx) ? reflect_idx(pi * q.cx + l - q.bx, q.vx) : -1; }
+    else if (tid >= 64 && tid < 64 + HY1) { const int t = tid - 64, l = y0 - 1 + t; mapy[t] = (l >= 0 && l < q.ny) ? reflect_idx(pj * q.cy + l - q.by, q.vy) : -1; }
+    else if (tid >= 128 && tid < 128 + HZ1) { const int t = tid - 128, l = z0 - 1 + t; mapz[t] = (l >= 0 && l < q.nz) ? reflect_idx(pk * q.cz + l - q.bz, q.vz) : -1; }
+    __syncthreads();
+    for (int e = tid; e < HX1 * HY1 * HZ1; e += 256) {
+        const int hz = e % HZ1, hy = (e / HZ1) % HY1, hx = e / (HZ1 * HY1);
+        const int sx = mapx[hx], sy = mapy[hy], sz = mapz[hz];
+        tile[e] = (sx >= 0 && sy >= 0 && sz >= 0) ? vol[((size_t)sx * q.vy + sy) * q.vz + sz] : 0.f;
+    }
+    const int g = lane >> 4, zl = lane & 15;
+    float wreg[9]; int off[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        wreg[t] = wfirst[t * 64 + lane];
+        const int k = 4 * t + g;                                  // tap' = (dx' * 3 + dy) * 3 + dz, dx' in 0..3
+        off[t] = ((k / 9) * HY1 + (k / 3) % 3) * HZ1 + k % 3;
+    }
+    __syncthreads();
+    // wave w owns pair-columns: x pair (w >> 1) * 2 + {0, 1}, y = (w & 1) * 4 + {0..3}  -> 8 pairs
+    f32x4 acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int px0 = (wave >> 1) * 2, py0 = (wave & 1) * 4;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int pxi = px0 + (m >> 2), pyi = py0 + (m & 3);
+            const float bv = tile[((2 * pxi) * HY1 + pyi) * HZ1 + zl + off[t]];
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t], bv, acc[m], 0, 0, 0);
+        }
+    const float alpha = act == 0 ? kLeakyAlpha : 0.f;
+    const int cb = 4 * (g & 1);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(epi + cb);
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(epi + 8 + cb);
+    const f32x4 shift = *reinterpret_cast<const f32x4*>(epi + 16 + cb);
+    const int z = z0 + zl;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int x = x0 + 2 * (px0 + (m >> 2)) + (g >> 1), y = y0 + py0 + (m & 3);
+        if (x >= q.nx || y >= q.ny || z >= q.nz) continue;
+        f32x4 r = acc[m] + bias;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = r[e]; r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e]; }
+        *reinterpret_cast<f32x4*>(out + (((size_t)(lp * q.nx + x) * q.ny + y) * q.nz + z) * 8 + cb) = r;
+    }
+}
+
 // blocked [X][Y][C/8][Z][8] (patch 0) -> Keras NDHWC [X][Y][Z][C]   (parity tests only)
 __global__ __launch_bounds__(256) void unblock_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       int X, int Y, int Z, int C) {
@@ -779,6 +933,7 @@ struct ct_unet {
     size_t floats_per_patch;         // workspace floats per patch (all intermediates)
     float* d_weights;                // device arena
     size_t first_w_off, head_off;    // float offsets
+    size_t first_mfma_off;           // packed weights of conv_first_mfma_kernel (Cout == 8)
     size_t arena_floats;
     // optional per-launch HIP-event timing (bench.py roofline): pairs recorded on the launch stream
     bool timing;
@@ -1046,6 +1201,16 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
             h->first_w_off = arena.size();
             arena.insert(arena.end(), kern, kern + (size_t)27 * c.cout);
             arena.resize(align_up(arena.size(), 4), 0.f);
+            if (c.cout == 8) {      // MFMA packing: wfirst[t][lane = g*16 + n] = K[dx' - xs][dy][dz][co], tap' = 4t + g, n = xs*8 + co
+                h->first_mfma_off = arena.size();
+                arena.resize(arena.size() + 9 * 64, 0.f);
+                for (int t = 0; t < 9; ++t)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = lane >> 4, n = lane & 15, xs = n >> 3, co = n & 7;
+                        const int kk = 4 * t + g, dxp = kk / 9, dy = (kk / 3) % 3, dz = kk % 3, dx = dxp - xs;
+                        if (dx >= 0 && dx <= 2) arena[h->first_mfma_off + t * 64 + lane] = kern[((dx * 3 + dy) * 3 + dz) * 8 + co];
+                    }
+            }
             c.epi_off = push_epi(bias, gamma, beta, mean, var, c.cout, c.cout);
             arena.resize(align_up(arena.size(), 4), 0.f);
         } else {
@@ -1096,7 +1261,10 @@ size_t ct_unet_workspace_bytes(const ct_unet_t* h, int n_patches) {
     return (h->floats_per_patch + vox0) * (size_t)n_patches * sizeof(float) + 256;
 }
 
-static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* layer_dump, hipStream_t st) {
+struct VolSource { const float* vol; TileGeom q; int p_begin; };
+
+static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* layer_dump, hipStream_t st,
+                       const VolSource* vsrc = nullptr) {
     // ws: tensor t of patch batch lives at ws + tensors[t].off * P  (each tensor is [P][...])
     auto tptr = [&](int t) { return ws + h->tensors[t].off * (size_t)P; };
     const ArchDesc& ad = h->ad;
@@ -1110,7 +1278,16 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             const unsigned nblk = (unsigned)((nvox + 255) / 256);
             const float* wt = h->d_weights + h->first_w_off;
             const float* epi = h->d_weights + c.epi_off;
-            if (c.cout == 8)
+            if (vsrc && c.cout == 8) {
+                const int nb1 = P * ((d[0] + F1X - 1) / F1X) * ((d[1] + F1Y - 1) / F1Y) * ((d[2] + F1Z - 1) / F1Z);
+                static const bool use_valu = getenv("CT_FIRST_VALU") != nullptr;
+                if (use_valu)
+                    hipLaunchKernelGGL(conv_first_vol_kernel<8>, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin, wt, epi,
+                                       tptr(c.dst), ad.act);
+                else
+                    hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin,
+                                       h->d_weights + h->first_mfma_off, epi, tptr(c.dst), ad.act);
+            } else if (c.cout == 8)
                 hipLaunchKernelGGL(conv_first_kernel<8>, dim3(nblk), dim3(256), 0, st, tptr(c.srcB), wt, epi, tptr(c.dst), P, d[0], d[1], d[2], ad.act);
             else if (c.cout == 64)
                 hipLaunchKernelGGL(conv_first_kernel<64>, dim3(nblk), dim3(256), 0, st, tptr(c.srcB), wt, epi, tptr(c.dst), P, d[0], d[1], d[2], ad.act);
@@ -1254,9 +1431,13 @@ int ct_unet_predict_volume(ct_unet_t* h, const float* vol, const int v[3], const
     for (int done = 0; done < n;) {
         const int nb = (n - done) < batch_cap ? (n - done) : batch_cap;
         float* prob = ws + h->floats_per_patch * (size_t)nb;          // [nb][X][Y][Z]
-        rc = ct_tile_gather_reflect(vol, v, h->ad.in, shrink, p_begin + done, nb, ws, stream);   // tensor 0
-        if (rc) return rc;
-        rc = run_network(h, ws, nb, prob, nullptr, st);
+        const bool fused_first = h->convs[0].cout == 8 && !getenv("CT_NO_FUSED_FIRST");
+        if (!fused_first) {
+            rc = ct_tile_gather_reflect(vol, v, h->ad.in, shrink, p_begin + done, nb, ws, stream);   // tensor 0
+            if (rc) return rc;
+        }
+        VolSource vs{vol, q, p_begin + done};
+        rc = run_network(h, ws, nb, prob, nullptr, st, fused_first ? &vs : nullptr);
         if (rc) return rc;
         rc = ct_tile_scatter_center(prob, v, h->ad.in, shrink, p_begin + done, nb, out_vol, stream);
         if (rc) return rc;
