@@ -148,3 +148,26 @@ def make_correction_case(seed=0, shape=(64, 56, 8), factor=5, n_cells=18, margin
             "voxel_size": np.array([1.0, 1.0, 4.0])}
 
 
+
+
+def make_prob_map(seed: int, shape, n_cells: int, radius=(4.0, 4.0, 1.5), speckle: float = 0.0005):
+    """Synthetic U-Net output: `n_cells` soft ellipsoids (peak ~0.95, many of them touching) plus isolated bright
+    speckle voxels (regions that min_size must remove).  float32 [x, y, z] in [0, 1]."""
+    rng = np.random.default_rng(seed)
+    X, Y, Z = (int(s) for s in shape)
+    prob = np.zeros((X, Y, Z), dtype=np.float32)
+    rx, ry, rz = radius
+    wx, wy, wz = int(3 * rx) + 1, int(3 * ry) + 1, int(3 * rz) + 1
+    centres = rng.uniform(0, 1, size=(n_cells, 3)) * np.array([X - 1, Y - 1, Z - 1])
+    for cx, cy, cz in centres:
+        x0, x1 = max(0, int(cx) - wx), min(X, int(cx) + wx + 1)
+        y0, y1 = max(0, int(cy) - wy), min(Y, int(cy) + wy + 1)
+        z0, z1 = max(0, int(cz) - wz), min(Z, int(cz) + wz + 1)
+        gx = ((np.arange(x0, x1) - cx) / rx) ** 2
+        gy = ((np.arange(y0, y1) - cy) / ry) ** 2
+        gz = ((np.arange(z0, z1) - cz) / rz) ** 2
+        blob = 0.95 * np.exp(-0.5 * (gx[:, None, None] + gy[None, :, None] + gz[None, None, :]))
+        np.maximum(prob[x0:x1, y0:y1, z0:z1], blob.astype(np.float32), out=prob[x0:x1, y0:y1, z0:z1])
+    if speckle > 0:
+        prob[rng.uniform(size=prob.shape) < speckle] = 0.9
+    return prob

@@ -57,6 +57,19 @@ class Tracker:
     def set_segmentation(self, r_coordinates_segment):
         self.segresult.r_coordinates_segment = np.asarray(r_coordinates_segment, dtype=np.float64)
 
+    def segment_prob(self, image_cell_bg, min_size=0, threshold=0.5, connectivity=1):
+        """The part of reference :636-650 (_segment) after the U-Net: regions -> centres -> real coordinates, on the GPU.
+
+        Regions come from threshold + connected components (segment.py; the skimage watershed is not rebuilt);
+        centres = center_of_mass(regions > 0, regions, 1..n) (:646), r = _transform_layer_to_real (:559-561, z * z_xy_ratio).
+        Returns (l_center_coordinates, segmentation_auto, r_coordinates_segment) and records the segmentation for match()."""
+        from .segment import segment_centroids
+        labels, l_centres, _ = segment_centroids(image_cell_bg, threshold, connectivity, min_size)
+        r = l_centres.copy()
+        r[:, 2] *= self.z_xy_ratio
+        self.set_segmentation(r)
+        return l_centres, labels, r
+
     # ---- matching
     def match(self, target_volume, r_coordinates_segment=None, method="min_size"):
         """reference :1138-1175.  Returns (None, [cells_on_boundary, target_volume, None, r_coor_predicted])."""

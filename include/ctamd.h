@@ -223,6 +223,24 @@ int ct_accurate_correction(const float* prob, const int dims_xyz[3], int factor,
                            const float* coord_vol1_raw, float* coords_raw, int max_repetition, int* iterations,
                            void* workspace, size_t workspace_bytes, ct_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Probability map -> labelled regions -> cell centres  (tracker.py:636-648)
+ * ------------------------------------------------------------------------------------------
+ * Stands in for _segment's region step with threshold + 3D connected components (the reference's skimage marker
+ * watershed, watershed.py:16-108, has no runnable reference in this image and is not restated -- touching cells are not
+ * split), then applies the reference's own scipy.ndimage.center_of_mass(regions > 0, regions, 1..n) (tracker.py:646).
+ * prob [dev] fp32 [x][y][z]; foreground = prob > threshold (watershed.py:38,48: 0.5); connectivity 1/2/3 =
+ * scipy.ndimage.generate_binary_structure(3, c); regions with fewer than min_size voxels are dropped
+ * (skimage remove_small_objects semantics) and the rest numbered 1..n in raster order of their first voxel
+ * (= scipy.ndimage.label followed by relabel_sequential).
+ * labels [dev] int32 [x][y][z] or NULL; centres [dev] fp64 [cap][3] voxel coordinates (x, y, z), first min(n, cap) rows;
+ * sizes [dev] int32 [cap] or NULL; n_labels [dev] int32 = n (may exceed cap: caller re-runs with a larger cap).
+ * Asynchronous on `stream`.                                                                                          */
+size_t ct_segment_workspace_bytes(const int dims_xyz[3], int cap);
+int ct_segment_centroids(const float* prob, const int dims_xyz[3], float threshold, int connectivity, int min_size,
+                         int cap, int32_t* labels, double* centres, int32_t* sizes, int32_t* n_labels,
+                         void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
