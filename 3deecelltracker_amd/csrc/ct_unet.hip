@@ -627,6 +627,330 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_c8_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Decoder convs: Conv3D over concat([UpSampling3D(2,2,*)(low), skip]).  For the upsampled channels a 3x3 (x, y)
+// stencil over nearest-neighbour-doubled data touches only 2 x 2 distinct low-res voxels, which ones depends on the
+// output voxel's parity (px, py): taps kx = {0 | 1,2} for even x, {0,1 | 2} for odd x (same in y).  With the weights
+// of coinciding taps summed on the host, those channels need 2 x 2 x 3 = 12 taps instead of 27 (6 slabs instead of
+// 13.5).  An MFMA shares its weight operand between its 16 columns, so every wave takes the 8 columns of ONE parity
+// class of the 4 x 8 tile: wave -> (px, py), column mt -> x = px + 2 (mt >> 2), y = py + 2 (mt & 3).  The LDS tile is
+// unchanged (the staging already materialises the upsampled data), the folded taps are a subset of its 27 positions;
+// the skip channels run the ordinary 13.5 slabs on the same column mapping.  'same' zero padding is preserved: a
+// folded tap that leaves the volume reads the zero halo exactly like the tap it replaces (dims are even).
+// ------------------------------------------------------------------------------------------------
+constexpr int NFSLAB = 6;                                // 12 folded taps x 8 cin / 16
+__host__ __device__ constexpr int ftap_off(int j) {      // folded tap j = (dxi * 2 + dyi) * 3 + dz, relative to (px, py)
+    return ((((j / 6) * HY + (j / 3) % 2) * HZ) + j % 3) * 8;
+}
+__host__ __device__ constexpr int mtf_off(int mt) {      // column mt of a parity class
+    return ((2 * (mt >> 2)) * HY + 2 * (mt & 3)) * HZ * 8;
+}
+
+// One 8-channel halo tile: global -> registers -> (barrier) -> LDS -> (barrier); zero 'same' padding, srcA read at >> u.
+__device__ __forceinline__ void stage_halo_tile(const ConvArgs& a, int c0, int p, int x0, int y0, int z0, int tid, float* lds) {
+    f32x4 v[NSTAGE];
+    const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
+    if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
+                     sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
+    else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
+                     sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        const int f = tid + 256 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (f < NF4) {
+            const int col = f / (HZ * 2), w = f - col * (HZ * 2);
+            const int hz = w >> 1, half = w & 1;
+            const int hx = col / HY, hy = col - hx * HY;
+            const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+            if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
+                const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
+                                    + (gz >> suz)) * 8 + half * 4;
+                v[i] = *reinterpret_cast<const f32x4*>(src + idx);
+            }
+        }
+    }
+    __syncthreads();                                          // every wave is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        const int f = tid + 256 * i;
+        if (f < NF4) *reinterpret_cast<f32x4*>(&lds[f * 4]) = v[i];
+    }
+    __syncthreads();
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void conv3_mfma_fold_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[NF4 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int cg = b % a.ngroups; b /= a.ngroups;
+    const int ntb = cg * NT;
+    const int zb = b % a.zblocks; b /= a.zblocks;
+    const int ty = b % a.tilesY;  b /= a.tilesY;
+    const int tx = b % a.tilesX;
+    const int p = b / a.tilesX;
+    const int x0 = tx * TX, y0 = ty * TY, z0 = zb * 16;
+
+    const int g = lane >> 4, zl = lane & 15;
+    const int px = wave >> 1, py = wave & 1;
+    const bool hi = (g >> 1) != 0;
+    const int cbase = ((px * HY + py) * HZ + zl) * 8;          // column mt = 0 of this wave's parity class
+    const int lbase = cbase + 4 * (g & 1);
+
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nA = a.CA >> 3;
+    // ---- upsampled channels: 6 slabs of (2 folded taps x 8 cin) with this parity class's summed weights
+    for (int stage = 0; stage < nA; ++stage) {
+        stage_halo_tile(a, stage * 8, p, x0, y0, z0, tid, lds);
+        const int fbase = lbase + (px * HY + py) * HZ * 8;      // folded taps start at halo offset (px, py)
+        const f32x4* wp = a.wpack + (((size_t)stage * 4 + (px * 2 + py)) * NFSLAB * a.nt_total + ntb) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NFSLAB; ++s) {
+            const int off = fbase + (hi ? ftap_off(2 * s + 1) : ftap_off(2 * s));
+            f32x4 wv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
+            f32x4 av[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mtf_off(mt)]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    // ---- skip channels: the ordinary 13 slabs + half slab (see conv3_mfma_kernel) on the parity column mapping
+    for (int stage = nA; stage < a.nchunks; ++stage) {
+        stage_halo_tile(a, stage * 8, p, x0, y0, z0, tid, lds);
+        const f32x4* wp = a.wpack + (((size_t)nA * 4 * NFSLAB + (size_t)(stage - nA) * NSLAB) * a.nt_total + ntb) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NSLAB - 1; ++s) {
+            const int off = lbase + (hi ? tap_off(2 * s + 1) : tap_off(2 * s));
+            f32x4 wv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
+            f32x4 av[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mtf_off(mt)]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
+        }
+        {
+            const int off = cbase + 2 * g + tap_off(26);
+            f32x4 wv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)((NSLAB - 1) * a.nt_total + nt) * 64];
+            f32x2 av[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x2*>(&lds[off + mtf_off(mt)]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue (bias -> activation -> BN affine), as in conv3_mfma_kernel but on the parity column mapping
+    const int CP = a.nt_total * 16;
+    const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cb = 16 * (ntb + nt) + 4 * g;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
+        const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + CP + cb);
+        const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 2 * CP + cb);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            f32x4 r = acc[mt][nt] + bias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = r[e];
+                r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+            }
+            acc[mt][nt] = r;
+        }
+    }
+    const int z = z0 + zl;
+    const int OQ = a.cout >> 3;
+    if (a.out) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int x = x0 + px + 2 * (mt >> 2), y = y0 + py + 2 * (mt & 3);
+            if (x < a.X && y < a.Y && z < a.Z) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int cb = 16 * (ntb + nt) + 4 * g;
+                    if (cb < a.cout) {
+                        const size_t idx = ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7);
+                        *reinterpret_cast<f32x4*>(a.out + idx) = acc[mt][nt];
+                    }
+                }
+            }
+        }
+    }
+    if (a.head) {
+        const float hb = a.head[CP];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            float part = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 hw = *reinterpret_cast<const f32x4*>(a.head + 16 * (ntb + nt) + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += acc[mt][nt][e] * hw[e];
+            }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            const int x = x0 + px + 2 * (mt >> 2), y = y0 + py + 2 * (mt & 3);
+            if (g == 0 && x < a.X && y < a.Y && z < a.Z)
+                a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + hb)));
+        }
+    }
+}
+
+// Cout = 8 decoder conv (paired-column kernel + upsample folding).  The pair (x even, x odd) of one MFMA column is
+// exactly one low-res x position, so the upsampled channels need the low-res x offsets {-1, 0, +1} (halo dx' = 0, 1, 3)
+// -- row (xs = 0) uses {-1: k0, 0: k1 + k2}, row (xs = 1) uses {0: k0 + k1, +1: k2} -- times 2 folded y taps (the wave's
+// y parity) times 3 z taps = 18 taps = 9 slabs instead of 18.  wave -> (x pair, py), column mt -> y = py + 2 mt.
+constexpr int NFSLAB8 = 9;
+__host__ __device__ constexpr int ftap_off8(int j) {       // j = (dxl * 2 + dyi) * 3 + dz, dxl -> halo dx' {0, 1, 3}
+    return ((((j / 6) == 2 ? 3 : (j / 6)) * HY + (j / 3) % 2) * HZ + j % 3) * 8;
+}
+
+__global__ __launch_bounds__(256, 2) void conv3_mfma_c8_fold_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[NF4 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int zb = b % a.zblocks; b /= a.zblocks;
+    const int ty = b % a.tilesY;  b /= a.tilesY;
+    const int tx = b % a.tilesX;
+    const int p = b / a.tilesX;
+    const int x0 = tx * TX, y0 = ty * TY, z0 = zb * 16;
+    const int g = lane >> 4, zl = lane & 15;
+    const int wx0 = 2 * (wave >> 1), py = wave & 1;
+    const int lbase = ((wx0 * HY + py) * HZ + zl) * 8 + 4 * (g & 1);
+    const int fbase = lbase + py * HZ * 8;
+    const bool hi = (g >> 1) != 0;
+    constexpr int MTS = 2 * HZ * 8;                        // y stride of the wave's columns
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nA = a.CA >> 3;
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
+        {
+            const int c0 = chunk * 8;
+            if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
+                             sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
+            else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
+                             sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
+        }
+        f32x4 v[NSTAGE];
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int f = tid + 256 * i;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (f < NF4) {
+                const int col = f / (HZ * 2), w = f - col * (HZ * 2);
+                const int hz = w >> 1, half = w & 1;
+                const int hx = col / HY, hy = col - hx * HY;
+                const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+                if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
+                    const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
+                                        + (gz >> suz)) * 8 + half * 4;
+                    v[i] = *reinterpret_cast<const f32x4*>(src + idx);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int f = tid + 256 * i;
+            if (f < NF4) *reinterpret_cast<f32x4*>(&lds[f * 4]) = v[i];
+        }
+        __syncthreads();
+
+        if (chunk < nA) {
+            const f32x4* wp = a.wpack + ((size_t)chunk * 2 + py) * NFSLAB8 * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < NFSLAB8; ++s) {
+                const int off = fbase + (hi ? ftap_off8(2 * s + 1) : ftap_off8(2 * s));
+                const f32x4 wv = wp[s * 64];
+                f32x4 av[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt * MTS]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], av[mt][t], acc[mt], 0, 0, 0);
+            }
+        } else {
+            const f32x4* wp = a.wpack + ((size_t)nA * 2 * NFSLAB8 + (size_t)(chunk - nA) * NSLAB8) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < NSLAB8; ++s) {
+                const int off = lbase + (hi ? tap_off4(2 * s + 1) : tap_off4(2 * s));
+                const f32x4 wv = wp[s * 64];
+                f32x4 av[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt * MTS]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], av[mt][t], acc[mt], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx0 + (g>>1), y = y0 + py + 2 mt
+    const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
+    const int cb = 4 * (g & 1);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + 16 + cb);
+    const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 32 + cb);
+    const int x = x0 + wx0 + (g >> 1), z = z0 + zl;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        f32x4 r = acc[mt] + bias;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = r[e];
+            r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+        }
+        const int y = y0 + py + 2 * mt;
+        const bool ok = x < a.X && y < a.Y && z < a.Z;
+        if (a.out && ok)
+            *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
+        if (a.head) {
+            const f32x4 hw = *reinterpret_cast<const f32x4*>(a.head + cb);
+            float part = r[0] * hw[0] + r[1] * hw[1] + r[2] * hw[2] + r[3] * hw[3];
+            part += __shfl_xor(part, 16);
+            if ((g & 1) == 0 && ok)
+                a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + a.head[16])));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // first conv (Cin = 1): HBM-bound (AI ~ 12 flop/B), plain VALU, one voxel per thread.
 // in [P][X][Y][Z]; w [27][COUT] (scalar loads); out blocked.
 // ------------------------------------------------------------------------------------------------
@@ -915,6 +1239,7 @@ struct ConvPlan {
     bool head;
     bool c8;              // Cout == 8: paired-column kernel
     bool pair;            // Cin % 16 == 0: two planes per stage
+    bool fold;            // decoder conv over concat([upsample(low), skip]): folded taps for the upsampled channels
     int nt_used;          // instantiation launched by the last run (small grids split NT = 4 into 2 x NT = 2)
     size_t wpack_off;     // float4 offset into the device weight arena
     size_t epi_off;       // float offset
@@ -1012,6 +1337,94 @@ void pack_conv_weights_c8(const float* k, int cin, float* dst) {
                 }
 }
 
+// Which original taps k (0..2) coincide on folded tap i (0..1) for output parity par: even -> {0 | 1,2}, odd -> {0,1 | 2}.
+inline bool fold_member(int par, int i, int k) { return par == 0 ? (i == 0 ? k == 0 : k >= 1) : (i == 0 ? k <= 1 : k == 2); }
+
+// conv3_mfma_fold_kernel packing.  Upsampled chunks (cin < CA), per parity class cls = px*2 + py:
+//   wfold[chunk][cls][slab][nt][lane = g*16 + n][t] = sum over coinciding (kx, ky) of K[kx][ky][dz][cin][cout],
+//   folded tap j = 2*slab + (g>>1) = (dxi*2 + dyi)*3 + dz, cin = 8*chunk + 4*(g&1) + t, cout = 16*nt + n;
+// skip chunks follow in pack_conv_weights order.
+void pack_conv_weights_fold(const float* k, int cin, int cout, int NT, int CA, float* dst) {
+    const int nA = CA / 8;
+    for (int ch = 0; ch < nA; ++ch)
+        for (int cls = 0; cls < 4; ++cls)
+            for (int s = 0; s < NFSLAB; ++s)
+                for (int nt = 0; nt < NT; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int t = 0; t < 4; ++t) {
+                            const int g = lane >> 4, n = lane & 15, px = cls >> 1, py = cls & 1;
+                            const int j = 2 * s + (g >> 1), dxi = j / 6, dyi = (j / 3) % 2, dz = j % 3;
+                            const int ci = 8 * ch + 4 * (g & 1) + t, co = 16 * nt + n;
+                            double v = 0.0;
+                            if (co < cout)
+                                for (int kx = 0; kx < 3; ++kx)
+                                    for (int ky = 0; ky < 3; ++ky)
+                                        if (fold_member(px, dxi, kx) && fold_member(py, dyi, ky))
+                                            v += (double)k[((size_t)((kx * 3 + ky) * 3 + dz) * cin + ci) * cout + co];
+                            dst[(((((size_t)ch * 4 + cls) * NFSLAB + s) * NT + nt) * 64 + lane) * 4 + t] = (float)v;
+                        }
+    float* d2 = dst + (size_t)nA * 4 * NFSLAB * NT * 64 * 4;
+    const int nB = (cin - CA) / 8;
+    for (int ch = 0; ch < nB; ++ch)
+        for (int s = 0; s < NSLAB; ++s)
+            for (int nt = 0; nt < NT; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int t = 0; t < 4; ++t) {
+                        const int g = lane >> 4, n = lane & 15;
+                        int tap = 2 * s + (g >> 1), ci = CA + 8 * ch + 4 * (g & 1) + t;
+                        const int co = 16 * nt + n;
+                        if (s == NSLAB - 1) { tap = (t < 2) ? 26 : 27; ci = CA + 8 * ch + 2 * g + t; }
+                        float v = 0.f;
+                        if (tap < 27 && co < cout) v = k[((size_t)tap * cin + ci) * cout + co];
+                        d2[((((size_t)ch * NSLAB + s) * NT + nt) * 64 + lane) * 4 + t] = v;
+                    }
+}
+inline size_t fold_pack_floats(int cin, int NT, int CA) {
+    return ((size_t)(CA / 8) * 4 * NFSLAB + (size_t)((cin - CA) / 8) * NSLAB) * NT * 64 * 4;
+}
+
+// conv3_mfma_c8_fold_kernel packing.  Upsampled chunks, per y parity py: rows n = xs*8 + co,
+//   wfold8[chunk][py][slab][lane][t]: folded tap j = 2*slab + (g>>1) = (dxl*2 + dyi)*3 + dz, dxl = low-res x offset + 1;
+//   row xs = 0 (even x): dxl 0 <- kx {0}, dxl 1 <- kx {1, 2};  row xs = 1 (odd x): dxl 1 <- kx {0, 1}, dxl 2 <- kx {2}.
+void pack_conv_weights_c8_fold(const float* k, int cin, int CA, float* dst) {
+    const int nA = CA / 8;
+    for (int ch = 0; ch < nA; ++ch)
+        for (int py = 0; py < 2; ++py)
+            for (int s = 0; s < NFSLAB8; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int t = 0; t < 4; ++t) {
+                        const int g = lane >> 4, n = lane & 15, xs = n >> 3, co = n & 7;
+                        const int j = 2 * s + (g >> 1), dxl = j / 6, dyi = (j / 3) % 2, dz = j % 3;
+                        const int ci = 8 * ch + 4 * (g & 1) + t;
+                        const int dxi = dxl - xs;                     // folded x tap index of this row's parity (0 or 1), else none
+                        double v = 0.0;
+                        if (dxi >= 0 && dxi <= 1)
+                            for (int kx = 0; kx < 3; ++kx)
+                                for (int ky = 0; ky < 3; ++ky)
+                                    if (fold_member(xs, dxi, kx) && fold_member(py, dyi, ky))
+                                        v += (double)k[((size_t)((kx * 3 + ky) * 3 + dz) * cin + ci) * 8 + co];
+                        dst[((((size_t)ch * 2 + py) * NFSLAB8 + s) * 64 + lane) * 4 + t] = (float)v;
+                    }
+    float* d2 = dst + (size_t)nA * 2 * NFSLAB8 * 64 * 4;
+    const int nB = (cin - CA) / 8;
+    for (int ch = 0; ch < nB; ++ch)
+        for (int s = 0; s < NSLAB8; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 4; ++t) {
+                    const int g = lane >> 4, n = lane & 15;
+                    const int tapp = 2 * s + (g >> 1), ci = CA + 8 * ch + 4 * (g & 1) + t;
+                    const int xs = n >> 3, co = n & 7;
+                    const int dxp = tapp / 9, dy = (tapp / 3) % 3, dz = tapp % 3;
+                    const int dx = dxp - xs;
+                    float v = 0.f;
+                    if (dx >= 0 && dx <= 2) v = k[((size_t)((dx * 3 + dy) * 3 + dz) * cin + ci) * 8 + co];
+                    d2[(((size_t)ch * NSLAB8 + s) * 64 + lane) * 4 + t] = v;
+                }
+}
+inline size_t fold_pack_floats_c8(int cin, int CA) {
+    return ((size_t)(CA / 8) * 2 * NFSLAB8 + (size_t)((cin - CA) / 8) * NSLAB8) * 64 * 4;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int conv_dma_mask() {      // which NT instantiations use the LDS-DMA kernel: bit 0 NT=1, bit 1 NT=2, bit 2 NT=4
@@ -1021,8 +1434,12 @@ int conv_dma_mask() {      // which NT instantiations use the LDS-DMA kernel: bi
 }
 
 template <int NT>
-int launch_conv(const ConvArgs& a, int P, bool pair, hipStream_t st) {
+int launch_conv(const ConvArgs& a, int P, bool pair, bool fold, hipStream_t st) {
     const int nblk = P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
+    if (fold) {
+        hipLaunchKernelGGL((conv3_mfma_fold_kernel<NT>), dim3(nblk), dim3(256), 0, st, a);
+        return (int)hipGetLastError();
+    }
     const int bit = NT == 1 ? 1 : (NT == 2 ? 2 : 4);
     if (!pair && (conv_dma_mask() & bit)) {
         hipLaunchKernelGGL((conv3_mfma_dma_kernel<NT>), dim3(nblk), dim3(256), 0, st, a);
@@ -1059,9 +1476,15 @@ int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int d
     const ConvPlan& c = h->convs[layer];
     if (cin) *cin = c.cin;
     if (cout) *cout = c.cout;
-    if (nt) *nt = layer == 0 ? 0 : (c.c8 ? -8 : (c.nt_used ? c.nt_used : c.NT));      // 0: conv_first_kernel, -8: conv3_mfma_c8_kernel, else conv3_mfma_kernel<nt>
+    // 0: first conv, -8: conv3_mfma_c8_kernel, -9: conv3_mfma_c8_fold_kernel, 1..4: conv3_mfma_kernel<nt>, 101..104: conv3_mfma_fold_kernel<nt - 100>
+    if (nt) *nt = layer == 0 ? 0 : (c.c8 ? (c.fold ? -9 : -8) : (c.nt_used ? c.nt_used : c.NT) + (c.fold ? 100 : 0));
     if (dims_xyz) for (int i = 0; i < 3; ++i) dims_xyz[i] = h->dims[c.level][i];
     return CT_OK;
+}
+
+int ct_unet_layer_fold_channels(const ct_unet_t* h, int layer) {
+    if (!h || layer < 0 || layer >= (int)h->convs.size()) return CT_EINVAL;
+    return h->convs[layer].fold ? h->convs[layer].CA : 0;
 }
 
 int ct_unet_set_timing(ct_unet_t* h, int enable) {
@@ -1215,7 +1638,18 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
             arena.resize(align_up(arena.size(), 4), 0.f);
         } else {
             c.wpack_off = arena.size();
-            if (c.cout == 8 && c.pool_dst < 0) {          // paired-column kernel
+            // decoder conv over concat([UpSampling3D(2, 2, *)(low), skip]): fold the coinciding taps (CT_CONV_FOLD=0: off)
+            static const bool fold_on = !(getenv("CT_CONV_FOLD") && atoi(getenv("CT_CONV_FOLD")) == 0);
+            c.fold = fold_on && c.srcA >= 0 && c.CA % 8 == 0 && ad.pool[0] == 2 && ad.pool[1] == 2 && c.pool_dst < 0
+                     && h->dims[c.level][0] % 2 == 0 && h->dims[c.level][1] % 2 == 0;
+            if (c.cout == 8 && c.pool_dst < 0 && c.fold) {
+                c.c8 = true;
+                arena.resize(arena.size() + fold_pack_floats_c8(c.cin, c.CA));
+                pack_conv_weights_c8_fold(kern, c.cin, c.CA, arena.data() + c.wpack_off);
+            } else if (c.fold) {
+                arena.resize(arena.size() + fold_pack_floats(c.cin, c.nt_total, c.CA));
+                pack_conv_weights_fold(kern, c.cin, c.cout, c.nt_total, c.CA, arena.data() + c.wpack_off);
+            } else if (c.cout == 8 && c.pool_dst < 0) {          // paired-column kernel
                 c.c8 = true;
                 arena.resize(arena.size() + (size_t)(c.cin / 8) * NSLAB8 * 64 * 4);
                 pack_conv_weights_c8(kern, c.cin, arena.data() + c.wpack_off);
@@ -1327,13 +1761,14 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             int rc;
             if (c.c8) {
                 const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
-                hipLaunchKernelGGL(conv3_mfma_c8_kernel, dim3(nblk), dim3(256), 0, st, a);
+                if (c.fold) hipLaunchKernelGGL(conv3_mfma_c8_fold_kernel, dim3(nblk), dim3(256), 0, st, a);
+                else        hipLaunchKernelGGL(conv3_mfma_c8_kernel, dim3(nblk), dim3(256), 0, st, a);
                 rc = (int)hipGetLastError();
             } else
             switch (NTsel) {
-                case 1: rc = launch_conv<1>(a, P, c.pair, st); break;
-                case 2: rc = launch_conv<2>(a, P, c.pair, st); break;
-                case 4: rc = launch_conv<4>(a, P, c.pair, st); break;
+                case 1: rc = launch_conv<1>(a, P, c.pair, c.fold, st); break;
+                case 2: rc = launch_conv<2>(a, P, c.pair, c.fold, st); break;
+                case 4: rc = launch_conv<4>(a, P, c.pair, c.fold, st); break;
                 default: return CT_ESHAPE;
             }
             if (rc) return rc;
