@@ -951,6 +951,300 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_c8_fold_kernel(ConvArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x6") variants of the conv kernels: fp32 results from the 16x-faster bf16 matrix pipe.
+//
+// An fp32 value splits EXACTLY into three bf16 numbers by truncation, a = h + m + l (8 + 8 + 8 significant bits;
+// bf16 has fp32's exponent range, so no scaling and no overflow/underflow cases).  A product then is
+//     a * b = hh + (hm + mh) + (mm + hl + lh) + [ml + lm + ll],
+// and dropping the bracket loses at most 2^-23 |ab| -- the size of fp32's own rounding.  bf16 x bf16 products are
+// exact in the MFMA's fp32 accumulator, so six v_mfma_f32_16x16x32_bf16 (K = 32 each) replace eight
+// v_mfma_f32_16x16x4_f32 (K = 4 each) at about 17 instead of 32 cycles apiece: 2.5x fewer matrix-pipe cycles for the
+// same fp32-faithful result (measured error vs an fp64 reference: see DESIGN.md / tests).
+//
+// Same implicit GEMM and HBM layout as conv3_mfma_kernel; what changes:
+//   * staging splits every activation once (4 VALU ops + pack) and writes three bf16 planes [pos][8 ch] (16 B per
+//     position per plane, 51.8 KB per workgroup -> still 3 workgroups per CU);
+//   * one MFMA consumes K = 32 = 4 taps x 8 channels: lane group g supplies tap 4 kb + g, its 8 channels are one
+//     ds_read_b128; 27 taps = 7 K-blocks (the 28th tap slot has zero weights), folded 12 taps = 3, Cout = 8 paired
+//     columns 36 taps = 9, folded 18 taps = 5;
+//   * weights are split on the host and packed [chunk][(class)][kb][nt][component][lane] x 16 B.
+// MODE bits: C8 (paired-column rows = (x-select, cout)), FOLD (decoder conv, parity column mapping, see above).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr int BF_POS = HX * HY * HZ;              // halo positions
+constexpr int BF_PLANE = BF_POS * 16;             // bytes per component plane
+constexpr int KB_STD = 7, KB_FOLD = 3, KB_C8 = 9, KB_C8F = 5;
+
+// LDS position offset of tap slot t for the four tap sets (0 for the zero-weight padding slots)
+__host__ __device__ constexpr int bf_tap_pos(bool c8, bool folded, int t) {
+    if (!folded) {
+        const int ntap = c8 ? 36 : 27;
+        return t < ntap ? ((t / 9) * HY + (t / 3) % 3) * HZ + t % 3 : 0;
+    }
+    if (!c8) return t < 12 ? ((t / 6) * HY + (t / 3) % 2) * HZ + t % 3 : 0;
+    return t < 18 ? (((t / 6) == 2 ? 3 : (t / 6)) * HY + (t / 3) % 2) * HZ + t % 3 : 0;
+}
+
+__device__ __forceinline__ void bf_split4(const f32x4 v, uint2& h, uint2& m, uint2& l) {
+    uint32_t hb[4], mb[4], lb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e];
+        hb[e] = __float_as_uint(x) & 0xffff0000u;
+        const float r = x - __uint_as_float(hb[e]);
+        mb[e] = __float_as_uint(r) & 0xffff0000u;
+        lb[e] = __float_as_uint(r - __uint_as_float(mb[e]));           // <= 8 significant bits left: exact in bf16
+    }
+    h = uint2{__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u)};
+    m = uint2{__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u)};
+    l = uint2{__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u)};
+}
+
+// One 8-channel halo tile -> three bf16 planes in LDS (see stage_halo_tile for the addressing).
+__device__ __forceinline__ void bf_stage_tile(const ConvArgs& a, int c0, int p, int x0, int y0, int z0, int tid, char* lds) {
+    f32x4 v[NSTAGE];
+    const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
+    if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
+                     sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
+    else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
+                     sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        const int f = tid + 256 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (f < NF4) {
+            const int col = f / (HZ * 2), w = f - col * (HZ * 2);
+            const int hz = w >> 1, half = w & 1;
+            const int hx = col / HY, hy = col - hx * HY;
+            const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+            if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
+                const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
+                                    + (gz >> suz)) * 8 + half * 4;
+                v[i] = *reinterpret_cast<const f32x4*>(src + idx);
+            }
+        }
+    }
+    __syncthreads();                                          // every wave is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        const int f = tid + 256 * i;                          // slot f = position f >> 1, channel half f & 1
+        if (f < NF4) {
+            uint2 h, m, l;
+            bf_split4(v[i], h, m, l);
+            char* d = lds + f * 8;
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + BF_PLANE) = m;
+            *reinterpret_cast<uint2*>(d + 2 * BF_PLANE) = l;
+        }
+    }
+    __syncthreads();
+}
+
+// K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * 3 + comp) * 64]
+template <int NT, int NCOL, int KB, bool C8, bool FOLDED, int COLSTRIDE_X, int COLSTRIDE_Y>
+__device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char* lds, int lanepos, int g,
+                                             const uint4* __restrict__ wp, int nt_total) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1),
+                  t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3);
+        const int tp = g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
+        const char* ab = lds + (lanepos + tp) * 16;
+        bf16x8 wv[NT][3];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                wv[nt][c] = __builtin_bit_cast(bf16x8, wp[((size_t)(kb * nt_total + nt) * 3 + c) * 64]);
+#pragma unroll
+        for (int cg = 0; cg < NCOL; cg += 4) {
+            bf16x8 av[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mt = cg + q;
+                const int cpos = C8 ? mt * COLSTRIDE_Y * HZ : ((mt >> 2) * COLSTRIDE_X * HY + (mt & 3) * COLSTRIDE_Y) * HZ;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    av[q][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + cpos * 16 + c * BF_PLANE));
+            }
+            // (weight component, activation component): hh, hm, mh, mm, hl, lh
+            constexpr int WI[6] = {0, 0, 1, 1, 0, 2}, AI[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+            for (int pr = 5; pr >= 0; --pr)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[cg + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[nt][WI[pr]], av[q][AI[pr]], acc[cg + q][nt], 0, 0, 0);
+        }
+    }
+}
+
+template <int NT, bool C8, bool FOLD>
+__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(ConvArgs a) {
+    static_assert(!C8 || NT == 1, "the Cout = 8 kernel has one row tile");
+    constexpr int NCOL = C8 ? 4 : 8;
+    __shared__ __attribute__((aligned(16))) char lds[3 * BF_PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int cg = b % a.ngroups; b /= a.ngroups;
+    const int ntb = cg * NT;
+    const int zb = b % a.zblocks; b /= a.zblocks;
+    const int ty = b % a.tilesY;  b /= a.tilesY;
+    const int tx = b % a.tilesX;
+    const int p = b / a.tilesX;
+    const int x0 = tx * TX, y0 = ty * TY, z0 = zb * 16;
+    const int g = lane >> 4, zl = lane & 15;
+
+    // wave -> columns.  plain: 2 x 4 block at (wx, wy); FOLD: parity class (wx, wy) = (px, py), stride 2;
+    // C8: x pair wx (stride-1 or parity-strided y)
+    const int wx = C8 ? 2 * (wave >> 1) : (FOLD ? (wave >> 1) : 2 * (wave >> 1));
+    const int wy = FOLD ? (wave & 1) : 4 * (wave & 1);
+    constexpr int CSX = FOLD ? 2 : 1, CSY = FOLD ? 2 : 1;
+    const int lanepos = (wx * HY + wy) * HZ + zl;
+    // folded taps start at halo offset (px, py) (C8: (0, py))
+    const int foldpos = lanepos + (C8 ? wy * HZ : (wx * HY + wy) * HZ);
+
+    f32x4 acc[NCOL][NT];
+#pragma unroll
+    for (int mt = 0; mt < NCOL; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.wpack) + lane;
+    constexpr int KBS = C8 ? KB_C8 : KB_STD;                  // skip / ordinary chunks
+    constexpr int KBF = C8 ? KB_C8F : KB_FOLD;                // folded chunks
+    constexpr int NCLS = C8 ? 2 : 4;
+    const int nA = FOLD ? (a.CA >> 3) : 0;
+    if constexpr (FOLD) {
+        const int cls = C8 ? wy : (wx * 2 + wy);
+        for (int chunk = 0; chunk < nA; ++chunk) {
+            bf_stage_tile(a, chunk * 8, p, x0, y0, z0, tid, lds);
+            const uint4* wp = wbase + (((size_t)chunk * NCLS + cls) * KBF * a.nt_total + ntb) * 3 * 64;
+            bf_chunk_mma<NT, NCOL, KBF, C8, true, CSX, CSY>(acc, lds, foldpos, g, wp, a.nt_total);
+        }
+    }
+    for (int chunk = nA; chunk < a.nchunks; ++chunk) {
+        bf_stage_tile(a, chunk * 8, p, x0, y0, z0, tid, lds);
+        const uint4* wp = wbase + (((size_t)nA * NCLS * KBF + (size_t)(chunk - nA) * KBS) * a.nt_total + ntb) * 3 * 64;
+        bf_chunk_mma<NT, NCOL, KBS, C8, false, CSX, CSY>(acc, lds, lanepos, g, wp, a.nt_total);
+    }
+
+    // ---- epilogue: bias -> activation -> BatchNorm affine; stores / fused pool / fused head as in the fp32 kernels
+    const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
+    const int z = z0 + zl;
+    if constexpr (C8) {
+        // lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx + (g>>1), y = y0 + wy + CSY * mt
+        const int cb = 4 * (g & 1);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
+        const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + 16 + cb);
+        const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 32 + cb);
+        const int x = x0 + wx + (g >> 1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x4 r = acc[mt][0] + bias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = r[e];
+                r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+            }
+            const int y = y0 + wy + CSY * mt;
+            const bool ok = x < a.X && y < a.Y && z < a.Z;
+            if (a.out && ok)
+                *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
+            if (a.head) {
+                const f32x4 hw = *reinterpret_cast<const f32x4*>(a.head + cb);
+                float part = r[0] * hw[0] + r[1] * hw[1] + r[2] * hw[2] + r[3] * hw[3];
+                part += __shfl_xor(part, 16);                    // the other channel half of the same voxel
+                if ((g & 1) == 0 && ok)
+                    a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + a.head[16])));
+            }
+        }
+    } else {
+        const int CP = a.nt_total * 16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int cb = 16 * (ntb + nt) + 4 * g;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
+            const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + CP + cb);
+            const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 2 * CP + cb);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                f32x4 r = acc[mt][nt] + bias;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = r[e];
+                    r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+                }
+                acc[mt][nt] = r;
+            }
+        }
+        const int OQ = a.cout >> 3;
+        if (a.out) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int x = x0 + wx + CSX * (mt >> 2), y = y0 + wy + CSY * (mt & 3);
+                if (x < a.X && y < a.Y && z < a.Z) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int cb = 16 * (ntb + nt) + 4 * g;
+                        if (cb < a.cout) {
+                            const size_t idx = ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7);
+                            *reinterpret_cast<f32x4*>(a.out + idx) = acc[mt][nt];
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (!FOLD) {
+            if (a.pool) {      // MaxPooling3D (2,2,pz): the wave's 2x4 columns are two 2x2 blocks
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int x = x0 + wx, y = y0 + wy + 2 * blk;
+                    const bool ok = (x + 1 < a.X) && (y + 1 < a.Y) && (z < a.Z);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x4 m;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = fmaxf(fmaxf(acc[2 * blk][nt][e], acc[2 * blk + 1][nt][e]),
+                                            fmaxf(acc[4 + 2 * blk][nt][e], acc[5 + 2 * blk][nt][e]));
+                            if (a.pz == 2) t = fmaxf(t, __shfl_xor(t, 1));
+                            m[e] = t;
+                        }
+                        const int cb = 16 * (ntb + nt) + 4 * g;
+                        const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
+                        if (ok && zok && cb < a.cout) {
+                            const int pzc = a.pz == 2 ? (z >> 1) : z;
+                            const size_t idx = ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7);
+                            *reinterpret_cast<f32x4*>(a.pool + idx) = m;
+                        }
+                    }
+                }
+            }
+        }
+        if (a.head) {      // Conv3D(1, 1, activation='sigmoid') fused: dot over channels, then sigmoid
+            const float hb = a.head[CP];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                float part = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 hw = *reinterpret_cast<const f32x4*>(a.head + 16 * (ntb + nt) + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part += acc[mt][nt][e] * hw[e];
+                }
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                const int x = x0 + wx + CSX * (mt >> 2), y = y0 + wy + CSY * (mt & 3);
+                if (g == 0 && x < a.X && y < a.Y && z < a.Z)
+                    a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + hb)));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // first conv (Cin = 1): HBM-bound (AI ~ 12 flop/B), plain VALU, one voxel per thread.
 // in [P][X][Y][Z]; w [27][COUT] (scalar loads); out blocked.
 // ------------------------------------------------------------------------------------------------
@@ -1240,6 +1534,7 @@ struct ConvPlan {
     bool c8;              // Cout == 8: paired-column kernel
     bool pair;            // Cin % 16 == 0: two planes per stage
     bool fold;            // decoder conv over concat([upsample(low), skip]): folded taps for the upsampled channels
+    bool bf;              // split-bf16 (bf16x6) matrix-pipe kernel instead of the f32-input MFMA kernel
     int nt_used;          // instantiation launched by the last run (small grids split NT = 4 into 2 x NT = 2)
     size_t wpack_off;     // float4 offset into the device weight arena
     size_t epi_off;       // float offset
@@ -1427,6 +1722,75 @@ inline size_t fold_pack_floats_c8(int cin, int CA) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- bf16x6 packing ------------------------------------------------------------------------------------------
+// effective fp32 weight of tap slot t / input channel ci / MFMA row `row` (cout index; Cout = 8: xs * 8 + co) for the
+// four tap sets of conv3_bf16x6_kernel (see bf_tap_pos); cls = parity class of a folded chunk
+float bf_weight(const float* k, int cin, int cout, bool c8, bool folded, int cls, int t, int ci, int row) {
+    if (!c8 && row >= cout) return 0.f;
+    const int xs = row >> 3, co8 = row & 7;
+    if (!folded) {
+        if (!c8) return t < 27 ? k[((size_t)t * cin + ci) * cout + row] : 0.f;
+        if (t >= 36) return 0.f;
+        const int dx = t / 9 - xs, dy = (t / 3) % 3, dz = t % 3;
+        return (dx >= 0 && dx <= 2) ? k[((size_t)((dx * 3 + dy) * 3 + dz) * cin + ci) * 8 + co8] : 0.f;
+    }
+    int px, py, dxi, dyi, dz, co, cstride;
+    if (!c8) {
+        if (t >= 12) return 0.f;
+        px = cls >> 1; py = cls & 1; dxi = t / 6; dyi = (t / 3) % 2; dz = t % 3; co = row; cstride = cout;
+    } else {
+        if (t >= 18) return 0.f;
+        px = xs; py = cls; dxi = t / 6 - xs; dyi = (t / 3) % 2; dz = t % 3; co = co8; cstride = 8;
+        if (dxi < 0 || dxi > 1) return 0.f;
+    }
+    double v = 0.0;
+    for (int kx = 0; kx < 3; ++kx)
+        for (int ky = 0; ky < 3; ++ky)
+            if (fold_member(px, dxi, kx) && fold_member(py, dyi, ky))
+                v += (double)k[((size_t)((kx * 3 + ky) * 3 + dz) * cin + ci) * cstride + co];
+    return (float)v;
+}
+
+inline void bf_split_host(float x, uint16_t out[3]) {       // exact: x = h + m + l (truncation split, see bf_split4)
+    uint32_t u; memcpy(&u, &x, 4);
+    const uint32_t hb = u & 0xffff0000u; float h; memcpy(&h, &hb, 4);
+    const float r = x - h; uint32_t ru; memcpy(&ru, &r, 4);
+    const uint32_t mb = ru & 0xffff0000u; float m; memcpy(&m, &mb, 4);
+    const float r2 = r - m; uint32_t lu; memcpy(&lu, &r2, 4);
+    out[0] = (uint16_t)(hb >> 16); out[1] = (uint16_t)(mb >> 16); out[2] = (uint16_t)(lu >> 16);
+}
+
+// uint4 (16 B) units of one conv's packed weights
+inline size_t bf_pack_units(int cin, int nt_total, int CA, bool c8, bool fold) {
+    const int nA = fold ? CA / 8 : 0, nB = cin / 8 - nA;
+    const int kbs = c8 ? KB_C8 : KB_STD, kbf = c8 ? KB_C8F : KB_FOLD, ncls = c8 ? 2 : 4;
+    return ((size_t)nA * ncls * kbf + (size_t)nB * kbs) * nt_total * 3 * 64;
+}
+
+// wbf[section][kb][nt][comp][lane = g*16 + n][e] = bf16 component of W(tap slot 4 kb + g, cin 8 chunk + e, row 16 nt + n)
+void pack_conv_weights_bf(const float* k, int cin, int cout, int nt_total, int CA, bool c8, bool fold, uint16_t* dst) {
+    const int nA = fold ? CA / 8 : 0, nchunks = cin / 8;
+    const int kbs = c8 ? KB_C8 : KB_STD, kbf = c8 ? KB_C8F : KB_FOLD, ncls = c8 ? 2 : 4;
+    size_t unit = 0;                                           // running uint4 index
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool folded = ch < nA;
+        const int ncl = folded ? ncls : 1, KB = folded ? kbf : kbs;
+        for (int cls = 0; cls < ncl; ++cls)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int nt = 0; nt < nt_total; ++nt) {
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = lane >> 4, n = lane & 15;
+                        for (int e = 0; e < 8; ++e) {
+                            uint16_t c3[3];
+                            bf_split_host(bf_weight(k, cin, cout, c8, folded, cls, 4 * kb + g, 8 * ch + e, 16 * nt + n), c3);
+                            for (int c = 0; c < 3; ++c) dst[((unit + (size_t)c * 64 + lane) * 8) + e] = c3[c];
+                        }
+                    }
+                    unit += 3 * 64;
+                }
+    }
+}
+
 int conv_dma_mask() {      // which NT instantiations use the LDS-DMA kernel: bit 0 NT=1, bit 1 NT=2, bit 2 NT=4
     static int mask = -1;
     if (mask < 0) { const char* e = getenv("CT_CONV_DMA"); mask = e ? atoi(e) : kConvDmaDefaultMask; }
@@ -1447,6 +1811,14 @@ int launch_conv(const ConvArgs& a, int P, bool pair, bool fold, hipStream_t st) 
     }
     if (pair) hipLaunchKernelGGL((conv3_mfma_kernel<NT, true>), dim3(nblk), dim3(256), 0, st, a);
     else      hipLaunchKernelGGL((conv3_mfma_kernel<NT, false>), dim3(nblk), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+template <int NT>
+int launch_conv_bf(const ConvArgs& a, int P, bool fold, hipStream_t st) {
+    const int nblk = P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
+    if (fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, true>), dim3(nblk), dim3(256), 0, st, a);
+    else      hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, false>), dim3(nblk), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -1642,7 +2014,15 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
             static const bool fold_on = !(getenv("CT_CONV_FOLD") && atoi(getenv("CT_CONV_FOLD")) == 0);
             c.fold = fold_on && c.srcA >= 0 && c.CA % 8 == 0 && ad.pool[0] == 2 && ad.pool[1] == 2 && c.pool_dst < 0
                      && h->dims[c.level][0] % 2 == 0 && h->dims[c.level][1] % 2 == 0;
-            if (c.cout == 8 && c.pool_dst < 0 && c.fold) {
+            static const bool bf_on = !(getenv("CT_CONV_MATH") && strcmp(getenv("CT_CONV_MATH"), "f32") == 0);
+            c.bf = bf_on;
+            if (c.bf) {                                    // split-bf16 kernels (all four tap sets)
+                c.c8 = (c.cout == 8 && c.pool_dst < 0);
+                const size_t units = bf_pack_units(c.cin, c.nt_total, c.CA, c.c8, c.fold);
+                arena.resize(arena.size() + units * 4);
+                pack_conv_weights_bf(kern, c.cin, c.cout, c.nt_total, c.CA, c.c8, c.fold,
+                                     reinterpret_cast<uint16_t*>(arena.data() + c.wpack_off));
+            } else if (c.cout == 8 && c.pool_dst < 0 && c.fold) {
                 c.c8 = true;
                 arena.resize(arena.size() + fold_pack_floats_c8(c.cin, c.CA));
                 pack_conv_weights_c8_fold(kern, c.cin, c.CA, arena.data() + c.wpack_off);
@@ -1759,7 +2139,20 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             }
             c.nt_used = NTsel;
             int rc;
-            if (c.c8) {
+            if (c.bf) {
+                if (c.c8) {
+                    const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
+                    if (c.fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<1, true, true>), dim3(nblk), dim3(256), 0, st, a);
+                    else        hipLaunchKernelGGL((conv3_bf16x6_kernel<1, true, false>), dim3(nblk), dim3(256), 0, st, a);
+                    rc = (int)hipGetLastError();
+                } else
+                switch (NTsel) {
+                    case 1: rc = launch_conv_bf<1>(a, P, c.fold, st); break;
+                    case 2: rc = launch_conv_bf<2>(a, P, c.fold, st); break;
+                    case 4: rc = launch_conv_bf<4>(a, P, c.fold, st); break;
+                    default: return CT_ESHAPE;
+                }
+            } else if (c.c8) {
                 const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
                 if (c.fold) hipLaunchKernelGGL(conv3_mfma_c8_fold_kernel, dim3(nblk), dim3(256), 0, st, a);
                 else        hipLaunchKernelGGL(conv3_mfma_c8_kernel, dim3(nblk), dim3(256), 0, st, a);
