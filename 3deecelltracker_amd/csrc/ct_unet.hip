@@ -1849,7 +1849,11 @@ int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int d
     if (cin) *cin = c.cin;
     if (cout) *cout = c.cout;
     // 0: first conv, -8: conv3_mfma_c8_kernel, -9: conv3_mfma_c8_fold_kernel, 1..4: conv3_mfma_kernel<nt>, 101..104: conv3_mfma_fold_kernel<nt - 100>
-    if (nt) *nt = layer == 0 ? 0 : (c.c8 ? (c.fold ? -9 : -8) : (c.nt_used ? c.nt_used : c.NT) + (c.fold ? 100 : 0));
+    // split-bf16 kernels (conv3_bf16x6_kernel<nt, c8, fold>): the same codes +1000 (Cout = 8: -1008 / -1009)
+    if (nt) {
+        *nt = layer == 0 ? 0 : (c.c8 ? (c.fold ? -9 : -8) : (c.nt_used ? c.nt_used : c.NT) + (c.fold ? 100 : 0));
+        if (layer > 0 && c.bf) *nt += (*nt < 0 ? -1000 : 1000);
+    }
     if (dims_xyz) for (int i = 0; i < 3; ++i) dims_xyz[i] = h->dims[c.level][i];
     return CT_OK;
 }

@@ -34,6 +34,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PKG = "3deecelltracker_amd"
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 = fp32 vector peak
+BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 dense MFMA peak (~2.5 PF; measured ceiling 2382)
 HBM_PEAK_TBS = 8.0
 
 
@@ -47,7 +48,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run: all ranks on cuda:0 (needs --backend gloo)")
-    ap.add_argument("--match-cus", type=int, default=24, help="CUs reserved for the matching chains (rest: U-Net)")
+    ap.add_argument("--match-cus", type=int, default=64, help="CUs reserved for the matching chains (rest: U-Net)")
     ap.add_argument("--disjoint-match-cus", action="store_true", help="give every match chain its own CU slice (measured: worse)")
     ap.add_argument("--match-workers", type=int, default=3, help="frames whose match chains are in flight concurrently")
     ap.add_argument("--cpu-patches", type=int, default=2, help="U-Net patches timed by the CPU baseline sample")
@@ -161,18 +162,25 @@ def main():
         L.ct_unet_layer_info(model._handle, i, C.byref(cin), C.byref(cout), d, C.byref(nt))
         flops = 2.0 * d[0] * d[1] * d[2] * 27 * cin.value * cout.value * n_patches       # per launch (one volume)
         abytes = 4.0 * d[0] * d[1] * d[2] * (cin.value + cout.value) * n_patches
-        if nt.value == 0:
+        code = nt.value
+        bf = abs(code) >= 1000
+        if bf:
+            code = code - 1000 if code > 0 else code + 1000
+        if code == 0:
             name = "conv_first_mfma_kernel"
-        elif nt.value in (-8, -9):
-            name = "conv3_mfma_c8_kernel" if nt.value == -8 else "conv3_mfma_c8_fold_kernel"
-        elif nt.value > 100:
-            name = f"conv3_mfma_fold_kernel<{nt.value - 100}>"
+        elif bf:
+            name = (f"conv3_bf16x6_kernel<1, true, {'true' if code == -9 else 'false'}>" if code < 0 else
+                    f"conv3_bf16x6_kernel<{code % 100}, false, {'true' if code > 100 else 'false'}>")
+        elif code in (-8, -9):
+            name = "conv3_mfma_c8_kernel" if code == -8 else "conv3_mfma_c8_fold_kernel"
+        elif code > 100:
+            name = f"conv3_mfma_fold_kernel<{code - 100}>"
         else:
-            name = f"conv3_mfma_kernel<{nt.value}, false>"
+            name = f"conv3_mfma_kernel<{code}, false>"
         # MFMA work actually issued: folded decoder convs run 12 instead of 27 taps on the upsampled channels (Cout = 8: 18 of 36)
         ca = max(L.ct_unet_layer_fold_channels(model._handle, i), 0)
         issued = flops * ((cin.value - ca) + ca * 12.0 / 27.0) / cin.value
-        k = by_kernel.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "issued": 0.0})
+        k = by_kernel.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "issued": 0.0, "bf": bf})
         k["ms"] += ms[i]; k["launches"] += cnt[i]; k["flops"] += flops * cnt[i]; k["bytes"] += abytes * cnt[i]
         k["issued"] += issued * cnt[i]
         layers.append({"layer": i, "cin": cin.value, "cout": cout.value, "dims": [d[0], d[1], d[2]], "kernel": name,
@@ -182,8 +190,11 @@ def main():
                        "gbps": round(abytes * cnt[i] / max(ms[i], 1e-9) / 1e6, 1)})
     dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
     dom = by_kernel[dom_name]
-    # flops the kernel really executes (== the reference op's 2*27*Cin*Cout per voxel unless the kernel folds upsampled taps)
-    achieved = dom["issued"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    # flops the kernel really executes (== the reference op's 2*27*Cin*Cout per voxel unless the kernel folds upsampled taps).
+    # Split-bf16 kernels execute 6 bf16 MFMA products per fp32 product and are priced against the bf16 dense peak.
+    dom_fp32_equiv = dom["issued"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    achieved = dom_fp32_equiv * (6.0 if dom["bf"] else 1.0)
+    peak_tf = BF16_MFMA_PEAK_TF if dom["bf"] else FP32_MFMA_PEAK_TF
     conv_ms_total = sum(k["ms"] for k in by_kernel.values()) / max(args.steps, 1)
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed
     # measurement (profiles/, scripts/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 fetch
@@ -198,8 +209,10 @@ def main():
                 break
         except Exception:
             pass
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": traffic, "kernel": dom_name,
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": round(achieved / peak_tf, 4), "traffic": traffic, "kernel": dom_name,
+                "math": "bf16x6 split (6 bf16 MFMA products per fp32 product, fp32 accumulate)" if dom["bf"] else "f32-input MFMA",
+                "fp32_equivalent_tflops": round(dom_fp32_equiv, 2),
                 "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4), "launches": dom["launches"],
                 "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                 "executed_gflop_per_launch": round(dom["issued"] / max(dom["launches"], 1) / 1e9, 2),
@@ -237,7 +250,7 @@ def main():
             "metric": "volumes/s segment+match, 512x512x32 stack ~600 cells",
             "value": round(value, 3), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (U-Net, FFN) / f64 (PR-GLS)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (U-Net convs: fp32 in/out, exact 3-way bf16 split on the matrix cores, fp32 accumulate; FFN f32) / f64 (PR-GLS)", "data": "synthetic",
             "config": {"workload": f"{shape[0]}x{shape[1]}x{shape[2]} synthetic stack, unet3_a sliding window "
                                    f"({n_patches} patches, shrink 24,24,2) + {args.cells}-cell TrackerLite match "
                                    f"(FFN all pairs, greedy prior, PR-GLS beta=lambda=3), seeded random-init weights",

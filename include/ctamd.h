@@ -85,7 +85,9 @@ int ct_unet_num_conv_layers(const ct_unet_t* h);
 int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int dims_xyz[3], int* nt);
 /* Decoder convs over concat([UpSampling3D(low), skip]) (unet3d.py:92-97) fold the taps of the upsampled channels that land
  * on the same low-res voxel (12 instead of 27 per channel): returns how many input channels of `layer` are folded (0 if
- * none).  `nt` above is then 100 + nt (conv3_mfma_fold_kernel) or -9 (Cout = 8 variant; -8 = unfolded Cout = 8 kernel). */
+ * none).  `nt` above is then 100 + nt (conv3_mfma_fold_kernel) or -9 (Cout = 8 variant; -8 = unfolded Cout = 8 kernel).
+ * Convs running the split-bf16 kernels (conv3_bf16x6_kernel<nt, c8, fold>; default, CT_CONV_MATH=f32 selects the f32-input
+ * MFMA kernels when the model is created) report the same codes offset by 1000 (Cout = 8: -1008 / -1009).             */
 int ct_unet_layer_fold_channels(const ct_unet_t* h, int layer);
 int ct_unet_set_timing(ct_unet_t* h, int enable);
 int ct_unet_get_timing(ct_unet_t* h, float* ms_per_layer, int* launches_per_layer, int n_layers);
