@@ -935,6 +935,147 @@ __device__ void chol_backsub3_lds(double* S, int ld, int r, int tid) {
     }
 }
 
+// Low-latency variants for the r x r low-rank system (lr_solve_kernel only; the dense paths keep the division-based
+// helpers above).  The critical path of the blocked factorisation is a chain of dependent fp64 sqrt and divide
+// sequences (~32 per 8-column block step); here each pivot costs ONE rsqrt (d = x * rsqrt(x)), the reciprocal pivots
+// are kept (idiag, LDS) and every later division by a pivot becomes a multiplication.  Differences to the division
+// form are a few ulp per entry; the low-rank M-step is verified against the exact Gram matrix every iteration anyway.
+__device__ __forceinline__ double rsqrt_nr(double x) {      // v_rsq_f64 (~2^-26) + one Newton step: a 5-op dependent chain
+    const double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * y;
+    const double e = fma(-x * y, h, 0.5);                    // 0.5 - x y^2 / 2
+    return fma(y, e, y);
+}
+__device__ void chol_factor_aug_lds_fast(double* S, double* idiag, int ld, int r, int naug, int tid) {
+    // All LDS reads of a phase are issued unconditionally (indices clamped into the matrix, padding selected afterwards)
+    // so that they pipeline: predicated reads compile to branches and serialise at ~120 cycles apiece.  Dependent fp64
+    // chains are the critical path (~25 cycles per op): explicit fma, split accumulators, one trailing entry per thread.
+    const int ra = r + naug;
+    for (int j0 = 0; j0 < r; j0 += LS_B) {
+        const int nb = min(LS_B, r - j0);
+        double Ld[LS_B][LS_B], inv[LS_B];
+#pragma unroll
+        for (int i = 0; i < LS_B; ++i)
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) {
+                if (k <= i) {
+                    const double v = S[min(j0 + i, r - 1) * ld + j0 + min(k, nb - 1)];
+                    Ld[i][k] = (i < nb) ? v : (i == k ? 1.0 : 0.0);
+                } else Ld[i][k] = 0.0;
+            }
+#pragma unroll
+        for (int k = 0; k < LS_B; ++k) {
+            const double ik = rsqrt_nr(Ld[k][k]);
+            inv[k] = ik;
+            Ld[k][k] = Ld[k][k] * ik;
+#pragma unroll
+            for (int i = k + 1; i < LS_B; ++i) Ld[i][k] *= ik;
+#pragma unroll
+            for (int i = k + 1; i < LS_B; ++i)
+#pragma unroll
+                for (int q = k + 1; q <= i; ++q) Ld[i][q] = fma(-Ld[i][k], Ld[q][k], Ld[i][q]);
+        }
+        for (int a2 = j0 + nb + tid; a2 < ra; a2 += 256) {
+            double x[LS_B];
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) { const double v = S[a2 * ld + j0 + min(k, nb - 1)]; x[k] = (k < nb) ? v : 0.0; }
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) {
+                double t = x[k];
+#pragma unroll
+                for (int q = 0; q < k; ++q) t = fma(-x[q], Ld[k][q], t);
+                x[k] = t * inv[k];
+            }
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) if (k < nb) S[a2 * ld + j0 + k] = x[k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < LS_B; ++i) {
+                if (i < nb) idiag[j0 + i] = inv[i];
+#pragma unroll
+                for (int k = 0; k < LS_B; ++k) if (i < nb && k <= i) S[(j0 + i) * ld + j0 + k] = Ld[i][k];
+            }
+        }
+        // trailing update S[a][b] -= L[a][:] . L[b][:] over the lower triangle of the remaining rows (b <= a, b < r) plus
+        // the full augmented rows: entries are enumerated linearly so every thread gets at most ceil(count / 256) of them
+        const int base = j0 + nb;
+        const int nt = r - base;                               // remaining matrix rows
+        const int ntri = nt * (nt + 1) / 2;
+        const int nent = ntri + naug * nt;
+        for (int e = tid; e < nent; e += 256) {
+            int ia, ib;
+            if (e < ntri) {
+                ia = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while (ia * (ia + 1) / 2 > e) --ia;
+                while ((ia + 1) * (ia + 2) / 2 <= e) ++ia;
+                ib = e - ia * (ia + 1) / 2;
+            } else { const int q = e - ntri; ia = nt + q / nt; ib = q - (q / nt) * nt; }
+            const int a2 = base + ia, b2 = base + ib;
+            double La[LS_B], Lb[LS_B];
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) {
+                const int ck = j0 + min(k, nb - 1);
+                const double va = S[a2 * ld + ck];
+                La[k] = (k < nb) ? va : 0.0;
+                Lb[k] = S[b2 * ld + ck];
+            }
+            const double cur = S[a2 * ld + b2];
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < LS_B; k += 2) { t0 = fma(La[k], Lb[k], t0); t1 = fma(La[k + 1], Lb[k + 1], t1); }
+            S[a2 * ld + b2] = cur - (t0 + t1);
+        }
+        __syncthreads();
+    }
+}
+__device__ void chol_backsub3_lds_fast(double* S, const double* idiag, int ld, int r, int tid) {
+    for (int j0 = ((r - 1) / LS_B) * LS_B; j0 >= 0; j0 -= LS_B) {
+        const int nb = min(LS_B, r - j0);
+        // this step's inputs, all reads in flight together: diagonal block (lower triangle), 3 right-hand sides, pivots
+        double Lb[LS_B][LS_B], rh[LS_B][3], idg[LS_B];
+#pragma unroll
+        for (int k = 0; k < LS_B; ++k) {
+            const int ck = j0 + min(k, nb - 1);
+            rh[k][0] = S[(r + 0) * ld + ck]; rh[k][1] = S[(r + 1) * ld + ck]; rh[k][2] = S[(r + 2) * ld + ck];
+            idg[k] = idiag[ck];
+#pragma unroll
+            for (int p2 = k + 1; p2 < LS_B; ++p2) Lb[p2][k] = S[(j0 + min(p2, nb - 1)) * ld + ck];
+        }
+        double qv[LS_B][3];
+#pragma unroll
+        for (int k = LS_B - 1; k >= 0; --k) {
+            double t0 = rh[k][0], t1 = rh[k][1], t2 = rh[k][2];
+#pragma unroll
+            for (int p2 = k + 1; p2 < LS_B; ++p2) {                    // qv[p2] = 0 for p2 >= nb
+                t0 = fma(-Lb[p2][k], qv[p2][0], t0); t1 = fma(-Lb[p2][k], qv[p2][1], t1); t2 = fma(-Lb[p2][k], qv[p2][2], t2);
+            }
+            const bool live = k < nb;
+            qv[k][0] = live ? t0 * idg[k] : 0.0; qv[k][1] = live ? t1 * idg[k] : 0.0; qv[k][2] = live ? t2 * idg[k] : 0.0;
+        }
+        __syncthreads();                                   // every thread has read this step's inputs
+        if (tid < j0) {
+            double l[LS_B];
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) l[k] = S[(j0 + min(k, nb - 1)) * ld + tid];
+            double u0 = S[(r + 0) * ld + tid], u1 = S[(r + 1) * ld + tid], u2 = S[(r + 2) * ld + tid];
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < LS_B; k += 2) {                        // qv = 0 beyond nb
+                u0 = fma(-l[k], qv[k][0], u0); u1 = fma(-l[k], qv[k][1], u1); u2 = fma(-l[k], qv[k][2], u2);
+                v0 = fma(-l[k + 1], qv[k + 1][0], v0); v1 = fma(-l[k + 1], qv[k + 1][1], v1); v2 = fma(-l[k + 1], qv[k + 1][2], v2);
+            }
+            S[(r + 0) * ld + tid] = u0 + v0; S[(r + 1) * ld + tid] = u1 + v1; S[(r + 2) * ld + tid] = u2 + v2;
+        } else if (tid == j0) {
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k)
+                if (k < nb) { S[(r + 0) * ld + j0 + k] = qv[k][0]; S[(r + 1) * ld + j0 + k] = qv[k][1]; S[(r + 2) * ld + j0 + k] = qv[k][2]; }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- dense path for n > DS_MAXN: blocked right-looking Cholesky of M = D^1/2 G D^1/2 + c I (NB = 32) --------------
 // The 3 right-hand sides W [3][n] ride through the factorisation as extra rows (forward substitution for free);
 // per panel: (1) every block factors the 32 x 32 diagonal block in LDS with the register-blocked routine above and
@@ -1086,23 +1227,42 @@ __global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict_
     const int ld = r | 1;                  // odd leading dimension (doubles): spreads rows over the LDS banks
     double* S = sm;                        // [ra][ld]
     __shared__ double red[4];
+    __shared__ double idiag[LR_RMAX];
     const int tid = threadIdx.x;
     const double c = lambda * sc[S_SIGMA2];
-    for (int e = tid; e < r * r; e += 256) {
-        const int a = e / r, b = e - a * r;
-        if (b <= a) S[a * ld + b] = Sin[a * LR_RMAX + b] + (a == b ? c : 0.0);
+    // loads in batches of 8 per thread, all in flight together (a runtime-bound loop would serialise the L2 round trips)
+    const float rinv = 1.0f / (float)r;
+    for (int e0 = 0; e0 < r * r; e0 += 256 * 8) {
+        double v[8]; int ai[8], bi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + tid + 256 * u;
+            int a = (int)(((float)e + 0.5f) * rinv);
+            a = (a * r > e) ? a - 1 : ((a + 1) * r <= e ? a + 1 : a);
+            const int b = e - a * r;
+            ai[u] = a; bi[u] = b;
+            v[u] = (e < r * r && b <= a) ? Sin[a * LR_RMAX + b] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + tid + 256 * u < r * r && bi[u] <= ai[u]) S[ai[u] * ld + bi[u]] = v[u] + (ai[u] == bi[u] ? c : 0.0);
     }
     for (int e = tid; e < r * 3; e += 256) { const int a = e / 3, d = e - a * 3; S[(r + d) * ld + a] = yin[e]; }
     {   // sumP = sum_i d_i
         double acc = 0.0;
-        for (int i = tid; i < n; i += 256) acc += dvec[i];
+        for (int i0 = 0; i0 < n; i0 += 256 * 4) {
+            double dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + tid + 256 * u; dv[u] = i < n ? dvec[i] : 0.0; }
+            acc += (dv[0] + dv[1]) + (dv[2] + dv[3]);
+        }
         acc = wave_sum_d(acc);
         if ((tid & 63) == 0) red[tid >> 6] = acc;
     }
     __syncthreads();
     if (tid == 0) { sc[S_SUMP] = (red[0] + red[1]) + (red[2] + red[3]); sc[S_C] = c; }
-    chol_factor_aug_lds(S, ld, r, 3, tid);
-    chol_backsub3_lds(S, ld, r, tid);
+    chol_factor_aug_lds_fast(S, idiag, ld, r, 3, tid);
+    chol_backsub3_lds_fast(S, idiag, ld, r, tid);
     for (int e = tid; e < r * 3; e += 256) { const int a2 = e / 3, d = e - a2 * 3; qout[e] = S[(r + d) * ld + a2]; }
 }
 
