@@ -840,6 +840,8 @@ constexpr int LS_B = 8;
 // In-LDS solve of the SPD system S q = y for 3 right-hand sides stored as rows r..r+2 of S (augmented Cholesky,
 // 8-column blocks, 2 barriers per block; then a blocked back-substitution).  256 threads.  On return rows r..r+2 hold q.
 __device__ void chol_factor_aug_lds(double* S, int ld, int r, int naug, int tid) {
+    // LDS reads are issued unconditionally (indices clamped into the matrix, padding selected afterwards): predicated
+    // reads compile to branches and serialise at ~120 cycles apiece.  Arithmetic and its order are unchanged.
     const int ra = r + naug;
     const int ty = tid >> 4, tx = tid & 15;
     for (int j0 = 0; j0 < r; j0 += LS_B) {
@@ -849,8 +851,12 @@ __device__ void chol_factor_aug_lds(double* S, int ld, int r, int naug, int tid)
 #pragma unroll
         for (int i = 0; i < LS_B; ++i)
 #pragma unroll
-            for (int k = 0; k < LS_B; ++k)
-                Ld[i][k] = (k <= i) ? ((i < nb) ? S[(j0 + i) * ld + j0 + k] : (i == k ? 1.0 : 0.0)) : 0.0;
+            for (int k = 0; k < LS_B; ++k) {
+                if (k <= i) {
+                    const double v = S[min(j0 + i, r - 1) * ld + j0 + min(k, nb - 1)];
+                    Ld[i][k] = (i < nb) ? v : (i == k ? 1.0 : 0.0);
+                } else Ld[i][k] = 0.0;
+            }
 #pragma unroll
         for (int k = 0; k < LS_B; ++k) {
             const double dk = sqrt(Ld[k][k]);
@@ -866,7 +872,7 @@ __device__ void chol_factor_aug_lds(double* S, int ld, int r, int naug, int tid)
         for (int a2 = j0 + nb + tid; a2 < ra; a2 += 256) {
             double x[LS_B];
 #pragma unroll
-            for (int k = 0; k < LS_B; ++k) x[k] = (k < nb) ? S[a2 * ld + j0 + k] : 0.0;
+            for (int k = 0; k < LS_B; ++k) { const double v = S[a2 * ld + j0 + min(k, nb - 1)]; x[k] = (k < nb) ? v : 0.0; }
 #pragma unroll
             for (int k = 0; k < LS_B; ++k) {
                 double t = x[k];
@@ -889,42 +895,56 @@ __device__ void chol_factor_aug_lds(double* S, int ld, int r, int naug, int tid)
         for (int a2 = base + ty; a2 < ra; a2 += 16) {
             double La[LS_B];
 #pragma unroll
-            for (int k = 0; k < LS_B; ++k) La[k] = (k < nb) ? S[a2 * ld + j0 + k] : 0.0;
+            for (int k = 0; k < LS_B; ++k) { const double v = S[a2 * ld + j0 + min(k, nb - 1)]; La[k] = (k < nb) ? v : 0.0; }
             const int bmax = a2 < r ? a2 : r - 1;
             for (int b2 = base + tx; b2 <= bmax; b2 += 16) {
+                double Lb[LS_B];
+#pragma unroll
+                for (int k = 0; k < LS_B; ++k) { const double v = S[b2 * ld + j0 + min(k, nb - 1)]; Lb[k] = (k < nb) ? v : 0.0; }
+                const double cur = S[a2 * ld + b2];
                 double t = 0.0;
 #pragma unroll
-                for (int k = 0; k < LS_B; ++k) t = fma(La[k], (k < nb) ? S[b2 * ld + j0 + k] : 0.0, t);
-                S[a2 * ld + b2] -= t;
+                for (int k = 0; k < LS_B; ++k) t = fma(La[k], Lb[k], t);
+                S[a2 * ld + b2] = cur - t;
             }
         }
         __syncthreads();
     }
 }
-
-// blocked backward substitution L^T q = w (w_d lives in row r+d): 8 unknowns per step; every thread solves the
-// 8 x 8 triangle redundantly in registers, then thread p < j0 removes their contribution from unknown p.
 __device__ void chol_backsub3_lds(double* S, int ld, int r, int tid) {
     for (int j0 = ((r - 1) / LS_B) * LS_B; j0 >= 0; j0 -= LS_B) {
         const int nb = min(LS_B, r - j0);
+        // this step's inputs, all reads in flight together (see chol_factor_aug_lds)
+        double Lb[LS_B][LS_B], rh[LS_B][3], dg[LS_B];
+#pragma unroll
+        for (int k = 0; k < LS_B; ++k) {
+            const int ck = j0 + min(k, nb - 1);
+            rh[k][0] = S[(r + 0) * ld + ck]; rh[k][1] = S[(r + 1) * ld + ck]; rh[k][2] = S[(r + 2) * ld + ck];
+            dg[k] = S[ck * ld + ck];
+#pragma unroll
+            for (int p2 = k + 1; p2 < LS_B; ++p2) Lb[p2][k] = S[(j0 + min(p2, nb - 1)) * ld + ck];
+        }
         double qv[LS_B][3];
 #pragma unroll
         for (int k = LS_B - 1; k >= 0; --k) {
-            if (k < nb) {
-                double t0 = S[(r + 0) * ld + j0 + k], t1 = S[(r + 1) * ld + j0 + k], t2 = S[(r + 2) * ld + j0 + k];
+            double t0 = rh[k][0], t1 = rh[k][1], t2 = rh[k][2];
 #pragma unroll
-                for (int p2 = k + 1; p2 < LS_B; ++p2)
-                    if (p2 < nb) { const double lpk = S[(j0 + p2) * ld + j0 + k]; t0 -= lpk * qv[p2][0]; t1 -= lpk * qv[p2][1]; t2 -= lpk * qv[p2][2]; }
-                const double idk = 1.0 / S[(j0 + k) * ld + j0 + k];
-                qv[k][0] = t0 * idk; qv[k][1] = t1 * idk; qv[k][2] = t2 * idk;
-            } else { qv[k][0] = qv[k][1] = qv[k][2] = 0.0; }
+            for (int p2 = k + 1; p2 < LS_B; ++p2) {
+                const double lpk = (p2 < nb) ? Lb[p2][k] : 0.0;        // (x - 0 * q == x exactly: same value as skipping)
+                t0 -= lpk * qv[p2][0]; t1 -= lpk * qv[p2][1]; t2 -= lpk * qv[p2][2];
+            }
+            const double idk = 1.0 / dg[k];
+            const bool live = k < nb;
+            qv[k][0] = live ? t0 * idk : 0.0; qv[k][1] = live ? t1 * idk : 0.0; qv[k][2] = live ? t2 * idk : 0.0;
         }
         __syncthreads();                                   // every thread has read this step's inputs
         if (tid < j0) {
+            double l[LS_B];
+#pragma unroll
+            for (int k = 0; k < LS_B; ++k) { const double v = S[(j0 + min(k, nb - 1)) * ld + tid]; l[k] = (k < nb) ? v : 0.0; }
             double u0 = S[(r + 0) * ld + tid], u1 = S[(r + 1) * ld + tid], u2 = S[(r + 2) * ld + tid];
 #pragma unroll
-            for (int k = 0; k < LS_B; ++k)
-                if (k < nb) { const double l = S[(j0 + k) * ld + tid]; u0 -= l * qv[k][0]; u1 -= l * qv[k][1]; u2 -= l * qv[k][2]; }
+            for (int k = 0; k < LS_B; ++k) { u0 -= l[k] * qv[k][0]; u1 -= l[k] * qv[k][1]; u2 -= l[k] * qv[k][2]; }
             S[(r + 0) * ld + tid] = u0; S[(r + 1) * ld + tid] = u1; S[(r + 2) * ld + tid] = u2;
         } else if (tid == j0) {
 #pragma unroll
