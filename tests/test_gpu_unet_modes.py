@@ -1,0 +1,51 @@
+"""The conv kernel families must agree with each other: f32-input MFMA vs split-bf16, decoder tap folding on/off.
+
+The family is chosen when the model is created (CT_CONV_MATH / CT_CONV_FOLD, read once per process), so every mode runs in
+its own child process on the same seeded patch; the default mode is additionally held to the oracle in test_gpu_unet.py."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+CHILD = r"""
+import importlib, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+name, out = sys.argv[2], sys.argv[3]
+synth = importlib.import_module("3deecelltracker_amd.synth")
+unet3d = importlib.import_module("3deecelltracker_amd.unet3d")
+arch = importlib.import_module("3deecelltracker_amd.arch").ARCHS[name]
+model = getattr(unet3d, name)().set_weights_dict(synth.make_unet_weights(name, seed=3))
+patches = np.random.default_rng(4).normal(size=(2,) + tuple(arch.input_shape)).astype(np.float32)
+got, dump = model.predict_device(torch.from_numpy(patches[:1]).cuda(), layer_dump=True)
+both = model.predict_device(torch.from_numpy(patches).cuda())
+torch.cuda.synchronize()
+np.savez(out, prob=both.cpu().numpy(), dump=dump.cpu().numpy())
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["unet3_a", "unet3_b", "unet3_c"])
+def test_kernel_families_agree(name, tmp_path):
+    res = {}
+    for math in ("f32", "bf16x6"):
+        for fold in ("0", "1"):
+            out = tmp_path / f"{name}_{math}_{fold}.npz"
+            env = dict(os.environ, CT_CONV_MATH=math, CT_CONV_FOLD=fold)
+            r = subprocess.run([sys.executable, "-c", CHILD, str(REPO), name, str(out)], env=env, capture_output=True, text=True,
+                               timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[(math, fold)] = np.load(out)
+    ref = res[("f32", "0")]                      # the exact-fp32 fmaf-chain kernels without any tap folding
+    scale = max(1.0, float(np.abs(ref["dump"]).max()))
+    for key, z in res.items():
+        assert np.isfinite(z["prob"]).all()
+        derr = float(np.abs(z["dump"] - ref["dump"]).max())
+        perr = float(np.abs(z["prob"] - ref["prob"]).max())
+        assert derr <= 1e-5 * scale, f"{name} {key}: conv blocks differ from the f32 kernels by {derr} (scale {scale})"
+        assert perr <= 5e-6, f"{name} {key}: probability maps differ by {perr}"
