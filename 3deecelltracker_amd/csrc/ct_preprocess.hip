@@ -35,31 +35,52 @@ __device__ __forceinline__ double value_of_key(uint32_t k, int dtype) {
 // select state (device): [0] prefix value, [1] prefix mask, [2..3] remaining rank (64-bit)
 struct SelState { uint32_t prefix, mask; unsigned long long rank; };
 
+// Both order statistics of np.median ((n-1)/2 and n/2) are selected in the same passes: st[0] / st[1] share one histogram
+// while their prefixes agree (almost always -- they are neighbours in sorted order) and get separate ones once they differ.
+// hist: [2][256].  A wave whose 64 keys fall into one bin (background voxels in the high-byte pass) adds once.
 __global__ __launch_bounds__(256) void radix_hist_kernel(const void* __restrict__ data, int dtype, size_t n, int shift,
                                                          const SelState* __restrict__ st, unsigned int* __restrict__ hist) {
-    __shared__ unsigned int h[256];
-    h[threadIdx.x] = 0;
+    __shared__ unsigned int h[2][256];
+    h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t prefix = st->prefix, mask = st->mask;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const uint32_t k = key_of(data, dtype, i);
-        if ((k & mask) == prefix) atomicAdd(&h[(k >> shift) & 0xFF], 1u);
+    const uint32_t p0 = st[0].prefix, p1 = st[1].prefix, mask = st[0].mask;      // the masks are always equal
+    const bool same = p0 == p1;
+    const size_t nround = (n + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
+    for (size_t rnd = 0; rnd < nround; ++rnd) {
+        const size_t i = (rnd * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        const bool live = i < n;
+        const uint32_t k = live ? key_of(data, dtype, i) : 0u;
+        const int d = (int)((k >> shift) & 0xFF);
+        const bool m0 = live && (k & mask) == p0, m1 = live && !same && (k & mask) == p1;
+        const unsigned long long b0 = __ballot(m0);
+        if (b0) {
+            const int lead = __ffsll((long long)b0) - 1;
+            const int dl = __shfl(d, lead);
+            if (__ballot(m0 && d == dl) == b0) { if ((int)(threadIdx.x & 63) == lead) atomicAdd(&h[0][dl], (unsigned)__popcll(b0)); }
+            else if (m0) atomicAdd(&h[0][d], 1u);
+        }
+        if (m1) atomicAdd(&h[1][d], 1u);
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    if (h[0][threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[0][threadIdx.x]);
+    if (h[1][threadIdx.x]) atomicAdd(&hist[256 + threadIdx.x], h[1][threadIdx.x]);
 }
 
 __global__ void radix_pick_kernel(unsigned int* __restrict__ hist, int shift, SelState* __restrict__ st) {
     if (threadIdx.x == 0) {
-        unsigned long long r = st->rank, acc = 0; int d = 0;
-        for (; d < 256; ++d) { if (acc + hist[d] > r) break; acc += hist[d]; }
-        if (d > 255) d = 255;
-        st->rank = r - acc;
-        st->prefix |= ((uint32_t)d << shift);
-        st->mask |= (0xFFu << shift);
+        const bool same = st[0].prefix == st[1].prefix;
+        for (int q = 0; q < 2; ++q) {
+            const unsigned int* hq = hist + ((q == 1 && !same) ? 256 : 0);
+            unsigned long long r = st[q].rank, acc = 0; int d = 0;
+            for (; d < 256; ++d) { if (acc + hq[d] > r) break; acc += hq[d]; }
+            if (d > 255) d = 255;
+            st[q].rank = r - acc;
+            st[q].prefix |= ((uint32_t)d << shift);
+            st[q].mask |= (0xFFu << shift);
+        }
     }
     __syncthreads();
-    hist[threadIdx.x] = 0;          // ready for the next pass (blockDim = 256)
+    hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;          // ready for the next pass (blockDim = 256)
 }
 
 __global__ void median_finish_kernel(const SelState* __restrict__ lo, const SelState* __restrict__ hi, int dtype,
@@ -102,6 +123,44 @@ __global__ __launch_bounds__(256) void box1d_kernel(const float* __restrict__ in
     out[i] = (float)acc;
 }
 
+// Sliding-window form of box1d_kernel for the x and y axes (stride >= Z): one thread walks a segment of one line, so an
+// output costs ~2.4 reads instead of `2 half + 1` (27 by default).  The window sum is carried in double with an
+// error-free TwoSum compensation term, i.e. it equals the directly accumulated double sum to ~2^-100 of the largest
+// partial sum; consecutive threads own consecutive lines (z fastest) so every read and write is a coalesced row.
+constexpr int BOX_SEG = 64;
+__device__ __forceinline__ float box_val(const float* __restrict__ in, size_t base, size_t stride, int q, int len, int mode) {
+    if (mode == 0) { if (q < 0 || q >= len) return 0.f; }
+    else {                                           // d c b a | a b c d | d c b a
+        const int period = 2 * len;
+        q %= period; if (q < 0) q += period;
+        if (q >= len) q = period - 1 - q;
+    }
+    return in[base + (size_t)q * stride];
+}
+__global__ __launch_bounds__(256) void box1d_run_kernel(const float* __restrict__ in, float* __restrict__ out, int X, int Y, int Z,
+                                                        int axis, int half, int mode) {
+    const int len = axis == 0 ? X : Y;
+    const size_t nlines = axis == 0 ? (size_t)Y * Z : (size_t)X * Z;
+    const int nseg = (len + BOX_SEG - 1) / BOX_SEG;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nlines * nseg) return;
+    const size_t line = t % nlines; const int seg = (int)(t / nlines);
+    const size_t stride = axis == 0 ? (size_t)Y * Z : (size_t)Z;
+    const size_t base = axis == 0 ? line : (line / Z) * (size_t)Y * Z + (line % Z);
+    const int p0 = seg * BOX_SEG, p1 = min(p0 + BOX_SEG, len);
+    double acc = 0.0, comp = 0.0;
+    for (int d = -half; d <= half; ++d) acc += (double)box_val(in, base, stride, p0 + d, len, mode);
+    out[base + (size_t)p0 * stride] = (float)acc;
+    for (int p = p0 + 1; p < p1; ++p) {
+        const double v = (double)box_val(in, base, stride, p + half, len, mode) - (double)box_val(in, base, stride, p - 1 - half, len, mode);
+        const double s = acc + v;                    // TwoSum: s + e == acc + v exactly
+        const double bb = s - acc;
+        comp += (acc - (s - bb)) + (v - bb);
+        acc = s;
+        out[base + (size_t)p * stride] = (float)(acc + comp);
+    }
+}
+
 // a = s / vol ; d = (x - a)^2
 __global__ __launch_bounds__(256) void avgdiff_kernel(const float* __restrict__ x, const float* __restrict__ s, float inv_vol, size_t n,
                                                       float* __restrict__ a, float* __restrict__ d) {
@@ -120,9 +179,10 @@ __global__ __launch_bounds__(256) void lcn_final_kernel(const float* __restrict_
     out[i] = (x[i] - a[i]) / (sqrtf(s2[i] * inv_vol) + noise);
 }
 
-int select_rank(const void* data, int dtype, size_t n, unsigned long long rank, SelState* st, unsigned int* hist, hipStream_t s) {
-    SelState init{0u, 0u, rank};
-    HIPCHK(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, s));
+int select_two_ranks(const void* data, int dtype, size_t n, unsigned long long rank_lo, unsigned long long rank_hi, SelState* st,
+                     unsigned int* hist, hipStream_t s) {
+    SelState init[2] = {{0u, 0u, rank_lo}, {0u, 0u, rank_hi}};
+    HIPCHK(hipMemcpyAsync(st, init, sizeof(init), hipMemcpyHostToDevice, s));
     const int top = dtype == 0 ? 8 : 24;
     const unsigned nblk = (unsigned)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
     for (int shift = top; shift >= 0; shift -= 8) {
@@ -149,13 +209,12 @@ int ct_median(const void* data, int dtype, size_t n, double* median_out, void* w
     if (workspace_bytes < 4096) return CT_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    unsigned int* hist = (unsigned int*)ws;                       // 256 bins
-    SelState* lo = (SelState*)(ws + 1024); SelState* hi = (SelState*)(ws + 1280);
-    HIPCHK(hipMemsetAsync(hist, 0, 1024, s));
+    unsigned int* hist = (unsigned int*)ws;                       // 2 x 256 bins
+    SelState* st = (SelState*)(ws + 2048);                         // [2]: ranks (n-1)/2 and n/2
+    HIPCHK(hipMemsetAsync(hist, 0, 2048, s));
     int rc;
-    if ((rc = select_rank(data, dtype, n, (unsigned long long)((n - 1) / 2), lo, hist, s))) return rc;
-    if ((rc = select_rank(data, dtype, n, (unsigned long long)(n / 2), hi, hist, s))) return rc;
-    hipLaunchKernelGGL(median_finish_kernel, dim3(1), dim3(1), 0, s, lo, hi, dtype, median_out);
+    if ((rc = select_two_ranks(data, dtype, n, (unsigned long long)((n - 1) / 2), (unsigned long long)(n / 2), st, hist, s))) return rc;
+    hipLaunchKernelGGL(median_finish_kernel, dim3(1), dim3(1), 0, s, st, st + 1, dtype, median_out);
     LAUNCH_CHECK();
     return CT_OK;
 }
@@ -171,7 +230,7 @@ int ct_normalize_image(const void* img, int dtype, const int dims[3], double noi
     const size_t slab = align_up(n * sizeof(float), 256);
     float* X = (float*)ws; float* A = (float*)(ws + slab); float* T1 = (float*)(ws + 2 * slab); float* T2 = (float*)(ws + 3 * slab);
     unsigned char* tail = ws + 4 * slab;
-    double* median = (double*)(tail + 2048);
+    double* median = (double*)(tail + 3072);
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (subtract_median) {
         int rc = ct_median(img, dtype, n, median, tail, 4096, stream);
@@ -187,7 +246,13 @@ int ct_normalize_image(const void* img, int dtype, const int dims[3], double noi
         w = (passes & 1) ? 0 : 1;                         // so that the last pass writes dst
         for (int ax = 0; ax < 3; ++ax) {
             if (filter[ax] == 1) continue;
-            hipLaunchKernelGGL(box1d_kernel, dim3(nb), dim3(256), 0, s, cur, bufs[w], dims[0], dims[1], dims[2], ax, filter[ax] / 2, mode);
+            if (ax < 2 && filter[ax] > 3) {                    // sliding window along x / y
+                const int len = dims[ax];
+                const size_t nthreads = (n / len) * (size_t)((len + BOX_SEG - 1) / BOX_SEG);
+                hipLaunchKernelGGL(box1d_run_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, cur, bufs[w], dims[0], dims[1],
+                                   dims[2], ax, filter[ax] / 2, mode);
+            } else
+                hipLaunchKernelGGL(box1d_kernel, dim3(nb), dim3(256), 0, s, cur, bufs[w], dims[0], dims[1], dims[2], ax, filter[ax] / 2, mode);
             LAUNCH_CHECK();
             cur = bufs[w]; w ^= 1;
         }

@@ -54,6 +54,15 @@ def test_device_median_is_exact():
         assert pre.median_device(torch.from_numpy(f).cuda()) == float(np.median(f.astype(np.float64)))
     z = np.zeros(100, np.uint16); z[:50] = 7
     assert pre.median_device(torch.from_numpy(z).cuda()) == float(np.median(z)) == 3.5
+    # the two middle order statistics differ already in the first radix digit (their selections run in the same passes)
+    z = np.zeros(1000, np.uint16); z[:500] = 65535
+    assert pre.median_device(torch.from_numpy(z).cuda()) == float(np.median(z)) == 32767.5
+    z = np.array([255, 256] * 8, np.uint16)
+    assert pre.median_device(torch.from_numpy(z).cuda()) == 255.5
+    f = np.concatenate([np.full(64, -3.0e20, np.float32), np.full(64, 2.5e-12, np.float32)])
+    assert pre.median_device(torch.from_numpy(f).cuda()) == float(np.median(f.astype(np.float64)))
+    f = np.array([-1.0, 1.0, -2.0, 2.0], np.float32)
+    assert pre.median_device(torch.from_numpy(f).cuda()) == 0.0
 
 
 @pytest.mark.gpu
