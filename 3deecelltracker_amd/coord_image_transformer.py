@@ -58,7 +58,10 @@ class CoordsToImageTransformer:
     image geometry.  `accurate_correction` returns the corrected Coordinates; the corrected *label image* of the reference
     goes through skimage's watershed and is outside this path."""
 
-    def __init__(self, proofed_shape, voxel_size, interpolation_factor, subregions, coord_vol1: Coordinates):
+    def __init__(self, proofed_shape, voxel_size, interpolation_factor, subregions, coord_vol1: Coordinates,
+                 results_folder=None):
+        from pathlib import Path
+        self.results_folder = Path(results_folder) if results_folder is not None else None
         self.proofed_shape = tuple(int(v) for v in proofed_shape)
         self.voxel_size = np.asarray(voxel_size)
         self.interpolation_factor = int(interpolation_factor)
@@ -97,8 +100,58 @@ class CoordsToImageTransformer:
         self._dev = (t.from_numpy(bbox).cuda(), t.from_numpy(np.concatenate(chunks)).cuda(), t.from_numpy(offs).cuda(),
                      t.from_numpy(np.ascontiguousarray(self.coord_vol1._raw, dtype=np.float32)).cuda())
 
-    def accurate_correction(self, prob_map, coords: Coordinates, ensemble: bool, max_repetition: int = 20, grid=(1, 1, 1)):
-        """reference :406-447 (coordinates only).  prob_map: numpy / cuda tensor (x, y, z); `grid` repeats it like the reference."""
+    # ---- on-disk layout of the reference: results_folder/seg/prob%06d.npy, track_results/coords_real/coords%06d.npy
+    def save_coords_vol1(self, t_start: int):
+        """reference :265-267: the confirmed coordinates of the first volume."""
+        path = self._coords_real_dir()
+        path.mkdir(parents=True, exist_ok=True)
+        np.save(str(path / ("coords%06d.npy" % t_start)), self.coord_vol1.real)
+
+    def save_coords(self, t2: int, coords: Coordinates):
+        """the coordinate part of reference :512 (label images / figures are outside this path)."""
+        path = self._coords_real_dir()
+        path.mkdir(parents=True, exist_ok=True)
+        np.save(str(path / ("coords%06d.npy" % t2)), coords.real)
+
+    def load_confirmed_coords(self, t1: int) -> np.ndarray:
+        """reference :516-517"""
+        return np.load(str(self._coords_real_dir() / f"coords{str(t1).zfill(6)}.npy"))
+
+    def _coords_real_dir(self):
+        if self.results_folder is None:
+            raise ValueError("results_folder was not given to CoordsToImageTransformer")
+        return self.results_folder / "track_results" / "coords_real"
+
+    def accurate_correction(self, t, *args, **kwargs):
+        """reference :406-447.  Two call forms:
+
+        accurate_correction(t: int, grid, coords, ensemble, max_repetition=20, format="prob%06d.npy")   -- the reference's:
+            loads results_folder/seg/prob%06d.npy, returns (coords, corrected_labels_image) with corrected_labels_image = None
+            (the reference rebuilds the label image with a skimage watershed, which is outside this path);
+        accurate_correction(prob_map, coords, ensemble, max_repetition=20, grid=(1, 1, 1))              -- array / cuda tensor in,
+            Coordinates out (no file access)."""
+        from_file = isinstance(t, (int, np.integer))
+        names = ("grid", "coords", "ensemble", "max_repetition", "format") if from_file else ("coords", "ensemble", "max_repetition", "grid")
+        if len(args) > len(names):
+            raise TypeError("accurate_correction: too many positional arguments")
+        params = dict(zip(names, args))
+        for k, v in kwargs.items():
+            if k not in names or k in params:
+                raise TypeError(f"accurate_correction: unexpected or repeated argument '{k}'")
+            params[k] = v
+        for need in ("coords", "ensemble") + (("grid",) if from_file else ()):
+            if need not in params:
+                raise TypeError(f"accurate_correction: missing argument '{need}'")
+        grid = tuple(params.get("grid", (1, 1, 1)))
+        if not from_file:
+            return self._accurate_correction(t, params["coords"], params["ensemble"], params.get("max_repetition", 20), grid)
+        if self.results_folder is None:
+            raise ValueError("results_folder was not given to CoordsToImageTransformer")
+        prob_map = np.load(str(self.results_folder / "seg" / (params.get("format", "prob%06d.npy") % t)))
+        return self._accurate_correction(prob_map, params["coords"], params["ensemble"], params.get("max_repetition", 20), grid), None
+
+    def _accurate_correction(self, prob_map, coords: Coordinates, ensemble: bool, max_repetition: int = 20, grid=(1, 1, 1)):
+        """prob_map: numpy / cuda tensor (x, y, z); `grid` repeats it like the reference (:432)."""
         import ctypes as C
         from . import _dev, _lib
         t = _dev.torch(); L = _lib.lib()

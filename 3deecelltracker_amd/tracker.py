@@ -1,8 +1,10 @@
 """Matching half of the reference's legacy ``CellTracker/tracker.py`` `Tracker`.
 
 Accelerated here (reference tracker.py):
-    match                 :1138-1175   (segmentation is supplied by the caller: the U-Net map ->
-                                        watershed -> centroid step is outside this path)
+    match                 :1138-1175
+    _predict_cellregions / _save_unet_regions :652-669   (LCN -> U-Net -> unet_cache/t%06i.npy float16)
+    segment_prob          the part of _segment (:636-650) after the U-Net, with connected components instead of the
+                          skimage watershed (segment.py)
     _predict_pos_once     :1193-1222   draw=False branch
     _fit_ffn_prgls        :1224-1254
     _ffn_prgls_once       :1256-1267
@@ -15,6 +17,7 @@ are re-applied to the tracked coordinates; nothing returns to the host in betwee
 """
 from __future__ import annotations
 
+import os
 from functools import reduce
 from types import SimpleNamespace
 
@@ -31,8 +34,14 @@ BOUNDARY_XY = 6
 
 class Tracker:
     def __init__(self, ffn_model, beta_tk=300, lambda_tk=0.1, max_iteration=20, ensemble=False, adjacent=False,
-                 volume_shape=None, z_xy_ratio=1.0, miss_frame=None):
+                 volume_shape=None, z_xy_ratio=1.0, miss_frame=None, unet_model=None, noise_level=None, shrink=(24, 24, 2),
+                 unet_cache=None):
         self.ffn_model = ffn_model
+        # segmentation half (optional): the U-Net, its pre-processing and the reference's on-disk cache of its output
+        self.unet_model = unet_model
+        self.noise_level = noise_level
+        self.shrink = tuple(shrink)
+        self.paths = SimpleNamespace(unet_cache=None if unet_cache is None else os.path.join(str(unet_cache), ""))
         self.beta_tk = beta_tk
         self.lambda_tk = lambda_tk
         self.max_iteration = max_iteration
@@ -56,6 +65,28 @@ class Tracker:
 
     def set_segmentation(self, r_coordinates_segment):
         self.segresult.r_coordinates_segment = np.asarray(r_coordinates_segment, dtype=np.float64)
+
+    def _predict_cellregions(self, image_raw, vol):
+        """reference :652-660: the U-Net output of volume `vol`, from unet_cache/t%06i.npy when it is there."""
+        if self.paths.unet_cache is not None:
+            try:
+                return np.load(self.paths.unet_cache + "t%06i.npy" % vol, allow_pickle=True)
+            except OSError:
+                pass
+        return self._save_unet_regions(image_raw, vol)
+
+    def _save_unet_regions(self, image_raw, vol):
+        """reference :662-669: _normalize_image -> unet3_prediction, cached as float16 [1, x, y, z, 1]."""
+        from .preprocess import _normalize_image
+        from .unet3d import unet3_prediction
+        if self.unet_model is None or self.noise_level is None:
+            raise ValueError("Tracker was created without unet_model / noise_level: no segmentation half")
+        image_norm = np.expand_dims(_normalize_image(image_raw, self.noise_level), axis=(0, 4))
+        image_cell_bg = unet3_prediction(image_norm, self.unet_model, shrink=self.shrink)
+        if self.paths.unet_cache is not None:
+            os.makedirs(self.paths.unet_cache, exist_ok=True)
+            np.save(self.paths.unet_cache + "t%06i.npy" % vol, np.array(image_cell_bg, dtype="float16"))
+        return image_cell_bg
 
     def segment_prob(self, image_cell_bg, min_size=0, threshold=0.5, connectivity=1):
         """The part of reference :636-650 (_segment) after the U-Net: regions -> centres -> real coordinates, on the GPU.

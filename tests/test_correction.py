@@ -80,3 +80,35 @@ def test_device_out_of_range_and_larger_case():
     want2, _ = cr.accurate_correction(case["prob"], (256, 256, 24), 5, case["subregions"], 150, case["vol1"], far, bd)
     np.testing.assert_allclose(got._raw, want2, rtol=0, atol=1e-5)
     assert got._raw[0, 0] == np.float32(np.round(np.float32(far[0, 0])))
+
+
+def test_coordinate_files_follow_the_reference_layout(tmp_path):
+    """SURVEY 8f #4: track_results/coords_real/coords%06d.npy holds real coordinates (reference :267, :512, :516)."""
+    case = synth.make_correction_case(0, (64, 56, 8), 5, 18, 8)
+    vol1 = cit.Coordinates(case["vol1"], 5, case["voxel_size"], dtype="raw")
+    tr = cit.CoordsToImageTransformer((64, 56, 8), case["voxel_size"], 5, case["subregions"], vol1, results_folder=tmp_path)
+    tr.save_coords_vol1(1)
+    moved = cit.Coordinates(case["coords0"], 5, case["voxel_size"], dtype="raw")
+    tr.save_coords(2, moved)
+    assert np.array_equal(np.load(tmp_path / "track_results" / "coords_real" / "coords000001.npy"), vol1.real)
+    assert np.array_equal(tr.load_confirmed_coords(2), moved.real)
+    with pytest.raises(ValueError, match="results_folder"):
+        cit.CoordsToImageTransformer((64, 56, 8), case["voxel_size"], 5, case["subregions"], vol1).save_coords(2, moved)
+    with pytest.raises(TypeError):
+        tr.accurate_correction(3, (1, 1, 1), moved)                    # the reference's form needs `ensemble`
+
+
+@pytest.mark.gpu
+def test_device_reference_call_form_reads_prob_file(g, tmp_path):
+    """accurate_correction(t, grid, coords, ensemble): loads seg/prob%06d.npy like the reference and returns (coords, None)."""
+    case, shape, f, n, ens = _case(g, 0)
+    vol1 = cit.Coordinates(case["vol1"], f, case["voxel_size"], dtype="raw")
+    tr = cit.CoordsToImageTransformer(shape, case["voxel_size"], f, case["subregions"], vol1, results_folder=tmp_path)
+    (tmp_path / "seg").mkdir()
+    np.save(tmp_path / "seg" / "prob000007.npy", case["prob"])
+    coords = cit.Coordinates(case["coords0"], f, case["voxel_size"], dtype="raw")
+    fin, labels = tr.accurate_correction(7, (1, 1, 1), coords, ens)
+    assert labels is None
+    assert np.abs(fin._raw - g["corr_final_0"]).max() <= 1e-5
+    same = tr.accurate_correction(case["prob"], coords, ensemble=ens)
+    assert np.array_equal(same._raw, fin._raw)

@@ -124,3 +124,22 @@ def test_gpu_tracker_segment_prob_feeds_match():
     tk.set_volume1(r)
     _, (bd, vol, _, pred) = tk.match(2)
     assert pred.shape == r.shape and np.isfinite(pred).all()
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_unet_cache_format(tmp_path):
+    """_predict_cellregions writes unet_cache/t%06i.npy as float16 [1, x, y, z, 1] (tracker.py:668) and reads it back."""
+    tracker = importlib.import_module("3deecelltracker_amd.tracker")
+    unet3d = importlib.import_module("3deecelltracker_amd.unet3d")
+    model = unet3d.unet3_a().set_weights_dict(synth.make_unet_weights("unet3_a", 0))
+    raw, _ = synth.make_stack((64, 64, 16), 12, 0)
+    tk = tracker.Tracker(None, volume_shape=(64, 64, 16), z_xy_ratio=2.0, unet_model=model, noise_level=20, unet_cache=tmp_path / "unet_cache")
+    a = tk._predict_cellregions(raw, 3)
+    f = tmp_path / "unet_cache" / "t000003.npy"
+    cached = np.load(f)
+    assert cached.dtype == np.float16 and cached.shape == (1, 64, 64, 16, 1) and a.shape == cached.shape
+    assert np.array_equal(cached, np.asarray(a, dtype=np.float16))
+    b = tk._predict_cellregions(None, 3)                      # served from the cache: the image is not touched
+    assert b.dtype == np.float16 and np.array_equal(b, cached)
+    with pytest.raises(ValueError, match="segmentation half"):
+        tracker.Tracker(None)._predict_cellregions(raw, 1)
