@@ -971,6 +971,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_c8_fold_kernel(ConvArgs a) 
 // MODE bits: C8 (paired-column rows = (x-select, cout)), FOLD (decoder conv, parity column mapping, see above).
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BF_POS = HX * HY * HZ;              // halo positions
 constexpr int BF_PLANE = BF_POS * 16;             // bytes per component plane
 constexpr int KB_STD = 7, KB_FOLD = 3, KB_C8 = 9, KB_C8F = 5;
@@ -1043,7 +1044,15 @@ __device__ __forceinline__ void bf_stage_tile(const ConvArgs& a, int c0, int p, 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * 3 + comp) * 64]
 template <int NT, int NCOL, int KB, bool C8, bool FOLDED, int COLSTRIDE_X, int COLSTRIDE_Y>
 __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char* lds, int lanepos, int g,
-                                             const uint4* __restrict__ wp, int nt_total) {
+                                             const uint4* wp, int nt_total) {          // (no __restrict__: see the prefetch)
+    // NT == 1: a K-block is only 24-48 MFMAs (400-800 cycles), less than the L2 round trip of its weight fragments, so the
+    // next block's fragments are requested before this block's MFMAs (12 more VGPRs).  Wider tiles hide it by themselves.
+    constexpr bool PREFETCH = NT == 1;
+    u32x4 wnext[NT][3];
+    if constexpr (PREFETCH) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wnext[0][c] = *reinterpret_cast<const u32x4*>(wp + (size_t)c * 64);
+    }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1),
@@ -1051,11 +1060,24 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
         const int tp = g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
         const char* ab = lds + (lanepos + tp) * 16;
         bf16x8 wv[NT][3];
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int c = 0; c < 3; ++c) wv[0][c] = __builtin_bit_cast(bf16x8, wnext[0][c]);
+            if (kb + 1 < KB) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                wv[nt][c] = __builtin_bit_cast(bf16x8, wp[((size_t)(kb * nt_total + nt) * 3 + c) * 64]);
+                for (int c = 0; c < 3; ++c)
+                    wnext[0][c] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((kb + 1) * nt_total) * 3 + c) * 64);
+            }
+            // keep the prefetch up here: instruction selection and the scheduler sink a plain load to its first use
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    wv[nt][c] = __builtin_bit_cast(bf16x8, wp[((size_t)(kb * nt_total + nt) * 3 + c) * 64]);
+        }
 #pragma unroll
         for (int cg = 0; cg < NCOL; cg += 4) {
             bf16x8 av[4][3];
@@ -1067,6 +1089,9 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
                 for (int c = 0; c < 3; ++c)
                     av[q][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + cpos * 16 + c * BF_PLANE));
             }
+            // all 12 fragment reads of the column group go out before its first MFMA (left alone, the scheduler issues them just in
+            // time to save registers and every pair of MFMAs then eats a full LDS round trip)
+            if constexpr (PREFETCH) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
             // (weight component, activation component): hh, hm, mh, mm, hl, lh
             constexpr int WI[6] = {0, 0, 1, 1, 0, 2}, AI[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
