@@ -60,7 +60,6 @@ struct ConvArgs {
     int cout;
     int nt_total;           // cout tiles of 16 in the packed weights (a block computes NT of them)
     int ngroups;            // nt_total / NT  (blocks along the cout dimension; 1 unless Cout > 64)
-    int xcd_remap;          // 1: XCD-aware block order
 };
 
 namespace {
@@ -70,10 +69,8 @@ constexpr int HX = TX + 2, HY = TY + 2, HZ = 18;  // halo tile (columns, z rows)
 constexpr int NF4 = HX * HY * HZ * 2;             // float4 slots of one 8-channel halo tile
 constexpr int NSTAGE = (NF4 + 255) / 256;
 constexpr int NSLAB = 14;                         // ceil(27 taps * 8 cin / 16 k per slab)
-// Two-plane staging (no tap padding, half the barriers) measured 24.7 vs 24.4 ms/volume: the 3.6 % fewer MFMAs are
-// eaten by the occupancy drop (69 KB LDS, +60 VGPRs).  Kept as a validated variant, switched off.
-constexpr bool kUsePairStaging = false;
-constexpr int kConvDmaDefaultMask = 0;          // LDS-DMA staged variant per NT (bit 0: NT=1, bit 1: NT=2, bit 2: NT=4)
+// (Variants measured and removed, see DESIGN.md 4.1: two 8-channel planes per stage, LDS-DMA double-buffered staging,
+// XCD-aware workgroup order, a VALU first conv fused with the gather.)
 
 __host__ __device__ constexpr int tap_off(int tap) {   // float offset of tap (dx,dy,dz) in the LDS tile
     return (((tap / 9) * HY + (tap / 3) % 3) * HZ + tap % 3) * 8;
@@ -82,24 +79,44 @@ __host__ __device__ constexpr int mt_off(int mt) {      // float offset of the w
     return (((mt >> 2) * HY + (mt & 3)) * HZ) * 8;
 }
 
-// PAIR = true: two 8-channel planes are staged per stage (LDS 2 x 34.5 KB) so that K = 27 taps x 16 cin is exactly
-// 27 slabs of 16 (slab = one tap; lane group g reads plane g>>1, channels 4(g&1)..+3): no tap padding and half as
-// many barriers.  PAIR = false (Cin == 8): one plane, 27 x 8 = 216 k-values padded to 14 slabs of 2 taps.
-
-// XCD-aware workgroup order: the dispatcher places block b on XCD b % 8 (observed, used for speed only), so a
-// contiguous run of the tile grid is handed to each XCD and neighbouring tiles (which share halos) hit the same L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;      // bijective for any nblk
+// One 8-channel halo tile: global -> registers -> (barrier) -> LDS -> (barrier); zero 'same' padding, srcA read at >> u.
+__device__ __forceinline__ void stage_halo_tile(const ConvArgs& a, int c0, int p, int x0, int y0, int z0, int tid, float* lds) {
+    f32x4 v[NSTAGE];
+    const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
+    if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
+                     sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
+    else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
+                     sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        const int f = tid + 256 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (f < NF4) {
+            const int col = f / (HZ * 2), w = f - col * (HZ * 2);
+            const int hz = w >> 1, half = w & 1;
+            const int hx = col / HY, hy = col - hx * HY;
+            const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
+            if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
+                const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
+                                    + (gz >> suz)) * 8 + half * 4;
+                v[i] = *reinterpret_cast<const f32x4*>(src + idx);
+            }
+        }
+    }
+    __syncthreads();                                          // every wave is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        const int f = tid + 256 * i;
+        if (f < NF4) *reinterpret_cast<f32x4*>(&lds[f * 4]) = v[i];
+    }
+    __syncthreads();
 }
 
-template <int NT, bool PAIR>
-__global__ __launch_bounds__(256, (NT == 2 && !PAIR) ? 3 : 2) void conv3_mfma_kernel(ConvArgs a) {
-    constexpr int PLANES = PAIR ? 2 : 1;
-    constexpr int PLANE_F = NF4 * 4;                 // floats per plane
-    __shared__ __attribute__((aligned(16))) float lds[PLANES * PLANE_F];
+template <int NT>
+__global__ __launch_bounds__(256, NT == 2 ? 3 : 2) void conv3_mfma_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[NF4 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = a.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    int b = blockIdx.x;
     const int cg = b % a.ngroups; b /= a.ngroups;
     const int ntb = cg * NT;                       // first cout tile of this block
     const int zb = b % a.zblocks; b /= a.zblocks;
@@ -111,282 +128,18 @@ __global__ __launch_bounds__(256, (NT == 2 && !PAIR) ? 3 : 2) void conv3_mfma_ke
     const int g = lane >> 4, zl = lane & 15;
     const int wx0 = 2 * (wave >> 1), wy0 = 4 * (wave & 1);
     const bool hi = (g >> 1) != 0;
-    const int lbase = ((wx0 * HY + wy0) * HZ + zl) * 8 + 4 * (g & 1) + (PAIR && hi ? PLANE_F : 0);
-
-    f32x4 acc[8][NT];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nstages = a.nchunks / PLANES;
-    for (int stage = 0; stage < nstages; ++stage) {
-        // ---- stage the halo tile(s): global -> registers -> LDS (zero 'same' padding).
-        // NT < 4: both planes are in flight together; NT == 4 (128 accumulator registers): one plane at a time.
-        constexpr int GROUP = (NT >= 4) ? 1 : PLANES;          // planes loaded per round
-#pragma unroll
-        for (int round = 0; round < PLANES / GROUP; ++round) {
-            f32x4 v[GROUP][NSTAGE];
-#pragma unroll
-            for (int q = 0; q < GROUP; ++q) {
-                const int pl = round * GROUP + q;
-                const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
-                {
-                    const int c0 = (stage * PLANES + pl) * 8;
-                    if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
-                                     sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
-                    else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
-                                     sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
-                }
-#pragma unroll
-                for (int i = 0; i < NSTAGE; ++i) {
-                    const int f = tid + 256 * i;
-                    v[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (f < NF4) {
-                        const int col = f / (HZ * 2), w = f - col * (HZ * 2);
-                        const int hz = w >> 1, half = w & 1;
-                        const int hx = col / HY, hy = col - hx * HY;
-                        const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-                        if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
-                            const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
-                                                + (gz >> suz)) * 8 + half * 4;
-                            v[q][i] = *reinterpret_cast<const f32x4*>(src + idx);
-                        }
-                    }
-                }
-            }
-            if (round == 0) __syncthreads();                  // every wave is done reading the previous tile
-#pragma unroll
-            for (int q = 0; q < GROUP; ++q)
-#pragma unroll
-                for (int i = 0; i < NSTAGE; ++i) {
-                    const int f = tid + 256 * i;
-                    if (f < NF4) *reinterpret_cast<f32x4*>(&lds[(round * GROUP + q) * PLANE_F + f * 4]) = v[q][i];
-                }
-        }
-        __syncthreads();
-
-        if constexpr (PAIR) {
-            // ---- 27 slabs = 27 taps x 16 cin
-            const f32x4* wp = a.wpack + ((size_t)stage * 27 * a.nt_total + ntb) * 64 + lane;
-#pragma unroll
-            for (int s = 0; s < 27; ++s) {
-                const int off = lbase + tap_off(s);
-                f32x4 wv[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
-                f32x4 av[8];
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt_off(mt)]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
-            }
-        } else {
-            // ---- 13 full slabs of 16 k-values (2 taps x 8 cin; lane group g owns tap 2s+(g>>1), cin 4(g&1)..+3) and a
-            //      half slab for tap 26 (lane group g owns cin 2g, 2g+1 -> two K=4 MFMAs): 27 x 8 = 216 k-values, no padding
-            const f32x4* wp = a.wpack + ((size_t)stage * NSLAB * a.nt_total + ntb) * 64 + lane;
-#pragma unroll
-            for (int s = 0; s < NSLAB - 1; ++s) {
-                const int off = lbase + (hi ? tap_off(2 * s + 1) : tap_off(2 * s));
-                f32x4 wv[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
-                f32x4 av[8];
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt_off(mt)]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
-            }
-            {
-                const int off = ((wx0 * HY + wy0) * HZ + zl) * 8 + 2 * g + tap_off(26);
-                f32x4 wv[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)((NSLAB - 1) * a.nt_total + nt) * 64];
-                f32x2 av[8];
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x2*>(&lds[off + mt_off(mt)]);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
-            }
-        }
-    }
-
-    // ---- epilogue: bias -> activation -> BatchNorm affine (BN follows the activation)
-    // lane (zl, g) holds, for column mt and n-tile nt, couts 16nt+4g .. +3 of voxel z0+zl
-    const int CP = a.nt_total * 16;
-    const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int cb = 16 * (ntb + nt) + 4 * g;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
-        const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + CP + cb);
-        const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 2 * CP + cb);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            f32x4 r = acc[mt][nt] + bias;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = r[e];
-                r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
-            }
-            acc[mt][nt] = r;
-        }
-    }
-    const int z = z0 + zl;
-    const int OQ = a.cout >> 3;
-    if (a.out) {
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int x = x0 + wx0 + (mt >> 2), y = y0 + wy0 + (mt & 3);
-            if (x < a.X && y < a.Y && z < a.Z) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int cb = 16 * (ntb + nt) + 4 * g;
-                    if (cb < a.cout) {
-                        const size_t idx = ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7);
-                        *reinterpret_cast<f32x4*>(a.out + idx) = acc[mt][nt];
-                    }
-                }
-            }
-        }
-    }
-    if (a.pool) {      // MaxPooling3D (2,2,pz): the wave's 2x4 columns are two 2x2 blocks
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const int x = x0 + wx0, y = y0 + wy0 + 2 * blk;
-            const bool ok = (x + 1 < a.X) && (y + 1 < a.Y) && (z < a.Z);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                f32x4 m;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = fmaxf(fmaxf(acc[2 * blk][nt][e], acc[2 * blk + 1][nt][e]),
-                                    fmaxf(acc[4 + 2 * blk][nt][e], acc[5 + 2 * blk][nt][e]));
-                    if (a.pz == 2) t = fmaxf(t, __shfl_xor(t, 1));
-                    m[e] = t;
-                }
-                const int cb = 16 * (ntb + nt) + 4 * g;
-                const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
-                if (ok && zok && cb < a.cout) {
-                    const int pzc = a.pz == 2 ? (z >> 1) : z;
-                    const size_t idx = ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7);
-                    *reinterpret_cast<f32x4*>(a.pool + idx) = m;
-                }
-            }
-        }
-    }
-    if (a.head) {      // Conv3D(1, 1, activation='sigmoid') fused: dot over channels, then sigmoid
-        const float hb = a.head[CP];
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            float part = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 hw = *reinterpret_cast<const f32x4*>(a.head + 16 * (ntb + nt) + 4 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) part += acc[mt][nt][e] * hw[e];
-            }
-            part += __shfl_xor(part, 16);
-            part += __shfl_xor(part, 32);
-            const int x = x0 + wx0 + (mt >> 2), y = y0 + wy0 + (mt & 3);
-            if (g == 0 && x < a.X && y < a.Y && z < a.Z) {
-                const float logit = part + hb;
-                a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-logit));
-            }
-        }
-    }
-}
-
-
-
-// ------------------------------------------------------------------------------------------------
-// LDS-DMA variant of the main conv kernel.  The LDS halo tile is a linear copy of global memory (blocked layout), so
-// the staging is done by `global_load_lds` (16 B per lane, wave-uniform LDS base + lane * 16): no staging VGPRs, no
-// register -> LDS pass.  Two LDS buffers: the DMA of chunk c+1 is issued while the last MFMAs of chunk c run, one
-// barrier per chunk.  Out-of-image halo voxels (zero 'same' padding) are the SAME lanes for every chunk of a workgroup:
-// both buffers are zeroed once and those lanes are simply masked (a masked lane leaves LDS untouched -- probed in
-// scripts/probe/glds_masked.hip).
-// ------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256, 2) void conv3_mfma_dma_kernel(ConvArgs a) {
-    constexpr bool PAIR = false;
-    constexpr int PLANE_F = NF4 * 4;
-    __shared__ __attribute__((aligned(16))) float lds[2 * PLANE_F];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int b = blockIdx.x;
-    const int cg = b % a.ngroups; b /= a.ngroups;
-    const int ntb = cg * NT;
-    const int zb = b % a.zblocks; b /= a.zblocks;
-    const int ty = b % a.tilesY;  b /= a.tilesY;
-    const int tx = b % a.tilesX;
-    const int p = b / a.tilesX;
-    const int x0 = tx * TX, y0 = ty * TY, z0 = zb * 16;
-
-    const int g = lane >> 4, zl = lane & 15;
-    const int wx0 = 2 * (wave >> 1), wy0 = 4 * (wave & 1);
-    const bool hi = (g >> 1) != 0;
     const int lbase = ((wx0 * HY + wy0) * HZ + zl) * 8 + 4 * (g & 1);
 
-    for (int i = tid; i < 2 * NF4; i += 256) *reinterpret_cast<f32x4*>(&lds[i * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
-
     f32x4 acc[8][NT];
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-thread halo coordinates of its NSTAGE float4 slots (identical for every chunk)
-    auto issue = [&](int chunk, int buf) {
-        const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
-        {
-            const int c0 = chunk * 8;
-            if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
-                             sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
-            else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
-                             sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
-        }
-#pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
-            const int f = tid + 256 * i;
-            if (f < NF4) {
-                const int col = f / (HZ * 2), w = f - col * (HZ * 2);
-                const int hz = w >> 1, half = w & 1;
-                const int hx = col / HY, hy = col - hx * HY;
-                const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-                if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
-                    const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
-                                        + (gz >> suz)) * 8 + half * 4;
-                    float* dstw = &lds[buf * PLANE_F + (wave_u * 64 + 256 * i) * 4];       // wave-uniform base
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx),
-                                                     (__attribute__((address_space(3))) void*)dstw, 16, 0, 0);
-                }
-            }
-        }
-    };
-
-    __syncthreads();                           // zero fill complete before any DMA lands
-    issue(0, 0);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    const int nstages = a.nchunks;
-    for (int stage = 0; stage < nstages; ++stage) {
-        const float* cur = &lds[(stage & 1) * PLANE_F];
+    for (int stage = 0; stage < a.nchunks; ++stage) {
+        stage_halo_tile(a, stage * 8, p, x0, y0, z0, tid, lds);
+        // ---- 13 full slabs of 16 k-values (2 taps x 8 cin; lane group g owns tap 2s+(g>>1), cin 4(g&1)..+3) and a
+        //      half slab for tap 26 (lane group g owns cin 2g, 2g+1 -> two K=4 MFMAs): 27 x 8 = 216 k-values, no padding
         const f32x4* wp = a.wpack + ((size_t)stage * NSLAB * a.nt_total + ntb) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < NSLAB - 1; ++s) {
@@ -396,10 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_dma_kernel(ConvArgs a) {
             for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)(s * a.nt_total + nt) * 64];
             f32x4 av[8];
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&cur[off + mt_off(mt)]);
-            if (s == NSLAB - 3) {              // weights of this slab are in flight/landed: the DMA queues behind them
-                if (stage + 1 < nstages) issue(stage + 1, (stage + 1) & 1);
-            }
+            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(&lds[off + mt_off(mt)]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -415,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_dma_kernel(ConvArgs a) {
             for (int nt = 0; nt < NT; ++nt) wv[nt] = wp[(size_t)((NSLAB - 1) * a.nt_total + nt) * 64];
             f32x2 av[8];
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x2*>(&cur[off + mt_off(mt)]);
+            for (int mt = 0; mt < 8; ++mt) av[mt] = *reinterpret_cast<const f32x2*>(&lds[off + mt_off(mt)]);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -424,10 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_dma_kernel(ConvArgs a) {
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[nt][t], av[mt][t], acc[mt][nt], 0, 0, 0);
         }
-        __builtin_amdgcn_s_waitcnt(0);         // next tile landed (DMA is tracked by vmcnt)
-        __syncthreads();
     }
-    (void)PAIR;
 
     // ---- epilogue: bias -> activation -> BatchNorm affine (BN follows the activation)
     // lane (zl, g) holds, for column mt and n-tile nt, couts 16nt+4g .. +3 of voxel z0+zl
@@ -532,7 +279,7 @@ __host__ __device__ constexpr int tap_off4(int tap) {   // tap = (dx' * 3 + dy) 
 __global__ __launch_bounds__(256, 2) void conv3_mfma_c8_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[NF4 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int b = a.xcd_remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    int b = blockIdx.x;
     const int zb = b % a.zblocks; b /= a.zblocks;
     const int ty = b % a.tilesY;  b /= a.tilesY;
     const int tx = b % a.tilesX;
@@ -548,38 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_c8_kernel(ConvArgs a) {
     for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
-        {
-            const int c0 = chunk * 8;
-            if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
-                             sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
-            else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
-                             sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
-        }
-        f32x4 v[NSTAGE];
-#pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
-            const int f = tid + 256 * i;
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (f < NF4) {
-                const int col = f / (HZ * 2), w = f - col * (HZ * 2);
-                const int hz = w >> 1, half = w & 1;
-                const int hx = col / HY, hy = col - hx * HY;
-                const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-                if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
-                    const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
-                                        + (gz >> suz)) * 8 + half * 4;
-                    v[i] = *reinterpret_cast<const f32x4*>(src + idx);
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
-            const int f = tid + 256 * i;
-            if (f < NF4) *reinterpret_cast<f32x4*>(&lds[f * 4]) = v[i];
-        }
-        __syncthreads();
+        stage_halo_tile(a, chunk * 8, p, x0, y0, z0, tid, lds);
 
         const f32x4* wp = a.wpack + (size_t)chunk * NSLAB8 * 64 + lane;
 #pragma unroll
@@ -643,39 +359,6 @@ __host__ __device__ constexpr int ftap_off(int j) {      // folded tap j = (dxi 
 }
 __host__ __device__ constexpr int mtf_off(int mt) {      // column mt of a parity class
     return ((2 * (mt >> 2)) * HY + 2 * (mt & 3)) * HZ * 8;
-}
-
-// One 8-channel halo tile: global -> registers -> (barrier) -> LDS -> (barrier); zero 'same' padding, srcA read at >> u.
-__device__ __forceinline__ void stage_halo_tile(const ConvArgs& a, int c0, int p, int x0, int y0, int z0, int tid, float* lds) {
-    f32x4 v[NSTAGE];
-    const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
-    if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
-                     sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
-    else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
-                     sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
-#pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
-        const int f = tid + 256 * i;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (f < NF4) {
-            const int col = f / (HZ * 2), w = f - col * (HZ * 2);
-            const int hz = w >> 1, half = w & 1;
-            const int hx = col / HY, hy = col - hx * HY;
-            const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-            if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
-                const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
-                                    + (gz >> suz)) * 8 + half * 4;
-                v[i] = *reinterpret_cast<const f32x4*>(src + idx);
-            }
-        }
-    }
-    __syncthreads();                                          // every wave is done reading the previous tile
-#pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
-        const int f = tid + 256 * i;
-        if (f < NF4) *reinterpret_cast<f32x4*>(&lds[f * 4]) = v[i];
-    }
-    __syncthreads();
 }
 
 template <int NT>
@@ -855,38 +538,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_c8_fold_kernel(ConvArgs a) 
 
     const int nA = a.CA >> 3;
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
-        {
-            const int c0 = chunk * 8;
-            if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
-                             sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
-            else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
-                             sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
-        }
-        f32x4 v[NSTAGE];
-#pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
-            const int f = tid + 256 * i;
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (f < NF4) {
-                const int col = f / (HZ * 2), w = f - col * (HZ * 2);
-                const int hz = w >> 1, half = w & 1;
-                const int hx = col / HY, hy = col - hx * HY;
-                const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-                if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
-                    const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
-                                        + (gz >> suz)) * 8 + half * 4;
-                    v[i] = *reinterpret_cast<const f32x4*>(src + idx);
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
-            const int f = tid + 256 * i;
-            if (f < NF4) *reinterpret_cast<f32x4*>(&lds[f * 4]) = v[i];
-        }
-        __syncthreads();
+        stage_halo_tile(a, chunk * 8, p, x0, y0, z0, tid, lds);
 
         if (chunk < nA) {
             const f32x4* wp = a.wpack + ((size_t)chunk * 2 + py) * NFSLAB8 * 64 + lane;
@@ -1370,95 +1022,16 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// first conv fused with the sliding-window gather (volume path): reads the reflect-padded volume directly (the patch
-// tensor is never materialised), stages the 1-channel halo tile of an 8 x 8 x 16 output block in LDS, 4 voxels x 8
-// channels per thread.  Zero 'same' padding applies at the PATCH border (patch-local coordinate outside [0, n)),
-// reflect padding at the VOLUME border -- exactly np.pad(..., 'reflect') followed by Conv3D(padding='same').
-// ------------------------------------------------------------------------------------------------
-constexpr int F1X = 8, F1Y = 8, F1Z = 16;
-template <int COUT>
-__global__ __launch_bounds__(256) void conv_first_vol_kernel(const float* __restrict__ vol, TileGeom q, int p_begin,
-                                                             const float* __restrict__ w, const float* __restrict__ epi,
-                                                             float* __restrict__ out, int act) {
-    __shared__ float tile[(F1X + 2) * (F1Y + 2) * (F1Z + 2)];
-    __shared__ int mapx[F1X + 2], mapy[F1Y + 2], mapz[F1Z + 2];       // volume index per halo coordinate, -1 = zero padding
-    const int tid = threadIdx.x;
-    const int tilesX = (q.nx + F1X - 1) / F1X, tilesY = (q.ny + F1Y - 1) / F1Y, tilesZ = (q.nz + F1Z - 1) / F1Z;
-    int b = blockIdx.x;
-    const int tz = b % tilesZ; b /= tilesZ;
-    const int ty = b % tilesY; b /= tilesY;
-    const int tx = b % tilesX; const int lp = b / tilesX;
-    const int pg = p_begin + lp;
-    const int pk = pg % q.gz, pj = (pg / q.gz) % q.gy, pi = pg / (q.gz * q.gy);
-    const int x0 = tx * F1X, y0 = ty * F1Y, z0 = tz * F1Z;
-    constexpr int HX1 = F1X + 2, HY1 = F1Y + 2, HZ1 = F1Z + 2;
-    if (tid < HX1) { const int l = x0 - 1 + tid; mapx[tid] = (l >= 0 && l < q.nx) ? reflect_idx(pi * q.cx + l - q.bx, q.vx) : -1; }
-    else if (tid >= 64 && tid < 64 + HY1) { const int t = tid - 64, l = y0 - 1 + t; mapy[t] = (l >= 0 && l < q.ny) ? reflect_idx(pj * q.cy + l - q.by, q.vy) : -1; }
-    else if (tid >= 128 && tid < 128 + HZ1) { const int t = tid - 128, l = z0 - 1 + t; mapz[t] = (l >= 0 && l < q.nz) ? reflect_idx(pk * q.cz + l - q.bz, q.vz) : -1; }
-    __syncthreads();
-    for (int e = tid; e < HX1 * HY1 * HZ1; e += 256) {
-        const int hz = e % HZ1, hy = (e / HZ1) % HY1, hx = e / (HZ1 * HY1);
-        const int sx = mapx[hx], sy = mapy[hy], sz = mapz[hz];
-        tile[e] = (sx >= 0 && sy >= 0 && sz >= 0) ? vol[((size_t)sx * q.vy + sy) * q.vz + sz] : 0.f;
-    }
-    __syncthreads();
-    // thread -> (column c in 0..63, z quarter): 4 consecutive z per thread
-    const int zq = tid & 3, col = tid >> 2;
-    const int cx = col >> 3, cy = col & 7;
-    float acc[4][COUT];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[v][c] = 0.f;
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            float in[6];
-            const int base = ((cx + dx) * HY1 + (cy + dy)) * HZ1 + zq * 4;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) in[k] = tile[base + k];
-#pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                const float* wt = w + ((dx * 3 + dy) * 3 + dz) * COUT;          // uniform address -> scalar loads
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-#pragma unroll
-                    for (int c = 0; c < COUT; ++c) acc[v][c] = fmaf(in[v + dz], wt[c], acc[v][c]);
-            }
-        }
-    const float alpha = act == 0 ? kLeakyAlpha : 0.f;
-    const float* ep = epi;
-    const int x = x0 + cx, y = y0 + cy;
-    if (x >= q.nx || y >= q.ny) return;
-    constexpr int OQ = COUT / 8;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int z = z0 + zq * 4 + v;
-        if (z >= q.nz) continue;
-#pragma unroll
-        for (int qq = 0; qq < OQ; ++qq) {
-            f32x4 o[2];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = qq * 8 + e;
-                const float t = acc[v][c] + ep[c];
-                o[e >> 2][e & 3] = (t >= 0.f ? t : t * alpha) * ep[COUT + c] + ep[2 * COUT + c];
-            }
-            float* dst = out + ((((size_t)(lp * q.nx + x) * q.ny + y) * OQ + qq) * q.nz + z) * 8;
-            *reinterpret_cast<f32x4*>(dst) = o[0];
-            *reinterpret_cast<f32x4*>(dst + 4) = o[1];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// First conv (Cin = 1, Cout = 8) on the matrix cores, fused with the sliding-window gather.  This layer is HBM-bound
+// First conv (Cin = 1, Cout = 8) on the matrix cores, fused with the sliding-window gather (volume path): reads the
+// reflect-padded volume directly (the patch tensor is never materialised).  Zero 'same' padding applies at the PATCH
+// border (patch-local coordinate outside [0, n)), reflect padding at the VOLUME border -- exactly np.pad(..., 'reflect')
+// followed by Conv3D(padding='same').  This layer is HBM-bound
 // (AI 12 flop/B: it writes 8 channels per input voxel), but a VALU version is issue-bound at 1.3 TB/s.  MFMA rows are
 // (x-select, cout) as in conv3_mfma_c8_kernel: one MFMA column = 16 z of TWO x-adjacent voxels sharing a 4 x 3 x 3
 // footprint: K = 36 taps = 9 MFMAs (lane group g owns tap 4t + g), the 9 weight values per lane stay in registers,
 // the B operand is one ds_read_b32 per MFMA from the 1-channel halo tile.  8 x 8 x 16 outputs per workgroup.
 // ------------------------------------------------------------------------------------------------
+constexpr int F1X = 8, F1Y = 8, F1Z = 16;
 __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ vol, TileGeom q, int p_begin,
                                                               const float* __restrict__ wfirst /* [9][64] */,
                                                               const float* __restrict__ epi /* [3][8] */,
@@ -1557,7 +1130,6 @@ struct ConvPlan {
     int pool_dst;         // tensor id or -1
     bool head;
     bool c8;              // Cout == 8: paired-column kernel
-    bool pair;            // Cin % 16 == 0: two planes per stage
     bool fold;            // decoder conv over concat([upsample(low), skip]): folded taps for the upsampled channels
     bool bf;              // split-bf16 (bf16x6) matrix-pipe kernel instead of the f32-input MFMA kernel
     int nt_used;          // instantiation launched by the last run (small grids split NT = 4 into 2 x NT = 2)
@@ -1618,23 +1190,6 @@ void pack_conv_weights(const float* k, int cin, int cout, int NT, float* dst) {
                         float v = 0.f;
                         if (tap < 27 && co < cout) v = k[((size_t)tap * cin + ci) * cout + co];
                         dst[((((size_t)ch * NSLAB + s) * NT + nt) * 64 + lane) * 4 + t] = v;
-                    }
-}
-
-// PAIR packing (Cin multiple of 16): slab = tap, lane group g -> plane g>>1, channels 4(g&1)..+3 of that plane:
-//   wpack[pair][tap][nt][lane = g*16 + n][t] = K[tap][cin = 16*pair + 8*(g>>1) + 4*(g&1) + t][cout = 16*nt + n]
-void pack_conv_weights_pair(const float* k, int cin, int cout, int NT, float* dst) {
-    const int npairs = cin / 16;
-    for (int pr = 0; pr < npairs; ++pr)
-        for (int s = 0; s < 27; ++s)
-            for (int nt = 0; nt < NT; ++nt)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int t = 0; t < 4; ++t) {
-                        const int g = lane >> 4, n = lane & 15;
-                        const int ci = 16 * pr + 8 * (g >> 1) + 4 * (g & 1) + t, co = 16 * nt + n;
-                        float v = 0.f;
-                        if (co < cout) v = k[((size_t)s * cin + ci) * cout + co];
-                        dst[((((size_t)pr * 27 + s) * NT + nt) * 64 + lane) * 4 + t] = v;
                     }
 }
 
@@ -1816,26 +1371,11 @@ void pack_conv_weights_bf(const float* k, int cin, int cout, int nt_total, int C
     }
 }
 
-int conv_dma_mask() {      // which NT instantiations use the LDS-DMA kernel: bit 0 NT=1, bit 1 NT=2, bit 2 NT=4
-    static int mask = -1;
-    if (mask < 0) { const char* e = getenv("CT_CONV_DMA"); mask = e ? atoi(e) : kConvDmaDefaultMask; }
-    return mask;
-}
-
 template <int NT>
-int launch_conv(const ConvArgs& a, int P, bool pair, bool fold, hipStream_t st) {
+int launch_conv(const ConvArgs& a, int P, bool fold, hipStream_t st) {
     const int nblk = P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
-    if (fold) {
-        hipLaunchKernelGGL((conv3_mfma_fold_kernel<NT>), dim3(nblk), dim3(256), 0, st, a);
-        return (int)hipGetLastError();
-    }
-    const int bit = NT == 1 ? 1 : (NT == 2 ? 2 : 4);
-    if (!pair && (conv_dma_mask() & bit)) {
-        hipLaunchKernelGGL((conv3_mfma_dma_kernel<NT>), dim3(nblk), dim3(256), 0, st, a);
-        return (int)hipGetLastError();
-    }
-    if (pair) hipLaunchKernelGGL((conv3_mfma_kernel<NT, true>), dim3(nblk), dim3(256), 0, st, a);
-    else      hipLaunchKernelGGL((conv3_mfma_kernel<NT, false>), dim3(nblk), dim3(256), 0, st, a);
+    if (fold) hipLaunchKernelGGL((conv3_mfma_fold_kernel<NT>), dim3(nblk), dim3(256), 0, st, a);
+    else      hipLaunchKernelGGL((conv3_mfma_kernel<NT>), dim3(nblk), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -2062,10 +1602,6 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
                 c.c8 = true;
                 arena.resize(arena.size() + (size_t)(c.cin / 8) * NSLAB8 * 64 * 4);
                 pack_conv_weights_c8(kern, c.cin, arena.data() + c.wpack_off);
-            } else if (kUsePairStaging && c.cin % 16 == 0 && c.NT < 4) {   // two planes per stage, 27 exact slabs (NT = 4 would spill)
-                c.pair = true;
-                arena.resize(arena.size() + (size_t)(c.cin / 16) * 27 * c.nt_total * 64 * 4);
-                pack_conv_weights_pair(kern, c.cin, c.cout, c.nt_total, arena.data() + c.wpack_off);
             } else {
                 arena.resize(arena.size() + (size_t)(c.cin / 8) * NSLAB * c.nt_total * 64 * 4);
                 pack_conv_weights(kern, c.cin, c.cout, c.nt_total, arena.data() + c.wpack_off);
@@ -2123,13 +1659,8 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             const float* epi = h->d_weights + c.epi_off;
             if (vsrc && c.cout == 8) {
                 const int nb1 = P * ((d[0] + F1X - 1) / F1X) * ((d[1] + F1Y - 1) / F1Y) * ((d[2] + F1Z - 1) / F1Z);
-                static const bool use_valu = getenv("CT_FIRST_VALU") != nullptr;
-                if (use_valu)
-                    hipLaunchKernelGGL(conv_first_vol_kernel<8>, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin, wt, epi,
-                                       tptr(c.dst), ad.act);
-                else
-                    hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin,
-                                       h->d_weights + h->first_mfma_off, epi, tptr(c.dst), ad.act);
+                hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin,
+                                   h->d_weights + h->first_mfma_off, epi, tptr(c.dst), ad.act);
             } else if (c.cout == 8)
                 hipLaunchKernelGGL(conv_first_kernel<8>, dim3(nblk), dim3(256), 0, st, tptr(c.srcB), wt, epi, tptr(c.dst), P, d[0], d[1], d[2], ad.act);
             else if (c.cout == 64)
@@ -2156,7 +1687,6 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             }
             if (c.head) { a.head = h->d_weights + h->head_off; a.head_out = prob_out; }
             a.act = ad.act;
-            a.xcd_remap = getenv("CT_XCD_REMAP") ? 1 : 0;      // measured: 24.0 vs 23.9 ms/volume -> off (kernel is MFMA-bound)
             a.tilesX = (d[0] + TX - 1) / TX; a.tilesY = (d[1] + TY - 1) / TY; a.zblocks = (d[2] + 15) / 16;
             // small grids: a wide layer whose NT = 4 grid is only a few "waves" of workgroups loses up to a third to the
             // tail; NT = 2 with two cout groups doubles the workgroups (and fits 3 per CU) at the price of staging twice
@@ -2164,7 +1694,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             {
                 const long nblk4 = (long)P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
                 static const int thr = getenv("CT_CONV_SPLIT_THR") ? atoi(getenv("CT_CONV_SPLIT_THR")) : 4096;
-                if (!c.c8 && !c.pair && !c.head && c.NT == 4 && nblk4 < thr) { NTsel = 2; a.ngroups = c.nt_total / 2; }   // (the fused head needs all channels in one block)
+                if (!c.c8 && !c.head && c.NT == 4 && nblk4 < thr) { NTsel = 2; a.ngroups = c.nt_total / 2; }   // (the fused head needs all channels in one block)
             }
             c.nt_used = NTsel;
             int rc;
@@ -2188,9 +1718,9 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 rc = (int)hipGetLastError();
             } else
             switch (NTsel) {
-                case 1: rc = launch_conv<1>(a, P, c.pair, c.fold, st); break;
-                case 2: rc = launch_conv<2>(a, P, c.pair, c.fold, st); break;
-                case 4: rc = launch_conv<4>(a, P, c.pair, c.fold, st); break;
+                case 1: rc = launch_conv<1>(a, P, c.fold, st); break;
+                case 2: rc = launch_conv<2>(a, P, c.fold, st); break;
+                case 4: rc = launch_conv<4>(a, P, c.fold, st); break;
                 default: return CT_ESHAPE;
             }
             if (rc) return rc;

@@ -176,7 +176,7 @@ def main():
         elif code > 100:
             name = f"conv3_mfma_fold_kernel<{code - 100}>"
         else:
-            name = f"conv3_mfma_kernel<{code}, false>"
+            name = f"conv3_mfma_kernel<{code}>"
         # MFMA work actually issued: folded decoder convs run 12 instead of 27 taps on the upsampled channels (Cout = 8: 18 of 36)
         ca = max(L.ct_unet_layer_fold_channels(model._handle, i), 0)
         issued = flops * ((cin.value - ca) + ca * 12.0 / 27.0) / cin.value
