@@ -9,11 +9,15 @@
 //   * activations live in HBM as fp32 blocks [patch][x][y][C/8][z][8]: one (x,y) column of one
 //     8-channel group is 16 voxels x 32 B = 512 contiguous bytes, so every halo-tile load and
 //     every epilogue store is a run of full 128-B lines;
-//   * a 3x3x3 conv is an implicit GEMM  D[cout][voxel] = sum_k W[cout][k] * A[k][voxel],
-//     k = (tap, cin), on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32 (an fmaf chain
-//     bit-for-bit; 157 TF peak = the fp32 vector peak, reached from one wave per SIMD);
-//     a 16-voxel MFMA column is one (x,y) column x 16 z; the A tile (halo included) is staged in
-//     LDS once per 8-channel chunk, weights stream L2 -> registers (1 KiB per wave-load, coalesced);
+//   * a 3x3x3 conv is an implicit GEMM  D[cout][voxel] = sum_k W[cout][k] * A[k][voxel],  k = (tap, cin); a 16-voxel
+//     MFMA column is one (x,y) column x 16 z; the A tile (halo included) is staged in LDS once per 8-channel chunk,
+//     weights stream L2 -> registers (1 KiB per wave-load, coalesced).  Two kernel families share this structure:
+//       - conv3_bf16x6_kernel (default): every fp32 operand is split exactly into three bf16 parts and multiplied on
+//         the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, six products, fp32 accumulate) -- fp32-faithful results at
+//         2.5x fewer matrix-pipe cycles than the f32-input instruction;
+//       - conv3_mfma_kernel / _fold / _c8 (CT_CONV_MATH=f32): the exact-fp32 instruction v_mfma_f32_16x16x4_f32
+//         (an fmaf chain bit-for-bit; 157 TF peak = the fp32 vector peak);
+//     decoder convs fold the taps that coincide after nearest-neighbour upsampling (12 of 27 per upsampled channel);
 //   * bias + LeakyReLU/ReLU + BatchNorm-affine run in the accumulator registers; max-pool, the
 //     nearest-upsample + concat of the decoder and the 1x1x1 sigmoid head are fused into the
 //     producing / consuming conv so no pooled/upsampled/concatenated tensor is ever materialised
