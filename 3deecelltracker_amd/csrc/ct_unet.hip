@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const float* __restri
 // the B operand is one ds_read_b32 per MFMA from the 1-channel halo tile.  8 x 8 x 16 outputs per workgroup.
 // ------------------------------------------------------------------------------------------------
 constexpr int F1X = 8, F1Y = 8, F1Z = 16;
-__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ vol, TileGeom q, int p_begin,
+__global__ __launch_bounds__(256, 8) void conv_first_mfma_kernel(const float* __restrict__ vol, TileGeom q, int p_begin,
                                                               const float* __restrict__ wfirst /* [9][64] */,
                                                               const float* __restrict__ epi /* [3][8] */,
                                                               float* __restrict__ out, int act) {
