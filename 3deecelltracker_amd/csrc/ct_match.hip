@@ -485,20 +485,10 @@ __global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restr
     if (t >= m) return;
     const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
     double acc = 0.0;
-    for (int r0 = lane; r0 < n; r0 += 64 * 8) {        // 8 columns per lane in flight together; accumulation order unchanged
-        double rx[8], ry[8], rz[8], pw[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = min(r0 + 64 * u, n - 1);
-            rx[u] = ref[3 * r]; ry[u] = ref[3 * r + 1]; rz[u] = ref[3 * r + 2];
-            pw[u] = P ? P[(size_t)t * n + r] : 1.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double dx = rx[u] - yx, dy = ry[u] - yy, dz = rz[u] - yz;
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            if (r0 + 64 * u < n) acc += P ? d2 * pw[u] : d2;
-        }
+    for (int r = lane; r < n; r += 64) {
+        const double dx = ref[3 * r] - yx, dy = ref[3 * r + 1] - yy, dz = ref[3 * r + 2] - yz;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        acc += P ? d2 * P[(size_t)t * n + r] : d2;
     }
     acc = wave_sum_d(acc);
     if (lane == 0) rowpart[t] = acc;
@@ -573,35 +563,17 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
     const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
     const double* pr = prior + (size_t)t * n;
     double* po = P + (size_t)t * n;
-    // batches of 8 columns per lane: all loads of a batch are issued before its exp chains start (a plain loop pays one
-    // L2 round trip per column); arithmetic and its order are unchanged
     double acc = 0.0;
-    for (int r0 = lane; r0 < n; r0 += 64 * 8) {
-        double px[8], py[8], pz[8], pv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = min(r0 + 64 * u, n - 1);
-            px[u] = pred[3 * r]; py[u] = pred[3 * r + 1]; pz[u] = pred[3 * r + 2]; pv[u] = pr[r];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = r0 + 64 * u;
-            const double dx = px[u] - yx, dy = py[u] - yy, dz = pz[u] - yz;
-            const double k = exp(-(dx * dx + dy * dy + dz * dz) / two_s2);
-            const double num = legacy ? pv[u] * k : (1.0 - gamma) * pv[u] * k / norm;
-            if (r < n) { po[r] = num; acc += num; }
-            pv[u] = num;
-        }
+    for (int r = lane; r < n; r += 64) {
+        const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
+        const double k = exp(-(dx * dx + dy * dy + dz * dz) / two_s2);
+        const double num = legacy ? pr[r] * k : (1.0 - gamma) * pr[r] * k / norm;
+        po[r] = num;
+        acc += num;
     }
     acc = wave_sum_d(acc);
     const double den = legacy ? acc + gamma * norm / ((1.0 - gamma) * vol) : acc + gamma / vol;
-    for (int r0 = lane; r0 < n; r0 += 64 * 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = po[min(r0 + 64 * u, n - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int r = r0 + 64 * u; if (r < n) po[r] = v[u] / den; }
-    }
+    for (int r = lane; r < n; r += 64) po[r] = po[r] / den;
 }
 
 // column statistics, stage 1: block (x: 64 columns, y: row segment) -> part[seg][4][n] = colsum, Y^T P
@@ -616,16 +588,9 @@ __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict_
     const int t0 = seg * per, t1 = min(m, t0 + per);
     double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
     if (r < n)
-        for (int tb = t0 + rl; tb < t1; tb += 4 * 8) {       // 8 rows in flight together; accumulation order unchanged
-            double p[8], gx[8], gy[8], gz[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = min(tb + 4 * u, m - 1);
-                p[u] = P[(size_t)t * n + r]; gx[u] = tgt[3 * t]; gy[u] = tgt[3 * t + 1]; gz[u] = tgt[3 * t + 2];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (tb + 4 * u < t1) { s += p[u]; sx = fma(gx[u], p[u], sx); sy = fma(gy[u], p[u], sy); sz = fma(gz[u], p[u], sz); }
+        for (int t = t0 + rl; t < t1; t += 4) {
+            const double p = P[(size_t)t * n + r];
+            s += p; sx = fma(tgt[3 * t], p, sx); sy = fma(tgt[3 * t + 1], p, sy); sz = fma(tgt[3 * t + 2], p, sz);
         }
     red[rl][cl][0] = s; red[rl][cl][1] = sx; red[rl][cl][2] = sy; red[rl][cl][3] = sz;
     __syncthreads();
@@ -734,16 +699,9 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
     if (second) j -= n;
     const double* row = second ? Gln + (size_t)j * n : G + (size_t)j * n;
     double ax = 0.0, ay = 0.0, az = 0.0;
-    for (int i0 = lane; i0 < n; i0 += 64 * 8) {        // 8 columns per lane in flight together; accumulation order unchanged
-        double g[8], cx[8], cy[8], cz[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = min(i0 + 64 * u, n - 1);
-            g[u] = row[i]; cx[u] = C[i]; cy[u] = C[n + i]; cz[u] = C[2 * n + i];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i0 + 64 * u < n) { ax = fma(cx[u], g[u], ax); ay = fma(cy[u], g[u], ay); az = fma(cz[u], g[u], az); }
+    for (int i = lane; i < n; i += 64) {
+        const double g = row[i];
+        ax = fma(C[i], g, ax); ay = fma(C[n + i], g, ay); az = fma(C[2 * n + i], g, az);
     }
     ax = wave_sum_d(ax); ay = wave_sum_d(ay); az = wave_sum_d(az);
     if (lane != 0) return;
