@@ -8,7 +8,7 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libctamd.so"
+LIB_PATH = Path(os.environ.get("CTAMD_LIB", _HERE / "libctamd.so"))    # CTAMD_LIB: A/B builds of the same ABI (dev)
 
 
 class CtamdError(RuntimeError):
