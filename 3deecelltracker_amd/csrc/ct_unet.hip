@@ -628,18 +628,35 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_c8_fold_kernel(ConvArgs a) 
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int BF_POS = HX * HY * HZ;              // halo positions
-constexpr int BF_PLANE = BF_POS * 16;             // bytes per component plane
 constexpr int KB_STD = 7, KB_FOLD = 3, KB_C8 = 9, KB_C8F = 5;
 
-// LDS position offset of tap slot t for the four tap sets (0 for the zero-weight padding slots)
-__host__ __device__ constexpr int bf_tap_pos(bool c8, bool folded, int t) {
+// Tile geometry.  Z8 = false: 4 x 8 columns x 16 z (an MFMA column = one (x, y) column).  Z8 = true (levels with Z <= 8,
+// e.g. every level of unet3_b): 8 x 8 columns x 8 z, an MFMA column = TWO y-adjacent columns x 8 z (lane bit 3 selects the
+// column), so no MFMA lane multiplies padding.
+template <bool Z8> struct BfGeom {
+    static constexpr int TXv = Z8 ? 8 : 4, TYv = 8, ZB = Z8 ? 8 : 16;
+    static constexpr int HXv = TXv + 2, HYv = TYv + 2, HZv = ZB + 2;
+    static constexpr int POS = HXv * HYv * HZv;               // halo positions
+    static constexpr int PLANE = POS * 16;                    // bytes per component plane
+    static constexpr int NF4v = POS * 2, NSTAGEv = (NF4v + 255) / 256;
+};
+static_assert(BfGeom<false>::HXv == HX && BfGeom<false>::HYv == HY && BfGeom<false>::HZv == HZ, "geometry of the f32 kernels");
+
+// LDS position offset of tap slot t for the four tap sets (0 for the zero-weight padding slots); hy, hz = halo tile strides
+__host__ __device__ constexpr int bf_tap_pos(bool c8, bool folded, int t, int hy, int hz) {
     if (!folded) {
         const int ntap = c8 ? 36 : 27;
-        return t < ntap ? ((t / 9) * HY + (t / 3) % 3) * HZ + t % 3 : 0;
+        return t < ntap ? ((t / 9) * hy + (t / 3) % 3) * hz + t % 3 : 0;
     }
-    if (!c8) return t < 12 ? ((t / 6) * HY + (t / 3) % 2) * HZ + t % 3 : 0;
-    return t < 18 ? (((t / 6) == 2 ? 3 : (t / 6)) * HY + (t / 3) % 2) * HZ + t % 3 : 0;
+    if (!c8) return t < 12 ? ((t / 6) * hy + (t / 3) % 2) * hz + t % 3 : 0;
+    return t < 18 ? (((t / 6) == 2 ? 3 : (t / 6)) * hy + (t / 3) % 2) * hz + t % 3 : 0;
+}
+
+// position offset of the wave's MFMA column mt (relative to the wave / lane base) for the column mappings of the kernel
+__host__ __device__ constexpr int bf_col_pos(bool c8, bool kfold, bool z8, int mt, int hy, int hz) {
+    if (c8) return mt * (kfold ? 2 : 1) * hz;
+    if (!z8) return kfold ? (2 * (mt >> 2) * hy + 2 * (mt & 3)) * hz : ((mt >> 2) * hy + (mt & 3)) * hz;
+    return kfold ? (2 * (mt >> 1) * hy + 4 * (mt & 1)) * hz : ((mt >> 2) * hy + 2 * (mt & 3)) * hz;
 }
 
 __device__ __forceinline__ void bf_split4(const f32x4 v, uint2& h, uint2& m, uint2& l) {
@@ -658,21 +675,23 @@ __device__ __forceinline__ void bf_split4(const f32x4 v, uint2& h, uint2& m, uin
 }
 
 // One 8-channel halo tile -> three bf16 planes in LDS (see stage_halo_tile for the addressing).
+template <bool Z8>
 __device__ __forceinline__ void bf_stage_tile(const ConvArgs& a, int c0, int p, int x0, int y0, int z0, int tid, char* lds) {
-    f32x4 v[NSTAGE];
+    using G = BfGeom<Z8>;
+    f32x4 v[G::NSTAGEv];
     const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
     if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
                      sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
     else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
                      sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
 #pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
+    for (int i = 0; i < G::NSTAGEv; ++i) {
         const int f = tid + 256 * i;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (f < NF4) {
-            const int col = f / (HZ * 2), w = f - col * (HZ * 2);
+        if (f < G::NF4v) {
+            const int col = f / (G::HZv * 2), w = f - col * (G::HZv * 2);
             const int hz = w >> 1, half = w & 1;
-            const int hx = col / HY, hy = col - hx * HY;
+            const int hx = col / G::HYv, hy = col - hx * G::HYv;
             const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
             if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
                 const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
@@ -683,26 +702,27 @@ __device__ __forceinline__ void bf_stage_tile(const ConvArgs& a, int c0, int p, 
     }
     __syncthreads();                                          // every wave is done reading the previous tile
 #pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
+    for (int i = 0; i < G::NSTAGEv; ++i) {
         const int f = tid + 256 * i;                          // slot f = position f >> 1, channel half f & 1
-        if (f < NF4) {
+        if (f < G::NF4v) {
             uint2 h, m, l;
             bf_split4(v[i], h, m, l);
             char* d = lds + f * 8;
             *reinterpret_cast<uint2*>(d) = h;
-            *reinterpret_cast<uint2*>(d + BF_PLANE) = m;
-            *reinterpret_cast<uint2*>(d + 2 * BF_PLANE) = l;
+            *reinterpret_cast<uint2*>(d + G::PLANE) = m;
+            *reinterpret_cast<uint2*>(d + 2 * G::PLANE) = l;
         }
     }
     __syncthreads();
 }
 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * 3 + comp) * 64]
-template <int NT, int NCOL, int KB, bool C8, bool FOLDED, int COLSTRIDE_X, int COLSTRIDE_Y>
+template <int NT, int NCOL, int KB, bool C8, bool FOLDED, bool KFOLD, bool Z8>
 __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char* lds, int lanepos, int g,
                                              const uint4* wp, int nt_total) {          // (no __restrict__: see the prefetch)
     // NT == 1: a K-block is only 24-48 MFMAs (400-800 cycles), less than the L2 round trip of its weight fragments, so the
     // next block's fragments are requested before this block's MFMAs (12 more VGPRs).  Wider tiles hide it by themselves.
+    using G = BfGeom<Z8>;
     constexpr bool PREFETCH = NT == 1;
     u32x4 wnext[NT][3];
     if constexpr (PREFETCH) {
@@ -711,8 +731,8 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-        const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1),
-                  t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3);
+        const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb, G::HYv, G::HZv), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1, G::HYv, G::HZv),
+                  t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2, G::HYv, G::HZv), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3, G::HYv, G::HZv);
         const int tp = g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
         const char* ab = lds + (lanepos + tp) * 16;
         bf16x8 wv[NT][3];
@@ -740,10 +760,10 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int mt = cg + q;
-                const int cpos = C8 ? mt * COLSTRIDE_Y * HZ : ((mt >> 2) * COLSTRIDE_X * HY + (mt & 3) * COLSTRIDE_Y) * HZ;
+                const int cpos = bf_col_pos(C8, KFOLD, Z8, mt, G::HYv, G::HZv);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    av[q][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + cpos * 16 + c * BF_PLANE));
+                    av[q][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + cpos * 16 + c * G::PLANE));
             }
             // all 12 fragment reads of the column group go out before its first MFMA (left alone, the scheduler issues them just in
             // time to save registers and every pair of MFMAs then eats a full LDS round trip)
@@ -761,11 +781,14 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
     }
 }
 
-template <int NT, bool C8, bool FOLD>
+template <int NT, bool C8, bool FOLD, bool Z8>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(ConvArgs a) {
     static_assert(!C8 || NT == 1, "the Cout = 8 kernel has one row tile");
+    static_assert(!(C8 && Z8), "Cout = 8 layers sit at the full-resolution level");
+    using G = BfGeom<Z8>;
     constexpr int NCOL = C8 ? 4 : 8;
-    __shared__ __attribute__((aligned(16))) char lds[3 * BF_PLANE];
+    constexpr int HYg = G::HYv, HZg = G::HZv;
+    __shared__ __attribute__((aligned(16))) char lds[3 * G::PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int b = blockIdx.x;
     const int cg = b % a.ngroups; b /= a.ngroups;
@@ -774,17 +797,24 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
     const int ty = b % a.tilesY;  b /= a.tilesY;
     const int tx = b % a.tilesX;
     const int p = b / a.tilesX;
-    const int x0 = tx * TX, y0 = ty * TY, z0 = zb * 16;
-    const int g = lane >> 4, zl = lane & 15;
+    const int x0 = tx * G::TXv, y0 = ty * G::TYv, z0 = zb * G::ZB;
+    const int g = lane >> 4;
+    const int zl = Z8 ? (lane & 7) : (lane & 15);
+    const int csel = Z8 ? ((lane >> 3) & 1) : 0;              // Z8: which of the MFMA column's two y-adjacent columns
 
-    // wave -> columns.  plain: 2 x 4 block at (wx, wy); FOLD: parity class (wx, wy) = (px, py), stride 2;
-    // C8: x pair wx (stride-1 or parity-strided y)
-    const int wx = C8 ? 2 * (wave >> 1) : (FOLD ? (wave >> 1) : 2 * (wave >> 1));
-    const int wy = FOLD ? (wave & 1) : 4 * (wave & 1);
-    constexpr int CSX = FOLD ? 2 : 1, CSY = FOLD ? 2 : 1;
-    const int lanepos = (wx * HY + wy) * HZ + zl;
+    // wave -> columns.  plain: 2 x 4 block at (wx, wy) (Z8: 2 x 8 at (2 wave, 0), lane bit 3 = y parity);
+    // FOLD: parity class (wx, wy) = (px, py), stride 2 (Z8: lane bit 3 = +2 in y); C8: x pair wx
+    const int wx = C8 ? 2 * (wave >> 1) : (FOLD ? (wave >> 1) : (Z8 ? 2 * wave : 2 * (wave >> 1)));
+    const int wy = FOLD ? (wave & 1) : (Z8 ? 0 : 4 * (wave & 1));
+    const int lanepos = (wx * HYg + wy + (FOLD ? 2 : 1) * csel) * HZg + zl;
     // folded taps start at halo offset (px, py) (C8: (0, py))
-    const int foldpos = lanepos + (C8 ? wy * HZ : (wx * HY + wy) * HZ);
+    const int foldpos = lanepos + (C8 ? wy * HZg : (wx * HYg + wy) * HZg);
+    // output coordinates of MFMA column mt (relative to the tile origin)
+    auto col_x = [&](int mt) { return C8 ? wx : (FOLD ? (Z8 ? wx + 2 * (mt >> 1) : wx + 2 * (mt >> 2)) : wx + (mt >> 2)); };
+    auto col_y = [&](int mt) {
+        return C8 ? wy + (FOLD ? 2 : 1) * mt
+                  : (FOLD ? (Z8 ? wy + 2 * (2 * (mt & 1) + csel) : wy + 2 * (mt & 3)) : (Z8 ? 2 * (mt & 3) + csel : wy + (mt & 3)));
+    };
 
     f32x4 acc[NCOL][NT];
 #pragma unroll
@@ -800,22 +830,22 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
     if constexpr (FOLD) {
         const int cls = C8 ? wy : (wx * 2 + wy);
         for (int chunk = 0; chunk < nA; ++chunk) {
-            bf_stage_tile(a, chunk * 8, p, x0, y0, z0, tid, lds);
+            bf_stage_tile<Z8>(a, chunk * 8, p, x0, y0, z0, tid, lds);
             const uint4* wp = wbase + (((size_t)chunk * NCLS + cls) * KBF * a.nt_total + ntb) * 3 * 64;
-            bf_chunk_mma<NT, NCOL, KBF, C8, true, CSX, CSY>(acc, lds, foldpos, g, wp, a.nt_total);
+            bf_chunk_mma<NT, NCOL, KBF, C8, true, FOLD, Z8>(acc, lds, foldpos, g, wp, a.nt_total);
         }
     }
     for (int chunk = nA; chunk < a.nchunks; ++chunk) {
-        bf_stage_tile(a, chunk * 8, p, x0, y0, z0, tid, lds);
+        bf_stage_tile<Z8>(a, chunk * 8, p, x0, y0, z0, tid, lds);
         const uint4* wp = wbase + (((size_t)nA * NCLS * KBF + (size_t)(chunk - nA) * KBS) * a.nt_total + ntb) * 3 * 64;
-        bf_chunk_mma<NT, NCOL, KBS, C8, false, CSX, CSY>(acc, lds, lanepos, g, wp, a.nt_total);
+        bf_chunk_mma<NT, NCOL, KBS, C8, false, FOLD, Z8>(acc, lds, lanepos, g, wp, a.nt_total);
     }
 
     // ---- epilogue: bias -> activation -> BatchNorm affine; stores / fused pool / fused head as in the fp32 kernels
     const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
     const int z = z0 + zl;
     if constexpr (C8) {
-        // lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx + (g>>1), y = y0 + wy + CSY * mt
+        // lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx + (g>>1), y = y0 + col_y(mt)
         const int cb = 4 * (g & 1);
         const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
         const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + 16 + cb);
@@ -829,7 +859,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
                 const float t = r[e];
                 r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
             }
-            const int y = y0 + wy + CSY * mt;
+            const int y = y0 + col_y(mt);
             const bool ok = x < a.X && y < a.Y && z < a.Z;
             if (a.out && ok)
                 *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
@@ -864,7 +894,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
         if (a.out) {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
-                const int x = x0 + wx + CSX * (mt >> 2), y = y0 + wy + CSY * (mt & 3);
+                const int x = x0 + col_x(mt), y = y0 + col_y(mt);
                 if (x < a.X && y < a.Y && z < a.Z) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
@@ -878,18 +908,27 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
             }
         }
         if constexpr (!FOLD) {
-            if (a.pool) {      // MaxPooling3D (2,2,pz): the wave's 2x4 columns are two 2x2 blocks
+            if (a.pool) {      // MaxPooling3D (2,2,pz)
+                // !Z8: the wave's 2 x 4 columns are two 2 x 2 blocks {2 blk, 2 blk + 1, 4 + 2 blk, 5 + 2 blk};
+                //  Z8: MFMA columns j and j + 4 are x neighbours, the y neighbour sits in lane ^ 8 -> four 2 x 2 blocks
+                constexpr int NBLK = Z8 ? 4 : 2;
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    const int x = x0 + wx, y = y0 + wy + 2 * blk;
-                    const bool ok = (x + 1 < a.X) && (y + 1 < a.Y) && (z < a.Z);
+                for (int blk = 0; blk < NBLK; ++blk) {
+                    const int x = x0 + wx, y = y0 + (Z8 ? 2 * blk : wy + 2 * blk);
+                    const bool ok = (x + 1 < a.X) && (y + 1 < a.Y) && (z < a.Z) && (!Z8 || csel == 0);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         f32x4 m;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = fmaxf(fmaxf(acc[2 * blk][nt][e], acc[2 * blk + 1][nt][e]),
-                                            fmaxf(acc[4 + 2 * blk][nt][e], acc[5 + 2 * blk][nt][e]));
+                            float t;
+                            if constexpr (Z8) {
+                                t = fmaxf(acc[blk][nt][e], acc[blk + 4][nt][e]);
+                                t = fmaxf(t, __shfl_xor(t, 8));
+                            } else {
+                                t = fmaxf(fmaxf(acc[2 * blk][nt][e], acc[2 * blk + 1][nt][e]),
+                                          fmaxf(acc[4 + 2 * blk][nt][e], acc[5 + 2 * blk][nt][e]));
+                            }
                             if (a.pz == 2) t = fmaxf(t, __shfl_xor(t, 1));
                             m[e] = t;
                         }
@@ -917,7 +956,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
                 }
                 part += __shfl_xor(part, 16);
                 part += __shfl_xor(part, 32);
-                const int x = x0 + wx + CSX * (mt >> 2), y = y0 + wy + CSY * (mt & 3);
+                const int x = x0 + col_x(mt), y = y0 + col_y(mt);
                 if (g == 0 && x < a.X && y < a.Y && z < a.Z)
                     a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + hb)));
             }
@@ -1384,10 +1423,15 @@ int launch_conv(const ConvArgs& a, int P, bool fold, hipStream_t st) {
 }
 
 template <int NT>
-int launch_conv_bf(const ConvArgs& a, int P, bool fold, hipStream_t st) {
+int launch_conv_bf(const ConvArgs& a, int P, bool fold, bool z8, hipStream_t st) {
     const int nblk = P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
-    if (fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, true>), dim3(nblk), dim3(256), 0, st, a);
-    else      hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, false>), dim3(nblk), dim3(256), 0, st, a);
+    if (z8) {
+        if (fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, true, true>), dim3(nblk), dim3(256), 0, st, a);
+        else      hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, false, true>), dim3(nblk), dim3(256), 0, st, a);
+    } else {
+        if (fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, true, false>), dim3(nblk), dim3(256), 0, st, a);
+        else      hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, false, false>), dim3(nblk), dim3(256), 0, st, a);
+    }
     return (int)hipGetLastError();
 }
 
@@ -1691,7 +1735,12 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             }
             if (c.head) { a.head = h->d_weights + h->head_off; a.head_out = prob_out; }
             a.act = ad.act;
-            a.tilesX = (d[0] + TX - 1) / TX; a.tilesY = (d[1] + TY - 1) / TY; a.zblocks = (d[2] + 15) / 16;
+            // levels with Z <= 8 (all of unet3_b, the bottom of unet3_c): 8 x 8 x 8 tiles whose MFMA columns hold two (x, y)
+            // columns x 8 z instead of one x 16 z with half the lanes on padding (split-bf16 kernels, CT_CONV_Z8=0: off)
+            static const bool z8_on = !(getenv("CT_CONV_Z8") && atoi(getenv("CT_CONV_Z8")) == 0);
+            const bool z8 = z8_on && c.bf && !c.c8 && d[2] <= 8;
+            a.tilesX = z8 ? (d[0] + 7) / 8 : (d[0] + TX - 1) / TX; a.tilesY = (d[1] + TY - 1) / TY;
+            a.zblocks = z8 ? (d[2] + 7) / 8 : (d[2] + 15) / 16;
             // small grids: a wide layer whose NT = 4 grid is only a few "waves" of workgroups loses up to a third to the
             // tail; NT = 2 with two cout groups doubles the workgroups (and fits 3 per CU) at the price of staging twice
             int NTsel = c.NT;
@@ -1705,14 +1754,14 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             if (c.bf) {
                 if (c.c8) {
                     const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
-                    if (c.fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<1, true, true>), dim3(nblk), dim3(256), 0, st, a);
-                    else        hipLaunchKernelGGL((conv3_bf16x6_kernel<1, true, false>), dim3(nblk), dim3(256), 0, st, a);
+                    if (c.fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<1, true, true, false>), dim3(nblk), dim3(256), 0, st, a);
+                    else        hipLaunchKernelGGL((conv3_bf16x6_kernel<1, true, false, false>), dim3(nblk), dim3(256), 0, st, a);
                     rc = (int)hipGetLastError();
                 } else
                 switch (NTsel) {
-                    case 1: rc = launch_conv_bf<1>(a, P, c.fold, st); break;
-                    case 2: rc = launch_conv_bf<2>(a, P, c.fold, st); break;
-                    case 4: rc = launch_conv_bf<4>(a, P, c.fold, st); break;
+                    case 1: rc = launch_conv_bf<1>(a, P, c.fold, z8, st); break;
+                    case 2: rc = launch_conv_bf<2>(a, P, c.fold, z8, st); break;
+                    case 4: rc = launch_conv_bf<4>(a, P, c.fold, z8, st); break;
                     default: return CT_ESHAPE;
                 }
             } else if (c.c8) {
