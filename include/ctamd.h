@@ -87,7 +87,8 @@ int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int d
  * on the same low-res voxel (12 instead of 27 per channel): returns how many input channels of `layer` are folded (0 if
  * none).  `nt` above is then 100 + nt (conv3_mfma_fold_kernel) or -9 (Cout = 8 variant; -8 = unfolded Cout = 8 kernel).
  * Convs running the split-bf16 kernels (conv3_bf16x6_kernel<nt, c8, fold>; default, CT_CONV_MATH=f32 selects the f32-input
- * MFMA kernels when the model is created) report the same codes offset by 1000 (Cout = 8: -1008 / -1009).             */
+ * MFMA kernels when the model is created) report the same codes offset by 1000 (Cout = 8: -1008 / -1009).  Levels with
+ * Z <= 8 run that kernel's 8 x 8 x 8 tile instantiation (CT_CONV_Z8=0: the 4 x 8 x 16 one).                            */
 int ct_unet_layer_fold_channels(const ct_unet_t* h, int layer);
 int ct_unet_set_timing(ct_unet_t* h, int enable);
 int ct_unet_get_timing(ct_unet_t* h, float* ms_per_layer, int* launches_per_layer, int n_layers);
