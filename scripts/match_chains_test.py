@@ -9,7 +9,7 @@ x, y = synth.make_point_pair(600, seed=100, box=(512, 512, 32))
 xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True); yn = (y - mean) / scale
 a, b, c = _dev.points_dev(xn), _dev.points_dev(yn), _dev.points_dev(xn)
 def job(): return tl.match_device(ffn, a, b, c, 3, 3)[0]
-for cus, workers in ((64, 3), (64, 4), (64, 6), (96, 6), (224, 6), (224, 8)):
+for cus, workers in ((32, 1), (32, 2), (32, 3), (64, 3)):
     pipe = par.FramePipeline(device=0, match_cus=cus, workers=workers)
     for _ in range(workers): pipe.submit_match(job)
     pipe.drain(); torch.cuda.synchronize()
