@@ -50,13 +50,51 @@ def all_gather_varlen(local, counts: Sequence[int]):
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
-def sharded_map_gather(fn: Callable, items: Sequence, tail_shape=None, dtype=None, device=None):
+def chain_map(fn: Callable, items: Sequence, chains: int = 3):
+    """[fn(it) for it in items] with up to `chains` items in flight, each on its own host thread and HIP stream.
+
+    A PR-GLS match is a chain of dependent tiny kernels that leaves most of the GPU idle (37 ms alone, 13.5 ms per match
+    with three chains in flight); the matches of an ensemble prediction are independent, so their chains
+    interleave.  `fn` must be thread-safe (the TrackerLite / Tracker match paths are: all scratch is allocated per
+    call, the models are read-only).  Results are identical to the sequential map."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    items = list(items)
+    if chains <= 1 or len(items) <= 1 or not torch.cuda.is_available():
+        return [fn(it) for it in items]
+    device = torch.cuda.current_device()
+    n = min(int(chains), len(items))
+    streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+    free = list(range(n)); lock = threading.Lock()
+    ready = torch.cuda.Event(); ready.record()               # inputs produced on the caller's stream
+
+    def run(it):
+        with lock:
+            idx = free.pop()
+        try:
+            torch.cuda.set_device(device)
+            st = streams[idx]
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                out = fn(it)
+            st.synchronize()
+            return out
+        finally:
+            with lock:
+                free.append(idx)
+    with ThreadPoolExecutor(max_workers=n) as pool:
+        return list(pool.map(run, items))
+
+
+def sharded_map_gather(fn: Callable, items: Sequence, tail_shape=None, dtype=None, device=None, chains: int = 1):
     """Apply `fn(item) -> tensor` to this rank's share of `items` and all-gather the stacked results
-    in item order: [len(items), ...] on every rank."""
+    in item order: [len(items), ...] on every rank.  chains > 1: the rank's own items run `chains` at a time
+    (chain_map)."""
     import torch
     rank, world = dist_info()
     b, e = shard_range(len(items), rank, world)
-    mine = [fn(it) for it in items[b:e]]
+    mine = chain_map(fn, items[b:e], chains)
     if mine:
         local = torch.stack(mine)
     else:

@@ -33,6 +33,8 @@ BOUNDARY_XY = 6
 
 
 class Tracker:
+    ensemble_chains = 4      # source-volume predictions of one ensemble step in flight on this GPU (parallel.chain_map)
+
     def __init__(self, ffn_model, beta_tk=300, lambda_tk=0.1, max_iteration=20, ensemble=False, adjacent=False,
                  volume_shape=None, z_xy_ratio=1.0, miss_frame=None, unet_model=None, noise_level=None, shrink=(24, 24, 2),
                  unet_cache=None):
@@ -184,5 +186,5 @@ class Tracker:
         def one(v):
             pred, _ = self._predict_pos_once(source_volume=v, draw=False)
             return _dev.to_dev(pred, t.float64)
-        stack = parallel.sharded_map_gather(one, vols)
+        stack = parallel.sharded_map_gather(one, vols, chains=self.ensemble_chains)
         return _dev.trim_mean(stack, 0.1).cpu().numpy()

@@ -147,6 +147,8 @@ def match_device(ffn_model: FFN, seg_t1_n, seg_t2_m, confirmed_l, beta, lambda_,
 class TrackerLite:
     """Tracks cells from pre-computed segmentations with a trained FFN (reference :33-150)."""
 
+    ensemble_chains = 4      # matches of one ensemble prediction in flight on this GPU (parallel.chain_map); 1 = one by one
+
     def __init__(self, results_dir: str, ffn_model_name: str, proofed_coords_vol1: Coordinates,
                  miss_frame: List[int] = None, basedir: str = "ffn_models"):
         if miss_frame is not None and not isinstance(miss_frame, List):
@@ -207,7 +209,7 @@ class TrackerLite:
             c = Coordinates(loaded, coord_t1.interpolation_factor, coord_t1.voxel_size, dtype="real")
             return _dev.to_dev(self.predict_cell_positions(t1=t1, t2=t2, confirmed_coord_t1=c, beta=beta, lambda_=lambda_).real,
                                t.float64)
-        stack = parallel.sharded_map_gather(one, vols)            # [k][l][3] fp64 device
+        stack = parallel.sharded_map_gather(one, vols, chains=self.ensemble_chains)            # [k][l][3] fp64 device
         mean = _dev.trim_mean(stack, 0.1).cpu().numpy()
         return Coordinates(mean, interpolation_factor=self.proofed_coords_vol1.interpolation_factor,
                            voxel_size=self.proofed_coords_vol1.voxel_size, dtype="real")

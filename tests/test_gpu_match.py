@@ -265,6 +265,11 @@ def test_trackerlite_end_to_end(tmp_path, ffn_w):
                for t1 in tl.get_volumes_list(5, [4])]
     from scipy.stats import trim_mean
     np.testing.assert_allclose(ens.real, cit.Coordinates(trim_mean(singles, 0.1, axis=0), 4, vs, "real").real, rtol=0, atol=1e-5)
+    # the ensemble members run four at a time on their own streams (parallel.chain_map): same bits as one by one
+    assert trk.ensemble_chains == 4
+    trk.ensemble_chains = 1
+    ens1 = trk.predict_cell_positions_ensemble([4], 5, proof, beta=3, lambda_=3, sampling_number=20)
+    assert np.array_equal(ens1.real, ens.real)
 
 
 # ------------------------------------------------------------------------------------ BASELINE sizes

@@ -74,3 +74,9 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_chain_map_keeps_order_and_falls_back_without_gpu():
+    par = importlib.import_module("3deecelltracker_amd.parallel")
+    assert par.chain_map(lambda v: v * v, [3, 1, 2], chains=3) == [9, 1, 4]
+    assert par.chain_map(lambda v: v, [], chains=3) == []
