@@ -169,8 +169,9 @@ def main():
         if code == 0:
             name = "conv_first_mfma_kernel"
         elif bf:
-            name = (f"conv3_bf16x6_kernel<1, true, {'true' if code == -9 else 'false'}>" if code < 0 else
-                    f"conv3_bf16x6_kernel<{code % 100}, false, {'true' if code > 100 else 'false'}>")
+            z8 = "true" if (code > 0 and d[2] <= 8 and os.environ.get("CT_CONV_Z8", "1") != "0") else "false"   # 8 x 8 x 8 tiles
+            name = (f"conv3_bf16x6_kernel<1, true, {'true' if code == -9 else 'false'}, false>" if code < 0 else
+                    f"conv3_bf16x6_kernel<{code % 100}, false, {'true' if code > 100 else 'false'}, {z8}>")
         elif code in (-8, -9):
             name = "conv3_mfma_c8_kernel" if code == -8 else "conv3_mfma_c8_fold_kernel"
         elif code > 100:
