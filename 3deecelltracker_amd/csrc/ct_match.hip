@@ -1296,6 +1296,7 @@ __global__ __launch_bounds__(256) void dense_small_solve_kernel(const double* __
                                                                 double* __restrict__ rhs_g, double* __restrict__ C) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double sq[DS_MAXN];
+    __shared__ double idiag[DS_MAXN];
     __shared__ double red[4];
     const int tid = threadIdx.x;
     const int ld = n | 1;
@@ -1319,13 +1320,25 @@ __global__ __launch_bounds__(256) void dense_small_solve_kernel(const double* __
     if ((tid & 63) == 0) red[tid >> 6] = tot;
     __syncthreads();
     if (tid == 0) { sc[S_SUMP] = (red[0] + red[1]) + (red[2] + red[3]); sc[S_C] = c; }
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, j = e - i * n;
-        if (j <= i) S[i * ld + j] = sq[i] * G[e] * sq[j] + (i == j ? c : 0.0);
+    // assembly of the scaled lower triangle: batches of 8 Gram entries per thread in flight together
+    const float ninv = 1.0f / (float)n;
+    for (int e0 = 0; e0 < n * n; e0 += 256 * 8) {
+        double gv[8]; int ii[8], jj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + tid + 256 * u;
+            int i = (int)(((float)e + 0.5f) * ninv);
+            i = (i * n > e) ? i - 1 : ((i + 1) * n <= e ? i + 1 : i);
+            ii[u] = i; jj[u] = e - i * n;
+            gv[u] = (e < n * n && jj[u] <= i) ? G[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + tid + 256 * u < n * n && jj[u] <= ii[u]) S[ii[u] * ld + jj[u]] = sq[ii[u]] * gv[u] * sq[jj[u]] + (ii[u] == jj[u] ? c : 0.0);
     }
     __syncthreads();
-    chol_factor_aug_lds(S, ld, n, 3, tid);
-    chol_backsub3_lds(S, ld, n, tid);
+    chol_factor_aug_lds_fast(S, idiag, ld, n, 3, tid);
+    chol_backsub3_lds_fast(S, idiag, ld, n, tid);
     for (int e = tid; e < 3 * n; e += 256) { const int d = e / n, i = e - d * n; C[e] = sq[i] * S[(n + d) * ld + i]; }
 }
 
