@@ -107,6 +107,43 @@ def unet_forward(patch: np.ndarray, weights: dict, arch, dtype=np.float32, colle
     return prob.reshape(x.shape[:3]).astype(dtype)
 
 
+def unet_forward_torch(patch: np.ndarray, weights: dict, arch, dtype=np.float32, threads: int | None = None) -> np.ndarray:
+    """The same network through torch's CPU conv3d (oneDNN, all host threads): an independent evaluation used (fp64) to
+    guard the numpy restatement above against restatement bugs, and (fp32) as the multi-threaded CPU baseline that
+    SURVEY 8d asks for -- the numpy shifted-matmul conv above is bound by skinny GEMMs and far slower.  torch is not the
+    reference; the Keras layer semantics are the ones listed in 3deecelltracker_amd/arch.py."""
+    import torch
+    import torch.nn.functional as F
+    if threads:
+        torch.set_num_threads(int(threads))
+    td = torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
+    t = lambda a: torch.tensor(np.asarray(a), dtype=td)
+    x = t(np.asarray(patch).reshape(np.asarray(patch).shape[:3]))[None, None]          # N C X Y Z
+
+    def block(x, layer):
+        k = t(layer["kernel"]).permute(4, 3, 0, 1, 2)                                  # Cout Cin kx ky kz
+        y = F.conv3d(x, k, t(layer["bias"]), padding=1)
+        y = F.leaky_relu(y, LEAKY_ALPHA) if arch.act == 0 else F.relu(y)
+        sh = (1, -1, 1, 1, 1)
+        return (y - t(layer["mean"]).view(sh)) / torch.sqrt(t(layer["var"]).view(sh) + BN_EPS) * \
+            t(layer["gamma"]).view(sh) + t(layer["beta"]).view(sh)
+    convs = weights["convs"]; i = 0; skips = []
+    with torch.no_grad():
+        for _ in arch.down:
+            x = block(x, convs[i]); i += 1
+            x = block(x, convs[i]); i += 1
+            skips.append(x)
+            x = F.max_pool3d(x, arch.pool)
+        for _ in arch.up:
+            x = block(x, convs[i]); i += 1
+            x = block(x, convs[i]); i += 1
+            x = torch.cat([F.interpolate(x, scale_factor=tuple(float(p) for p in arch.pool), mode="nearest"), skips.pop()], 1)
+        for _ in range(2):
+            x = block(x, convs[i]); i += 1
+        k = t(weights["head"]["kernel"]).permute(4, 3, 0, 1, 2)
+        return torch.sigmoid(F.conv3d(x, k, t(weights["head"]["bias"])))[0, 0].numpy()
+
+
 # --------------------------------------------------------------------------- tiler
 def padded_size(img_size: int, centre: int):
     """unet3d.py:259-279: number of sub-regions and the padded extent along one axis."""

@@ -53,46 +53,18 @@ def test_patch_counts():
         assert int(np.prod(plan["grid"])) == want
 
 
-def _torch_unet(patch, w, arch):
-    import torch
-    import torch.nn.functional as F
-    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))
-    x = t(patch)[None, None]                                  # N C X Y Z
-
-    def block(x, layer):
-        k = t(layer["kernel"]).permute(4, 3, 0, 1, 2)          # Cout Cin kx ky kz
-        y = F.conv3d(x, k, t(layer["bias"]), padding=1)
-        y = F.leaky_relu(y, 0.3) if arch.act == 0 else F.relu(y)
-        sh = (1, -1, 1, 1, 1)
-        return (y - t(layer["mean"]).view(sh)) / torch.sqrt(t(layer["var"]).view(sh) + 1e-3) * \
-            t(layer["gamma"]).view(sh) + t(layer["beta"]).view(sh)
-    convs = w["convs"]; i = 0; skips = []
-    for _ in arch.down:
-        x = block(x, convs[i]); i += 1
-        x = block(x, convs[i]); i += 1
-        skips.append(x)
-        x = F.max_pool3d(x, arch.pool)
-    for _ in arch.up:
-        x = block(x, convs[i]); i += 1
-        x = block(x, convs[i]); i += 1
-        x = torch.cat([F.interpolate(x, scale_factor=tuple(float(p) for p in arch.pool), mode="nearest"), skips.pop()], 1)
-    for _ in range(2):
-        x = block(x, convs[i]); i += 1
-    k = t(w["head"]["kernel"]).permute(4, 3, 0, 1, 2)
-    return torch.sigmoid(F.conv3d(x, k, t(w["head"]["bias"])))[0, 0].numpy()
-
-
 @pytest.mark.parametrize("name,shape", [("unet3_a", (16, 24, 8)), ("unet3_c", (16, 16, 24)), ("unet3_b", (12, 8, 4))])
 def test_unet_forward_against_torch_fp64(name, shape):
     pytest.importorskip("torch")
     arch = arch_mod.ARCHS[name]
     w = synth.make_unet_weights(name, seed=3)
     patch = np.random.default_rng(5).normal(size=shape).astype(np.float32)
-    ref = _torch_unet(patch, w, arch)
+    ref = ur.unet_forward_torch(patch, w, arch, dtype=np.float64)
     got64 = ur.unet_forward(patch, w, arch, dtype=np.float64)
     np.testing.assert_allclose(got64, ref, rtol=0, atol=1e-12)
     got32 = ur.unet_forward(patch, w, arch, dtype=np.float32)
     np.testing.assert_allclose(got32, ref, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ur.unet_forward_torch(patch, w, arch, dtype=np.float32), ref, rtol=0, atol=2e-5)   # the CPU-baseline path
 
 
 def test_arch_work_figures():
