@@ -1679,6 +1679,7 @@ int lowrank_prepare(const PrglsWs& w, int n, double tol, hipStream_t st, int* ra
     return CT_OK;
 }
 constexpr double kLowRankTol = 1e-10;     // |G - U^T U|_max; diag(G) = 1
+constexpr double kLowRankTolTight = 1e-13; // second attempt after a rejection (sigma2 -> 0 shrinks c = lambda sigma2, the truncation matters more)
 constexpr double kLowRankMaxResidual = 1e-6;   // accepted relative residual of the exact system (monitored every iteration)
 }  // namespace
 
@@ -1723,7 +1724,7 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
     // The low-rank M-step is verified on the fly against the exact Gram matrix (S_RES); if its residual
     // is not negligible the whole loop is redone with the dense Cholesky M-step.
     const int total = max_iteration - 1;
-    int done_iters = 0;
+    int done_iters = 0, lr_level = 0;
     double hsc[S_NUM] = {0};
     // state checkpoint (ref set, tracked set, scalars) taken at every chunk start: if the monitor rejects the
     // low-rank M-step inside a chunk, that chunk is redone with the dense M-step from the last verified state
@@ -1752,9 +1753,21 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
         HIPCHK(hipMemcpyAsync(hsc, w.sc, sizeof(hsc), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (rank > 0 && !(hsc[S_RES] <= kLowRankMaxResidual)) {
+            int tighter = 0;
+            if (lr_level == 0 && ck_fits) {      // once: a finer factorisation (higher rank) before giving up on the low-rank path
+                lr_level = 1;
+                if ((rc = lowrank_prepare(w, n, kLowRankTolTight, st, &tighter))) return rc;
+            }
             if (getenv("CT_DEBUG"))
-                fprintf(stderr, "[ct_prgls_two_ref] low-rank M-step rejected after %d iterations (rank %d, residual %.3e, sigma2 %.3e): dense from the last checkpoint\n",
-                        (int)hsc[S_IT], rank, hsc[S_RES], hsc[S_SIGMA2]);
+                fprintf(stderr, "[ct_prgls_two_ref] low-rank M-step rejected after %d iterations (rank %d, residual %.3e, sigma2 %.3e): %s from the last checkpoint\n",
+                        (int)hsc[S_IT], rank, hsc[S_RES], hsc[S_SIGMA2], tighter > 0 ? "rank raised, low-rank again" : "dense");
+            if (tighter > 0) {
+                rank = tighter;
+                HIPCHK(hipMemcpyAsync(w.predn, ck_n, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (l > 0) HIPCHK(hipMemcpyAsync(w.predl, ck_l, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(w.sc, ck_sc, S_NUM * sizeof(double), hipMemcpyDeviceToDevice, st));
+                continue;
+            }
             rank = 0;
             if (ck_fits) {           // restore the last verified state and redo this chunk
                 HIPCHK(hipMemcpyAsync(w.predn, ck_n, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
