@@ -463,6 +463,12 @@ __global__ void row_match_set_kernel(int* __restrict__ row_match, const int32_t*
 // ------------------------------------------------------------------------------------------------
 // scalars block (device): [0] sigma2  [1] gamma  [2] sumP  [3] move_norm2  [4] c = lambda*sigma2  [5] iteration
 enum { S_SIGMA2 = 0, S_GAMMA = 1, S_SUMP = 2, S_NORM2 = 3, S_C = 4, S_IT = 5, S_DONE = 6, S_RES = 7, S_NUM = 8 };
+// Low-rank M-step (see "Low-rank fast path" below): tolerances of the nested pivoted-Cholesky factorisation |G - U^T U|_max
+// (diag(G) = 1) and the relative residuals of the exact system at which the rank is raised / the step is rejected.
+constexpr double kLowRankTol = 1e-10;              // coarse rank (~40): enough while c = lambda sigma2 is large
+constexpr double kLowRankTolTight = 1e-13;         // fine rank (~65): needed once sigma2 has shrunk (c small, truncation / c matters)
+constexpr double kLowRankSwitchResidual = 2e-7;    // device-side: the residual predicted for the next iteration above this -> fine rank from then on
+constexpr double kLowRankMaxResidual = 1e-6;       // host-side: the chunk is redone (fine rank, then dense)
 
 // out[i][j] = exp(-|a_j - b_i|^2 / (2 s2)),  i < nb, j < na      (trackerlite.py:368-372)
 __global__ __launch_bounds__(256) void gauss_kernel(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restr
 // mode 2 (legacy, track.py:103-112):      gamma = 1 - sumP/m;            sigma2 = max(sum / (3 sumP), 1)
 __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ rowpart, int m, int n, int mode,
                                                       double* __restrict__ sc, const double* __restrict__ normpart = nullptr,
-                                                      const double* __restrict__ respart = nullptr) {
+                                                      const double* __restrict__ respart = nullptr, int* __restrict__ rank_p = nullptr) {
     __shared__ double red[4];
     __shared__ double red2[4];
     __shared__ double red3[4], red4[4];
@@ -527,6 +533,7 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
         if (mode == 0) { sc[S_SIGMA2] = s / (3.0 * (double)m * (double)n); }
         else {
             const double sp = sc[S_SUMP];
+            const double s2_prev = sc[S_SIGMA2];              // the sigma2 this iteration's M-step (and its residual) used
             double g = 1.0 - sp / (double)m;
             double s2 = s / (3.0 * sp);
             if (mode == 1) { if (g < 1e-4) g = 1e-4; }
@@ -543,6 +550,11 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
                 const double r2 = fmax(fmax(red4[0], red4[1]), fmax(red4[2], red4[3]));
                 const double rel = r2 > 0.0 ? r1 / r2 : (r1 > 0.0 ? INFINITY : 0.0);
                 if (!(rel <= sc[S_RES])) sc[S_RES] = rel;
+                // the monitor also steers the rank: well before the residual reaches the rejection level the following
+                // iterations use the finer rows of the (nested) factorisation -- rank_p[0] current, rank_p[1] finest
+                // (the truncation error of the M-step scales with 1 / c = 1 / (lambda sigma2): predict the next iteration's)
+                const double predicted = s2 > 0.0 ? rel * (s2_prev / s2) : INFINITY;
+                if (rank_p && !(fmax(rel, predicted) <= kLowRankSwitchResidual) && rank_p[0] < rank_p[1]) rank_p[0] = rank_p[1];
             }
         }
     }
@@ -732,8 +744,10 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
 constexpr int LR_RMAX = 128;
 
 // pivoted Cholesky of the symmetric PSD matrix G (n x n); single workgroup.
-// U [LR_RMAX][n] (row k contiguous), *rank_out = r, or -1 if tol was not reached within LR_RMAX steps.
-__global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __restrict__ G, int n, double tol,
+// U [LR_RMAX][n] (row k contiguous).  The factorisation is nested (row k does not depend on later rows), so one run to the fine
+// tolerance serves both ranks: rank_out[0] = rows needed for tol_coarse (-1 if not reached within LR_RMAX steps),
+// rank_out[1] = rows computed (tol_fine reached, or LR_RMAX).
+__global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __restrict__ G, int n, double tol_coarse, double tol,
                                                               double* __restrict__ U, double* __restrict__ resid,
                                                               int* __restrict__ rank_out) {
     __shared__ double redv[16];
@@ -743,7 +757,7 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < n; i += 1024) resid[i] = G[(size_t)i * n + i];
     __syncthreads();
-    int k = 0;
+    int k = 0, k_coarse = -1;
     for (; k < LR_RMAX; ++k) {
         double best = -1.0; int bi = 0x7fffffff;
         for (int i = tid; i < n; i += 1024) { const double d = resid[i]; if (d > best) { best = d; bi = i; } }
@@ -760,6 +774,7 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
             pivv = b; pivi = ix;
         }
         __syncthreads();
+        if (k_coarse < 0 && !(pivv > tol_coarse)) k_coarse = k;
         if (!(pivv > tol)) break;
         const int p = pivi; const double piv = sqrt(pivv);
         if (tid < k) urow[tid] = U[(size_t)tid * n + p];
@@ -773,7 +788,7 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
         }
         __syncthreads();
     }
-    if (tid == 0) *rank_out = (k == LR_RMAX && pivv > tol) ? -1 : k;
+    if (tid == 0) { rank_out[0] = k_coarse; rank_out[1] = k; }
 }
 
 // column statistics, stage 2 (parallel): 64 columns per block, the CS_SEG segment partials split over
@@ -1664,23 +1679,20 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
 }
 
 // pivoted Cholesky of w.G -> w.U; returns the rank (host value; one stream sync), <= 0 => use the dense path
-int lowrank_prepare(const PrglsWs& w, int n, double tol, hipStream_t st, int* rank_out) {
+int lowrank_prepare(const PrglsWs& w, int n, hipStream_t st, int* rank_coarse, int* rank_fine) {
     static bool attr_set = false;      // r x r system (r <= 128) lives in LDS: needs more than the 64 KiB default
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute((const void*)lr_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1), dim3(1024), 0, st, w.G, n, tol, w.U, w.resid, w.rank);
+    hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1), dim3(1024), 0, st, w.G, n, kLowRankTol, kLowRankTolTight, w.U, w.resid, w.rank);
     LAUNCH_CHECK();
-    int r = 0;
-    HIPCHK(hipMemcpyAsync(&r, w.rank, sizeof(int), hipMemcpyDeviceToHost, st));
+    int r[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(r, w.rank, sizeof(r), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    *rank_out = r;
+    *rank_coarse = r[0]; *rank_fine = r[1];
     return CT_OK;
 }
-constexpr double kLowRankTol = 1e-10;     // |G - U^T U|_max; diag(G) = 1
-constexpr double kLowRankTolTight = 1e-13; // second attempt after a rejection (sigma2 -> 0 shrinks c = lambda sigma2, the truncation matters more)
-constexpr double kLowRankMaxResidual = 1e-6;   // accepted relative residual of the exact system (monitored every iteration)
 }  // namespace
 
 size_t ct_prgls_workspace_bytes(int m, int n, int l) {
@@ -1716,9 +1728,11 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
     LAUNCH_CHECK();
     hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart0, m, n, 0, w.sc, (const double*)nullptr, (const double*)nullptr);
     LAUNCH_CHECK();
-    int rank = 0, rc;
-    if ((rc = lowrank_prepare(w, n, kLowRankTol, st, &rank))) return rc;
-    if (getenv("CT_PRGLS_DENSE")) rank = 0;
+    // `rank` sizes the launches (grids, LDS) for the finest rank; the kernels read the rank in force from w.rank[0], which
+    // starts at the coarse rank and is raised on the device by the residual monitor (scalars_kernel)
+    int rank = 0, rank_coarse = 0, rc;
+    if ((rc = lowrank_prepare(w, n, st, &rank_coarse, &rank))) return rc;
+    if (rank_coarse <= 0 || getenv("CT_PRGLS_DENSE")) rank = 0;
     // EM iterations are enqueued in chunks; every kernel returns immediately once the device-side
     // convergence flag is set, the host looks at the flag once per chunk (trackerlite.py:353-356).
     // The low-rank M-step is verified on the fly against the exact Gram matrix (S_RES); if its residual
@@ -1747,22 +1761,21 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
             hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, tgt, m, w.P, w.rowpart, w.sc);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 1, w.sc, w.normpart,
-                               rank > 0 ? w.respart : (const double*)nullptr);
+                               rank > 0 ? w.respart : (const double*)nullptr, rank > 0 ? w.rank : (int*)nullptr);
             LAUNCH_CHECK();
         }
         HIPCHK(hipMemcpyAsync(hsc, w.sc, sizeof(hsc), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (rank > 0 && !(hsc[S_RES] <= kLowRankMaxResidual)) {
-            int tighter = 0;
-            if (lr_level == 0 && ck_fits) {      // once: a finer factorisation (higher rank) before giving up on the low-rank path
-                lr_level = 1;
-                if ((rc = lowrank_prepare(w, n, kLowRankTolTight, st, &tighter))) return rc;
-            }
+            // first rejection: redo the chunk from its checkpoint with the fine rank in force from its first iteration (the
+            // device had raised it at most part of the way through); second rejection: dense path
+            const bool retry_fine = lr_level == 0 && ck_fits;
+            lr_level = 1;
             if (getenv("CT_DEBUG"))
-                fprintf(stderr, "[ct_prgls_two_ref] low-rank M-step rejected after %d iterations (rank %d, residual %.3e, sigma2 %.3e): %s from the last checkpoint\n",
-                        (int)hsc[S_IT], rank, hsc[S_RES], hsc[S_SIGMA2], tighter > 0 ? "rank raised, low-rank again" : "dense");
-            if (tighter > 0) {
-                rank = tighter;
+                fprintf(stderr, "[ct_prgls_two_ref] low-rank M-step rejected after %d iterations (ranks %d/%d, residual %.3e, sigma2 %.3e): %s from the last checkpoint\n",
+                        (int)hsc[S_IT], rank_coarse, rank, hsc[S_RES], hsc[S_SIGMA2], retry_fine ? "fine rank throughout" : "dense");
+            if (retry_fine) {
+                HIPCHK(hipMemcpyAsync(w.rank, w.rank + 1, sizeof(int), hipMemcpyDeviceToDevice, st));
                 HIPCHK(hipMemcpyAsync(w.predn, ck_n, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
                 if (l > 0) HIPCHK(hipMemcpyAsync(w.predl, ck_l, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
                 HIPCHK(hipMemcpyAsync(w.sc, ck_sc, S_NUM * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -1788,8 +1801,8 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
         if (hsc[S_DONE] != 0.0) break;
     }
     if (getenv("CT_DEBUG"))
-        fprintf(stderr, "[ct_prgls_two_ref] rank %d iterations %d done %g residual %.3e sigma2 %.6e norm2 %.3e\n",
-                rank, done_iters, hsc[S_DONE], hsc[S_RES], hsc[S_SIGMA2], hsc[S_NORM2]);
+        fprintf(stderr, "[ct_prgls_two_ref] ranks %d/%d%s iterations %d done %g residual %.3e sigma2 %.6e norm2 %.3e\n",
+                rank_coarse, rank, rank > 0 ? "" : " (dense)", done_iters, hsc[S_DONE], hsc[S_RES], hsc[S_SIGMA2], hsc[S_NORM2]);
     if (iters) *iters = done_iters;
     if (l > 0) HIPCHK(hipMemcpyAsync(out_tracked, w.predl, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (out_ref) HIPCHK(hipMemcpyAsync(out_ref, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
