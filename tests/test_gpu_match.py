@@ -290,6 +290,32 @@ def test_match_600_cells_against_oracle(ffn, ffn_w):
     np.testing.assert_allclose(post, post_o, rtol=0, atol=COORD_TOL)
 
 
+@pytest.mark.parametrize("n", (150, 400))
+def test_prgls_converging_prior_against_oracle(n):
+    """The regime a trained FFN produces (true pairs score high): sigma2 shrinks to the jitter level within a few iterations,
+    c = lambda sigma2 becomes tiny and the low-rank M-step has to raise its rank on the way (device-side, predicted residual);
+    coordinates, posterior and the iteration count must still equal the reference formulation's."""
+    rng = np.random.default_rng(7 + n)
+    xn = mr.normalize_points(rng.uniform(0, 1, (n, 3)) * np.array([512.0, 512.0, 128.0]))
+    a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.2
+    yn = xn @ a + (rng.uniform(0, 1, xn.shape) - 0.5) * 0.004
+    rep = rng.choice(n, int(0.15 * n), replace=False)
+    yn[rep] = rng.uniform(-0.5, 0.5, (len(rep), 3))
+    perm = rng.permutation(n); yn = yn[perm]
+    corr = rng.uniform(0, 0.05, (n, n)).astype(np.float32)
+    keep = ~np.isin(perm, rep)
+    corr[np.arange(n)[keep], perm[keep]] = rng.uniform(0.7, 0.99, keep.sum()).astype(np.float32)
+    prior, pairs = tl.simple_match(corr)
+    prior_o, pairs_o = mr.simple_match(corr)
+    assert np.array_equal(pairs, pairs_o) and len(pairs) >= keep.sum()
+    ref, post_o, iters = mr.prgls_with_two_ref(prior_o, yn, xn, xn, beta=3, lambda_=3, return_iters=True)
+    assert 3 <= iters <= 12                                               # converges like the reference's probe runs (7-9)
+    got, post = tl.prgls_with_two_ref(prior, yn, xn, xn, beta=3, lambda_=3)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post, post_o, rtol=0, atol=COORD_TOL)
+    assert float(np.abs(got[perm[keep]] - yn[keep]).max()) < 0.02          # the true pairs end up on top of each other
+
+
 def test_match_2000_cells_properties(ffn):
     """config 5 size (N = 2000): size-independent properties instead of a multi-minute oracle run."""
     x, y = synth.make_point_pair(2000, seed=2, box=(512, 1024, 21))
