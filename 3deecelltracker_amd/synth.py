@@ -171,3 +171,12 @@ def make_prob_map(seed: int, shape, n_cells: int, radius=(4.0, 4.0, 1.5), speckl
     if speckle > 0:
         prob[rng.uniform(size=prob.shape) < speckle] = 0.9
     return prob
+
+
+def load_ffn_npz(path) -> dict:
+    """FFN weights stored flat (w1, w2, w3, b3, bn{1,2}_{gamma,beta,mean,var}; any float dtype) -> the nested float32 dict of
+    make_ffn_weights.  tests/golden/ffn_synthetic_trained.npz (made by tests/golden/train_synthetic_ffn.py) is such a file."""
+    z = np.load(path)
+    f = lambda k: np.asarray(z[k], dtype=np.float32)
+    bn = lambda p: {k: f(f"{p}_{k}") for k in ("gamma", "beta", "mean", "var")}
+    return {"w1": f("w1"), "bn1": bn("bn1"), "w2": f("w2"), "bn2": bn("bn2"), "w3": f("w3").reshape(FFN_HID, 1), "b3": f("b3").reshape(1)}

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--match-cus", type=int, default=64, help="CUs reserved for the matching chains (rest: U-Net)")
     ap.add_argument("--disjoint-match-cus", action="store_true", help="give every match chain its own CU slice (measured: worse)")
     ap.add_argument("--match-workers", type=int, default=3, help="frames whose match chains are in flight concurrently")
+    ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative second pass with the synthetic-trained FFN")
     ap.add_argument("--cpu-patches", type=int, default=20, help="U-Net patches timed by the CPU baseline sample")
     args = ap.parse_args()
 
@@ -105,8 +106,10 @@ def main():
     iters_log = []
     pending = []
 
+    active = {"ffn": ffn}
+
     def match_job():
-        tracked, iters = tl.match_device(ffn, seg1, seg2, conf, beta=3, lambda_=3)
+        tracked, iters = tl.match_device(active["ffn"], seg1, seg2, conf, beta=3, lambda_=3)
         iters_log.append(iters)
         return tracked
 
@@ -150,6 +153,33 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # ---- informative second pass (never the headline value): the same pipeline with an FFN that discriminates -- the small
+    # model trained on synthetic pairs by tests/golden/train_synthetic_ffn.py -- so that PR-GLS converges in a handful of
+    # iterations as it does with the reference's trained weights instead of the 364 a random-init FFN's noise prior needs
+    realistic = None
+    trained_path = ROOT / "tests" / "golden" / "ffn_synthetic_trained.npz"
+    if trained_path.exists() and not args.no_realistic_pass:
+        iters_main = list(iters_log)
+        active["ffn"] = ffn_mod.FFN(device=local).set_weights_dict(synth.load_ffn_npz(trained_path))
+        for _ in range(args.warmup):
+            step()
+        finish(); sync_all(); iters_log.clear()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        finish(); sync_all()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([dt2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt2 = float(tmax.item())
+        realistic = {"volumes_per_s": round(world * args.steps / dt2, 3), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                     "prgls_iterations": int(np.median(iters_log)) if iters_log else None,
+                     "ffn": "tests/golden/ffn_synthetic_trained.npz (synthetic-pair training, 76 % of the true pairs found at 600 cells)",
+                     "note": "same partition and inputs as the headline run; only the FFN weights differ"}
+        active["ffn"] = ffn
+        iters_log[:] = iters_main
 
     # ---- roofline of the dominant kernel from the live HIP-event log
     nl = L.ct_unet_num_conv_layers(model._handle)
@@ -260,6 +290,7 @@ def main():
                                    f"(FFN all pairs, greedy prior, PR-GLS beta=lambda=3), seeded random-init weights",
                        "patches_per_volume": n_patches, "cells": args.cells,
                        "prgls_iterations": int(np.median(iters_log)) if iters_log else None,
+                       "with_discriminating_ffn": realistic,
                        "cu_partition": {"unet": n_cu - k_match, "match": k_match}, "match_chains_in_flight": args.match_workers,
                        "parallelism": f"frames sharded, {world} rank(s), all-gather of tracked centroids"},
             "roofline": roofline,

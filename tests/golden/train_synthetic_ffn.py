@@ -1,0 +1,93 @@
+"""Fixture generator: a small FFN trained on synthetic point-set pairs (torch CPU, a few minutes on 8 cores).
+
+Why: the repository cannot ship the reference's trained weights (no network, none in the reference tree), and a random-init
+FFN gives a noise prior -- PR-GLS then runs 364 iterations instead of the 6-9 a real model needs.  This script follows the
+reference's training-data recipe (ffn.py:18-53: normalised points, affine_level 0.2, random_movement_level 0.001, 15 %
+segmentation errors, k = 20 neighbour features) with a short Adam schedule and writes tests/golden/ffn_synthetic_trained.npz
+in the layout of 3deecelltracker_amd.synth.make_ffn_weights (fp16 storage).  It is test/bench data, not a port of the
+reference's training loop."""
+import os, sys, time
+from pathlib import Path
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+K = 20
+
+
+def knn_features(p: np.ndarray) -> np.ndarray:
+    """vectorised twin of oracle.match_ref.knn_features (ties are measure-zero for random points)"""
+    d = np.sqrt(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1))
+    order = np.argsort(d, axis=1, kind="stable")[:, :K + 1]
+    dist = np.take_along_axis(d, order, 1)
+    mean_d = dist.mean(1)
+    rel = (p[order[:, 1:]] - p[:, None, :]) / mean_d[:, None, None]
+    return np.concatenate([rel.reshape(len(p), 3 * K), mean_d[:, None]], 1).astype(np.float32)
+
+
+def normalize(p):
+    c = p - p.mean(0)
+    u, s, vt = np.linalg.svd(c, full_matrices=False)
+    return c / (3.0 * (c @ vt[0]).std())
+
+
+def sample_pairs(rng, n_sets=8):
+    xa, xb, y = [], [], []
+    for _ in range(n_sets):
+        n = int(rng.integers(80, 400))
+        ext = np.array([1.0, rng.uniform(0.5, 1.5), rng.uniform(0.1, 1.0)])
+        x = normalize(rng.uniform(0, 1, (n, 3)) * ext)
+        a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.2
+        t = x @ a + (rng.uniform(0, 1, x.shape) - 0.5) * 0.004
+        rep = rng.choice(n, int(0.15 * n), replace=False)
+        t[rep] = x[rng.choice(n, len(rep))] + rng.normal(0, 0.05, (len(rep), 3))          # segmentation errors
+        keep = np.setdiff1d(np.arange(n), rep)
+        fx, ft = knn_features(x), knn_features(t)
+        neg = rng.integers(0, n, len(keep)); neg = np.where(neg == keep, (neg + 1) % n, neg)
+        # half of the negatives are near neighbours (hard), half uniform
+        near = np.argsort(((x[keep][:, None, :] - x[None, :, :]) ** 2).sum(-1), 1)[:, 1 + rng.integers(0, 6)]
+        neg = np.where(rng.uniform(size=len(keep)) < 0.5, near, neg)
+        xa += [fx[keep], fx[keep]]; xb += [ft[keep], ft[neg]]; y += [np.ones(len(keep)), np.zeros(len(keep))]
+    return (torch.from_numpy(np.concatenate(xa)), torch.from_numpy(np.concatenate(xb)),
+            torch.from_numpy(np.concatenate(y).astype(np.float32)))
+
+
+class FFN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.l1 = nn.Linear(61, 512, bias=False); self.b1 = nn.BatchNorm1d(512, eps=1e-3, momentum=0.01)
+        self.l2 = nn.Linear(1024, 512, bias=False); self.b2 = nn.BatchNorm1d(512, eps=1e-3, momentum=0.01)
+        self.l3 = nn.Linear(512, 1)
+        self.act = nn.LeakyReLU(0.3)
+
+    def forward(self, a, b):
+        h = torch.cat([self.act(self.b1(self.l1(a))), self.act(self.b1(self.l1(b)))], 1)
+        return self.l3(self.act(self.b2(self.l2(h))))[:, 0]
+
+
+def main(steps=int(os.environ.get("FFN_STEPS", 2500))):
+    torch.manual_seed(0); rng = np.random.default_rng(0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = FFN(); opt = torch.optim.Adam(net.parameters(), 1e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, max(steps // 3, 1), 0.3)
+    lossf = nn.BCEWithLogitsLoss(); t0 = time.time()
+    for it in range(steps):
+        a, b, y = sample_pairs(rng)
+        net.train(); opt.zero_grad(); out = net(a, b); loss = lossf(out, y); loss.backward(); opt.step(); sched.step()
+        if it % 100 == 0 or it == steps - 1:
+            acc = ((out > 0) == (y > 0.5)).float().mean().item()
+            print(f"step {it}: loss {loss.item():.4f} acc {acc:.3f} ({time.time() - t0:.0f} s)", flush=True)
+    net.eval()
+    f16 = lambda t_: t_.detach().numpy().astype(np.float16)
+    out = {"w1": f16(net.l1.weight.T), "w2": f16(net.l2.weight.T), "w3": f16(net.l3.weight.T), "b3": f16(net.l3.bias)}
+    for name, bn in (("bn1", net.b1), ("bn2", net.b2)):
+        out[f"{name}_gamma"] = f16(bn.weight); out[f"{name}_beta"] = f16(bn.bias)
+        out[f"{name}_mean"] = f16(bn.running_mean); out[f"{name}_var"] = f16(bn.running_var)
+    np.savez_compressed(ROOT / "tests" / "golden" / "ffn_synthetic_trained.npz", **out)
+    print("saved", sum(v.size for v in out.values()), "values")
+
+
+if __name__ == "__main__":
+    main()

@@ -316,6 +316,45 @@ def test_prgls_converging_prior_against_oracle(n):
     assert float(np.abs(got[perm[keep]] - yn[keep]).max()) < 0.02          # the true pairs end up on top of each other
 
 
+@pytest.mark.parametrize("n", (150, 400))
+def test_end_to_end_with_a_discriminating_ffn(golden_dir, n):
+    """Whole match (features -> FFN -> greedy -> PR-GLS) with the small FFN trained on synthetic pairs
+    (tests/golden/ffn_synthetic_trained.npz): most true pairs are recovered, PR-GLS converges in a handful of iterations as with
+    the reference's trained weights, and scores / correspondence indices / coordinates equal the oracle's."""
+    w = synth.load_ffn_npz(golden_dir / "ffn_synthetic_trained.npz")
+    model = ffn_mod.FFN().set_weights_dict(w)
+    rng = np.random.default_rng(11 + n)
+    xn = mr.normalize_points(rng.uniform(0, 1, (n, 3)) * np.array([512.0, 512.0, 128.0]))
+    a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.2
+    yn = xn @ a + (rng.uniform(0, 1, xn.shape) - 0.5) * 0.004
+    rep = rng.choice(n, int(0.15 * n), replace=False)
+    yn[rep] = rng.uniform(-0.5, 0.5, (len(rep), 3))
+    perm = rng.permutation(n); yn = yn[perm]
+    keep = ~np.isin(perm, rep)
+    corr = ffn_mod.initial_matching_ffn(model, xn, yn, 20)
+    want = mr.initial_matching(lambda q: mr.ffn_forward(w, q), xn, yn, 20)
+    np.testing.assert_allclose(corr, want, rtol=0, atol=SCORE_TOL)
+    prior, pairs = tl.simple_match(corr)
+    prior_o, pairs_o = mr.simple_match(corr)                              # the reference algorithm on the device's scores
+    assert np.array_equal(pairs, pairs_o) and np.array_equal(prior, prior_o)
+    truth = {int(t): int(perm[t]) for t in np.arange(n)[keep]}
+    assert sum(1 for r, t in pairs if truth.get(int(t)) == int(r)) >= 0.7 * keep.sum()
+    # correspondence indices from the oracle's own scores: identical whenever every greedy decision has a margin
+    _, pairs_ref = mr.simple_match(want)
+    work = want.copy(); margin = np.inf
+    for r, t in pairs_ref:
+        top2 = np.partition(work.ravel(), -2)[-2:]
+        margin = min(margin, float(top2[1] - top2[0]), float(top2[1] - 0.1))
+        work[t, :] = 0; work[:, r] = 0
+    if margin > 2 * SCORE_TOL:
+        assert np.array_equal(pairs, pairs_ref), (n, margin)
+    ref, post_o, iters = mr.prgls_with_two_ref(prior_o, yn, xn, xn, beta=3, lambda_=3, return_iters=True)
+    assert 4 <= iters <= 15
+    got, post = tl.prgls_with_two_ref(prior, yn, xn, xn, beta=3, lambda_=3)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post, post_o, rtol=0, atol=COORD_TOL)
+
+
 def test_match_2000_cells_properties(ffn):
     """config 5 size (N = 2000): size-independent properties instead of a multi-minute oracle run."""
     x, y = synth.make_point_pair(2000, seed=2, box=(512, 1024, 21))

@@ -91,3 +91,21 @@ def test_trackerlite_constructor_errors(tmp_path, g):
     with pytest.raises(ValueError):                  # missing weight file -> ValueError wrapping OSError
         tl.TrackerLite(str(tmp_path), "missing_model", proof, basedir=str(tmp_path))
     assert (tmp_path / "track_results" / "coords_real").is_dir()
+
+
+def test_trained_ffn_fixture_loads_and_discriminates(golden_dir):
+    """tests/golden/ffn_synthetic_trained.npz (train_synthetic_ffn.py): layout of make_ffn_weights; through the oracle it scores a
+    true pair near 1 and a wrong pair near 0."""
+    import importlib
+    from oracle import match_ref as mr
+    synth = importlib.import_module("3deecelltracker_amd.synth")
+    w = synth.load_ffn_npz(golden_dir / "ffn_synthetic_trained.npz")
+    ref = synth.make_ffn_weights(0)
+    assert {k: (v.shape if hasattr(v, "shape") else {kk: vv.shape for kk, vv in v.items()}) for k, v in w.items()} == \
+           {k: (v.shape if hasattr(v, "shape") else {kk: vv.shape for kk, vv in v.items()}) for k, v in ref.items()}
+    rng = np.random.default_rng(3)
+    x = mr.normalize_points(rng.uniform(0, 1, (80, 3)))
+    y = x @ (np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.1) + rng.normal(0, 1e-3, x.shape)
+    corr = mr.initial_matching(lambda q: mr.ffn_forward(w, q), x, y, 20)
+    diag = np.diag(corr); off = corr[~np.eye(80, dtype=bool)]
+    assert np.median(diag) > 0.9 and np.median(off) < 0.01
