@@ -176,7 +176,7 @@ def main():
             dt2 = float(tmax.item())
         realistic = {"volumes_per_s": round(world * args.steps / dt2, 3), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
                      "prgls_iterations": int(np.median(iters_log)) if iters_log else None,
-                     "ffn": "tests/golden/ffn_synthetic_trained.npz (synthetic-pair training, 76 % of the true pairs found at 600 cells)",
+                     "ffn": "tests/golden/ffn_synthetic_trained.npz (synthetic-pair training, 84 % of the true pairs found at 600 cells)",
                      "note": "same partition and inputs as the headline run; only the FFN weights differ"}
         active["ffn"] = ffn
         iters_log[:] = iters_main

@@ -1,4 +1,4 @@
-"""Fixture generator: a small FFN trained on synthetic point-set pairs (torch CPU, a few minutes on 8 cores).
+"""Fixture generator: a small FFN trained on synthetic point-set pairs (torch CPU, about 20 minutes on 8 cores).
 
 Why: the repository cannot ship the reference's trained weights (no network, none in the reference tree), and a random-init
 FFN gives a noise prior -- PR-GLS then runs 364 iterations instead of the 6-9 a real model needs.  This script follows the
@@ -67,7 +67,7 @@ class FFN(nn.Module):
         return self.l3(self.act(self.b2(self.l2(h))))[:, 0]
 
 
-def main(steps=int(os.environ.get("FFN_STEPS", 2500))):
+def main(steps=int(os.environ.get("FFN_STEPS", 9000))):
     torch.manual_seed(0); rng = np.random.default_rng(0)
     torch.set_num_threads(os.cpu_count() or 1)
     net = FFN(); opt = torch.optim.Adam(net.parameters(), 1e-3)
