@@ -42,12 +42,38 @@ def workspace(nbytes, device=None):
     return empty((int(nbytes),), torch().uint8, device)
 
 
+# ----------------------------------------------------------------------------------------- size limits of the kernels
+# (documented in include/ctamd.h; the reference's numpy code has none, so they are checked here with an actionable
+# message before any kernel of the pipeline runs, instead of surfacing as CT_ESHAPE half-way through)
+KNN_MAX_POINTS = 4096        # knn_features_kernel keeps one point set's distances per wave in LDS
+KNN_MAX_K = 31
+GREEDY_MAX_SIDE = 16384      # min(m, n): one bitonic sort of the accepted pairs in LDS
+PRGLS_MAX_POINTS = 5461      # dense M-step scratch: 3 n <= 128^2 doubles
+TRIM_MEAN_MAX_K = 64
+
+
+def check_match_sizes(n_ref: int, n_tgt: int, k: int = 20, what: str = "matching"):
+    if n_ref > KNN_MAX_POINTS or n_tgt > KNN_MAX_POINTS:
+        raise ValueError(f"{what}: point sets of {n_ref} / {n_tgt} cells exceed the kNN-feature kernel's limit of "
+                         f"{KNN_MAX_POINTS} points per set (include/ctamd.h, ct_knn_features)")
+    if k > KNN_MAX_K:
+        raise ValueError(f"{what}: k_ptrs = {k} exceeds the kNN-feature kernel's limit of {KNN_MAX_K} neighbours")
+    if min(n_ref, n_tgt) > GREEDY_MAX_SIDE:
+        raise ValueError(f"{what}: min(m, n) = {min(n_ref, n_tgt)} exceeds the greedy matcher's limit of {GREEDY_MAX_SIDE}")
+    if n_ref > PRGLS_MAX_POINTS:
+        raise ValueError(f"{what}: {n_ref} reference points exceed the PR-GLS dense M-step limit of {PRGLS_MAX_POINTS} "
+                         f"(include/ctamd.h, ct_prgls_two_ref / ct_prgls_legacy)")
+
+
 # ----------------------------------------------------------------------------------------- wrappers
 def knn_features(points_d, k):
     t = torch(); L = _lib.lib()
     n = points_d.shape[0]
     if n < k + 1:
         raise ValueError(f"Expected n_neighbors <= n_samples,  but n_samples = {n}, n_neighbors = {k + 1}")
+    if n > KNN_MAX_POINTS or k > KNN_MAX_K:
+        raise ValueError(f"kNN features: n = {n} (limit {KNN_MAX_POINTS}) / k = {k} (limit {KNN_MAX_K}) unsupported by "
+                         f"ct_knn_features")
     feat = empty((n, 3 * k + 1), t.float32, points_d.device)
     _lib.check(L.ct_knn_features(points_d.data_ptr(), n, k, feat.data_ptr(), stream(points_d.device)), "ct_knn_features")
     return feat
@@ -57,6 +83,8 @@ def greedy_match(corr_d, threshold, mode, want_prior=True):
     """corr_d fp32 [m][n] -> (pairs int32 [n][2] (ref, tgt), n_pairs tensor, prior fp64 [m][n] or None)."""
     t = torch(); L = _lib.lib()
     m, n = corr_d.shape
+    if min(m, n) > GREEDY_MAX_SIDE:
+        raise ValueError(f"greedy matching: min(m, n) = {min(m, n)} exceeds the kernel's limit of {GREEDY_MAX_SIDE}")
     pairs = empty((n, 2), t.int32, corr_d.device)
     npairs = empty((1,), t.int32, corr_d.device)
     prior = empty((m, n), t.float64, corr_d.device) if want_prior else None
@@ -70,6 +98,8 @@ def greedy_match(corr_d, threshold, mode, want_prior=True):
 def prgls_two_ref(prior_d, tgt_d, ref_d, tracked_d, beta, lambda_, max_iteration, want_posterior=True, want_ref=False):
     t = torch(); L = _lib.lib()
     m, n = prior_d.shape
+    if n > PRGLS_MAX_POINTS:
+        raise ValueError(f"PR-GLS: {n} reference points exceed the dense M-step limit of {PRGLS_MAX_POINTS}")
     l = 0 if tracked_d is None else tracked_d.shape[0]
     dev = prior_d.device
     out_l = empty((l, 3), t.float64, dev) if l else None
@@ -88,6 +118,8 @@ def prgls_two_ref(prior_d, tgt_d, ref_d, tracked_d, beta, lambda_, max_iteration
 def prgls_legacy(X_d, Y_d, corr_d, BETA, max_iteration, LAMBDA, vol, want_P=True):
     t = torch(); L = _lib.lib()
     n, m = X_d.shape[0], Y_d.shape[0]
+    if n > PRGLS_MAX_POINTS:
+        raise ValueError(f"PR-GLS (legacy): {n} reference points exceed the dense M-step limit of {PRGLS_MAX_POINTS}")
     dev = X_d.device
     P = empty((m, n), t.float64, dev) if want_P else None
     TX = empty((n, 3), t.float64, dev)
@@ -110,6 +142,8 @@ def trim_mean(stack_d, cut=0.1):
     """stack_d fp64 [k][n][3] -> [n][3]  (scipy.stats.trim_mean(..., cut, axis=0))"""
     t = torch(); L = _lib.lib()
     k = stack_d.shape[0]
+    if k > TRIM_MEAN_MAX_K:
+        raise ValueError(f"trim_mean: {k} predictions exceed the kernel's limit of {TRIM_MEAN_MAX_K}")
     n3 = int(stack_d[0].numel())
     out = empty(tuple(stack_d.shape[1:]), t.float64, stack_d.device)
     _lib.check(L.ct_trim_mean(stack_d.contiguous().data_ptr(), k, n3, float(cut), out.data_ptr(), stream(stack_d.device)),

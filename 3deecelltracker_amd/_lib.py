@@ -43,6 +43,8 @@ SIGNATURES = {
     "ct_tile_plan": (_i, [_ip, _ip, _ip, _ip, _ip]),
     "ct_tile_gather_reflect": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),
     "ct_tile_scatter_center": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),
+    "ct_tile_pack_crops": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),
+    "ct_tile_unpack_crops": (_i, [_vp, _ip, _ip, _ip, _i, _i, _vp, _vp]),
     "ct_unet_predict_volume": (_i, [_vp, _vp, _ip, _ip, _i, _i, _vp, _vp, _sz, _vp]),
     "ct_normalize_points": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "ct_denormalize_points": (_i, [_vp, _i, _vp, _vp, _vp]),

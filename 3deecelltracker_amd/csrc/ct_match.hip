@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -41,6 +42,32 @@ constexpr float kBnEps = 1e-3f;
 constexpr int FEAT = 61, HID = 512;
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Entry points that take a handle run on the handle's device whatever the calling thread's current device is
+// (restored on return so that torch's view of the current device is not changed behind its back).
+struct DeviceGuard {
+    int prev = -1, want; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) : want(device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != want) err = hipSetDevice(want);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+
+// Kernels whose working set lives in LDS need more than the 64 KiB default.  hipFuncSetAttribute is a per-device setting
+// and the match paths run from several host threads (parallel.chain_map / FramePipeline): one bit per device, set after
+// the (idempotent) call has succeeded, so a concurrent first use on the same device merely sets the attribute twice.
+int ensure_big_lds(const void* fn, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return CT_OK;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    done.fetch_or(bit, std::memory_order_release);
+    return CT_OK;
+}
+#define ENSURE_BIG_LDS(kernel) do { static std::atomic<uint64_t> done_{0}; int rc_ = ensure_big_lds((const void*)kernel, done_); \
+                                    if (rc_ != CT_OK) return rc_; } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers (64 lanes)
@@ -1495,6 +1522,8 @@ static int gemm(const float* A, int lda, const float* B, float* Cm, int M, int N
 int ct_ffn_pairgrid(ct_ffn_t* h, const float* feat_ref, int n, const float* feat_tgt, int m, float* corr,
                     void* workspace, size_t workspace_bytes, ct_stream_t stream) {
     if (!h || !feat_ref || !feat_tgt || !corr || !workspace || n <= 0 || m <= 0) return CT_EINVAL;
+    DeviceGuard dg(h->device);
+    if (dg.err != hipSuccess) return (int)dg.err;
     if (workspace_bytes < ct_ffn_workspace_bytes(n, m)) return CT_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -1515,6 +1544,8 @@ size_t ct_ffn_predict_workspace_bytes(int rows) { return rows <= 0 ? 0 : (size_t
 int ct_ffn_predict(ct_ffn_t* h, const float* x, int rows, float* out, void* workspace, size_t workspace_bytes,
                    ct_stream_t stream) {
     if (!h || !x || !out || !workspace || rows <= 0) return CT_EINVAL;
+    DeviceGuard dg(h->device);
+    if (dg.err != hipSuccess) return (int)dg.err;
     if (workspace_bytes < ct_ffn_predict_workspace_bytes(rows)) return CT_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -1554,11 +1585,7 @@ int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, 
     unsigned long long* keys = (unsigned long long*)ws; ws += align_up((size_t)(m > n ? m : n) * 8, 256);
     int* ctr = (int*)ws;
     HIPCHK(hipMemsetAsync(row_used, 0, (size_t)(ws - row_used) + 256, st));     // flags, tables and counters
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)gd_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    ENSURE_BIG_LDS(gd_finalize_kernel);
     const int max_rounds = (m < n ? m : n) + 1;
     int hctr[4] = {0, 0, 0, 0};
     for (int done_rounds = 0; done_rounds < max_rounds;) {
@@ -1659,11 +1686,7 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
         return CT_OK;
     }
     if (n <= DS_MAXN) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute((const void*)dense_small_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set = true;
-        }
+        ENSURE_BIG_LDS(dense_small_solve_kernel);
         const size_t lds = (size_t)(n + 3) * (n | 1) * sizeof(double);
         hipLaunchKernelGGL(dense_small_solve_kernel, dim3(1), dim3(256), lds, st, w.part, n, xref, w.G, lambda, w.sc, w.dvec, w.sqd, w.rhs, w.C);
         LAUNCH_CHECK();
@@ -1680,11 +1703,7 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
 
 // pivoted Cholesky of w.G -> w.U; returns the rank (host value; one stream sync), <= 0 => use the dense path
 int lowrank_prepare(const PrglsWs& w, int n, hipStream_t st, int* rank_coarse, int* rank_fine) {
-    static bool attr_set = false;      // r x r system (r <= 128) lives in LDS: needs more than the 64 KiB default
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)lr_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    ENSURE_BIG_LDS(lr_solve_kernel);
     hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1), dim3(1024), 0, st, w.G, n, kLowRankTol, kLowRankTolTight, w.U, w.resid, w.rank);
     LAUNCH_CHECK();
     int r[2] = {0, 0};

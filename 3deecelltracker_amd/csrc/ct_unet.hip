@@ -1048,6 +1048,27 @@ __global__ __launch_bounds__(256) void tile_gather_kernel(const float* __restric
     patches[gid] = vol[((size_t)sx * q.vy + sy) * q.vz + sz];
 }
 
+// centre crops <-> dense slab [n][cx][cy][cz] (the unit of the multi-GPU gather, SURVEY 8e: every rank contributes the centre
+// crops of its own patch range, receives everybody else's and places them).  PACK: volume -> slab (voxels of a crop that lie
+// beyond the volume's upper faces are written as 0 so that the slab is fully defined), !PACK: slab -> volume.
+template <bool PACK>
+__global__ __launch_bounds__(256) void tile_crops_kernel(float* __restrict__ vol, TileGeom q, int p_begin, int n,
+                                                         float* __restrict__ crops) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)q.cx * q.cy * q.cz;
+    if (gid >= per * n) return;
+    const int lp = (int)(gid / per); size_t r = gid - (size_t)lp * per;
+    const int z = (int)(r % q.cz); r /= q.cz;
+    const int y = (int)(r % q.cy); const int x = (int)(r / q.cy);
+    const int pg = p_begin + lp;
+    const int k = pg % q.gz, j = (pg / q.gz) % q.gy, i = pg / (q.gz * q.gy);
+    const int ox = i * q.cx + x, oy = j * q.cy + y, oz = k * q.cz + z;
+    const bool inside = ox < q.vx && oy < q.vy && oz < q.vz;
+    const size_t vi = ((size_t)ox * q.vy + oy) * q.vz + oz;
+    if (PACK) crops[gid] = inside ? vol[vi] : 0.f;
+    else if (inside) vol[vi] = crops[gid];
+}
+
 __global__ __launch_bounds__(256) void tile_scatter_kernel(const float* __restrict__ pred, TileGeom q, int p_begin,
                                                            int n, float* __restrict__ out) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1180,6 +1201,17 @@ struct ConvPlan {
     size_t epi_off;       // float offset
 };
 struct TensorPlan { int level; int C; size_t off; /* floats per patch offset */ };
+
+// Entry points that take a handle run on the handle's device whatever the calling thread's current device is
+// (restored on return so that torch's view of the current device is not changed behind its back).
+struct DeviceGuard {
+    int prev = -1, want; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) : want(device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != want) err = hipSetDevice(want);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
 
 }  // namespace
 
@@ -1802,6 +1834,8 @@ int ct_unet_predict_patches(ct_unet_t* h, const float* patches_in, int n_patches
                             void* workspace, size_t workspace_bytes, float* layer_dump, ct_stream_t stream) {
     if (!h || !patches_in || !prob_out || !workspace || n_patches <= 0) return CT_EINVAL;
     if (workspace_bytes < ct_unet_workspace_bytes(h, n_patches)) return CT_EWORKSPACE;
+    DeviceGuard dg(h->device);
+    if (dg.err != hipSuccess) return (int)dg.err;
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const size_t vox0 = (size_t)h->dims[0][0] * h->dims[0][1] * h->dims[0][2];
@@ -1855,10 +1889,33 @@ int ct_tile_scatter_center(const float* pred, const int v[3], const int net[3], 
     return (int)hipGetLastError();
 }
 
+static int tile_crops(bool pack, float* vol, const int v[3], const int net[3], const int shrink[3], int p_begin, int n,
+                      float* crops, ct_stream_t stream) {
+    TileGeom q; int rc = make_geom(v, net, shrink, q);
+    if (rc) return rc;
+    if (!vol || !crops || n <= 0 || p_begin < 0 || p_begin + n > q.gx * q.gy * q.gz) return CT_EINVAL;
+    const size_t tot = (size_t)q.cx * q.cy * q.cz * n;
+    if (pack) hipLaunchKernelGGL(tile_crops_kernel<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vol, q, p_begin, n, crops);
+    else hipLaunchKernelGGL(tile_crops_kernel<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vol, q, p_begin, n, crops);
+    return (int)hipGetLastError();
+}
+
+int ct_tile_pack_crops(const float* vol, const int v[3], const int net[3], const int shrink[3], int p_begin, int n,
+                       float* crops, ct_stream_t stream) {
+    return tile_crops(true, const_cast<float*>(vol), v, net, shrink, p_begin, n, crops, stream);
+}
+
+int ct_tile_unpack_crops(const float* crops, const int v[3], const int net[3], const int shrink[3], int p_begin, int n,
+                         float* out_vol, ct_stream_t stream) {
+    return tile_crops(false, out_vol, v, net, shrink, p_begin, n, const_cast<float*>(crops), stream);
+}
+
 int ct_unet_predict_volume(ct_unet_t* h, const float* vol, const int v[3], const int shrink[3],
                            int p_begin, int n, float* out_vol, void* workspace, size_t workspace_bytes,
                            ct_stream_t stream) {
     if (!h || !vol || !out_vol || !workspace || n <= 0) return CT_EINVAL;
+    DeviceGuard dg(h->device);
+    if (dg.err != hipSuccess) return (int)dg.err;
     TileGeom q; int rc = make_geom(v, h->ad.in, shrink, q);
     if (rc) return rc;
     if (p_begin < 0 || p_begin + n > q.gx * q.gy * q.gz) return CT_EINVAL;

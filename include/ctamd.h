@@ -15,7 +15,19 @@
  *     positive hipError_t value; nothing throws;
  *   - no global mutable state: handles own their device-side weights only; all scratch memory is a
  *     caller-provided workspace whose size the *_workspace_bytes functions report;
- *   - thread-compatible: one stream per host thread, a handle may be shared for inference.
+ *   - thread-compatible: one stream per host thread, a handle may be shared for inference;
+ *   - entry points that take a handle run on the handle's device (the caller's current device is restored on return);
+ *     all others run on the calling thread's current device;
+ *   - size limits of the kernels (CT_ESHAPE beyond them; the Python mirrors check them up front, _dev.check_match_sizes):
+ *       ct_knn_features        n <= 4096 points, k <= 31 neighbours
+ *       ct_greedy_match        min(m, n) <= 16384, m * n < 2^32
+ *       ct_prgls_two_ref / ct_prgls_legacy / ct_solve_movements   n <= 5461 reference points (dense M-step: 3 n <= 128^2)
+ *       ct_trim_mean           k <= 64 predictions
+ *   - collectives: there are no ct_comm_* entry points.  The path's only inter-GPU exchange is a gather of results
+ *     (centre crops, centroid sets, ensemble predictions), issued by the host layer through
+ *     torch.distributed (backend "nccl" == RCCL over xGMI on ROCm) on the buffers these entry points fill
+ *     (3deecelltracker_amd/parallel.py); a C wrapper around ncclAllGather would add nothing but a second RCCL
+ *     communicator next to torch's.
  */
 #ifndef CTAMD_H
 #define CTAMD_H
@@ -103,6 +115,15 @@ int ct_tile_gather_reflect(const float* vol, const int vol_xyz[3], const int net
                            int p_begin, int n, float* patches, ct_stream_t stream);
 int ct_tile_scatter_center(const float* pred, const int vol_xyz[3], const int net_xyz[3], const int shrink[3],
                            int p_begin, int n, float* out_vol, ct_stream_t stream);
+
+/* Centre crops of the patch range [p_begin, p_begin+n) as a dense slab [n][cx][cy][cz] (centre = net - 2 shrink), the unit
+ * of the multi-GPU exchange (BASELINE config 3; replaces the sequential patch loop unet3d.py:246-254 across ranks): a rank
+ * packs the crops it computed out of its volume, all-gathers the slabs (host layer, RCCL) and unpacks the other ranks'
+ * crops into its volume.  Crop voxels beyond the volume's upper faces are packed as 0 and skipped when unpacking.          */
+int ct_tile_pack_crops(const float* vol, const int vol_xyz[3], const int net_xyz[3], const int shrink[3],
+                       int p_begin, int n, float* crops, ct_stream_t stream);
+int ct_tile_unpack_crops(const float* crops, const int vol_xyz[3], const int net_xyz[3], const int shrink[3],
+                         int p_begin, int n, float* out_vol, ct_stream_t stream);
 
 /* Whole unet3_prediction(img, model, shrink) for the patch range [p_begin, p_begin+n) of one
  * volume (unet3d.py:203-256): gather -> network -> scatter, processed in batches that fit the

@@ -42,20 +42,31 @@ def _worker(rank, world, port, q):
         assert tuple(stack.shape) == (5, 4, 3)
         for i in items:
             assert torch.equal(stack[i], fn(i))
-        # rank with an empty shard
+        # rank with an empty shard: with and without the tail_shape hint (the product callers at early time points of an
+        # ensemble have world_size > len(items); round-1 code raised on the empty rank while the other blocked in all_gather)
         one = par.sharded_map_gather(fn, [7], tail_shape=(4, 3), dtype=torch.float64, device="cpu")
         assert tuple(one.shape) == (1, 4, 3) and torch.equal(one[0], fn(7))
+        one = par.sharded_map_gather(fn, [7])
+        assert tuple(one.shape) == (1, 4, 3) and one.dtype == torch.float64 and torch.equal(one[0], fn(7))
+        f32 = par.sharded_map_gather(lambda i: torch.full((2,), float(i), dtype=torch.float32), [3], chains=4)
+        assert tuple(f32.shape) == (1, 2) and f32.dtype == torch.float32 and float(f32[0, 0]) == 3.0
+        none = par.sharded_map_gather(fn, [], tail_shape=(4, 3), dtype=torch.float64, device="cpu")
+        assert tuple(none.shape) == (0, 4, 3)
         # variable-size centroid sets
         local = torch.arange((rank + 2) * 3, dtype=torch.float64).reshape(-1, 3) + 100 * rank
         sets = par.gather_centroids(local, cap=16)
         assert [s.shape[0] for s in sets] == [2, 3] and torch.equal(sets[rank], local)
         assert torch.equal(sets[1 - rank], torch.arange((1 - rank + 2) * 3, dtype=torch.float64).reshape(-1, 3) + 100 * (1 - rank))
-        # disjoint-support sum == gather (what predict_volume_sharded does with the partial volumes)
-        vol = torch.zeros(10, dtype=torch.float32)
-        b, e = par.shard_range(10, rank, world)
-        vol[b:e] = torch.arange(b, e, dtype=torch.float32) + 1
-        dist.all_reduce(vol)
-        assert torch.equal(vol, torch.arange(10, dtype=torch.float32) + 1)
+        # slab gather of predict_volume_sharded: 5 units over 2 ranks (3 + 2), slabs padded to the maximum count
+        total, per = 5, 4
+        mx = -(-total // world)
+        b, e = par.shard_range(total, rank, world)
+        slab = torch.zeros((mx, per), dtype=torch.float32)
+        slab[:e - b] = (torch.arange(b, e, dtype=torch.float32) + 1)[:, None]
+        allslabs = torch.empty((world, mx, per), dtype=torch.float32)
+        dist.all_gather_into_tensor(allslabs.view(-1), slab.view(-1))
+        got = torch.cat([allslabs[r, :par.shard_range(total, r, world)[1] - par.shard_range(total, r, world)[0]] for r in range(world)])
+        assert torch.equal(got, (torch.arange(total, dtype=torch.float32) + 1)[:, None].expand(total, per))
         q.put((rank, "ok"))
     except Exception as ex:   # pragma: no cover
         q.put((rank, repr(ex)))
