@@ -9,7 +9,7 @@ import importlib
 import sys
 
 __version__ = "0.1.0"
-_MIRRORS = ("unet3d", "ffn", "track", "trackerlite", "tracker", "coord_image_transformer")
+_MIRRORS = ("unet3d", "ffn", "track", "trackerlite", "tracker", "coord_image_transformer", "preprocess")
 
 
 def install_as(name: str = "CellTracker"):

@@ -71,6 +71,8 @@ SIGNATURES = {
     "ct_normalize_image": (_i, [_vp, _i, _ip, _d, _ip, _i, _i, _vp, _vp, _sz, _vp]),
     "ct_correction_workspace_bytes": (_sz, [_ip, _i]),
     "ct_accurate_correction": (_i, [_vp, _ip, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ip, _vp, _sz, _vp]),
+    "ct_correction_legacy_workspace_bytes": (_sz, [_ip, _i]),
+    "ct_accurate_correction_legacy": (_i, [_vp, _vp, _i, _ip, _i, _i, _d, _i, _vp, _vp, _vp, _ip, _vp, _vp, _vp, _vp, _i, _ip, _vp, _sz, _vp]),
     "ct_trim_mean": (_i, [_vp, _i, _i, _d, _vp, _vp]),
     "ct_segment_workspace_bytes": (_sz, [_ip, _i]),
     "ct_segment_centroids": (_i, [_vp, _ip, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

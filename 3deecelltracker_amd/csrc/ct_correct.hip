@@ -120,6 +120,103 @@ __global__ __launch_bounds__(256) void centre_of_mass_kernel(CorrGeom g, const f
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Legacy dialect: Tracker._accurate_correction (reference CellTracker/tracker.py:1177-1191) with
+//   _transform_cells_quick  :1350-1389   labels moved by integer displacements on the interpolated grid inside an image
+//                                        padded by the largest sub-region; a cell whose moved box leaves the padded
+//                                        image is skipped (shape mismatch -> continue); overlap counts as above
+//   _correction_once_interp :1310-1348   labels[overlap > 1] = 0, boundary cells = 0, centre of mass of
+//                                        (image_cell_bg + image_gcn) per label, lost cells (NaN) get correction 0
+//   _evaluate_correction    :1402-1413   stop when max |correction| (interpolated units) < 0.5
+// State per cell: integer displacement from volume 1 (interpolated grid) and the real displacement.
+// ------------------------------------------------------------------------------------------------------------------
+struct LegacyGeom { int X, Y, Z, zs, ZI, padx, pady, padz; };
+
+template <typename F>
+__device__ __forceinline__ bool for_cell_voxels_legacy(const LegacyGeom g, const int32_t* bbox, const uint8_t* sub, const int32_t* disp, F&& f) {
+    const int sx = bbox[3], sy = bbox[4], sz = bbox[5];
+    const int ox = bbox[0] + disp[0], oy = bbox[1] + disp[1], oz = bbox[2] + disp[2];
+    // padded-image slice [o + pad, o + pad + s) must lie inside [0, dim + 2 pad): otherwise numpy returns a slice of another
+    // shape and the reference skips the cell (a start below zero would wrap around in numpy; treated as skipped as well)
+    if (ox + g.padx < 0 || ox + sx > g.X + g.padx || oy + g.pady < 0 || oy + sy > g.Y + g.pady ||
+        oz + g.padz < 0 || oz + sz > g.ZI + g.padz) return false;
+    const int nvox = sx * sy * sz;
+    for (int v = threadIdx.x; v < nvox; v += blockDim.x) {
+        if (!sub[v]) continue;
+        const int vz = v % sz, vy = (v / sz) % sy, vx = v / (sz * sy);
+        const int x = ox + vx, y = oy + vy, zi = oz + vz;
+        if (x < 0 || x >= g.X || y < 0 || y >= g.Y || zi < 0 || zi >= g.ZI) continue;
+        const int dz = zi - g.zs / 2;                              // slices zs//2 : Z*zs : zs
+        if (dz < 0 || dz % g.zs) continue;
+        const int k = dz / g.zs;
+        if (k >= g.Z) continue;
+        f(x, y, k);
+    }
+    return true;
+}
+
+// i_disp = rint(r_disp * (1, 1, zs / ratio))   (_transform_real_to_interpolated :563-565)
+__global__ void legacy_to_interp_kernel(const double* __restrict__ r_disp, int n, double zfac, int32_t* __restrict__ i_disp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const double v = (i % 3 == 2) ? r_disp[i] * zfac : r_disp[i];
+    i_disp[i] = (int32_t)rint(v);
+}
+
+__global__ __launch_bounds__(256) void legacy_scatter_kernel(LegacyGeom g, const int32_t* __restrict__ bbox, const uint8_t* __restrict__ subs,
+                                                             const long long* __restrict__ offs, const int32_t* __restrict__ disp,
+                                                             unsigned int* __restrict__ cnt) {
+    const int i = blockIdx.x;
+    for_cell_voxels_legacy(g, bbox + 6 * i, subs + offs[i], disp + 3 * i,
+                           [&](int x, int y, int k) { atomicAdd(&cnt[((size_t)x * g.Y + y) * g.Z + k], 1u); });
+}
+
+template <typename RAW>
+__global__ __launch_bounds__(256) void legacy_com_kernel(LegacyGeom g, double ratio, const float* __restrict__ prob, const RAW* __restrict__ raw,
+                                                         const int32_t* __restrict__ bbox, const uint8_t* __restrict__ subs,
+                                                         const long long* __restrict__ offs, const uint8_t* __restrict__ on_boundary,
+                                                         const unsigned int* __restrict__ cnt, const double* __restrict__ t0,
+                                                         const int32_t* __restrict__ disp_in, int32_t* __restrict__ disp_out,
+                                                         double* __restrict__ r_disp, unsigned int* __restrict__ flag) {
+    __shared__ double red[4][4];
+    const int i = blockIdx.x;
+    double sw = 0.0, swx = 0.0, swy = 0.0, swz = 0.0;
+    if (!on_boundary[i])
+        for_cell_voxels_legacy(g, bbox + 6 * i, subs + offs[i], disp_in + 3 * i, [&](int x, int y, int k) {
+            const size_t idx = ((size_t)x * g.Y + y) * g.Z + k;
+            if (cnt[idx] == 1u) {
+                double w = (double)prob[idx];
+                if (raw) w += (double)raw[idx] / 65536.0;          // image_cell_bg + image_gcn  (:635, :1332)
+                sw += w; swx += w * x; swy += w * y; swz += w * k;
+            }
+        });
+    sw = wave_sum(sw); swx = wave_sum(swx); swy = wave_sum(swy); swz = wave_sum(swz);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wv][0] = sw; red[wv][1] = swx; red[wv][2] = swy; red[wv][3] = swz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4];
+        for (int q = 0; q < 4; ++q) t[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+        const double zs = (double)g.zs;
+        const double inv_ratio = 1.0 / ratio, inv_zs = 1.0 / zs, r_over_zs = ratio / zs, zs_over_r = zs / ratio;
+        double com[3] = {t[1] / t[0], t[2] / t[0], t[3] / t[0]};
+        const bool lost = (com[0] != com[0]);
+        bool big = false;
+        for (int d = 0; d < 3; ++d) {
+            const double id = (double)disp_in[3 * i + d];
+            const double lc = (d == 2) ? t0[3 * i + 2] * inv_ratio + id * inv_zs : t0[3 * i + d] + id;
+            double corr = lost ? 0.0 : com[d] - lc;
+            if (d == 2) corr = corr * ratio;
+            const double rd = ((d == 2) ? id * r_over_zs : id) + corr;
+            r_disp[3 * i + d] = rd;
+            disp_out[3 * i + d] = (int32_t)rint((d == 2) ? rd * zs_over_r : rd);
+            const double test = (d == 2) ? corr * zs_over_r : corr;
+            if (fabs(test) >= 0.5) big = true;
+        }
+        if (big) atomicOr(flag, 1u);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -160,6 +257,55 @@ int ct_accurate_correction(const float* prob, const int dims[3], int factor, int
         const int mx = (int)h[0] - (1 << 30);
         if (mx < 1) break;                                             // np.max(delta.interp) < 0.5  (signed max, as in the reference)
     }
+    if (iterations) *iterations = it > max_repetition ? max_repetition : it;
+    return CT_OK;
+}
+
+size_t ct_correction_legacy_workspace_bytes(const int dims[3], int n_cells) {
+    if (!dims || dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0 || n_cells <= 0) return 0;
+    return align_up((size_t)dims[0] * dims[1] * dims[2] * 4, 256) + 2 * align_up((size_t)n_cells * 12, 256) + 1024;
+}
+
+int ct_accurate_correction_legacy(const float* prob, const void* raw, int raw_dtype, const int dims[3], int z_scaling, int interp_depth,
+                                  double z_xy_ratio, int n_cells, const int32_t* bbox, const uint8_t* subimages,
+                                  const long long* sub_offsets, const int pad_xyz[3], const uint8_t* on_boundary,
+                                  const double* tracked_t0, double* r_disp, int32_t* i_disp, int max_repetition, int* iterations,
+                                  void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (!prob || !dims || !bbox || !subimages || !sub_offsets || !pad_xyz || !on_boundary || !tracked_t0 || !r_disp || !i_disp ||
+        !workspace || z_scaling <= 0 || interp_depth <= 0 || !(z_xy_ratio > 0.0) || n_cells <= 0 || max_repetition <= 0 ||
+        (raw && raw_dtype != 0 && raw_dtype != 1)) return CT_EINVAL;
+    if (workspace_bytes < ct_correction_legacy_workspace_bytes(dims, n_cells)) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    LegacyGeom g{dims[0], dims[1], dims[2], z_scaling, interp_depth, pad_xyz[0], pad_xyz[1], pad_xyz[2]};
+    unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const size_t nvox = (size_t)dims[0] * dims[1] * dims[2];
+    unsigned int* cnt = (unsigned int*)ws; ws += align_up(nvox * 4, 256);
+    int32_t* da = (int32_t*)ws; ws += align_up((size_t)n_cells * 12, 256);
+    int32_t* db = (int32_t*)ws; ws += align_up((size_t)n_cells * 12, 256);
+    unsigned int* flag = (unsigned int*)ws;
+    hipLaunchKernelGGL(legacy_to_interp_kernel, dim3((3 * n_cells + 255) / 256), dim3(256), 0, st, r_disp, n_cells,
+                       (double)z_scaling / z_xy_ratio, da);
+    LAUNCH_CHECK();
+    int it = 0;
+    for (it = 1; it <= max_repetition; ++it) {
+        HIPCHK(hipMemsetAsync(cnt, 0, nvox * 4, st));
+        HIPCHK(hipMemsetAsync(flag, 0, 64, st));
+        hipLaunchKernelGGL(legacy_scatter_kernel, dim3(n_cells), dim3(256), 0, st, g, bbox, subimages, sub_offsets, da, cnt);
+        LAUNCH_CHECK();
+        if (raw && raw_dtype == 1)
+            hipLaunchKernelGGL(legacy_com_kernel<float>, dim3(n_cells), dim3(256), 0, st, g, z_xy_ratio, prob, (const float*)raw, bbox, subimages,
+                               sub_offsets, on_boundary, cnt, tracked_t0, da, db, r_disp, flag);
+        else
+            hipLaunchKernelGGL(legacy_com_kernel<uint16_t>, dim3(n_cells), dim3(256), 0, st, g, z_xy_ratio, prob, (const uint16_t*)raw, bbox,
+                               subimages, sub_offsets, on_boundary, cnt, tracked_t0, da, db, r_disp, flag);
+        LAUNCH_CHECK();
+        int32_t* t = da; da = db; db = t;
+        unsigned int h = 0;
+        HIPCHK(hipMemcpyAsync(&h, flag, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (!h) break;                                                  // _evaluate_correction: every |correction| < 0.5
+    }
+    HIPCHK(hipMemcpyAsync(i_disp, da, (size_t)n_cells * 12, hipMemcpyDeviceToDevice, st));
     if (iterations) *iterations = it > max_repetition ? max_repetition : it;
     return CT_OK;
 }

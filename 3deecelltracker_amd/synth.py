@@ -180,3 +180,84 @@ def load_ffn_npz(path) -> dict:
     f = lambda k: np.asarray(z[k], dtype=np.float32)
     bn = lambda p: {k: f(f"{p}_{k}") for k in ("gamma", "beta", "mean", "var")}
     return {"w1": f("w1"), "bn1": bn("bn1"), "w2": f("w2"), "bn2": bn("bn2"), "w3": f("w3").reshape(FFN_HID, 1), "b3": f("b3").reshape(1)}
+
+
+def make_passthrough_unet_weights(arch_name: str = "unet3_a", seed: int = 0, gain: float = 4.0, bias: float = -3.0,
+                                  noise: float = 0.02) -> dict:
+    """U-Net weights that turn a normalised stack into a cell-like probability map, for tests of the *chained* frame
+    (LCN -> U-Net -> regions -> match -> correction), where a Glorot-init net would only produce noise regions.
+
+    Every conv block carries its first input channel through (centre tap 1 -> channel 0; identity BatchNorm statistics; the
+    decoder reads channel 0 of the skip tensor), all other taps are small seeded noise so that no kernel path is trivially
+    sparse; the head is sigmoid(gain * channel0 + bias).  Not a trained model: prob ~ sigmoid(gain * relu(lcn) + bias)."""
+    arch = ARCHS[arch_name]
+    rng = np.random.default_rng(seed + 77)
+    layers = arch.conv_layers()
+    # input channel that carries the signal into conv i: 0 everywhere, except decoder convs over concat([up(low), skip]),
+    # where the skip tensor starts after the upsampled channels
+    n_down = len(arch.down)
+    signal_in = [0] * len(layers)
+    c = arch.down[-1][1]
+    for i in range(n_down):                       # first conv of decoder stage i (also the output stage)
+        li = 2 * n_down + 2 * i
+        signal_in[li] = 0 if i == 0 else arch.up[i - 1][1]
+    signal_in[2 * n_down + 2 * n_down] = arch.up[-1][1] if len(layers) > 4 * n_down else 0
+    convs = []
+    for li, (cin, cout) in enumerate(layers):
+        k = (rng.normal(0.0, noise / np.sqrt(27.0 * cin), (3, 3, 3, cin, cout))).astype(np.float32)
+        # the bottleneck path (decoder stage 0 reads the pooled tensor) carries no fine signal: feed the skip instead
+        k[1, 1, 1, signal_in[li], 0] = 1.0
+        convs.append({"kernel": k, "bias": np.zeros(cout, np.float32), "gamma": np.ones(cout, np.float32),
+                      "beta": np.zeros(cout, np.float32), "mean": np.zeros(cout, np.float32),
+                      "var": np.full(cout, 1.0 - 1e-3, np.float32)})
+    hk = (rng.normal(0.0, noise, (1, 1, 1, arch.out[1], 1))).astype(np.float32)
+    hk[0, 0, 0, 0, 0] = gain
+    return {"arch": arch_name, "convs": convs, "head": {"kernel": hk, "bias": np.array([bias], np.float32)}}
+
+
+def make_legacy_frame_case(seed: int = 0, siz_xyz=(120, 136, 14), z_scaling: int = 5, z_xy_ratio: float = 4.0, n_cells: int = 40,
+                           move: float = 2.5, margin: float = 10.0, edge_cells: int = 0):
+    """Synthetic state for one frame of the legacy Tracker (tracker.py:1138-1175): a volume-1 label image on the
+    z-interpolated grid (non-touching ellipsoids = what interpolate_seg leaves in seg_cells_interpolated_corrected), the raw
+    uint16 stack of a later volume in which every cell has moved by a smooth field plus jitter, and a cell/background
+    probability map of that stack (float16, the dtype of the reference's unet_cache files)."""
+    rng = np.random.default_rng(seed)
+    X, Y, Z = (int(v) for v in siz_xyz)
+    ZI = Z * z_scaling
+    rad = np.array([4.5, 4.5, 1.3])                                   # layer units
+    centres = [np.array([X * (k + 1.0) / (edge_cells + 1.0), margin, Z / 2.0]) for k in range(edge_cells)]   # cells that will drift
+    tries = 0                                                                                                # into the boundary zone
+    while len(centres) < n_cells and tries < 20000:
+        tries += 1
+        c = rng.uniform([margin, margin, 2.0], [X - margin, Y - margin, Z - 2.0])
+        if all(np.sum(((c - o) / (2.4 * rad)) ** 2) > 1.0 for o in centres):
+            centres.append(c)
+    centres = np.asarray(centres)
+    n = len(centres)
+    seg = np.zeros((X, Y, ZI), dtype=np.int32)
+    for i, c in enumerate(centres):
+        r = rad * rng.uniform(0.8, 1.1, 3)
+        ci = np.array([c[0], c[1], c[2] * z_scaling + z_scaling // 2]); ri = np.array([r[0], r[1], r[2] * z_scaling])
+        lo = np.maximum(np.floor(ci - ri).astype(int), 0); hi = np.minimum(np.ceil(ci + ri).astype(int) + 1, (X, Y, ZI))
+        g = np.meshgrid(*(np.arange(lo[a], hi[a]) for a in range(3)), indexing="ij")
+        inside = sum(((g[a] - ci[a]) / ri[a]) ** 2 for a in range(3)) <= 1.0
+        sub = seg[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        sub[inside & (sub == 0)] = i + 1
+    # smooth displacement field (layer units) + jitter
+    A = (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.04
+    ctr = np.array([X / 2, Y / 2, Z / 2])
+    disp = (centres - ctr) @ A + rng.normal(0, 0.4, centres.shape) + np.array([move, -0.6 * move, 0.15])
+    disp[:, 2] *= 0.3
+    moved = centres + disp
+    gx, gy, gz = np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij")
+    raw = rng.normal(100.0, 20.0, (X, Y, Z))
+    blob = np.zeros((X, Y, Z))
+    amps = rng.uniform(500, 2000, n)
+    for c, a in zip(moved, amps):
+        e = np.exp(-0.5 * (((gx - c[0]) / 2.6) ** 2 + ((gy - c[1]) / 2.6) ** 2 + ((gz - c[2]) / 0.8) ** 2))
+        raw += a * e
+        blob = np.maximum(blob, e)
+    raw = np.clip(raw, 0, 65535).astype(np.uint16)
+    prob = (1.0 / (1.0 + np.exp(-(9.0 * blob - 4.0)))).astype(np.float16)      # > 0.5 inside ~1 sigma... a soft ellipsoid per cell
+    return {"siz_xyz": (X, Y, Z), "z_scaling": int(z_scaling), "z_xy_ratio": float(z_xy_ratio), "seg_interp": seg,
+            "centres_vol1": centres, "centres_moved": moved, "raw": raw, "prob_f16": prob}

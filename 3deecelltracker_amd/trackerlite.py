@@ -209,7 +209,8 @@ class TrackerLite:
             c = Coordinates(loaded, coord_t1.interpolation_factor, coord_t1.voxel_size, dtype="real")
             return _dev.to_dev(self.predict_cell_positions(t1=t1, t2=t2, confirmed_coord_t1=c, beta=beta, lambda_=lambda_).real,
                                t.float64)
-        stack = parallel.sharded_map_gather(one, vols, chains=self.ensemble_chains)            # [k][l][3] fp64 device
+        stack = parallel.sharded_map_gather(one, vols, tail_shape=(coord_t1.cell_num, 3), dtype=t.float64,
+                                            chains=self.ensemble_chains)                        # [k][l][3] fp64 device
         mean = _dev.trim_mean(stack, 0.1).cpu().numpy()
         return Coordinates(mean, interpolation_factor=self.proofed_coords_vol1.interpolation_factor,
                            voxel_size=self.proofed_coords_vol1.voxel_size, dtype="real")

@@ -185,6 +185,31 @@ def unet3_c(device=None) -> UNet3Model:
     return UNet3Model(ARCHS["unet3_c"], device)
 
 
+def load_model(path, device=None) -> UNet3Model:
+    """Stand-in for keras `load_model(path)` on a U-Net file (reference tracker.py:579): the architecture is recognised from
+    the stored conv shapes (`.npz` of save_weights) or, for a Keras `.h5`, by trying the three reference architectures."""
+    path = Path(path)
+    if not path.exists():
+        raise OSError(f"Unable to open file {path}")
+    if path.suffix == ".npz":
+        z = np.load(path)
+        shapes = []
+        i = 0
+        while f"conv{i}_kernel" in z.files:
+            shapes.append(tuple(int(v) for v in z[f"conv{i}_kernel"].shape[3:])); i += 1
+        for arch in ARCHS.values():
+            if [tuple(l) for l in arch.conv_layers()] == shapes:
+                return UNet3Model(arch, device).load_weights(path)
+        raise ValueError(f"{path}: conv shapes {shapes} match none of {list(ARCHS)}")
+    last = None
+    for arch in ARCHS.values():
+        try:
+            return UNet3Model(arch, device).load_weights(path)
+        except ValueError as e:
+            last = e
+    raise ValueError(f"{path}: not a weight file of {list(ARCHS)} ({last})")
+
+
 def _get_sizes_padded_im(img_siz_i: int, out_centr_siz_i: int):
     """reference unet3d.py:259-279"""
     num = -(-int(img_siz_i) // int(out_centr_siz_i))

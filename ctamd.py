@@ -14,5 +14,5 @@ if _root not in _sys.path:
 _pkg = _il.import_module("3deecelltracker_amd")
 install_as = _pkg.install_as
 __version__ = _pkg.__version__
-for _m in ("arch", "synth", "unet3d", "ffn", "track", "trackerlite", "tracker", "coord_image_transformer", "parallel"):
+for _m in ("arch", "synth", "unet3d", "ffn", "track", "trackerlite", "tracker", "coord_image_transformer", "parallel", "preprocess", "segment"):
     globals()[_m] = _il.import_module(f"3deecelltracker_amd.{_m}")

@@ -251,6 +251,24 @@ int ct_accurate_correction(const float* prob, const int dims_xyz[3], int factor,
                            const float* coord_vol1_raw, float* coords_raw, int max_repetition, int* iterations,
                            void* workspace, size_t workspace_bytes, ct_stream_t stream);
 
+/* Legacy dialect: Tracker._accurate_correction (tracker.py:1177-1191; _correction_once_interp :1310-1348,
+ * _transform_cells_quick :1350-1389, _evaluate_correction :1402-1413).
+ * prob [dev] fp32 [x][y][z] (image_cell_bg); raw [dev] the raw frame (raw_dtype 0 = uint16, 1 = float32; NULL: no image_gcn
+ * term): the centre-of-mass weight is prob + raw / 65536 in fp64 (:635, :1332).  Sub-regions as above but on the grid of
+ * seg_cells_interpolated_corrected (depth interp_depth = z * z_scaling); pad_xyz = max sub-region width per axis (:1107): a
+ * cell whose moved box leaves the image padded by that much is skipped for the round, like the reference's shape test.
+ * on_boundary [dev] uint8 [n]; tracked_t0 [dev] fp64 [n][3] = r_coordinates_tracked_t0.
+ * r_disp [dev] fp64 [n][3]: in = real displacement from volume 1 before the correction (:1179-1180), out = corrected;
+ * i_disp [dev] int32 [n][3]: out = corrected displacement on the interpolated grid (i_disp_from_vol1_updated).
+ * At most max_repetition rounds (reference: 20); synchronises the stream once per round.                                */
+size_t ct_correction_legacy_workspace_bytes(const int dims_xyz[3], int n_cells);
+int ct_accurate_correction_legacy(const float* prob, const void* raw, int raw_dtype, const int dims_xyz[3], int z_scaling,
+                                  int interp_depth, double z_xy_ratio, int n_cells, const int32_t* bbox,
+                                  const uint8_t* subimages, const long long* sub_offsets, const int pad_xyz[3],
+                                  const uint8_t* on_boundary, const double* tracked_t0, double* r_disp, int32_t* i_disp,
+                                  int max_repetition, int* iterations, void* workspace, size_t workspace_bytes,
+                                  ct_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Probability map -> labelled regions -> cell centres  (tracker.py:636-648)
  * ------------------------------------------------------------------------------------------

@@ -62,7 +62,7 @@ def cmd_unet(args):
     print(f"shape {shape} patches {npatch}: {dt*1e3:.2f} ms/vol  {1/dt:.2f} vol/s  {npatch*arch.flops_per_patch()/dt/1e12:.1f} TFLOP/s fp32")
     if "--layers" in args:
         import ctypes
-        L = mod("_lib").lib(); h = model._h
+        L = mod("_lib").lib(); h = model._handle
         L.ct_unet_set_timing(h, 1)
         for _ in range(3):
             model.predict_volume_device(vol, out=out)
@@ -196,7 +196,7 @@ def cmd_legacy(args):
         box = (168, 401, 32) if n < 300 else (512, 512, 32)
         x, y = synth.make_point_pair(n, seed=n, box=box)
         trk = tracker_mod.Tracker.for_matching(ffn, beta_tk=1000.0, lambda_tk=1e-5, maxiter_tk=10)
-        trk.set_volume1(x, x + 0.3); trk.set_segmentation(y)
+        trk.set_volume1(x, x + 0.3); trk.inject_segmentation(y)
         dt, _ = timeit(lambda: trk._predict_pos_once(1), reps=5)
         print(f"legacy _predict_pos_once N={n}: {dt*1e3:.2f} ms (5 reps x 9 EM iterations)")
 

@@ -308,11 +308,93 @@ def gen_correction():
     np.savez_compressed(HERE / "correction.npz", **out)
 
 
+def gen_legacy_tracker():
+    """The reference's own legacy Tracker on synthetic state (tracker.py): the real constructor (:854-887, makes its folders in
+    a temp dir), cal_subregions (:1095-1112), initiate_tracking, _get_cells_onBoundary, _transform_cells_quick,
+    _correction_once_interp, _accurate_correction and match (:1138-1175).
+
+    What cannot run here and is replaced, nothing else: tifffile's imread inside read_image_ts (the stack is handed over in
+    memory), the skimage watershed inside _segment (`_watershed` -> threshold + connected components, the region step the
+    build implements, oracle/segment_ref.py), the matplotlib animation of _predict_pos_once(draw=True) (draw forced off) and
+    interpolate_seg (skimage; its results -- seg_cells_interpolated_corrected, Z_RANGE_INTERP, r_coordinates_tracked_t0 --
+    are set from a synthetic label image with the same scipy.ndimage.center_of_mass call, :1070-1075).  The probability map
+    comes from unet_cache/t%06i.npy (float16), i.e. the reference's cache-hit path (:656-660): no Keras call is involved."""
+    import contextlib
+    import io
+    import tempfile
+    import scipy.ndimage as ndm
+    from oracle import segment_ref as sr
+    from oracle.match_ref import FFNRef as _FFN
+    out = {}
+    ffn_w = ct_synth.load_ffn_npz(HERE / "ffn_synthetic_trained.npz")
+    for ci, (seed, siz, zs, ratio, ncell, ens, margin) in enumerate(((0, (120, 136, 14), 5, 4.0, 40, False, 6.5), (1, (96, 110, 12), 3, 2.5, 30, 5, 10.0))):
+        case = ct_synth.make_legacy_frame_case(seed, siz, zs, ratio, ncell, margin=margin, edge_cells=2 if margin < 10 else 0)
+        tmp = tempfile.mkdtemp()
+        with contextlib.redirect_stdout(io.StringIO()):
+            trk = ref_tracker.Tracker(volume_num=8, siz_xyz=siz, z_xy_ratio=ratio, z_scaling=zs, noise_level=100, min_size=20,
+                                      beta_tk=300, lambda_tk=0.1, maxiter_tk=20, folder_path=tmp, image_name="img_t%04i_z%04i.tif",
+                                      unet_model_file="unet.h5", ffn_model_file="ffn.h5", ensemble=ens)
+            # what interpolate_seg leaves (:1057-1075)
+            seg = case["seg_interp"]
+            trk.seg_cells_interpolated_corrected = seg
+            trk.Z_RANGE_INTERP = range(zs // 2, seg.shape[2], zs)
+            trk.segmentation_manual_relabels = seg[:, :, trk.Z_RANGE_INTERP]
+            c0 = ndm.center_of_mass(trk.segmentation_manual_relabels > 0, trk.segmentation_manual_relabels,
+                                    range(1, trk.segmentation_manual_relabels.max() + 1))
+            trk.r_coordinates_tracked_t0 = trk._transform_layer_to_real(c0).copy()
+            trk.cell_num_t0 = trk.r_coordinates_tracked_t0.shape[0]
+            trk.cal_subregions()
+            rng = np.random.default_rng(seed + 50)
+            trk.r_coordinates_segment_t0 = (trk.r_coordinates_tracked_t0 + rng.normal(0, 0.3, trk.r_coordinates_tracked_t0.shape))[rng.permutation(trk.cell_num_t0)]
+            trk.ffn_model = _FFN(ffn_w)
+            trk.initiate_tracking()
+            np.save(trk.paths.unet_cache + "t%06i.npy" % 7, case["prob_f16"][None, :, :, :, None])
+            ref_tracker.read_image_ts = lambda vol, path, name, z_range, print_=False: case["raw"]
+
+            def cc_watershed(image_cell_bg, method, _t=trk):
+                labels, _, _ = sr.segment_centroids(np.asarray(image_cell_bg[0, :, :, :, 0], dtype=np.float32), 0.5, 1, _t.min_size)
+                if method == "min_size":
+                    _t.cell_num = int(labels.max())
+                return labels
+            trk._watershed = cc_watershed
+            orig = trk._predict_pos_once
+            trk._predict_pos_once = lambda source_volume, draw=False: orig(source_volume, draw=False)
+            anim, (bd_local, vol, i_disp, r_pred) = trk.match(7, "min_size")
+            r_disp, i_disp2 = trk._accurate_correction(bd_local, r_pred)
+            assert np.array_equal(i_disp, i_disp2)
+            # one round + the moved-label bookkeeping, for the oracle's unit test
+            i0 = trk._transform_real_to_interpolated(trk.history.r_displacements[-1] + (r_pred - trk.history.r_tracked_coordinates[-1]))
+            lab_q, msk_q = trk._transform_cells_quick(i0)
+            r1, i1, corr1 = trk._correction_once_interp(i0, bd_local)
+            # a displacement set that pushes two cells out of the padded image and two onto each other
+            iw = i0.copy(); iw[0] = (-1000, 0, 0); iw[1] = (0, 4000, 0)
+            iw[3] = iw[2] + (np.asarray(trk.region_xyz_min[2]) - np.asarray(trk.region_xyz_min[3]))
+            lab_w, msk_w = trk._transform_cells_quick(iw)
+            r1w, i1w, corr1w = trk._correction_once_interp(iw, bd_local)
+        out[f"lt_case_{ci}"] = np.array([seed, *siz, zs, ncell, int(ens)]); out[f"lt_ratio_{ci}"] = np.float64(ratio)
+        out[f"lt_margin_{ci}"] = np.float64(margin)
+        out[f"lt_tracked_t0_{ci}"] = trk.r_coordinates_tracked_t0; out[f"lt_seg_t0_{ci}"] = trk.r_coordinates_segment_t0
+        out[f"lt_pad_{ci}"] = np.array([trk.pad_x, trk.pad_y, trk.pad_z])
+        out[f"lt_region_min_{ci}"] = np.asarray(trk.region_xyz_min); out[f"lt_region_width_{ci}"] = np.asarray(trk.region_width)
+        out[f"lt_r_seg_{ci}"] = trk.segresult.r_coordinates_segment
+        out[f"lt_l_centres_{ci}"] = np.asarray(trk.segresult.l_center_coordinates)
+        out[f"lt_r_pred_{ci}"] = r_pred; out[f"lt_bd_local_{ci}"] = bd_local
+        out[f"lt_i_disp_{ci}"] = i_disp; out[f"lt_r_disp_{ci}"] = r_disp
+        out[f"lt_i0_{ci}"] = i0; out[f"lt_once_r_{ci}"] = r1; out[f"lt_once_i_{ci}"] = i1; out[f"lt_once_corr_{ci}"] = corr1
+        out[f"lt_quick_sums_{ci}"] = np.array([int(lab_q.astype(np.int64).sum()), int(msk_q.astype(np.int64).sum()), int((msk_q > 1).sum())])
+        out[f"lt_iw_{ci}"] = iw; out[f"lt_wild_r_{ci}"] = r1w; out[f"lt_wild_i_{ci}"] = i1w
+        out[f"lt_wild_sums_{ci}"] = np.array([int(lab_w.astype(np.int64).sum()), int(msk_w.astype(np.int64).sum()), int((msk_w > 1).sum())])
+        print("legacy tracker case", ci, "cells", trk.cell_num_t0, "segmented", len(trk.segresult.r_coordinates_segment),
+              "boundary", int(bd_local.sum()), "max |i_disp|", int(np.abs(i_disp).max()), "wild overlaps", int((msk_w > 1).sum()))
+    np.savez_compressed(HERE / "legacy_tracker.npz", **out)
+
+
 if __name__ == "__main__":
-    gen_tiler()
-    gen_match()
-    gen_preprocess()
-    gen_correction()
+    only = sys.argv[1:]
+    for name, fn in (("tiler", gen_tiler), ("match", gen_match), ("preprocess", gen_preprocess), ("correction", gen_correction),
+                     ("legacy_tracker", gen_legacy_tracker)):
+        if not only or name in only:
+            fn()
     leftovers = [p for p in Path("/root/reference").rglob("__pycache__")]
     assert not leftovers, leftovers
     print("golden vectors written to", HERE)

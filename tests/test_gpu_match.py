@@ -192,13 +192,15 @@ def test_prgls_legacy_dialect_vs_reference(g, n):
 
 @pytest.mark.parametrize("n", (50, 113, 180))
 def test_tracker_predict_pos_once_vs_reference(g, ffn, n):
-    trk = tracker_mod.Tracker(ffn, beta_tk=1000.0, lambda_tk=1e-5, max_iteration=10)
+    trk = tracker_mod.Tracker.for_matching(ffn, beta_tk=1000.0, lambda_tk=1e-5, maxiter_tk=10)
     trk.set_volume1(g[f"lg_X_{n}"], g[f"trk_tracked0_{n}"])
-    trk.set_segmentation(g[f"lg_Y_{n}"])
+    trk.inject_segmentation(g[f"lg_Y_{n}"])
     pred, _ = trk._predict_pos_once(source_volume=1, draw=False)
     np.testing.assert_allclose(pred, g[f"trk_pred_{n}"], rtol=0, atol=1e-4)
-    anim, (bd, vol, _, pred2) = trk.match(7, g[f"lg_Y_{n}"])
-    assert vol == 7 and np.array_equal(pred, pred2)
+    anim, (bd, vol, i_disp, pred2) = trk.match(7, "min_size")          # reference signature: match(target_volume, method)
+    assert vol == 7 and np.array_equal(pred, pred2) and i_disp is None and anim is None
+    with pytest.raises(ValueError, match="no image source"):
+        trk.match(8)                                                   # the injected segmentation is consumed by one match
     trk.miss_frame = [9]
     with pytest.raises(ValueError):
         trk.match(9)
@@ -433,10 +435,10 @@ def test_tracker_ensemble_prediction_against_oracle(ffn, ffn_w):
         pts = (base - base.mean(0)) @ a + base.mean(0) + rng.normal(0, 0.5, base.shape)
         segs.append(pts[rng.permutation(n)]); trks.append(pts + rng.normal(0, 0.3, base.shape))
     target_seg = segs[-1]
-    trk = tracker_mod.Tracker(ffn, beta_tk=1000.0, lambda_tk=1e-5, max_iteration=6, ensemble=5, adjacent=False)
+    trk = tracker_mod.Tracker.for_matching(ffn, beta_tk=1000.0, lambda_tk=1e-5, maxiter_tk=6, ensemble=5, adjacent=False)
     trk.history.r_segmented_coordinates = segs[:-1]; trk.history.r_tracked_coordinates = trks[:-1]
     trk.cell_num_t0 = n
-    trk.set_segmentation(target_seg)
+    trk.inject_segmentation(target_seg)
     vol = vols                                             # predicting volume 9 from volumes chosen among 1..8
     got = trk.predict_ensemble(vol)
     src = mr.get_reference_vols(5, vol, False)
@@ -444,3 +446,56 @@ def test_tracker_ensemble_prediction_against_oracle(ffn, ffn_w):
     preds = [mr.predict_pos_once(lambda q: mr.ffn_forward(ffn_w, q), segs[v - 1], trks[v - 1], target_seg, 1000.0, 1e-5, 6)
              for v in src]
     np.testing.assert_allclose(got, mr.trim_mean(np.stack(preds), 0.1), rtol=0, atol=1e-4)
+
+
+def test_match_2000_cells_against_oracle(ffn, ffn_w):
+    """config 5 size (N = 2000) against the oracle: FFN scores, greedy pairs on identical scores, and three EM iterations of
+    prgls_with_two_ref (max_iteration=3: the reference formulation's full run takes minutes on the CPU)."""
+    x, y = synth.make_point_pair(2000, seed=2, box=(512, 1024, 21))
+    xn, (mean, scale) = mr.normalize_points(x, return_para=True); yn = (y - mean) / scale
+    corr = ffn_mod.initial_matching_ffn(ffn, xn, yn, 20)
+    want = mr.initial_matching(lambda q: mr.ffn_forward(ffn_w, q), xn, yn, 20)
+    np.testing.assert_allclose(corr, want, rtol=0, atol=SCORE_TOL)
+    prior, pairs = tl.simple_match(corr)
+    prior_o, pairs_o = mr.simple_match(corr)
+    assert np.array_equal(pairs, pairs_o) and np.array_equal(prior, prior_o)
+    tracked = xn[:700] + np.random.default_rng(0).normal(0, 0.002, (700, 3))
+    got, post = tl.prgls_with_two_ref(prior, yn, xn, tracked, beta=3, lambda_=3, max_iteration=3)
+    ref, post_o = mr.prgls_with_two_ref(prior_o, yn, xn, tracked, beta=3, lambda_=3, max_iteration=3)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post, post_o, rtol=0, atol=COORD_TOL)
+
+
+def test_trackerlite_ensemble_20_volumes_113_cells_against_oracle(tmp_path, ffn_w):
+    """BASELINE config 4 pattern at the worm4 size: 20 source volumes x 113 cells (trackerlite.py:111-125), each prediction and
+    the trim-mean against the oracle formulation."""
+    frames = tuple(range(1, 23))
+    vs, coords = _write_case(tmp_path, ffn_w, n=113, frames=frames)
+    proof = cit.Coordinates(coords[1], interpolation_factor=4, voxel_size=vs, dtype="raw")
+    trk = tl.TrackerLite(str(tmp_path), "synthetic", proof, basedir=str(tmp_path / "ffn_models"))
+    rng = np.random.default_rng(9)
+    confirmed = {}
+    for t in frames[:-1]:
+        confirmed[t] = cit.Coordinates(coords[t][np.argsort(rng.permutation(113))] + rng.normal(0, 0.2, (113, 3)).astype(np.float32), 4, vs, "raw").real
+        np.save(tmp_path / "track_results" / "coords_real" / f"coords{str(t).zfill(6)}.npy", confirmed[t])
+    t2 = 22
+    vols = tl.get_volumes_list(t2, [], 20)
+    assert len(vols) == 20 and vols == mr.get_volumes_list(t2, [], 20)
+    ens = trk.predict_cell_positions_ensemble([], t2, proof, beta=3, lambda_=3, sampling_number=20)
+    f = lambda q: mr.ffn_forward(ffn_w, q)
+    seg2 = cit.Coordinates(coords[t2], 4, vs, "raw").real
+    preds, same_pairs = [], 0
+    for t1 in vols:
+        conf = cit.Coordinates(confirmed[t1], 4, vs, "real").real            # through the float32 raw storage like the reference
+        seg1 = cit.Coordinates(coords[t1], 4, vs, "raw").real
+        conf_n, (mean, scale) = mr.normalize_points(conf, return_para=True)
+        s1, s2 = (seg1 - mean) / scale, (seg2 - mean) / scale
+        corr = mr.initial_matching(f, s1, s2, 20)
+        prior, pairs = mr.simple_match(corr)
+        moved, _ = mr.prgls_with_two_ref(prior, s2, s1, conf_n, beta=3, lambda_=3)
+        preds.append(cit.Coordinates(moved * scale + mean, 4, vs, "real").real)
+    want = cit.Coordinates(mr.trim_mean(np.stack(preds), 0.1), 4, vs, "real").real
+    # correspondences come from arg-maxes of fp32 scores: a flipped near-tie in one of the 20 matches moves single cells; the
+    # trimmed mean absorbs at most 2 outliers per coordinate, so compare robustly and require near-total agreement
+    close = np.abs(ens.real - want).max(axis=1) <= 1e-3
+    assert close.mean() >= 0.97, f"only {close.mean():.3f} of the cells agree with the oracle ensemble"

@@ -162,3 +162,57 @@ def test_worm4_shape_88_patches():
     assert grid[0] * grid[1] * grid[2] == 88
     out = model.predict_volume_device(vol)
     assert out.shape == vol.shape and bool(torch.isfinite(out).all()) and float(out.min()) > 0 and float(out.max()) < 1
+
+
+def test_tiler_512_golden_with_the_fake_model_on_device(golden_dir):
+    """The 512x512x32 / 75-patch golden case (the reference's own unet3_prediction output with the fake model, sha256):
+    reflect gather of all 75 patches on the device, the fake model's arithmetic (x * 0.5 + ramp, two fp32 roundings like
+    numpy's) applied on the device, centre-crop stitch -> bit-identical to the reference's output."""
+    import torch
+    lib = importlib.import_module("3deecelltracker_amd._lib"); L = lib.lib()
+    meta = [c for c in json.loads((golden_dir / "tiler.json").read_text()) if tuple(c["vol"]) == (512, 512, 32)]
+    assert len(meta) == 1
+    c = meta[0]
+    net, shrink = tuple(c["net"]), tuple(c["shrink"])
+    img = np.random.default_rng(c["seed"]).normal(0, 1, (1, *c["vol"], 1)).astype(np.float32)
+    vol = torch.from_numpy(np.ascontiguousarray(img[0, :, :, :, 0])).cuda()
+    centre, grid = unet3d.tile_plan(vol.shape, net, shrink)
+    n = grid[0] * grid[1] * grid[2]
+    assert n == 75
+    patches = torch.empty((n, *net), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    lib.check(L.ct_tile_gather_reflect(vol.data_ptr(), lib.ivec(vol.shape), lib.ivec(net), lib.ivec(shrink), 0, n, patches.data_ptr(), st))
+    ramp = torch.from_numpy(FakeUNet(net).ramp).cuda()
+    pred = (patches * 0.5 + ramp[None]).contiguous()
+    out = torch.zeros_like(vol)
+    lib.check(L.ct_tile_scatter_center(pred.data_ptr(), lib.ivec(vol.shape), lib.ivec(net), lib.ivec(shrink), 0, n, out.data_ptr(), st))
+    res = out.cpu().numpy()[None, :, :, :, None]
+    assert hashlib.sha256(np.ascontiguousarray(res).tobytes()).hexdigest() == c["sha256"]
+    # the multi-GPU exchange unit: centre crops packed into slabs and unpacked elsewhere reproduce the same volume
+    per = centre[0] * centre[1] * centre[2]
+    slab = torch.empty((n, per), device="cuda"); back = torch.zeros_like(vol)
+    lib.check(L.ct_tile_pack_crops(out.data_ptr(), lib.ivec(vol.shape), lib.ivec(net), lib.ivec(shrink), 0, n, slab.data_ptr(), st))
+    for b, e in ((0, 10), (10, 19), (19, 28), (28, 37), (37, 46), (46, 55), (55, 65), (65, 75)):       # 8-rank split
+        lib.check(L.ct_tile_unpack_crops(slab[b:e].contiguous().data_ptr(), lib.ivec(vol.shape), lib.ivec(net), lib.ivec(shrink), b, e - b,
+                                         back.data_ptr(), st))
+    assert torch.equal(back, out)
+
+
+def test_config2_512x512x32_against_oracle_patches():
+    """BASELINE metric size (512x512x32 -> 75 patches): the device volume against the oracle on the centre crops of a corner
+    patch (reflect padding on three sides), an interior patch and the far-corner patch (crop clipped by the volume)."""
+    arch = arch_mod.UNET3_A
+    w = synth.make_unet_weights("unet3_a", seed=0)
+    model = unet3d.unet3_a().set_weights_dict(w)
+    stack, _ = synth.make_stack((512, 512, 32), 600, seed=0)
+    img = synth.normalize_stack(stack)
+    got = unet3d.unet3_prediction(img, model)[0, :, :, :, 0]
+    plan = ur.tile_plan((512, 512, 32), arch.input_shape, arch.input_shape, (24, 24, 2))
+    assert plan["grid"] == (5, 5, 3)
+    patches = ur.gather_patches(img[0, :, :, :, 0], plan)
+    for p in (0, 2 * 15 + 2 * 3 + 1, 74):
+        i, j, k = p // 15, (p // 3) % 5, p % 3
+        want = ur.unet_forward(patches[p], w, arch)[24:136, 24:136, 2:14]
+        sl = got[i * 112:(i + 1) * 112, j * 112:(j + 1) * 112, k * 12:(k + 1) * 12]
+        want = want[:sl.shape[0], :sl.shape[1], :sl.shape[2]]
+        assert sl.size > 0 and float(np.abs(sl - want).max()) <= 1e-4, p

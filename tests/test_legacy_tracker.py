@@ -1,0 +1,212 @@
+"""Legacy `Tracker` frame (reference CellTracker/tracker.py:1138-1191, :1291-1413).
+
+* oracle/tracker_ref.py vs golden vectors recorded from the reference's own Tracker (tests/golden/make_golden.py
+  gen_legacy_tracker): CPU tests;
+* the device Tracker -- constructed with the reference's keyword names, `match(7, "min_size")` called positionally like a
+  legacy notebook does -- vs the same golden vectors (cache-hit path) and vs the oracle chain with the U-Net in the loop.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import match_ref as mr
+from oracle import tracker_ref as tr
+
+synth = importlib.import_module("3deecelltracker_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(golden_dir / "legacy_tracker.npz")
+
+
+@pytest.fixture(scope="module")
+def ffn_w(golden_dir):
+    return synth.load_ffn_npz(golden_dir / "ffn_synthetic_trained.npz")
+
+
+def _case(g, ci):
+    seed, sx, sy, sz, zs, ncell, ens = [int(v) for v in g[f"lt_case_{ci}"]]
+    margin = float(g[f"lt_margin_{ci}"])
+    case = synth.make_legacy_frame_case(seed, (sx, sy, sz), zs, float(g[f"lt_ratio_{ci}"]), ncell, margin=margin,
+                                        edge_cells=2 if margin < 10 else 0)
+    return case, (sx, sy, sz), zs, float(g[f"lt_ratio_{ci}"]), (ens if ens else False)
+
+
+# ------------------------------------------------------------------------------------------------ oracle vs reference (CPU)
+@pytest.mark.parametrize("ci", (0, 1))
+def test_oracle_state_and_bookkeeping_against_reference(g, ci):
+    case, siz, zs, ratio, ens = _case(g, ci)
+    st = tr.LegacyState(case["seg_interp"], siz, ratio, zs)
+    assert np.array_equal(st.tracked_t0, g[f"lt_tracked_t0_{ci}"])
+    assert np.array_equal(np.asarray(st.region_xyz_min), g[f"lt_region_min_{ci}"])
+    assert np.array_equal(np.asarray(st.region_width), g[f"lt_region_width_{ci}"])
+    assert list(st.pad) == g[f"lt_pad_{ci}"].tolist()
+    for key_i, key_s in (("lt_i0", "lt_quick_sums"), ("lt_iw", "lt_wild_sums")):
+        lab, msk = tr.transform_cells_quick(st, g[f"{key_i}_{ci}"])
+        assert [int(lab.astype(np.int64).sum()), int(msk.astype(np.int64).sum()), int((msk > 1).sum())] == g[f"{key_s}_{ci}"].tolist()
+
+
+@pytest.mark.parametrize("ci", (0, 1))
+def test_oracle_correction_against_reference(g, ci):
+    case, siz, zs, ratio, ens = _case(g, ci)
+    st = tr.LegacyState(case["seg_interp"], siz, ratio, zs)
+    prob = case["prob_f16"]; gcn = case["raw"].copy() / 65536.0
+    bd = g[f"lt_bd_local_{ci}"]
+    r1, i1, c1 = tr.correction_once_interp(st, prob, gcn, g[f"lt_i0_{ci}"], bd)
+    assert np.array_equal(i1, g[f"lt_once_i_{ci}"])
+    np.testing.assert_allclose(r1, g[f"lt_once_r_{ci}"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(c1, g[f"lt_once_corr_{ci}"], rtol=0, atol=1e-10)
+    rw, iw, _ = tr.correction_once_interp(st, prob, gcn, g[f"lt_iw_{ci}"], bd)        # cells out of the padded image + overlaps
+    assert np.array_equal(iw, g[f"lt_wild_i_{ci}"])
+    np.testing.assert_allclose(rw, g[f"lt_wild_r_{ci}"], rtol=0, atol=1e-10)
+    r_disp, i_disp = tr.accurate_correction(st, prob, gcn, np.zeros_like(st.tracked_t0), st.tracked_t0, bd, g[f"lt_r_pred_{ci}"])
+    assert np.array_equal(i_disp, g[f"lt_i_disp_{ci}"])
+    np.testing.assert_allclose(r_disp, g[f"lt_r_disp_{ci}"], rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("ci", (0, 1))
+def test_oracle_match_frame_against_reference(g, ffn_w, ci):
+    case, siz, zs, ratio, ens = _case(g, ci)
+    st = tr.LegacyState(case["seg_interp"], siz, ratio, zs)
+    out = tr.match_frame(st, lambda q: mr.ffn_forward(ffn_w, q), case["prob_f16"].astype(np.float32), case["raw"], g[f"lt_seg_t0_{ci}"],
+                         min_size=20, beta_tk=300, lambda_tk=0.1, maxiter_tk=20, ensemble=ens)
+    np.testing.assert_allclose(out["r_coordinates_segment"], g[f"lt_r_seg_{ci}"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out["r_coor_predicted"], g[f"lt_r_pred_{ci}"], rtol=0, atol=1e-8)
+    assert np.array_equal(out["cells_on_boundary_local"], g[f"lt_bd_local_{ci}"])
+    assert np.array_equal(out["i_disp"], g[f"lt_i_disp_{ci}"])
+    np.testing.assert_allclose(out["r_disp"], g[f"lt_r_disp_{ci}"], rtol=0, atol=1e-8)
+    if ci == 0:
+        assert out["cells_on_boundary_local"].sum() == 2            # the two edge cells drift into the 6-pixel boundary zone
+
+
+# ------------------------------------------------------------------------------------------------ device vs reference (GPU)
+def _device_tracker(tmp_path, case, siz, zs, ratio, ens, ffn_w, g, ci, unet_weights=None):
+    tracker = importlib.import_module("3deecelltracker_amd.tracker")
+    ffn_mod = importlib.import_module("3deecelltracker_amd.ffn")
+    unet3d = importlib.import_module("3deecelltracker_amd.unet3d")
+    (tmp_path / "models").mkdir(parents=True, exist_ok=True)
+    ffn_mod.FFN().set_weights_dict(ffn_w).save_weights(tmp_path / "models" / "ffn.npz")
+    if unet_weights is not None:
+        unet3d.unet3_a().set_weights_dict(unet_weights).save_weights(tmp_path / "models" / "unet.npz")
+    # the reference's keyword names (tracker.py:854-859), as a legacy notebook passes them
+    trk = tracker.Tracker(volume_num=8, siz_xyz=siz, z_xy_ratio=ratio, z_scaling=zs, noise_level=100, min_size=20, beta_tk=300,
+                          lambda_tk=0.1, maxiter_tk=20, folder_path=str(tmp_path), image_name="img_t%04i_z%04i.tif",
+                          unet_model_file="unet.npz", ffn_model_file="ffn.npz", ensemble=ens)
+    for sub in ("data", "auto_vol1", "manual_vol1", "track_information", "models", "unet_cache", "anim", "models/unet_weights"):
+        assert (tmp_path / sub).is_dir()
+    assert (tmp_path / ("track_results_EnsembleDstrbtMode" if ens else "track_results_SingleMode")).is_dir()
+    trk.load_ffn()
+    if unet_weights is not None:
+        trk.load_unet()
+        assert (tmp_path / "models" / "unet_weights" / "weights_initial.npz").exists()
+    trk.set_interpolated_segmentation(case["seg_interp"])
+    trk.cal_subregions()
+    trk.r_coordinates_segment_t0 = g[f"lt_seg_t0_{ci}"]
+    trk.initiate_tracking()
+    return trk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", (0, 1))
+def test_device_match_against_reference_golden(g, ffn_w, tmp_path, ci):
+    """Cache-hit frame: unet_cache/t000007.npy + TIFF layers on disk -> match(7, "min_size") -> the reference's 4-list."""
+    from PIL import Image
+    case, siz, zs, ratio, ens = _case(g, ci)
+    trk = _device_tracker(tmp_path, case, siz, zs, ratio, ens, ffn_w, g, ci)
+    assert np.array_equal(trk.r_coordinates_tracked_t0, g[f"lt_tracked_t0_{ci}"])
+    assert [trk.pad_x, trk.pad_y, trk.pad_z] == g[f"lt_pad_{ci}"].tolist()
+    assert np.array_equal(np.asarray(trk.region_xyz_min), g[f"lt_region_min_{ci}"])
+    for z in range(siz[2]):                                                  # the raw volume as the reference's data/ folder holds it
+        Image.fromarray(case["raw"][:, :, z]).save(tmp_path / "data" / ("img_t%04i_z%04i.tif" % (7, z + 1)))
+    np.save(tmp_path / "unet_cache" / "t000007.npy", case["prob_f16"][None, :, :, :, None])
+    anim, (bd_local, vol, i_disp, r_pred) = trk.match(7, "min_size")
+    assert anim is None and vol == 7
+    np.testing.assert_allclose(trk.segresult.r_coordinates_segment, g[f"lt_r_seg_{ci}"], rtol=0, atol=1e-12)   # centres are bit-exact integers/counts
+    np.testing.assert_allclose(r_pred, g[f"lt_r_pred_{ci}"], rtol=0, atol=1e-4)
+    assert np.array_equal(bd_local, g[f"lt_bd_local_{ci}"])
+    assert np.array_equal(i_disp, g[f"lt_i_disp_{ci}"]), "i_disp_from_vol1_updated differs from the reference"
+    r_disp, i_disp2 = trk._accurate_correction(bd_local, g[f"lt_r_pred_{ci}"])
+    assert np.array_equal(i_disp2, g[f"lt_i_disp_{ci}"])
+    np.testing.assert_allclose(r_disp, g[f"lt_r_disp_{ci}"], rtol=0, atol=1e-9)
+    # reference-shaped views of the device-resident results
+    assert trk.segresult.image_cell_bg.shape == (1, *siz, 1) and trk.segresult.segmentation_auto.shape == siz
+    assert np.array_equal(trk.segresult.image_gcn, case["raw"] / 65536.0)
+    assert trk.cell_num == len(g[f"lt_r_seg_{ci}"])
+    with pytest.raises(ValueError, match="miss_frame"):
+        trk.miss_frame = [5]; trk.match(5)
+
+
+@pytest.mark.gpu
+def test_device_correction_out_of_image_and_overlaps(g, ffn_w, tmp_path):
+    """One round from a displacement set that pushes cells out of the padded image (skipped) and onto each other (overlap
+    voxels discarded): integers equal to the reference's _correction_once_interp."""
+    ci = 0
+    case, siz, zs, ratio, ens = _case(g, ci)
+    trk = _device_tracker(tmp_path, case, siz, zs, ratio, ens, ffn_w, g, ci)
+    trk.inject_segmentation(g[f"lt_r_seg_{ci}"], image_cell_bg=case["prob_f16"].astype(np.float32), image_raw=case["raw"])
+    import ctypes as C
+    import torch
+    _lib = importlib.import_module("3deecelltracker_amd._lib"); L = _lib.lib()
+    for key_i, key_r, key_o in (("lt_i0", "lt_once_r", "lt_once_i"), ("lt_iw", "lt_wild_r", "lt_wild_i")):
+        i_in = g[f"{key_i}_{ci}"]
+        # r_disp whose interpolated rounding is exactly i_in:  r = i * (1, 1, ratio / zs)
+        r0 = i_in * np.array([1.0, 1.0, ratio / zs])
+        assert np.array_equal(trk._transform_real_to_interpolated(r0), i_in)
+        n = trk.cell_num_t0
+        r_d = torch.from_numpy(r0).cuda(); i_d = torch.empty((n, 3), dtype=torch.int32, device="cuda")
+        bd = torch.from_numpy(np.ascontiguousarray(g[f"lt_bd_local_{ci}"] != 0, dtype=np.uint8)).cuda()
+        t0 = torch.from_numpy(trk.r_coordinates_tracked_t0).cuda()
+        bbox, subs, offs = trk._regions_dev
+        dims = _lib.ivec(siz)
+        ws = torch.empty(L.ct_correction_legacy_workspace_bytes(dims, n), dtype=torch.uint8, device="cuda")
+        it = C.c_int(0)
+        _lib.check(L.ct_accurate_correction_legacy(trk.segresult.image_cell_bg_d.data_ptr(), trk.segresult.raw_d.data_ptr(), 0, dims, zs,
+                                                   case["seg_interp"].shape[2], ratio, n, bbox.data_ptr(), subs.data_ptr(), offs.data_ptr(),
+                                                   _lib.ivec((trk.pad_x, trk.pad_y, trk.pad_z)), bd.data_ptr(), t0.data_ptr(), r_d.data_ptr(),
+                                                   i_d.data_ptr(), 1, C.byref(it), ws.data_ptr(), ws.numel(),
+                                                   torch.cuda.current_stream().cuda_stream))
+        assert it.value == 1
+        assert np.array_equal(i_d.cpu().numpy(), g[f"{key_o}_{ci}"])
+        np.testing.assert_allclose(r_d.cpu().numpy(), g[f"{key_r}_{ci}"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_device_full_chain_against_oracle(g, ffn_w, tmp_path):
+    """No cache: raw stack -> LCN -> U-Net -> regions -> centres -> FFN + PR-GLS -> boundary -> correction on the device, compared
+    with the oracle chain (oracle LCN + torch-CPU U-Net twin + oracle/tracker_ref.match_frame).  The U-Net weights pass the
+    normalised stack through (synth.make_passthrough_unet_weights) so that the probability map has cell-like regions."""
+    from oracle import preprocess_ref as pr
+    from oracle import unet_ref as ur
+    arch = importlib.import_module("3deecelltracker_amd.arch").UNET3_A
+    ci = 0
+    case, siz, zs, ratio, ens = _case(g, ci)
+    uw = synth.make_passthrough_unet_weights("unet3_a", 0)
+    trk = _device_tracker(tmp_path, case, siz, zs, ratio, ens, ffn_w, g, ci, unet_weights=uw)
+    trk.image_reader = lambda vol: case["raw"]                                  # stacks held in memory instead of data/*.tif
+    anim, (bd_local, vol, i_disp, r_pred) = trk.match(7, "min_size")
+    cached = np.load(tmp_path / "unet_cache" / "t000007.npy")
+    assert cached.dtype == np.float16 and cached.shape == (1, *siz, 1)          # reference :668
+    # oracle chain
+    norm = pr.normalize_image(case["raw"].astype(np.float64), 100).astype(np.float32)
+    prob = ur.unet3_prediction_ref(norm[None, :, :, :, None], lambda p: ur.unet_forward_torch(p, uw, arch), arch.input_shape,
+                                   shrink=(24, 24, 2))[0, :, :, :, 0]
+    got_prob = trk.segresult.image_cell_bg[0, :, :, :, 0]
+    assert np.abs(got_prob - prob).max() <= 1e-4
+    assert not (np.abs(prob - 0.5) < 2e-4).any(), "a voxel sits on the region threshold: pick another seed"
+    st = tr.LegacyState(case["seg_interp"], siz, ratio, zs)
+    want = tr.match_frame(st, lambda q: mr.ffn_forward(ffn_w, q), got_prob, case["raw"], g[f"lt_seg_t0_{ci}"], min_size=20,
+                          beta_tk=300, lambda_tk=0.1, maxiter_tk=20, ensemble=ens)
+    _, _, r_seg_oracle_prob = tr.segment_from_prob(prob, ratio, 20)
+    assert np.array_equal(r_seg_oracle_prob, want["r_coordinates_segment"])     # same regions from the oracle's own prob map
+    assert np.array_equal(trk.segresult.r_coordinates_segment, want["r_coordinates_segment"])
+    np.testing.assert_allclose(r_pred, want["r_coor_predicted"], rtol=0, atol=1e-4)
+    assert np.array_equal(bd_local, want["cells_on_boundary_local"])
+    assert np.array_equal(i_disp, want["i_disp"])
+    # a second frame through track_one_vol appends to the history like the reference (:1532-1534)
+    trk.track_one_vol(7)
+    assert len(trk.history.r_displacements) == 2 and trk.history.r_tracked_coordinates[1].shape == (trk.cell_num_t0, 3)
+    trk.save_coordinates()
+    tab = np.loadtxt(tmp_path / "track_information" / "tracked_coordinates.csv", delimiter=",", skiprows=1)
+    assert tab.shape == (2 * trk.cell_num_t0, 5)

@@ -117,13 +117,14 @@ def test_gpu_tracker_segment_prob_feeds_match():
     ffn = importlib.import_module("3deecelltracker_amd.ffn")
     prob = synth.make_prob_map(7, (96, 96, 12), 50, speckle=0.0)
     model = ffn.FFN(); model.set_weights_dict(synth.make_ffn_weights(0))
-    tk = tracker.Tracker(model, volume_shape=(96, 96, 12), z_xy_ratio=3.0)
+    tk = tracker.Tracker.for_matching(model, siz_xyz=(96, 96, 12), z_xy_ratio=3.0)
     l_c, lab, r = tk.segment_prob(prob[None, ..., None], min_size=10)
     _, cen_r, _ = sr.segment_centroids(prob, 0.5, 1, 10)
     assert np.array_equal(l_c, cen_r) and np.array_equal(r, cen_r * [1.0, 1.0, 3.0]) and lab.max() == len(l_c)
     tk.set_volume1(r)
+    tk.inject_segmentation(r)                 # set_volume1 reset nothing; segment_prob already injected once -- be explicit
     _, (bd, vol, _, pred) = tk.match(2)
-    assert pred.shape == r.shape and np.isfinite(pred).all()
+    assert pred.shape == r.shape and np.isfinite(pred).all() and bd.shape == (len(r),)
 
 
 @pytest.mark.gpu
@@ -133,7 +134,10 @@ def test_gpu_tracker_unet_cache_format(tmp_path):
     unet3d = importlib.import_module("3deecelltracker_amd.unet3d")
     model = unet3d.unet3_a().set_weights_dict(synth.make_unet_weights("unet3_a", 0))
     raw, _ = synth.make_stack((64, 64, 16), 12, 0)
-    tk = tracker.Tracker(None, volume_shape=(64, 64, 16), z_xy_ratio=2.0, unet_model=model, noise_level=20, unet_cache=tmp_path / "unet_cache")
+    tk = tracker.Tracker(volume_num=5, siz_xyz=(64, 64, 16), z_xy_ratio=2.0, z_scaling=1, noise_level=20, min_size=10, beta_tk=300,
+                         lambda_tk=0.1, maxiter_tk=20, folder_path=str(tmp_path), image_name="img_t%04i_z%04i.tif",
+                         unet_model_file="unet.npz", ffn_model_file="ffn.npz")
+    tk.unet_model = model
     a = tk._predict_cellregions(raw, 3)
     f = tmp_path / "unet_cache" / "t000003.npy"
     cached = np.load(f)
@@ -141,5 +145,6 @@ def test_gpu_tracker_unet_cache_format(tmp_path):
     assert np.array_equal(cached, np.asarray(a, dtype=np.float16))
     b = tk._predict_cellregions(None, 3)                      # served from the cache: the image is not touched
     assert b.dtype == np.float16 and np.array_equal(b, cached)
-    with pytest.raises(ValueError, match="segmentation half"):
-        tracker.Tracker(None)._predict_cellregions(raw, 1)
+    tk.unet_model = None
+    with pytest.raises(ValueError, match="load_unet"):
+        tk._predict_cellregions(raw, 1)
