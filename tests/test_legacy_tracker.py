@@ -194,7 +194,7 @@ def test_device_full_chain_against_oracle(g, ffn_w, tmp_path):
                                    shrink=(24, 24, 2))[0, :, :, :, 0]
     got_prob = trk.segresult.image_cell_bg[0, :, :, :, 0]
     assert np.abs(got_prob - prob).max() <= 1e-4
-    assert not (np.abs(prob - 0.5) < 2e-4).any(), "a voxel sits on the region threshold: pick another seed"
+    assert np.array_equal(got_prob > 0.5, prob > 0.5), "a voxel sits within the U-Net's rounding of the region threshold: pick another seed"
     st = tr.LegacyState(case["seg_interp"], siz, ratio, zs)
     want = tr.match_frame(st, lambda q: mr.ffn_forward(ffn_w, q), got_prob, case["raw"], g[f"lt_seg_t0_{ci}"], min_size=20,
                           beta_tk=300, lambda_tk=0.1, maxiter_tk=20, ensemble=ens)
@@ -205,7 +205,7 @@ def test_device_full_chain_against_oracle(g, ffn_w, tmp_path):
     assert np.array_equal(bd_local, want["cells_on_boundary_local"])
     assert np.array_equal(i_disp, want["i_disp"])
     # a second frame through track_one_vol appends to the history like the reference (:1532-1534)
-    trk.track_one_vol(7)
+    trk.track_one_vol(2)                                                        # single mode: source volume = target - 1
     assert len(trk.history.r_displacements) == 2 and trk.history.r_tracked_coordinates[1].shape == (trk.cell_num_t0, 3)
     trk.save_coordinates()
     tab = np.loadtxt(tmp_path / "track_information" / "tracked_coordinates.csv", delimiter=",", skiprows=1)
