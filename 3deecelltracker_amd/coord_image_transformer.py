@@ -174,11 +174,15 @@ class CoordsToImageTransformer:
         for b in boundary_ids:
             missed[b - 1] = 1
         bbox, subs, offs, vol1 = self._dev
-        cur = t.from_numpy(np.ascontiguousarray(coords._raw, dtype=np.float32)).cuda()
+        if bbox.device != prob_d.device:
+            self._dev = tuple(x.to(prob_d.device) for x in self._dev)
+            bbox, subs, offs, vol1 = self._dev
+        cur = t.from_numpy(np.ascontiguousarray(coords._raw, dtype=np.float32)).to(prob_d.device)
+        missed_d = t.from_numpy(missed).to(prob_d.device)          # stays referenced until the call has been issued
         ws = _dev.workspace(L.ct_correction_workspace_bytes(_lib.ivec(self.proofed_shape), n), cur.device)
         iters = C.c_int(0)
         rc = L.ct_accurate_correction(prob_d.data_ptr(), _lib.ivec(self.proofed_shape), self.interpolation_factor, n, bbox.data_ptr(),
-                                      subs.data_ptr(), offs.data_ptr(), t.from_numpy(missed).cuda().data_ptr(), vol1.data_ptr(),
+                                      subs.data_ptr(), offs.data_ptr(), missed_d.data_ptr(), vol1.data_ptr(),
                                       cur.data_ptr(), int(max_repetition), C.byref(iters), ws.data_ptr(), ws.numel(), _dev.stream(cur.device))
         if rc == -2:
             raise ValueError(f"Slices are out of range for image of size {self.proofed_shape}")

@@ -1,0 +1,158 @@
+"""The whole per-frame chain on one HIP stream, TrackerLite dialect (what a user of the reference runs for every volume):
+
+    raw uint16 stack                          (already in HBM, or uploaded from a pinned host buffer)
+      -> ct_normalize_image                   preprocess._normalize_image            (preprocess.py:170-188)
+      -> ct_unet_predict_volume               unet3d.unet3_prediction                (unet3d.py:203-256)
+      -> ct_segment_centroids                 prob map -> regions -> centres         (tracker.py:636-648; seg/coords%06d.npy)
+      -> normalise / kNN features / FFN / greedy prior / PR-GLS / de-normalise       (trackerlite.py:70-109)
+      -> ct_accurate_correction               CoordsToImageTransformer.accurate_correction (coord_image_transformer.py:406-489)
+
+Only (n, 3) coordinate arrays and a few scalars (region count, convergence flags) visit the host.  `FrameChain.synthetic`
+builds a self-consistent synthetic sequence (two consecutive frames of moving blobs, pass-through U-Net weights so that the
+probability map has cell-like regions, the synthetic-trained FFN) for the benchmark's `chained` pass and scripts/microbench.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _dev
+from .coord_image_transformer import Coordinates, CoordsToImageTransformer
+from .preprocess import normalize_image_device
+from .segment import segment_centroids_device
+from .trackerlite import match_device
+
+
+class FrameChain:
+    def __init__(self, unet_model, ffn_model, transformer: CoordsToImageTransformer, noise_level: float, shrink=(24, 24, 2),
+                 min_size: int = 20, beta: float = 3.0, lambda_: float = 3.0, ensemble: bool = True):
+        self.unet_model = unet_model
+        self.ffn_model = ffn_model
+        self.transformer = transformer
+        self.noise_level = float(noise_level)
+        self.shrink = tuple(shrink)
+        self.min_size = int(min_size)
+        self.beta, self.lambda_ = float(beta), float(lambda_)
+        self.ensemble = ensemble
+        self._events = None
+        self._prob = None
+        self.raw_t2 = None
+        self.seg_real_t1 = None
+        self.confirmed_real_t1 = None
+
+    def segment(self, raw_d):
+        """raw stack -> (prob fp32 [x,y,z], centres fp64 [n,3] voxel units), both on the device."""
+        norm = normalize_image_device(raw_d, self.noise_level, (27, 27, 1), mode=0, subtract_median=True)
+        self._mark("lcn")
+        if self._prob is None or self._prob.shape != norm.shape:
+            self._prob = _dev.torch().empty_like(norm)
+        prob = self.unet_model.predict_volume_device(norm, self.shrink, out=self._prob)
+        self._mark("unet")
+        _, centres, _ = segment_centroids_device(prob, 0.5, 1, self.min_size, want_labels=False)
+        self._mark("regions")
+        return prob, centres
+
+    def run(self, raw_d=None, seg_real_t1=None, confirmed_real_t1=None):
+        """One frame: segment `raw_d` (t2), match it against frame t1's segmentation, move t1's confirmed cells, correct them on
+        t2's probability map.  Coordinates are real units (numpy or device fp64 [n, 3]).  Returns a dict with the corrected
+        `Coordinates`, the number of segmented cells and the iteration counts."""
+        t = _dev.torch()
+        raw_d = self.raw_t2 if raw_d is None else raw_d
+        seg_real_t1 = self.seg_real_t1 if seg_real_t1 is None else seg_real_t1
+        confirmed_real_t1 = self.confirmed_real_t1 if confirmed_real_t1 is None else confirmed_real_t1
+        self._mark(None)
+        prob, centres = self.segment(raw_d)
+        vs = t.as_tensor(np.asarray(self.transformer.voxel_size, dtype=np.float64), device=centres.device)
+        seg_real_t2 = centres * vs
+        conf_d = _dev.points_dev(confirmed_real_t1, centres.device)
+        conf_n, para = _dev.normalize_points(conf_d)
+        s2, _ = _dev.normalize_points(seg_real_t2, apply_para=para)
+        s1, _ = _dev.normalize_points(_dev.points_dev(seg_real_t1, centres.device), apply_para=para)
+        _dev.check_match_sizes(s1.shape[0], s2.shape[0], 20, "FrameChain")
+        tracked_n, iters = match_device(self.ffn_model, s1, s2, conf_n, self.beta, self.lambda_)
+        tracked = _dev.denormalize_points(tracked_n, para)
+        self._mark("match")
+        coords = Coordinates(tracked.cpu().numpy(), self.transformer.interpolation_factor, self.transformer.voxel_size, dtype="real")
+        corrected = self.transformer.accurate_correction(prob, coords, ensemble=self.ensemble)
+        self._mark("correction")
+        return {"coords": corrected, "n_segmented": int(centres.shape[0]), "prgls_iterations": int(iters),
+                "correction_rounds": int(self.transformer.last_iterations), "seg_real_t2": seg_real_t2}
+
+    # ---- optional per-stage timing (HIP events on the current stream)
+    def enable_timing(self, on=True):
+        self._events = [] if on else None
+
+    def _mark(self, name):
+        if self._events is None:
+            return
+        t = _dev.torch()
+        ev = t.cuda.Event(enable_timing=True); ev.record()
+        self._events.append((name, ev))
+
+    def stage_times(self):
+        """ms per stage, averaged over the runs recorded since enable_timing()."""
+        t = _dev.torch()
+        t.cuda.synchronize()
+        acc, cnt = {}, {}
+        ev = self._events or []
+        for (_, e0), (n1, e1) in zip(ev, ev[1:]):
+            if n1 is None:
+                continue
+            acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1); cnt[n1] = cnt.get(n1, 0) + 1
+        return {k: acc[k] / cnt[k] for k in acc}
+
+    # ---- synthetic sequence
+    @classmethod
+    def synthetic(cls, shape=(512, 512, 32), n_cells=600, seed=0, ffn_weights=None, device=None, factor=5):
+        """Two consecutive synthetic frames: blobs at c1 (frame t1) and at c1 + smooth motion (frame t2)."""
+        from pathlib import Path
+        from . import synth, unet3d
+        from .ffn import FFN
+        t = _dev.torch()
+        rng = np.random.default_rng(seed)
+        stack1, c1 = synth.make_stack(shape, n_cells, seed)
+        A = (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.02
+        ctr = np.asarray(shape) / 2.0
+        c2 = c1 + (c1 - ctr) @ A + rng.normal(0, 0.3, c1.shape) * np.array([1, 1, 0.3]) + np.array([1.5, -1.0, 0.0])
+        c2 = np.clip(c2, [6, 6, 1], [shape[0] - 6, shape[1] - 6, shape[2] - 1.5])
+        stack2 = _render(shape, c2, rng)
+        vs = np.array([1.0, 1.0, 4.0])
+        subregions = []
+        for c in c1:
+            r = np.array([4, 4, max(2, int(1.5 * factor))])
+            ci = np.array([c[0], c[1], c[2] * factor + factor // 2])
+            lo = np.maximum(np.floor(ci - r).astype(int), 0); hi = np.minimum(np.ceil(ci + r).astype(int) + 1, (shape[0], shape[1], shape[2] * factor))
+            g = np.meshgrid(*(np.arange(lo[a], hi[a]) for a in range(3)), indexing="ij")
+            sub = sum(((g[a] - ci[a]) / r[a]) ** 2 for a in range(3)) <= 1.0
+            subregions.append((tuple(slice(int(lo[a]), int(hi[a])) for a in range(3)), sub))
+        vol1 = Coordinates(c1.astype(np.float32), factor, vs, "raw")
+        tr = CoordsToImageTransformer(shape, vs, factor, subregions, vol1)
+        model = unet3d.unet3_a(device=device).set_weights_dict(synth.make_passthrough_unet_weights("unet3_a", seed))
+        if ffn_weights is None:
+            trained = Path(__file__).resolve().parent.parent / "tests" / "golden" / "ffn_synthetic_trained.npz"
+            ffn_weights = synth.load_ffn_npz(trained) if trained.exists() else synth.make_ffn_weights(0, 6.0, -3.0)
+        ffn = FFN(device=device).set_weights_dict(ffn_weights)
+        chain = cls(model, ffn, tr, noise_level=100.0)
+        dev = "cuda" if device is None else f"cuda:{device}"
+        chain.raw_t1 = t.from_numpy(stack1).to(dev)
+        chain.raw_t2 = t.from_numpy(stack2).to(dev)
+        _, cen1 = chain.segment(chain.raw_t1)                       # frame t1's segmentation = what seg/coords%06d.npy would hold
+        chain.seg_real_t1 = (cen1 * t.as_tensor(vs, device=cen1.device)).clone()
+        chain.confirmed_real_t1 = vol1.real
+        chain.true_t2 = c2
+        return chain
+
+
+def _render(shape, centres, rng):
+    sx, sy, sz = shape
+    img = rng.normal(100.0, 20.0, shape).astype(np.float32)
+    np.clip(img, 0, None, out=img)
+    amps = rng.uniform(400, 2000, len(centres))
+    sig = np.array([3.0, 3.0, 1.0]); rad = np.array([9, 9, 3])
+    for c, a in zip(centres, amps):
+        c0 = np.maximum(np.floor(c - rad).astype(int), 0)
+        c1 = np.minimum(np.ceil(c + rad).astype(int) + 1, shape)
+        gx = np.exp(-0.5 * ((np.arange(c0[0], c1[0]) - c[0]) / sig[0]) ** 2)
+        gy = np.exp(-0.5 * ((np.arange(c0[1], c1[1]) - c[1]) / sig[1]) ** 2)
+        gz = np.exp(-0.5 * ((np.arange(c0[2], c1[2]) - c[2]) / sig[2]) ** 2)
+        img[c0[0]:c1[0], c0[1]:c1[1], c0[2]:c1[2]] += a * gx[:, None, None] * gy[None, :, None] * gz[None, None, :]
+    return np.clip(img, 0, 65535).astype(np.uint16)

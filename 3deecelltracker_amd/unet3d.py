@@ -234,7 +234,8 @@ def unet3_prediction(img, model, shrink=(24, 24, 2)):
     img = np.asarray(img)
     if img.ndim != 5:
         raise ValueError(f"img must have shape (sample, x, y, z, channel), got {img.shape}")
-    vol = torch.from_numpy(np.ascontiguousarray(img[0, :, :, :, 0], dtype=np.float32)).cuda()
+    on = f"cuda:{model._device}" if isinstance(model, UNet3Model) and model._device is not None else "cuda"
+    vol = torch.from_numpy(np.ascontiguousarray(img[0, :, :, :, 0], dtype=np.float32)).to(on)
     if isinstance(model, UNet3Model):
         out = model.predict_volume_device(vol, shrink)
         return out.cpu().numpy()[None, :, :, :, None]

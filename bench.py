@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: volumes/s, segment + match, 512x512x32 stack, ~600 cells.
 
-One "step" = one frame: 3D U-Net sliding-window inference of a synthetic 512x512x32 stack (75
-patches of unet3_a, reflect pad + stitch on device) AND one TrackerLite-style match of two ~600-point
-sets (kNN features -> FFN all pairs -> greedy prior -> PR-GLS), inputs resident in HBM.
-N GPUs: frames are independent units -> every rank processes its own frame per step (weak scaling),
-followed by the all-gather of the tracked centroid sets (RCCL).
+One "step" = one frame: LCN pre-processing + 3D U-Net sliding-window inference of a synthetic 512x512x32 uint16 stack (75
+patches of unet3_a, reflect pad + stitch on device) AND one TrackerLite-style match of two ~600-point sets (kNN features -> FFN
+all pairs -> greedy prior -> PR-GLS), inputs resident in HBM.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events recorded on the launch
-stream around every launch of the dominant kernel (conv3_mfma_kernel instantiation with the largest
-share of time); `cpu_baseline` times the CPU oracle (torch-CPU conv3d U-Net on 32 host threads + numpy reference-formulation match) on a
-bounded sample at N=1.
+--mode frames   (default, the contract line) frames are independent units: every rank processes its own frame per step (weak
+                scaling), followed by the all-gather of the tracked centroid sets (RCCL);
+--mode patches  BASELINE config 3: ONE frame per step, its 75 patches sharded over the N ranks, input broadcast from rank 0,
+                one all_gather_into_tensor of the per-rank centre-crop slabs, match on rank 0 (strong scaling);
+--mode ensemble BASELINE config 4: one ensemble prediction per step = 20 source volumes x 113-cell legacy FFN + PR-GLS
+                predictions sharded over the N ranks, all-gather of the predictions, device trim_mean (strong scaling).
+At N > 1 the default run appends short `patches` and `ensemble` passes to config (so one SCALE run measures configs 3 and 4).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events recorded on the launch stream around every launch of
+the dominant kernel; `cpu_baseline` times the CPU oracle (torch-CPU conv3d U-Net on 32 host threads + numpy
+reference-formulation match) on a bounded sample at N=1.
 """
 from __future__ import annotations
 
@@ -36,155 +41,185 @@ PKG = "3deecelltracker_amd"
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 = fp32 vector peak
 BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 dense MFMA peak (~2.5 PF; measured ceiling 2382)
 HBM_PEAK_TBS = 8.0
+NOISE_LEVEL = 100.0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--shape", type=int, nargs=3, default=(512, 512, 32))
-    ap.add_argument("--cells", type=int, default=600)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU dry runs)")
-    ap.add_argument("--same-device", action="store_true", help="dry run: all ranks on cuda:0 (needs --backend gloo)")
-    ap.add_argument("--match-cus", type=int, default=64, help="CUs reserved for the matching chains (rest: U-Net)")
-    ap.add_argument("--disjoint-match-cus", action="store_true", help="give every match chain its own CU slice (measured: worse)")
-    ap.add_argument("--match-workers", type=int, default=3, help="frames whose match chains are in flight concurrently")
-    ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative second pass with the synthetic-trained FFN")
-    ap.add_argument("--cpu-patches", type=int, default=20, help="U-Net patches timed by the CPU baseline sample")
-    args = ap.parse_args()
+def mod(name):
+    return importlib.import_module(f"{PKG}.{name}")
 
+
+class Ctx:
+    pass
+
+
+def timed(ctx, step, finish, steps, warmup):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks."""
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if args.same_device:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
 
-    arch = importlib.import_module(f"{PKG}.arch").UNET3_A
-    synth = importlib.import_module(f"{PKG}.synth")
-    unet3d = importlib.import_module(f"{PKG}.unet3d")
-    ffn_mod = importlib.import_module(f"{PKG}.ffn")
-    tl = importlib.import_module(f"{PKG}.trackerlite")
-    _dev = importlib.import_module(f"{PKG}._dev")
-    _lib = importlib.import_module(f"{PKG}._lib")
-    L = _lib.lib()
+    def sync_all():
+        torch.cuda.synchronize(ctx.dev)
+        if ctx.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(ctx.dev)
+    for _ in range(warmup):
+        step()
+    finish(); sync_all()
+    if ctx.on_timed_start:
+        ctx.on_timed_start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    finish(); sync_all()
+    dt = time.perf_counter() - t0
+    if ctx.world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=ctx.dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt
 
-    # ---- synthetic, seeded inputs (different frame per rank), resident in HBM before timing
-    shape = tuple(args.shape)
-    unet_w = synth.make_unet_weights("unet3_a", seed=0)
-    ffn_w = synth.make_ffn_weights(seed=0)
-    model = unet3d.unet3_a(device=local).set_weights_dict(unet_w)
-    ffn = ffn_mod.FFN(device=local).set_weights_dict(ffn_w)
-    stack, _ = synth.make_stack(shape, n_cells=args.cells, seed=rank)
-    vol = torch.from_numpy(np.ascontiguousarray(synth.normalize_stack(stack)[0, :, :, :, 0])).to(dev)
-    prob = torch.zeros_like(vol)
-    x, y = synth.make_point_pair(args.cells, seed=100 + rank, box=shape, voxel_size=(1.0, 1.0, 4.0))
-    xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True)
-    yn = (y - mean) / scale
-    seg1, seg2, conf = _dev.points_dev(xn, dev), _dev.points_dev(yn, dev), _dev.points_dev(xn, dev)
-    centre, grid = unet3d.tile_plan(shape, arch.input_shape, (24, 24, 2))
-    n_patches = grid[0] * grid[1] * grid[2]
 
-    # Two plain streams do not interleave on this GPU (the dispatcher drains the conv kernel's workgroups first, so the
-    # dependent chain of tiny matching kernels only advances between conv launches: measured step = sum, not max), and one
-    # PR-GLS chain is latency-bound (~31 ms of dependent ~5 us kernels).  FramePipeline splits the CUs with masked streams
-    # and lets `--match-workers` host threads each drive the match of a different frame (frames are independent units).
-    par = importlib.import_module(f"{PKG}.parallel")
-    pipe = par.FramePipeline(device=local, match_cus=args.match_cus, workers=args.match_workers, disjoint=args.disjoint_match_cus)
-    s_seg = pipe.seg_stream
-    n_cu, k_match = pipe.n_cu, pipe.match_cus
-    gather_buf = [torch.empty((args.cells, 3), dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
-    iters_log = []
+def make_frames_mode(ctx, args):
+    """frames sharded: each rank its own frame (LCN -> U-Net on the big CU partition, match chains on the small one)."""
+    import torch
+    import torch.distributed as dist
+    tl = mod("trackerlite"); pre = mod("preprocess")
+    gather_buf = [torch.empty((args.cells, 3), dtype=torch.float64, device=ctx.dev) for _ in range(ctx.world)] if ctx.world > 1 else None
+    comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
     pending = []
 
-    active = {"ffn": ffn}
-
     def match_job():
-        tracked, iters = tl.match_device(active["ffn"], seg1, seg2, conf, beta=3, lambda_=3)
-        iters_log.append(iters)
+        tracked, iters = tl.match_device(ctx.active["ffn"], ctx.seg1, ctx.seg2, ctx.conf, beta=3, lambda_=3)
+        ctx.iters_log.append(iters)
         return tracked
 
     def collect(fut):
-        tracked = fut.result()
-        if world > 1:
-            dist.all_gather(gather_buf, tracked)           # "gather of centroid sets" (14 KB / rank), main thread only
+        tracked = fut.result()                               # the worker has synchronised its stream: `tracked` is complete
+        if ctx.world > 1:
+            with torch.cuda.stream(comm):                    # "gather of centroid sets" (14 KB / rank) on its own stream
+                dist.all_gather(gather_buf, tracked)
         return tracked
 
     def step():
-        with torch.cuda.stream(s_seg):
-            model.predict_volume_device(vol, out=prob)
-        pending.append(pipe.submit_match(match_job))
+        with torch.cuda.stream(ctx.pipe.seg_stream):
+            norm = pre.normalize_image_device(ctx.raw, NOISE_LEVEL, (27, 27, 1), mode=0, subtract_median=True)
+            ctx.model.predict_volume_device(norm, out=ctx.prob)
+        pending.append(ctx.pipe.submit_match(match_job))
         while len(pending) > args.match_workers:
             collect(pending.pop(0))
 
     def finish():
         while pending:
             collect(pending.pop(0))
+        if comm is not None:
+            comm.synchronize()
+    return step, finish
 
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    finish()
-    sync_all()
-    L.ct_unet_set_timing(model._handle, 1)
-    iters_log.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    finish()                                   # every frame's match (and gather) has completed
-    sync_all()
-    dt = time.perf_counter() - t0
-    L.ct_unet_set_timing(model._handle, 0)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+def make_patches_mode(ctx, args):
+    """config 3: one frame per step, patches sharded over the ranks (parallel.predict_volume_sharded), match on rank 0."""
+    import torch
+    import torch.distributed as dist
+    tl = mod("trackerlite"); pre = mod("preprocess"); par = mod("parallel")
+    comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
+    pending = []
 
-    # ---- informative second pass (never the headline value): the same pipeline with an FFN that discriminates -- the small
-    # model trained on synthetic pairs by tests/golden/train_synthetic_ffn.py -- so that PR-GLS converges in a handful of
-    # iterations as it does with the reference's trained weights instead of the 364 a random-init FFN's noise prior needs
-    realistic = None
-    trained_path = ROOT / "tests" / "golden" / "ffn_synthetic_trained.npz"
-    if trained_path.exists() and not args.no_realistic_pass:
-        iters_main = list(iters_log)
-        active["ffn"] = ffn_mod.FFN(device=local).set_weights_dict(synth.load_ffn_npz(trained_path))
-        for _ in range(args.warmup):
-            step()
-        finish(); sync_all(); iters_log.clear()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        finish(); sync_all()
-        dt2 = time.perf_counter() - t1
-        if world > 1:
-            tmax = torch.tensor([dt2], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt2 = float(tmax.item())
-        realistic = {"volumes_per_s": round(world * args.steps / dt2, 3), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
-                     "prgls_iterations": int(np.median(iters_log)) if iters_log else None,
-                     "ffn": "tests/golden/ffn_synthetic_trained.npz (synthetic-pair training, 84 % of the true pairs found at 600 cells)",
-                     "note": "same partition and inputs as the headline run; only the FFN weights differ"}
-        active["ffn"] = ffn
-        iters_log[:] = iters_main
+    def match_job():
+        tracked, iters = tl.match_device(ctx.active["ffn"], ctx.seg1, ctx.seg2, ctx.conf, beta=3, lambda_=3)
+        ctx.iters_log.append(iters)
+        return tracked
 
-    # ---- roofline of the dominant kernel from the live HIP-event log
+    def step():
+        with torch.cuda.stream(ctx.pipe.seg_stream):
+            if ctx.world > 1:
+                dist.broadcast(ctx.raw.view(torch.uint8), src=0)   # the frame's raw uint16 stack (16.8 MB) reaches every rank
+            norm = pre.normalize_image_device(ctx.raw, NOISE_LEVEL, (27, 27, 1), mode=0, subtract_median=True)
+            ctx.prob = par.predict_volume_sharded(ctx.model, norm, src=None, comm_stream=comm)
+        if ctx.rank == 0:
+            pending.append(ctx.pipe.submit_match(match_job))
+            while len(pending) > args.match_workers:
+                pending.pop(0).result()
+
+    def finish():
+        while pending:
+            pending.pop(0).result()
+    return step, finish
+
+
+def make_ensemble_mode(ctx, args):
+    """config 4: 20 source volumes x 113 cells (worm4), legacy FFN + PR-GLS predictions sharded over the ranks + trim_mean."""
+    synth, tracker_mod = mod("synth"), mod("tracker")
+    n, nvol = 113, 21
+    rng = np.random.default_rng(12)
+    base = rng.uniform(0, 1, (n, 3)) * np.array([168, 401, 128])
+    segs, trks = [], []
+    for _ in range(nvol):
+        a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.04
+        pts = (base - base.mean(0)) @ a + base.mean(0) + rng.normal(0, 0.5, base.shape)
+        segs.append(pts[rng.permutation(n)]); trks.append(pts + rng.normal(0, 0.3, base.shape))
+    trk = tracker_mod.Tracker.for_matching(ctx.ffn_trained or ctx.ffn, beta_tk=1000.0, lambda_tk=1e-5, maxiter_tk=10, ensemble=20)
+    trk.history.r_segmented_coordinates = segs[:-1]; trk.history.r_tracked_coordinates = trks[:-1]
+    trk.cell_num_t0 = n
+    trk.inject_segmentation(segs[-1])
+
+    def step():
+        ctx.ensemble_out = trk.predict_ensemble(nvol)        # get_reference_vols(20, 21) = volumes 1..20
+
+    return step, (lambda: None)
+
+
+def measure_pcie(ctx):
+    """Host-buffer-inclusive frame: H2D of the raw uint16 stack (pinned), LCN, U-Net, D2H of the fp32 probability map."""
+    import torch
+    pre = mod("preprocess")
+    pin = ctx.raw.cpu().pin_memory()
+    out_h = torch.empty(tuple(ctx.raw.shape), dtype=torch.float32).pin_memory()
+
+    def frame():
+        d = pin.to(ctx.dev, non_blocking=True)
+        norm = pre.normalize_image_device(d, NOISE_LEVEL, (27, 27, 1), mode=0, subtract_median=True)
+        ctx.model.predict_volume_device(norm, out=ctx.prob)
+        out_h.copy_(ctx.prob, non_blocking=True)
+    for _ in range(2):
+        frame()
+    torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
+    for _ in range(5):
+        frame()
+    torch.cuda.synchronize(ctx.dev)
+    dt = (time.perf_counter() - t0) / 5
+    return {"segment_ms_per_frame": round(dt * 1e3, 3), "segment_volumes_per_s": round(1.0 / dt, 2),
+            "what": "pinned H2D of the raw uint16 stack + LCN + U-Net + pinned D2H of the fp32 probability map, full chip, one frame at a time"}
+
+
+def measure_chained(ctx, args):
+    """The chained per-frame pipeline (frame.FrameChain): the match consumes the centroids of the probability map just
+    produced and the correction runs on that map -- one frame at a time on one stream."""
+    import torch
+    frame = mod("frame")
+    chain = frame.FrameChain.synthetic(shape=tuple(args.shape), n_cells=args.cells, seed=0, device=ctx.local)
+    for _ in range(2):
+        out = chain.run()
+    chain.enable_timing()
+    torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
+    K = 5
+    for _ in range(K):
+        out = chain.run()
+    torch.cuda.synchronize(ctx.dev)
+    dt = (time.perf_counter() - t0) / K
+    err = float(np.abs(out["coords"].real - chain.true_t2 * np.array([1.0, 1.0, 4.0])).max(axis=1).mean())
+    return {"volumes_per_s": round(1.0 / dt, 2), "ms_per_frame": round(dt * 1e3, 3),
+            "stage_ms": {k: round(v, 3) for k, v in chain.stage_times().items()},
+            "cells_segmented": out["n_segmented"], "prgls_iterations": out["prgls_iterations"],
+            "correction_rounds": out["correction_rounds"], "mean_abs_error_vs_true_centres": round(err, 3),
+            "what": "raw stack -> LCN -> U-Net (pass-through weights) -> regions/centres -> FFN (synthetic-trained) + greedy + PR-GLS -> "
+                    "accurate correction on the same probability map; one frame at a time, one stream, full chip"}
+
+
+def roofline_from_timing(ctx, args, n_patches, steps):
+    L = ctx.L; model = ctx.model; arch = ctx.arch
     nl = L.ct_unet_num_conv_layers(model._handle)
     ms = (C.c_float * nl)(); cnt = (C.c_int * nl)()
-    _lib.check(L.ct_unet_get_timing(model._handle, ms, cnt, nl), "ct_unet_get_timing")
+    ctx._lib.check(L.ct_unet_get_timing(model._handle, ms, cnt, nl), "ct_unet_get_timing")
     by_kernel = {}
     layers = []
     for i in range(nl):
@@ -214,11 +249,16 @@ def main():
         k = by_kernel.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "issued": 0.0, "bf": bf})
         k["ms"] += ms[i]; k["launches"] += cnt[i]; k["flops"] += flops * cnt[i]; k["bytes"] += abytes * cnt[i]
         k["issued"] += issued * cnt[i]
+        t_ms = ms[i] / max(cnt[i], 1)
+        hbm_frac = abytes / max(t_ms * 1e-3, 1e-12) / 1e12 / HBM_PEAK_TBS
+        mfma_frac = issued * (6.0 if bf else 1.0) / max(t_ms * 1e-3, 1e-12) / 1e12 / (BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF)
         layers.append({"layer": i, "cin": cin.value, "cout": cout.value, "dims": [d[0], d[1], d[2]], "kernel": name,
-                       "ms": round(ms[i] / max(cnt[i], 1), 4),
+                       "ms": round(t_ms, 4),
                        "tflops": round(flops * cnt[i] / max(ms[i], 1e-9) / 1e9, 2),
                        "issued_tflops": round(issued * cnt[i] / max(ms[i], 1e-9) / 1e9, 2),
-                       "gbps": round(abytes * cnt[i] / max(ms[i], 1e-9) / 1e6, 1)})
+                       "gbps": round(abytes * cnt[i] / max(ms[i], 1e-9) / 1e6, 1),
+                       "hbm_frac": round(hbm_frac, 4), "mfma_frac": round(mfma_frac, 4),
+                       "binding_roof": "hbm" if hbm_frac >= mfma_frac else "mfma"})
     dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
     dom = by_kernel[dom_name]
     # flops the kernel really executes (== the reference op's 2*27*Cin*Cout per voxel unless the kernel folds upsampled taps).
@@ -226,10 +266,9 @@ def main():
     dom_fp32_equiv = dom["issued"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     achieved = dom_fp32_equiv * (6.0 if dom["bf"] else 1.0)
     peak_tf = BF16_MFMA_PEAK_TF if dom["bf"] else FP32_MFMA_PEAK_TF
-    conv_ms_total = sum(k["ms"] for k in by_kernel.values()) / max(args.steps, 1)
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed
-    # measurement (profiles/, scripts/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 fetch
-    # correction) is attached when it exists for this kernel
+    conv_ms_total = sum(k["ms"] for k in by_kernel.values()) / max(steps, 1)
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed measurement
+    # (profiles/, scripts/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 fetch correction) is attached
     traffic = None
     for cand in sorted((ROOT / "profiles").glob("r*_unet_hbm_traffic.json"), reverse=True):
         try:
@@ -240,6 +279,7 @@ def main():
                 break
         except Exception:
             pass
+    first = layers[0]
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4), "traffic": traffic, "kernel": dom_name,
                 "math": "bf16x6 split (6 bf16 MFMA products per fp32 product, fp32 accumulate)" if dom["bf"] else "f32-input MFMA",
@@ -249,56 +289,190 @@ def main():
                 "executed_gflop_per_launch": round(dom["issued"] / max(dom["launches"], 1) / 1e9, 2),
                 "conv_stack_ms_per_volume": round(conv_ms_total, 3),
                 "conv_stack_tflops": round(n_patches * arch.flops_per_patch() / (conv_ms_total * 1e-3) / 1e12, 2) if conv_ms_total else None,
-                "conv_stack_hbm_frac": round(n_patches * arch.algorithmic_bytes_per_patch() / (conv_ms_total * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if conv_ms_total else None}
+                "conv_stack_hbm_frac": round(n_patches * arch.algorithmic_bytes_per_patch() / (conv_ms_total * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if conv_ms_total else None,
+                "hbm_bound_kernel": {"kernel": first["kernel"], "layer": 0, "achieved_GBps": first["gbps"], "peak_GBps": HBM_PEAK_TBS * 1e3,
+                                     "frac": first["hbm_frac"], "avg_launch_ms": first["ms"],
+                                     "note": "the Cin = 1 first conv is the only HBM-bound instantiation (AI 12 flop/B); SURVEY 8d's fused bytes"}}
+    return roofline, layers
 
-    # ---- CPU baseline: the numpy oracle (reference formulation) on the host cores, bounded sample
+
+def cpu_baseline(ctx, args, n_patches):
+    from oracle import match_ref as mr
+    from oracle import preprocess_ref as pr
+    from oracle import unet_ref as ur
+    arch = ctx.arch; shape = tuple(args.shape)
+    plan = ur.tile_plan(shape, arch.input_shape, arch.input_shape, (24, 24, 2))
+    tl0 = time.perf_counter()
+    vol_h = pr.normalize_image(ctx.raw.cpu().numpy().astype(np.float64), NOISE_LEVEL).astype(np.float32)
+    t_lcn = time.perf_counter() - tl0
+    patches = ur.gather_patches(vol_h, plan)[:args.cpu_patches]
+    # 32 threads: measured on the 256-thread GPU box 8/16/32/64 threads -> 0.122/0.114/0.085/0.197 s per patch (256: 18 s)
+    cpu_threads = min(os.cpu_count() or 1, 32)
+    ur.unet_forward_torch(patches[0], ctx.unet_w, arch, threads=cpu_threads)              # warm-up (thread pool, oneDNN primitives)
+    tp = time.perf_counter()
+    for p in patches:
+        ur.unet_forward_torch(p, ctx.unet_w, arch)
+    t_patch = (time.perf_counter() - tp) / len(patches)
+    tm = time.perf_counter()
+    corr = mr.initial_matching(lambda q: mr.ffn_forward(ctx.ffn_w, q), ctx.xn, ctx.yn, 20)
+    prior, _ = mr.simple_match(corr)
+    _, _, it_cpu = mr.prgls_with_two_ref(prior, ctx.yn, ctx.xn, ctx.xn, beta=3, lambda_=3, return_iters=True)
+    t_match = time.perf_counter() - tm
+    t_vol = t_lcn + n_patches * t_patch + t_match
+    return {"value": round(1.0 / t_vol, 6), "unit": "volumes/s", "cores": cpu_threads, "kind": "port",
+            "sample": f"LCN ({t_lcn:.2f} s, numpy) + {len(patches)} of {n_patches} unet3_a patches ({t_patch:.3f} s/patch, fp32 torch-CPU conv3d on "
+                      f"{cpu_threads} host threads, the fastest count measured) + one full {args.cells}-cell match ({t_match:.2f} s, {it_cpu} "
+                      f"PR-GLS iterations); volume time extrapolated as LCN + {n_patches} x patch + match"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=("frames", "patches", "ensemble"), default="frames")
+    ap.add_argument("--shape", type=int, nargs=3, default=(512, 512, 32))
+    ap.add_argument("--cells", type=int, default=600)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--same-device", action="store_true", help="dry run: all ranks on cuda:0 (needs --backend gloo)")
+    ap.add_argument("--match-cus", type=int, default=64, help="CUs reserved for the matching chains (rest: U-Net)")
+    ap.add_argument("--disjoint-match-cus", action="store_true", help="give every match chain its own CU slice (measured: worse)")
+    ap.add_argument("--match-workers", type=int, default=3, help="frames whose match chains are in flight concurrently")
+    ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
+    ap.add_argument("--cpu-patches", type=int, default=20, help="U-Net patches timed by the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    ctx = Ctx()
+    ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = int(os.environ.get("RANK", "0"))
+    ctx.local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device:
+        ctx.local = 0
+    torch.cuda.set_device(ctx.local)
+    if ctx.world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=ctx.rank, world_size=ctx.world)
+    assert ctx.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}"
+    ctx.dev = f"cuda:{ctx.local}"
+    world, rank, dev = ctx.world, ctx.rank, ctx.dev
+
+    ctx.arch = arch = mod("arch").UNET3_A
+    synth, unet3d, ffn_mod, _dev = mod("synth"), mod("unet3d"), mod("ffn"), mod("_dev")
+    ctx._lib = mod("_lib"); ctx.L = L = ctx._lib.lib()
+    par = mod("parallel")
+
+    # ---- synthetic, seeded inputs (frames mode: a different frame per rank), resident in HBM before timing
+    shape = tuple(args.shape)
+    ctx.unet_w = synth.make_unet_weights("unet3_a", seed=0)
+    ctx.ffn_w = synth.make_ffn_weights(seed=0)
+    ctx.model = unet3d.unet3_a(device=ctx.local).set_weights_dict(ctx.unet_w)
+    ctx.ffn = ffn_mod.FFN(device=ctx.local).set_weights_dict(ctx.ffn_w)
+    trained_path = ROOT / "tests" / "golden" / "ffn_synthetic_trained.npz"
+    ctx.ffn_trained = ffn_mod.FFN(device=ctx.local).set_weights_dict(synth.load_ffn_npz(trained_path)) if trained_path.exists() else None
+    frame_seed = rank if args.mode == "frames" else 0
+    stack, _ = synth.make_stack(shape, n_cells=args.cells, seed=frame_seed)
+    ctx.raw = torch.from_numpy(stack).to(dev)                                   # uint16, LCN runs inside the step
+    ctx.prob = torch.zeros(shape, dtype=torch.float32, device=dev)
+    x, y = synth.make_point_pair(args.cells, seed=100 + frame_seed, box=shape, voxel_size=(1.0, 1.0, 4.0))
+    ctx.xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True)
+    ctx.yn = (y - mean) / scale
+    ctx.seg1, ctx.seg2, ctx.conf = _dev.points_dev(ctx.xn, dev), _dev.points_dev(ctx.yn, dev), _dev.points_dev(ctx.xn, dev)
+    centre, grid = unet3d.tile_plan(shape, arch.input_shape, (24, 24, 2))
+    n_patches = grid[0] * grid[1] * grid[2]
+
+    # Two plain streams do not interleave on this GPU (the dispatcher drains the conv kernel's workgroups first, so the
+    # dependent chain of tiny matching kernels only advances between conv launches: measured step = sum, not max), and one
+    # PR-GLS chain is latency-bound.  FramePipeline splits the CUs with masked streams and lets `--match-workers` host threads
+    # each drive the match of a different frame (frames are independent units).
+    ctx.pipe = par.FramePipeline(device=ctx.local, match_cus=args.match_cus, workers=args.match_workers, disjoint=args.disjoint_match_cus)
+    ctx.iters_log = []
+    ctx.active = {"ffn": ctx.ffn}
+    ctx.on_timed_start = None
+    makers = {"frames": make_frames_mode, "patches": make_patches_mode, "ensemble": make_ensemble_mode}
+
+    # ---- the headline pass
+    step, finish = makers[args.mode](ctx, args)
+
+    def start_timing():
+        L.ct_unet_set_timing(ctx.model._handle, 1); ctx.iters_log.clear()
+    ctx.on_timed_start = start_timing
+    dt = timed(ctx, step, finish, args.steps, args.warmup)
+    L.ct_unet_set_timing(ctx.model._handle, 0)
+    ctx.on_timed_start = None
+    iters_main = list(ctx.iters_log)
+    roofline, layers = (None, None)
+    if args.mode != "ensemble":
+        roofline, layers = roofline_from_timing(ctx, args, n_patches, args.steps)
+    units = world * args.steps if args.mode == "frames" else args.steps
+
+    # ---- informative passes (never the headline value)
+    extra = {}
+    if not args.no_realistic_pass:
+        if ctx.ffn_trained is not None and args.mode != "ensemble":
+            # the same pipeline with an FFN that discriminates (trained on synthetic pairs, tests/golden/train_synthetic_ffn.py):
+            # PR-GLS converges in a handful of iterations as with the reference's trained weights instead of the ~364 a
+            # random-init FFN's noise prior needs
+            ctx.active["ffn"] = ctx.ffn_trained
+            ctx.iters_log.clear()
+            dt2 = timed(ctx, step, finish, args.steps, args.warmup)
+            extra["with_discriminating_ffn"] = {
+                "volumes_per_s": round(units / dt2, 3), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                "prgls_iterations": int(np.median(ctx.iters_log)) if ctx.iters_log else None,
+                "ffn": "tests/golden/ffn_synthetic_trained.npz (synthetic-pair training, 84 % of the true pairs found at 600 cells)",
+                "note": "same partition and inputs as the headline run; only the FFN weights differ"}
+            ctx.active["ffn"] = ctx.ffn
+        if world == 1 and args.mode == "frames":
+            extra["chained"] = measure_chained(ctx, args)
+            extra["pcie_inclusive"] = measure_pcie(ctx)
+        if world > 1 and args.mode == "frames":
+            # BASELINE configs 3 and 4 inside the same launch, so that one scaling run measures them too
+            k2 = max(3, min(args.steps, 10))
+            for name in ("patches", "ensemble"):           # (patches: rank 0's frame is broadcast inside the step)
+                s2, f2 = makers[name](ctx, args)
+                d2 = timed(ctx, s2, f2, k2, 2)
+                extra[f"{name}_sharded"] = {"per_s": round(k2 / d2, 3), "ms_per_step": round(d2 / k2 * 1e3, 3), "steps": k2, "scaling": "strong",
+                                            "what": ("one 512x512x32 frame per step, 75 patches over the ranks, input broadcast + one all_gather_into_tensor of centre-crop slabs, match on rank 0"
+                                                     if name == "patches" else
+                                                     "one ensemble prediction per step: 20 source volumes x 113 cells (legacy FFN + PR-GLS) over the ranks, all-gather + device trim_mean")}
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import match_ref as mr
-        from oracle import unet_ref as ur
-        rng = np.random.default_rng(0)
-        plan = ur.tile_plan(shape, arch.input_shape, arch.input_shape, (24, 24, 2))
-        vol_h = vol.cpu().numpy()
-        patches = ur.gather_patches(vol_h, plan)[:args.cpu_patches]
-        # 32 threads: measured on the 256-thread GPU box 8/16/32/64 threads -> 0.122/0.114/0.085/0.197 s per patch (256: 18 s)
-        cpu_threads = min(os.cpu_count() or 1, 32)
-        ur.unet_forward_torch(patches[0], unet_w, arch, threads=cpu_threads)              # warm-up (thread pool, oneDNN primitives)
-        tp = time.perf_counter()
-        for p in patches:
-            ur.unet_forward_torch(p, unet_w, arch)
-        t_patch = (time.perf_counter() - tp) / len(patches)
-        tm = time.perf_counter()
-        corr = mr.initial_matching(lambda q: mr.ffn_forward(ffn_w, q), xn, yn, 20)
-        prior, _ = mr.simple_match(corr)
-        _, _, it_cpu = mr.prgls_with_two_ref(prior, yn, xn, xn, beta=3, lambda_=3, return_iters=True)
-        t_match = time.perf_counter() - tm
-        t_vol = n_patches * t_patch + t_match
-        cpu = {"value": round(1.0 / t_vol, 6), "unit": "volumes/s", "cores": cpu_threads, "kind": "port",
-               "sample": f"{len(patches)} of {n_patches} unet3_a patches ({t_patch:.3f} s/patch, fp32 torch-CPU conv3d on {cpu_threads} host threads, the fastest count measured) "
-                         f"+ one full {args.cells}-cell match ({t_match:.2f} s, {it_cpu} PR-GLS iterations); "
-                         f"volume time extrapolated as {n_patches} x patch + match"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "frames":
+        cpu = cpu_baseline(ctx, args, n_patches)
 
     if rank == 0:
-        value = world * args.steps / dt
+        value = units / dt
+        if args.mode == "ensemble":
+            metric = "ensemble predictions/s (20 source volumes x 113 cells, legacy FFN + PR-GLS + trim_mean; BASELINE config 4)"
+            workload = "20 x 113-cell legacy Tracker predictions (beta 1000, lambda 1e-5, maxiter 10, 5 repetitions) + trim_mean(0.1)"
+            parallelism = f"source volumes sharded over {world} rank(s), all-gather of predictions"
+        else:
+            metric = "volumes/s segment+match, 512x512x32 stack ~600 cells"
+            workload = (f"{shape[0]}x{shape[1]}x{shape[2]} synthetic uint16 stack, LCN (27x27x1, noise_level {NOISE_LEVEL:g}) + unet3_a sliding window "
+                        f"({n_patches} patches, shrink 24,24,2) + {args.cells}-cell TrackerLite match (FFN all pairs, greedy prior, PR-GLS "
+                        f"beta=lambda=3), seeded random-init weights")
+            parallelism = (f"frames sharded, {world} rank(s), all-gather of tracked centroids" if args.mode == "frames" else
+                           f"patches of one frame sharded over {world} rank(s), input broadcast + all-gather of centre-crop slabs, match on rank 0")
         out = {
-            "metric": "volumes/s segment+match, 512x512x32 stack ~600 cells",
-            "value": round(value, 3), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (U-Net convs: fp32 in/out, exact 3-way bf16 split on the matrix cores, fp32 accumulate; FFN f32) / f64 (PR-GLS)", "data": "synthetic",
-            "config": {"workload": f"{shape[0]}x{shape[1]}x{shape[2]} synthetic stack, unet3_a sliding window "
-                                   f"({n_patches} patches, shrink 24,24,2) + {args.cells}-cell TrackerLite match "
-                                   f"(FFN all pairs, greedy prior, PR-GLS beta=lambda=3), seeded random-init weights",
-                       "patches_per_volume": n_patches, "cells": args.cells,
-                       "prgls_iterations": int(np.median(iters_log)) if iters_log else None,
-                       "with_discriminating_ffn": realistic,
-                       "cu_partition": {"unet": n_cu - k_match, "match": k_match}, "match_chains_in_flight": args.match_workers,
-                       "parallelism": f"frames sharded, {world} rank(s), all-gather of tracked centroids"},
+            "metric": metric,
+            "value": round(value, 3), "unit": "volumes/s" if args.mode != "ensemble" else "predictions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if args.mode == "frames" else "strong",
+            "vs_baseline": None,
+            "dtype": "f32 (U-Net convs: fp32 in/out, exact 3-way bf16 split on the matrix cores, fp32 accumulate; FFN f32) / f64 (PR-GLS)",
+            "data": "synthetic",
+            "config": dict({"workload": workload, "mode": args.mode, "patches_per_volume": n_patches, "cells": args.cells,
+                            "prgls_iterations": int(np.median(iters_main)) if iters_main else None,
+                            "cu_partition": {"unet": ctx.pipe.n_cu - ctx.pipe.match_cus, "match": ctx.pipe.match_cus},
+                            "match_chains_in_flight": args.match_workers, "parallelism": parallelism}, **extra),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "layers": layers,
         }
         print(json.dumps(out))
-    pipe.close()
+    ctx.pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

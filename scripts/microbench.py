@@ -304,7 +304,8 @@ def cmd_frame(args):
     """The chained per-frame pipeline (frame.FrameChain): raw stack -> LCN -> U-Net -> regions/centres -> match -> correction."""
     synth, frame = mod("synth"), mod("frame")
     chain = frame.FrameChain.synthetic(shape=(512, 512, 32), n_cells=600, seed=0)
-    dt, out = timeit(lambda: chain.run(), reps=5, warm=2)
+    chain.run(); chain.enable_timing()
+    dt, out = timeit(lambda: chain.run(), reps=5, warm=1)
     print(f"chained frame 512x512x32: {dt*1e3:.2f} ms  ({out['n_segmented']} cells segmented, {out['prgls_iterations']} PR-GLS iterations, "
           f"{out['correction_rounds']} correction rounds)")
     for k, v in chain.stage_times().items():

@@ -1,0 +1,74 @@
+"""bench.py contract and its sharding modes on the GPU box (1 GPU: 2 ranks over gloo share cuda:0; the nccl path runs when the
+box has >= 2 devices)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline", "cpu_baseline"}
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_modes_share_one_schema():
+    base = [sys.executable, "bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-realistic-pass"]
+    frames = _run(base)
+    patches = _run(base + ["--mode", "patches"])
+    for line in (frames, patches):
+        assert KEYS <= set(line) and line["n_gpus"] == 1 and line["steps"] == 4 and line["unit"] == "volumes/s"
+        assert line["metric"].startswith("volumes/s segment+match") and "workload" in line["config"] and "model" not in line["config"]
+        r = line["roofline"]
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert r["hbm_bound_kernel"]["kernel"] == "conv_first_mfma_kernel"
+    assert frames["scaling"] == "weak" and patches["scaling"] == "strong"
+    # at N = 1 the two modes do the same work: same frame rate within noise
+    assert 0.8 < patches["value"] / frames["value"] < 1.25, (frames["value"], patches["value"])
+    ens = _run(base + ["--mode", "ensemble"])
+    assert ens["unit"] == "predictions/s" and ens["value"] > 0 and ens["scaling"] == "strong"
+
+
+def _two_ranks(backend, extra):
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", backend] + extra
+    return _run(cmd, timeout=1500)
+
+
+def test_two_ranks_gloo_same_device_runs_all_sharding_passes():
+    line = _two_ranks("gloo", ["--same-device"])
+    assert KEYS <= set(line) and line["n_gpus"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    cfg = line["config"]
+    assert cfg["patches_sharded"]["per_s"] > 0 and cfg["ensemble_sharded"]["per_s"] > 0
+    assert cfg["with_discriminating_ffn"]["prgls_iterations"] <= 30
+
+
+def test_two_ranks_nccl():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one device per rank: this box has a single GPU")
+    line = _two_ranks("nccl", [])
+    assert line["n_gpus"] == 2 and line["config"]["patches_sharded"]["per_s"] > 0 and line["config"]["ensemble_sharded"]["per_s"] > 0
+    for mode in ("patches", "ensemble"):
+        port = _free_port()
+        out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode,
+                    "--no-realistic-pass"], timeout=1500)
+        assert out["scaling"] == "strong" and out["value"] > 0
