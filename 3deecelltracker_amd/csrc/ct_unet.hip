@@ -27,6 +27,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <cmath>
 #include <vector>
 #include <new>
 
@@ -64,6 +65,11 @@ struct ConvArgs {
     int cout;
     int nt_total;           // cout tiles of 16 in the packed weights (a block computes NT of them)
     int ngroups;            // nt_total / NT  (blocks along the cout dimension; 1 unless Cout > 64)
+    // split-fp16 kernels: per-patch absolute maxima of the tensors (uint32 bit patterns of non-negative floats)
+    const uint32_t* amaxA;  // srcA's tensor [P] (or null)
+    const uint32_t* amaxB;  // srcB's tensor [P]
+    uint32_t* amax_out;     // this conv's output tensor [P] (null for the head layer)
+    float wscale_inv;       // 1 / (power-of-two scale applied to the packed fp16 weights)
 };
 
 namespace {
@@ -627,8 +633,65 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_c8_fold_kernel(ConvArgs a) 
 // MODE bits: C8 (paired-column rows = (x-select, cout)), FOLD (decoder conv, parity column mapping, see above).
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KB_STD = 7, KB_FOLD = 3, KB_C8 = 9, KB_C8F = 5;
+
+// ------------------------------------------------------------------------------------------------
+// Split-fp16 ("f16x3") family: the same kernels with TWO fp16 components per operand and THREE products.
+//
+// fp16 carries 11 significant bits: x = hi + lo with hi = the top 11 bits of x and lo = fp16(x - hi) represents x to
+// 2^-21 |x| as long as both parts stay inside fp16's exponent range; a * b = hi hi + hi lo + lo hi (+ lo lo ~ 2^-22 |ab|,
+// dropped), and fp16 x fp16 products are exact in the MFMA's fp32 accumulator.  Three v_mfma_f32_16x16x32_f16 replace
+// the six bf16 products -- half the matrix-pipe cycles again -- for an error of the size of fp32's own rounding.
+// fp16's narrow exponent range is handled by exact power-of-two scaling: every conv's epilogue records the per-patch
+// absolute maximum of the tensor it writes (one atomicMax per wave), the consumer scales the activations so that this
+// maximum lands in [2^13, 2^14) before splitting (values down to 2^-17 of the maximum keep full precision, smaller ones
+// an absolute error of 2^-39 of the maximum), the packed weights carry a per-layer power-of-two scale from the host, and
+// the epilogue multiplies the accumulators by the exact inverse.  Per-PATCH maxima keep results independent of how
+// patches are batched or sharded.
+// ------------------------------------------------------------------------------------------------
+template <bool F16> struct SplitMath { static constexpr int NC = F16 ? 2 : 3, NP = F16 ? 3 : 6; };
+
+__device__ __forceinline__ void h_split4(const f32x4 v, float s, uint2& h, uint2& l) {
+    float hs[4], ls[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e] * s;
+        hs[e] = __uint_as_float(__float_as_uint(x) & 0xffffe000u);     // top 11 significant bits: exact in fp16
+        ls[e] = x - hs[e];                                             // exact; <= 13 significant bits, cut to 11 below
+    }
+    h = uint2{__builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(hs[0], hs[1])),
+              __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(hs[2], hs[3]))};
+    l = uint2{__builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(ls[0], ls[1])),
+              __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(ls[2], ls[3]))};
+}
+
+// exponent k such that m * 2^-k lies in [2^13, 2^14); 0 for m == 0 / inf / nan; clamped so that 2^+-k stay normal floats
+__device__ __forceinline__ int amax_exponent(uint32_t mbits) {
+    const int e = (int)(mbits >> 23) & 0xff;
+    if (e == 0 || e == 0xff) return 0;
+    int k = e - 127 - 13;
+    return k < -100 ? -100 : (k > 100 ? 100 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }
+
+// Every patch's slot has its own 128-B line (same-line atomics serialise in one L2 channel: with the 75 slots of a volume on
+// three lines, one atomic per wave cost 1.3 ms per volume) and a workgroup issues ONE no-return atomic (fire and forget; a
+// load-and-compare first makes every wave wait for a memory round trip right before it retires: +0.2 ms on the first conv).
+constexpr int AMAX_STRIDE = 32;        // uint32 words between the slots of consecutive patches
+
+// block-wide max of non-negative floats (256 threads = 4 waves) -> one atomicMax on the tensor's per-patch slot
+__device__ __forceinline__ void amax_publish(float m, uint32_t* slot, int tid, float* red /* [4] LDS */) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0)
+        (void)__hip_atomic_fetch_max(slot, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Tile geometry.  Z8 = false: 4 x 8 columns x 16 z (an MFMA column = one (x, y) column).  Z8 = true (levels with Z <= 8,
 // e.g. every level of unet3_b): 8 x 8 columns x 8 z, an MFMA column = TWO y-adjacent columns x 8 z (lane bit 3 selects the
@@ -675,8 +738,8 @@ __device__ __forceinline__ void bf_split4(const f32x4 v, uint2& h, uint2& m, uin
 }
 
 // One 8-channel halo tile -> three bf16 planes in LDS (see stage_halo_tile for the addressing).
-template <bool Z8>
-__device__ __forceinline__ void bf_stage_tile(const ConvArgs& a, int c0, int p, int x0, int y0, int z0, int tid, char* lds) {
+template <bool Z8, bool F16>
+__device__ __forceinline__ void bf_stage_tile(const ConvArgs& a, int c0, int p, int x0, int y0, int z0, int tid, char* lds, float in_scale) {
     using G = BfGeom<Z8>;
     f32x4 v[G::NSTAGEv];
     const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
@@ -705,29 +768,37 @@ __device__ __forceinline__ void bf_stage_tile(const ConvArgs& a, int c0, int p, 
     for (int i = 0; i < G::NSTAGEv; ++i) {
         const int f = tid + 256 * i;                          // slot f = position f >> 1, channel half f & 1
         if (f < G::NF4v) {
-            uint2 h, m, l;
-            bf_split4(v[i], h, m, l);
             char* d = lds + f * 8;
-            *reinterpret_cast<uint2*>(d) = h;
-            *reinterpret_cast<uint2*>(d + G::PLANE) = m;
-            *reinterpret_cast<uint2*>(d + 2 * G::PLANE) = l;
+            if constexpr (F16) {
+                uint2 h, l;
+                h_split4(v[i], in_scale, h, l);
+                *reinterpret_cast<uint2*>(d) = h;
+                *reinterpret_cast<uint2*>(d + G::PLANE) = l;
+            } else {
+                uint2 h, m, l;
+                bf_split4(v[i], h, m, l);
+                *reinterpret_cast<uint2*>(d) = h;
+                *reinterpret_cast<uint2*>(d + G::PLANE) = m;
+                *reinterpret_cast<uint2*>(d + 2 * G::PLANE) = l;
+            }
         }
     }
     __syncthreads();
 }
 
-// K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * 3 + comp) * 64]
-template <int NT, int NCOL, int KB, bool C8, bool FOLDED, bool KFOLD, bool Z8>
+// K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
+template <bool F16, int NT, int NCOL, int KB, bool C8, bool FOLDED, bool KFOLD, bool Z8>
 __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char* lds, int lanepos, int g,
                                              const uint4* wp, int nt_total) {          // (no __restrict__: see the prefetch)
-    // NT == 1: a K-block is only 24-48 MFMAs (400-800 cycles), less than the L2 round trip of its weight fragments, so the
-    // next block's fragments are requested before this block's MFMAs (12 more VGPRs).  Wider tiles hide it by themselves.
+    // NT == 1: a K-block is only 12-48 MFMAs, less than the L2 round trip of its weight fragments, so the next block's
+    // fragments are requested before this block's MFMAs.  Wider tiles hide it by themselves.
     using G = BfGeom<Z8>;
+    constexpr int NC = SplitMath<F16>::NC, NP = SplitMath<F16>::NP;
     constexpr bool PREFETCH = NT == 1;
-    u32x4 wnext[NT][3];
+    u32x4 wnext[NT][NC];
     if constexpr (PREFETCH) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) wnext[0][c] = *reinterpret_cast<const u32x4*>(wp + (size_t)c * 64);
+        for (int c = 0; c < NC; ++c) wnext[0][c] = *reinterpret_cast<const u32x4*>(wp + (size_t)c * 64);
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -735,14 +806,14 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
                   t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2, G::HYv, G::HZv), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3, G::HYv, G::HZv);
         const int tp = g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
         const char* ab = lds + (lanepos + tp) * 16;
-        bf16x8 wv[NT][3];
+        u32x4 wv[NT][NC];
         if constexpr (PREFETCH) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) wv[0][c] = __builtin_bit_cast(bf16x8, wnext[0][c]);
+            for (int c = 0; c < NC; ++c) wv[0][c] = wnext[0][c];
             if (kb + 1 < KB) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    wnext[0][c] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((kb + 1) * nt_total) * 3 + c) * 64);
+                for (int c = 0; c < NC; ++c)
+                    wnext[0][c] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((kb + 1) * nt_total) * NC + c) * 64);
             }
             // keep the prefetch up here: instruction selection and the scheduler sink a plain load to its first use
             asm volatile("" ::: "memory");
@@ -751,44 +822,51 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    wv[nt][c] = __builtin_bit_cast(bf16x8, wp[((size_t)(kb * nt_total + nt) * 3 + c) * 64]);
+                for (int c = 0; c < NC; ++c)
+                    wv[nt][c] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(kb * nt_total + nt) * NC + c) * 64);
         }
 #pragma unroll
         for (int cg = 0; cg < NCOL; cg += 4) {
-            bf16x8 av[4][3];
+            u32x4 av[4][NC];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int mt = cg + q;
                 const int cpos = bf_col_pos(C8, KFOLD, Z8, mt, G::HYv, G::HZv);
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    av[q][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ab + cpos * 16 + c * G::PLANE));
+                for (int c = 0; c < NC; ++c)
+                    av[q][c] = *reinterpret_cast<const u32x4*>(ab + cpos * 16 + c * G::PLANE);
             }
-            // all 12 fragment reads of the column group go out before its first MFMA (left alone, the scheduler issues them just in
+            // all fragment reads of the column group go out before its first MFMA (left alone, the scheduler issues them just in
             // time to save registers and every pair of MFMAs then eats a full LDS round trip)
             if constexpr (PREFETCH) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-            // (weight component, activation component): hh, hm, mh, mm, hl, lh
-            constexpr int WI[6] = {0, 0, 1, 1, 0, 2}, AI[6] = {0, 1, 0, 1, 2, 0};
+            // (weight component, activation component), smallest terms first: bf16 hh, hm, mh, mm, hl, lh; fp16 hh, hl, lh
+            constexpr int WI[6] = {0, 0, 1, F16 ? 0 : 1, 0, 2}, AI[6] = {0, 1, 0, F16 ? 0 : 1, 2, 0};
 #pragma unroll
-            for (int pr = 5; pr >= 0; --pr)
+            for (int pr = NP - 1; pr >= 0; --pr)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[cg + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[nt][WI[pr]], av[q][AI[pr]], acc[cg + q][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (F16)
+                            acc[cg + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wv[nt][WI[pr]]),
+                                                                                     __builtin_bit_cast(f16x8, av[q][AI[pr]]), acc[cg + q][nt], 0, 0, 0);
+                        else
+                            acc[cg + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[nt][WI[pr]]),
+                                                                                      __builtin_bit_cast(bf16x8, av[q][AI[pr]]), acc[cg + q][nt], 0, 0, 0);
+                    }
         }
     }
 }
 
-template <int NT, bool C8, bool FOLD, bool Z8>
-__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(ConvArgs a) {
+template <bool F16, int NT, bool C8, bool FOLD, bool Z8>
+__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvArgs a) {
     static_assert(!C8 || NT == 1, "the Cout = 8 kernel has one row tile");
     static_assert(!(C8 && Z8), "Cout = 8 layers sit at the full-resolution level");
     using G = BfGeom<Z8>;
     constexpr int NCOL = C8 ? 4 : 8;
     constexpr int HYg = G::HYv, HZg = G::HZv;
-    __shared__ __attribute__((aligned(16))) char lds[3 * G::PLANE];
+    __shared__ __attribute__((aligned(16))) char lds[SplitMath<F16>::NC * G::PLANE];
+    __shared__ float amax_red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int b = blockIdx.x;
     const int cg = b % a.ngroups; b /= a.ngroups;
@@ -822,6 +900,15 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // split-fp16: one power-of-two scale for all input channels of this patch (the larger of the two source tensors' maxima)
+    float in_scale = 1.f, out_mul = 1.f;
+    if constexpr (F16) {
+        uint32_t mb = a.amaxB[p * AMAX_STRIDE];
+        if (a.amaxA) { const uint32_t ma = a.amaxA[p * AMAX_STRIDE]; mb = ma > mb ? ma : mb; }
+        const int k = amax_exponent(mb);
+        in_scale = pow2f(-k); out_mul = pow2f(k) * a.wscale_inv;
+    }
+    constexpr int NC = SplitMath<F16>::NC;
     const uint4* wbase = reinterpret_cast<const uint4*>(a.wpack) + lane;
     constexpr int KBS = C8 ? KB_C8 : KB_STD;                  // skip / ordinary chunks
     constexpr int KBF = C8 ? KB_C8F : KB_FOLD;                // folded chunks
@@ -830,20 +917,21 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
     if constexpr (FOLD) {
         const int cls = C8 ? wy : (wx * 2 + wy);
         for (int chunk = 0; chunk < nA; ++chunk) {
-            bf_stage_tile<Z8>(a, chunk * 8, p, x0, y0, z0, tid, lds);
-            const uint4* wp = wbase + (((size_t)chunk * NCLS + cls) * KBF * a.nt_total + ntb) * 3 * 64;
-            bf_chunk_mma<NT, NCOL, KBF, C8, true, FOLD, Z8>(acc, lds, foldpos, g, wp, a.nt_total);
+            bf_stage_tile<Z8, F16>(a, chunk * 8, p, x0, y0, z0, tid, lds, in_scale);
+            const uint4* wp = wbase + (((size_t)chunk * NCLS + cls) * KBF * a.nt_total + ntb) * NC * 64;
+            bf_chunk_mma<F16, NT, NCOL, KBF, C8, true, FOLD, Z8>(acc, lds, foldpos, g, wp, a.nt_total);
         }
     }
     for (int chunk = nA; chunk < a.nchunks; ++chunk) {
-        bf_stage_tile<Z8>(a, chunk * 8, p, x0, y0, z0, tid, lds);
-        const uint4* wp = wbase + (((size_t)nA * NCLS * KBF + (size_t)(chunk - nA) * KBS) * a.nt_total + ntb) * 3 * 64;
-        bf_chunk_mma<NT, NCOL, KBS, C8, false, FOLD, Z8>(acc, lds, lanepos, g, wp, a.nt_total);
+        bf_stage_tile<Z8, F16>(a, chunk * 8, p, x0, y0, z0, tid, lds, in_scale);
+        const uint4* wp = wbase + (((size_t)nA * NCLS * KBF + (size_t)(chunk - nA) * KBS) * a.nt_total + ntb) * NC * 64;
+        bf_chunk_mma<F16, NT, NCOL, KBS, C8, false, FOLD, Z8>(acc, lds, lanepos, g, wp, a.nt_total);
     }
 
-    // ---- epilogue: bias -> activation -> BatchNorm affine; stores / fused pool / fused head as in the fp32 kernels
+    // ---- epilogue: (un-scale) -> bias -> activation -> BatchNorm affine; stores / fused pool / fused head as in the fp32 kernels
     const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
     const int z = z0 + zl;
+    float vmax = 0.f;                                         // |max| of what this wave writes (split-fp16 consumers scale by it)
     if constexpr (C8) {
         // lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx + (g>>1), y = y0 + col_y(mt)
         const int cb = 4 * (g & 1);
@@ -853,11 +941,12 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
         const int x = x0 + wx + (g >> 1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            f32x4 r = acc[mt][0] + bias;
+            f32x4 r = F16 ? acc[mt][0] * out_mul + bias : acc[mt][0] + bias;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float t = r[e];
                 r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+                if constexpr (F16) vmax = fmaxf(vmax, fabsf(r[e]));
             }
             const int y = y0 + col_y(mt);
             const bool ok = x < a.X && y < a.Y && z < a.Z;
@@ -871,6 +960,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
                     a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + a.head[16])));
             }
         }
+        if constexpr (F16) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
     } else {
         const int CP = a.nt_total * 16;
 #pragma unroll
@@ -881,15 +971,17 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
             const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 2 * CP + cb);
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
-                f32x4 r = acc[mt][nt] + bias;
+                f32x4 r = F16 ? acc[mt][nt] * out_mul + bias : acc[mt][nt] + bias;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = r[e];
                     r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+                    if constexpr (F16) vmax = fmaxf(vmax, fabsf(r[e]));
                 }
                 acc[mt][nt] = r;
             }
         }
+        if constexpr (F16) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
         const int OQ = a.cout >> 3;
         if (a.out) {
 #pragma unroll
@@ -971,10 +1063,12 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_bf16x6_kernel(Conv
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ epi, float* __restrict__ out,
-                                                         int P, int X, int Y, int Z, int act) {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                         int P, int X, int Y, int Z, int act, uint32_t* __restrict__ amax_out) {
+    __shared__ float amax_red[4];
+    const size_t gid0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t nvox = (size_t)P * X * Y * Z;
-    if (gid >= nvox) return;
+    const bool live = gid0 < nvox;
+    const size_t gid = live ? gid0 : nvox - 1;                 // dead lanes recompute the last voxel and do not store
     const int z = (int)(gid % Z); size_t r = gid / Z;
     const int y = (int)(r % Y); r /= Y;
     const int x = (int)(r % X); const int p = (int)(r / X);
@@ -998,6 +1092,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
             }
     const float alpha = act == 0 ? kLeakyAlpha : 0.f;
     constexpr int OQ = COUT / 8;
+    float vmax = 0.f;
 #pragma unroll
     for (int q = 0; q < OQ; ++q) {
         f32x4 o[2];
@@ -1006,10 +1101,19 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
             const int c = q * 8 + e;
             const float t = acc[c] + epi[c];
             o[e >> 2][e & 3] = (t >= 0.f ? t : t * alpha) * epi[COUT + c] + epi[2 * COUT + c];
+            vmax = fmaxf(vmax, fabsf(o[e >> 2][e & 3]));
         }
         float* dst = out + ((((size_t)(p * X + x) * Y + y) * OQ + q) * Z + z) * 8;
-        *reinterpret_cast<f32x4*>(dst) = o[0];
-        *reinterpret_cast<f32x4*>(dst + 4) = o[1];
+        if (live) {
+            *reinterpret_cast<f32x4*>(dst) = o[0];
+            *reinterpret_cast<f32x4*>(dst + 4) = o[1];
+        }
+    }
+    // per-patch |max| of the tensor for the split-fp16 consumers: a block of 256 consecutive voxels lies inside one patch when
+    // the patch volume is a multiple of 256 (every reference architecture); otherwise one atomic per lane
+    if (amax_out) {
+        if (((size_t)X * Y * Z) % 256 == 0) amax_publish(vmax, amax_out + p * AMAX_STRIDE, threadIdx.x, amax_red);
+        else (void)__hip_atomic_fetch_max(amax_out + p * AMAX_STRIDE, __float_as_uint(vmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1099,10 +1203,11 @@ constexpr int F1X = 8, F1Y = 8, F1Z = 16;
 __global__ __launch_bounds__(256, 8) void conv_first_mfma_kernel(const float* __restrict__ vol, TileGeom q, int p_begin,
                                                               const float* __restrict__ wfirst /* [9][64] */,
                                                               const float* __restrict__ epi /* [3][8] */,
-                                                              float* __restrict__ out, int act) {
+                                                              float* __restrict__ out, int act, uint32_t* __restrict__ amax_out) {
     constexpr int HX1 = F1X + 2, HY1 = F1Y + 2, HZ1 = F1Z + 2;
     __shared__ float tile[HX1 * HY1 * HZ1];
     __shared__ int mapx[HX1], mapy[HY1], mapz[HZ1];
+    __shared__ float amax_red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tilesX = (q.nx + F1X - 1) / F1X, tilesY = (q.ny + F1Y - 1) / F1Y, tilesZ = (q.nz + F1Z - 1) / F1Z;
     int b = blockIdx.x;
@@ -1149,15 +1254,17 @@ __global__ __launch_bounds__(256, 8) void conv_first_mfma_kernel(const float* __
     const f32x4 scale = *reinterpret_cast<const f32x4*>(epi + 8 + cb);
     const f32x4 shift = *reinterpret_cast<const f32x4*>(epi + 16 + cb);
     const int z = z0 + zl;
+    float vmax = 0.f;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int x = x0 + 2 * (px0 + (m >> 2)) + (g >> 1), y = y0 + py0 + (m & 3);
         if (x >= q.nx || y >= q.ny || z >= q.nz) continue;
         f32x4 r = acc[m] + bias;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float t = r[e]; r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e]; }
+        for (int e = 0; e < 4; ++e) { const float t = r[e]; r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e]; vmax = fmaxf(vmax, fabsf(r[e])); }
         *reinterpret_cast<f32x4*>(out + (((size_t)(lp * q.nx + x) * q.ny + y) * q.nz + z) * 8 + cb) = r;
     }
+    if (amax_out) amax_publish(vmax, amax_out + lp * AMAX_STRIDE, tid, amax_red);
 }
 
 // blocked [X][Y][C/8][Z][8] (patch 0) -> Keras NDHWC [X][Y][Z][C]   (parity tests only)
@@ -1195,12 +1302,14 @@ struct ConvPlan {
     bool head;
     bool c8;              // Cout == 8: paired-column kernel
     bool fold;            // decoder conv over concat([upsample(low), skip]): folded taps for the upsampled channels
-    bool bf;              // split-bf16 (bf16x6) matrix-pipe kernel instead of the f32-input MFMA kernel
+    bool bf;              // split (bf16x6 / f16x3) matrix-pipe kernel instead of the f32-input MFMA kernel
+    bool f16;             // the split kernel's f16x3 variant (2 fp16 components, 3 products, per-patch power-of-two scaling)
+    float wscale_inv;     // f16x3: 1 / power-of-two scale of the packed weights
     int nt_used;          // instantiation launched by the last run (small grids split NT = 4 into 2 x NT = 2)
     size_t wpack_off;     // float4 offset into the device weight arena
     size_t epi_off;       // float offset
 };
-struct TensorPlan { int level; int C; size_t off; /* floats per patch offset */ };
+struct TensorPlan { int level; int C; size_t off; /* floats per patch offset */ int amax_slot; /* pooled tensors share their parent's */ };
 
 // Entry points that take a handle run on the handle's device whatever the calling thread's current device is
 // (restored on return so that torch's view of the current device is not changed behind its back).
@@ -1415,15 +1524,23 @@ inline void bf_split_host(float x, uint16_t out[3]) {       // exact: x = h + m 
     out[0] = (uint16_t)(hb >> 16); out[1] = (uint16_t)(mb >> 16); out[2] = (uint16_t)(lu >> 16);
 }
 
-// uint4 (16 B) units of one conv's packed weights
-inline size_t bf_pack_units(int cin, int nt_total, int CA, bool c8, bool fold) {
-    const int nA = fold ? CA / 8 : 0, nB = cin / 8 - nA;
-    const int kbs = c8 ? KB_C8 : KB_STD, kbf = c8 ? KB_C8F : KB_FOLD, ncls = c8 ? 2 : 4;
-    return ((size_t)nA * ncls * kbf + (size_t)nB * kbs) * nt_total * 3 * 64;
+inline void h_split_host(float x, uint16_t out[2]) {          // x ~ hi + lo in fp16 (round to nearest), |error| <= 2^-22 |x|
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    memcpy(&out[0], &hi, 2); memcpy(&out[1], &lo, 2);
 }
 
-// wbf[section][kb][nt][comp][lane = g*16 + n][e] = bf16 component of W(tap slot 4 kb + g, cin 8 chunk + e, row 16 nt + n)
-void pack_conv_weights_bf(const float* k, int cin, int cout, int nt_total, int CA, bool c8, bool fold, uint16_t* dst) {
+// uint4 (16 B) units of one conv's packed weights (ncomp = 3 bf16 or 2 fp16 components)
+inline size_t bf_pack_units(int cin, int nt_total, int CA, bool c8, bool fold, int ncomp) {
+    const int nA = fold ? CA / 8 : 0, nB = cin / 8 - nA;
+    const int kbs = c8 ? KB_C8 : KB_STD, kbf = c8 ? KB_C8F : KB_FOLD, ncls = c8 ? 2 : 4;
+    return ((size_t)nA * ncls * kbf + (size_t)nB * kbs) * nt_total * ncomp * 64;
+}
+
+// wbf[section][kb][nt][comp][lane = g*16 + n][e] = component of W(tap slot 4 kb + g, cin 8 chunk + e, row 16 nt + n) * wscale
+// (ncomp = 3: exact bf16 truncation split, wscale 1; ncomp = 2: fp16 hi/lo of the scaled weight)
+void pack_conv_weights_bf(const float* k, int cin, int cout, int nt_total, int CA, bool c8, bool fold, uint16_t* dst,
+                          int ncomp = 3, float wscale = 1.f) {
     const int nA = fold ? CA / 8 : 0, nchunks = cin / 8;
     const int kbs = c8 ? KB_C8 : KB_STD, kbf = c8 ? KB_C8F : KB_FOLD, ncls = c8 ? 2 : 4;
     size_t unit = 0;                                           // running uint4 index
@@ -1437,13 +1554,34 @@ void pack_conv_weights_bf(const float* k, int cin, int cout, int nt_total, int C
                         const int g = lane >> 4, n = lane & 15;
                         for (int e = 0; e < 8; ++e) {
                             uint16_t c3[3];
-                            bf_split_host(bf_weight(k, cin, cout, c8, folded, cls, 4 * kb + g, 8 * ch + e, 16 * nt + n), c3);
-                            for (int c = 0; c < 3; ++c) dst[((unit + (size_t)c * 64 + lane) * 8) + e] = c3[c];
+                            const float wv = bf_weight(k, cin, cout, c8, folded, cls, 4 * kb + g, 8 * ch + e, 16 * nt + n);
+                            if (ncomp == 3) bf_split_host(wv, c3); else h_split_host(wv * wscale, c3);
+                            for (int c = 0; c < ncomp; ++c) dst[((unit + (size_t)c * 64 + lane) * 8) + e] = c3[c];
                         }
                     }
-                    unit += 3 * 64;
+                    unit += (size_t)ncomp * 64;
                 }
     }
+}
+
+// largest |effective weight| of a conv (folded taps summed) -> power-of-two scale that puts it into [2^13, 2^14)
+float f16_weight_scale(const float* k, int cin, int cout, int nt_total, int CA, bool c8, bool fold) {
+    const int nA = fold ? CA / 8 : 0, nchunks = cin / 8;
+    const int kbs = c8 ? KB_C8 : KB_STD, kbf = c8 ? KB_C8F : KB_FOLD, ncls = c8 ? 2 : 4;
+    float m = 0.f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool folded = ch < nA;
+        const int ncl = folded ? ncls : 1, KB = folded ? kbf : kbs;
+        for (int cls = 0; cls < ncl; ++cls)
+            for (int t = 0; t < 4 * KB; ++t)
+                for (int e = 0; e < 8; ++e)
+                    for (int row = 0; row < 16 * nt_total; ++row)
+                        m = fmaxf(m, fabsf(bf_weight(k, cin, cout, c8, folded, cls, t, 8 * ch + e, row)));
+    }
+    if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+    int ex; frexpf(m, &ex);                                   // m = f * 2^ex, f in [0.5, 1)  ->  m * 2^(14 - ex) in [2^13, 2^14)
+    int sh = 14 - ex; sh = sh < -100 ? -100 : (sh > 100 ? 100 : sh);
+    return ldexpf(1.f, sh);
 }
 
 template <int NT>
@@ -1454,17 +1592,32 @@ int launch_conv(const ConvArgs& a, int P, bool fold, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int NT>
+template <bool F16, int NT>
 int launch_conv_bf(const ConvArgs& a, int P, bool fold, bool z8, hipStream_t st) {
     const int nblk = P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
     if (z8) {
-        if (fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, true, true>), dim3(nblk), dim3(256), 0, st, a);
-        else      hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, false, true>), dim3(nblk), dim3(256), 0, st, a);
+        if (fold) hipLaunchKernelGGL((conv3_split_kernel<F16, NT, false, true, true>), dim3(nblk), dim3(256), 0, st, a);
+        else      hipLaunchKernelGGL((conv3_split_kernel<F16, NT, false, false, true>), dim3(nblk), dim3(256), 0, st, a);
     } else {
-        if (fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, true, false>), dim3(nblk), dim3(256), 0, st, a);
-        else      hipLaunchKernelGGL((conv3_bf16x6_kernel<NT, false, false, false>), dim3(nblk), dim3(256), 0, st, a);
+        if (fold) hipLaunchKernelGGL((conv3_split_kernel<F16, NT, false, true, false>), dim3(nblk), dim3(256), 0, st, a);
+        else      hipLaunchKernelGGL((conv3_split_kernel<F16, NT, false, false, false>), dim3(nblk), dim3(256), 0, st, a);
     }
     return (int)hipGetLastError();
+}
+template <bool F16>
+int launch_conv_split(const ConvArgs& a, int P, int NTsel, bool c8, bool fold, bool z8, hipStream_t st) {
+    if (c8) {
+        const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
+        if (fold) hipLaunchKernelGGL((conv3_split_kernel<F16, 1, true, true, false>), dim3(nblk), dim3(256), 0, st, a);
+        else      hipLaunchKernelGGL((conv3_split_kernel<F16, 1, true, false, false>), dim3(nblk), dim3(256), 0, st, a);
+        return (int)hipGetLastError();
+    }
+    switch (NTsel) {
+        case 1: return launch_conv_bf<F16, 1>(a, P, fold, z8, st);
+        case 2: return launch_conv_bf<F16, 2>(a, P, fold, z8, st);
+        case 4: return launch_conv_bf<F16, 4>(a, P, fold, z8, st);
+        default: return CT_ESHAPE;
+    }
 }
 
 struct TimedScope {     // records an event pair around one launch when the handle has timing enabled
@@ -1494,10 +1647,11 @@ int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int d
     if (cin) *cin = c.cin;
     if (cout) *cout = c.cout;
     // 0: first conv, -8: conv3_mfma_c8_kernel, -9: conv3_mfma_c8_fold_kernel, 1..4: conv3_mfma_kernel<nt>, 101..104: conv3_mfma_fold_kernel<nt - 100>
-    // split-bf16 kernels (conv3_bf16x6_kernel<nt, c8, fold>): the same codes +1000 (Cout = 8: -1008 / -1009)
+    // split kernels (conv3_split_kernel<f16, nt, c8, fold, z8>): the same codes +1000 for bf16x6 (Cout = 8: -1008 / -1009),
+    // +2000 for f16x3 (-2008 / -2009)
     if (nt) {
         *nt = layer == 0 ? 0 : (c.c8 ? (c.fold ? -9 : -8) : (c.nt_used ? c.nt_used : c.NT) + (c.fold ? 100 : 0));
-        if (layer > 0 && c.bf) *nt += (*nt < 0 ? -1000 : 1000);
+        if (layer > 0 && c.bf) *nt += (*nt < 0 ? -1 : 1) * (c.f16 ? 2000 : 1000);
     }
     if (dims_xyz) for (int i = 0; i < 3; ++i) dims_xyz[i] = h->dims[c.level][i];
     return CT_OK;
@@ -1581,7 +1735,7 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
     auto vox = [&](int l) { return (size_t)h->dims[l][0] * h->dims[l][1] * h->dims[l][2]; };
     size_t off = 0;
     auto add_tensor = [&](int level, int C) {
-        h->tensors.push_back({level, C, off});
+        h->tensors.push_back({level, C, off, (int)h->tensors.size()});
         off += vox(level) * C;
         return (int)h->tensors.size() - 1;
     };
@@ -1595,6 +1749,7 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
         c.srcA = srcA; c.srcB = srcB; c.CA = CA; c.CB = CB; c.head = head;
         c.dst = add_tensor(level, cout);     // the head layer's tensor is only written for parity dumps
         c.pool_dst = pool ? add_tensor(level + 1, cout) : -1;
+        if (pool) h->tensors[c.pool_dst].amax_slot = h->tensors[c.dst].amax_slot;      // max-pooling cannot raise the maximum
         h->convs.push_back(c);
         ++li;
         return c.dst;
@@ -1663,14 +1818,20 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
             static const bool fold_on = !(getenv("CT_CONV_FOLD") && atoi(getenv("CT_CONV_FOLD")) == 0);
             c.fold = fold_on && c.srcA >= 0 && c.CA % 8 == 0 && ad.pool[0] == 2 && ad.pool[1] == 2 && c.pool_dst < 0
                      && h->dims[c.level][0] % 2 == 0 && h->dims[c.level][1] % 2 == 0;
-            static const bool bf_on = !(getenv("CT_CONV_MATH") && strcmp(getenv("CT_CONV_MATH"), "f32") == 0);
-            c.bf = bf_on;
-            if (c.bf) {                                    // split-bf16 kernels (all four tap sets)
+            // CT_CONV_MATH (read when the model is created): f16x3 (default) | bf16x6 | f32
+            const char* math = getenv("CT_CONV_MATH");
+            c.bf = !(math && strcmp(math, "f32") == 0);
+            c.f16 = c.bf && !(math && strcmp(math, "bf16x6") == 0);
+            c.wscale_inv = 1.f;
+            if (c.bf) {                                    // split kernels (all four tap sets)
                 c.c8 = (c.cout == 8 && c.pool_dst < 0);
-                const size_t units = bf_pack_units(c.cin, c.nt_total, c.CA, c.c8, c.fold);
+                const int ncomp = c.f16 ? 2 : 3;
+                float wscale = 1.f;
+                if (c.f16) { wscale = f16_weight_scale(kern, c.cin, c.cout, c.nt_total, c.CA, c.c8, c.fold); c.wscale_inv = 1.f / wscale; }
+                const size_t units = bf_pack_units(c.cin, c.nt_total, c.CA, c.c8, c.fold, ncomp);
                 arena.resize(arena.size() + units * 4);
                 pack_conv_weights_bf(kern, c.cin, c.cout, c.nt_total, c.CA, c.c8, c.fold,
-                                     reinterpret_cast<uint16_t*>(arena.data() + c.wpack_off));
+                                     reinterpret_cast<uint16_t*>(arena.data() + c.wpack_off), ncomp, wscale);
             } else if (c.cout == 8 && c.pool_dst < 0 && c.fold) {
                 c.c8 = true;
                 arena.resize(arena.size() + fold_pack_floats_c8(c.cin, c.CA));
@@ -1713,11 +1874,14 @@ void ct_unet_destroy(ct_unet_t* h) {
     delete h;
 }
 
+// per-patch |max| slots of every tensor (split-fp16 kernels), placed after the tensors of a batch: [n_tensors][P][AMAX_STRIDE] uint32
+static size_t amax_words(const ct_unet_t* h, int P) { return h->tensors.size() * (size_t)P * AMAX_STRIDE; }
+
 size_t ct_unet_workspace_bytes(const ct_unet_t* h, int n_patches) {
     if (!h || n_patches <= 0) return 0;
     // intermediates of every patch + one prob buffer [n][X][Y][Z] used by ct_unet_predict_volume
     const size_t vox0 = (size_t)h->dims[0][0] * h->dims[0][1] * h->dims[0][2];
-    return (h->floats_per_patch + vox0) * (size_t)n_patches * sizeof(float) + 256;
+    return ((h->floats_per_patch + vox0) * (size_t)n_patches + amax_words(h, n_patches)) * sizeof(float) + 256;
 }
 
 struct VolSource { const float* vol; TileGeom q; int p_begin; };
@@ -1726,6 +1890,12 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                        const VolSource* vsrc = nullptr) {
     // ws: tensor t of patch batch lives at ws + tensors[t].off * P  (each tensor is [P][...])
     auto tptr = [&](int t) { return ws + h->tensors[t].off * (size_t)P; };
+    // per-patch |max| slots (split-fp16 kernels): after the tensors of this batch, zeroed per run
+    uint32_t* amax = reinterpret_cast<uint32_t*>(ws + h->floats_per_patch * (size_t)P);
+    auto aptr = [&](int t) { return amax + (size_t)h->tensors[t].amax_slot * P * AMAX_STRIDE; };
+    bool any_f16 = false;
+    for (const ConvPlan& c : h->convs) any_f16 = any_f16 || c.f16;
+    if (any_f16) HIPCHK(hipMemsetAsync(amax, 0, amax_words(h, P) * sizeof(uint32_t), st));
     const ArchDesc& ad = h->ad;
     size_t dump_off = 0;
     for (size_t i = 0; i < h->convs.size(); ++i) {
@@ -1740,11 +1910,13 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             if (vsrc && c.cout == 8) {
                 const int nb1 = P * ((d[0] + F1X - 1) / F1X) * ((d[1] + F1Y - 1) / F1Y) * ((d[2] + F1Z - 1) / F1Z);
                 hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin,
-                                   h->d_weights + h->first_mfma_off, epi, tptr(c.dst), ad.act);
+                                   h->d_weights + h->first_mfma_off, epi, tptr(c.dst), ad.act, any_f16 ? aptr(c.dst) : nullptr);
             } else if (c.cout == 8)
-                hipLaunchKernelGGL(conv_first_kernel<8>, dim3(nblk), dim3(256), 0, st, tptr(c.srcB), wt, epi, tptr(c.dst), P, d[0], d[1], d[2], ad.act);
+                hipLaunchKernelGGL(conv_first_kernel<8>, dim3(nblk), dim3(256), 0, st, tptr(c.srcB), wt, epi, tptr(c.dst), P, d[0], d[1], d[2], ad.act,
+                                   any_f16 ? aptr(c.dst) : nullptr);
             else if (c.cout == 64)
-                hipLaunchKernelGGL(conv_first_kernel<64>, dim3(nblk), dim3(256), 0, st, tptr(c.srcB), wt, epi, tptr(c.dst), P, d[0], d[1], d[2], ad.act);
+                hipLaunchKernelGGL(conv_first_kernel<64>, dim3(nblk), dim3(256), 0, st, tptr(c.srcB), wt, epi, tptr(c.dst), P, d[0], d[1], d[2], ad.act,
+                                   any_f16 ? aptr(c.dst) : nullptr);
             else return CT_ESHAPE;
             HIPCHK(hipGetLastError());
         } else {
@@ -1767,6 +1939,11 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             }
             if (c.head) { a.head = h->d_weights + h->head_off; a.head_out = prob_out; }
             a.act = ad.act;
+            if (c.f16) {
+                a.amaxB = aptr(c.srcB); a.amaxA = c.srcA >= 0 ? aptr(c.srcA) : nullptr;
+                a.amax_out = c.head ? nullptr : aptr(c.dst);
+                a.wscale_inv = c.wscale_inv;
+            }
             // levels with Z <= 8 (all of unet3_b, the bottom of unet3_c): 8 x 8 x 8 tiles whose MFMA columns hold two (x, y)
             // columns x 8 z instead of one x 16 z with half the lanes on padding (split-bf16 kernels, CT_CONV_Z8=0: off)
             static const bool z8_on = !(getenv("CT_CONV_Z8") && atoi(getenv("CT_CONV_Z8")) == 0);
@@ -1784,18 +1961,8 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             c.nt_used = NTsel;
             int rc;
             if (c.bf) {
-                if (c.c8) {
-                    const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
-                    if (c.fold) hipLaunchKernelGGL((conv3_bf16x6_kernel<1, true, true, false>), dim3(nblk), dim3(256), 0, st, a);
-                    else        hipLaunchKernelGGL((conv3_bf16x6_kernel<1, true, false, false>), dim3(nblk), dim3(256), 0, st, a);
-                    rc = (int)hipGetLastError();
-                } else
-                switch (NTsel) {
-                    case 1: rc = launch_conv_bf<1>(a, P, c.fold, z8, st); break;
-                    case 2: rc = launch_conv_bf<2>(a, P, c.fold, z8, st); break;
-                    case 4: rc = launch_conv_bf<4>(a, P, c.fold, z8, st); break;
-                    default: return CT_ESHAPE;
-                }
+                rc = c.f16 ? launch_conv_split<true>(a, P, NTsel, c.c8, c.fold, z8, st)
+                           : launch_conv_split<false>(a, P, NTsel, c.c8, c.fold, z8, st);
             } else if (c.c8) {
                 const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
                 if (c.fold) hipLaunchKernelGGL(conv3_mfma_c8_fold_kernel, dim3(nblk), dim3(256), 0, st, a);
@@ -1927,7 +2094,7 @@ int ct_unet_predict_volume(ct_unet_t* h, const float* vol, const int v[3], const
     hipStream_t st = (hipStream_t)stream;
     for (int done = 0; done < n;) {
         const int nb = (n - done) < batch_cap ? (n - done) : batch_cap;
-        float* prob = ws + h->floats_per_patch * (size_t)nb;          // [nb][X][Y][Z]
+        float* prob = ws + h->floats_per_patch * (size_t)nb + amax_words(h, nb);          // [nb][X][Y][Z]
         const bool fused_first = h->convs[0].cout == 8 && !getenv("CT_NO_FUSED_FIRST");
         if (!fused_first) {
             rc = ct_tile_gather_reflect(vol, v, h->ad.in, shrink, p_begin + done, nb, ws, stream);   // tensor 0

@@ -229,14 +229,18 @@ def roofline_from_timing(ctx, args, n_patches, steps):
         abytes = 4.0 * d[0] * d[1] * d[2] * (cin.value + cout.value) * n_patches
         code = nt.value
         bf = abs(code) >= 1000
+        f16 = abs(code) >= 2000
         if bf:
-            code = code - 1000 if code > 0 else code + 1000
+            off = 2000 if f16 else 1000
+            code = code - off if code > 0 else code + off
+        nprod = 3.0 if f16 else 6.0                       # matrix-pipe products executed per fp32 product
         if code == 0:
             name = "conv_first_mfma_kernel"
         elif bf:
             z8 = "true" if (code > 0 and d[2] <= 8 and os.environ.get("CT_CONV_Z8", "1") != "0") else "false"   # 8 x 8 x 8 tiles
-            name = (f"conv3_bf16x6_kernel<1, true, {'true' if code == -9 else 'false'}, false>" if code < 0 else
-                    f"conv3_bf16x6_kernel<{code % 100}, false, {'true' if code > 100 else 'false'}, {z8}>")
+            fl = "true" if f16 else "false"
+            name = (f"conv3_split_kernel<{fl}, 1, true, {'true' if code == -9 else 'false'}, false>" if code < 0 else
+                    f"conv3_split_kernel<{fl}, {code % 100}, false, {'true' if code > 100 else 'false'}, {z8}>")
         elif code in (-8, -9):
             name = "conv3_mfma_c8_kernel" if code == -8 else "conv3_mfma_c8_fold_kernel"
         elif code > 100:
@@ -246,12 +250,12 @@ def roofline_from_timing(ctx, args, n_patches, steps):
         # MFMA work actually issued: folded decoder convs run 12 instead of 27 taps on the upsampled channels (Cout = 8: 18 of 36)
         ca = max(L.ct_unet_layer_fold_channels(model._handle, i), 0)
         issued = flops * ((cin.value - ca) + ca * 12.0 / 27.0) / cin.value
-        k = by_kernel.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "issued": 0.0, "bf": bf})
+        k = by_kernel.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "issued": 0.0, "bf": bf, "nprod": nprod, "f16": f16})
         k["ms"] += ms[i]; k["launches"] += cnt[i]; k["flops"] += flops * cnt[i]; k["bytes"] += abytes * cnt[i]
         k["issued"] += issued * cnt[i]
         t_ms = ms[i] / max(cnt[i], 1)
         hbm_frac = abytes / max(t_ms * 1e-3, 1e-12) / 1e12 / HBM_PEAK_TBS
-        mfma_frac = issued * (6.0 if bf else 1.0) / max(t_ms * 1e-3, 1e-12) / 1e12 / (BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF)
+        mfma_frac = issued * (nprod if bf else 1.0) / max(t_ms * 1e-3, 1e-12) / 1e12 / (BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF)
         layers.append({"layer": i, "cin": cin.value, "cout": cout.value, "dims": [d[0], d[1], d[2]], "kernel": name,
                        "ms": round(t_ms, 4),
                        "tflops": round(flops * cnt[i] / max(ms[i], 1e-9) / 1e9, 2),
@@ -262,9 +266,10 @@ def roofline_from_timing(ctx, args, n_patches, steps):
     dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
     dom = by_kernel[dom_name]
     # flops the kernel really executes (== the reference op's 2*27*Cin*Cout per voxel unless the kernel folds upsampled taps).
-    # Split-bf16 kernels execute 6 bf16 MFMA products per fp32 product and are priced against the bf16 dense peak.
+    # Split kernels execute 3 (fp16 hi/lo) or 6 (bf16 h/m/l) matrix-pipe products per fp32 product and are priced against the
+    # 16-bit dense peak.
     dom_fp32_equiv = dom["issued"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-    achieved = dom_fp32_equiv * (6.0 if dom["bf"] else 1.0)
+    achieved = dom_fp32_equiv * (dom["nprod"] if dom["bf"] else 1.0)
     peak_tf = BF16_MFMA_PEAK_TF if dom["bf"] else FP32_MFMA_PEAK_TF
     conv_ms_total = sum(k["ms"] for k in by_kernel.values()) / max(steps, 1)
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the committed measurement
@@ -282,7 +287,8 @@ def roofline_from_timing(ctx, args, n_patches, steps):
     first = layers[0]
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4), "traffic": traffic, "kernel": dom_name,
-                "math": "bf16x6 split (6 bf16 MFMA products per fp32 product, fp32 accumulate)" if dom["bf"] else "f32-input MFMA",
+                "math": ("f16x3 split (2 fp16 components per operand, 3 MFMA products per fp32 product, per-patch power-of-two scaling, fp32 accumulate)" if dom.get("f16") else
+                         "bf16x6 split (6 bf16 MFMA products per fp32 product, fp32 accumulate)") if dom["bf"] else "f32-input MFMA",
                 "fp32_equivalent_tflops": round(dom_fp32_equiv, 2),
                 "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4), "launches": dom["launches"],
                 "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
@@ -461,7 +467,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak" if args.mode == "frames" else "strong",
             "vs_baseline": None,
-            "dtype": "f32 (U-Net convs: fp32 in/out, exact 3-way bf16 split on the matrix cores, fp32 accumulate; FFN f32) / f64 (PR-GLS)",
+            "dtype": "f32 (U-Net convs: fp32 in/out, fp16 hi/lo split on the matrix cores with exact power-of-two scaling, fp32 accumulate; FFN f32) / f64 (PR-GLS)",
             "data": "synthetic",
             "config": dict({"workload": workload, "mode": args.mode, "patches_per_volume": n_patches, "cells": args.cells,
                             "prgls_iterations": int(np.median(iters_main)) if iters_main else None,

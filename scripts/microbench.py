@@ -85,7 +85,7 @@ def cmd_arch(args):
 
 
 def cmd_families(args):
-    for math, fold in (("f32", "0"), ("f32", "1"), ("bf16x6", "0"), ("bf16x6", "1")):
+    for math, fold in (("f32", "0"), ("f32", "1"), ("bf16x6", "0"), ("bf16x6", "1"), ("f16x3", "0"), ("f16x3", "1")):
         env = dict(os.environ, CT_CONV_FOLD=fold, CT_CONV_MATH=math)
         out = subprocess.run([sys.executable, __file__, "unet"], env=env, capture_output=True, text=True)
         print(f"CT_CONV_MATH={math} CT_CONV_FOLD={fold}:", out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-600:])
@@ -115,10 +115,10 @@ def cmd_accuracy(args):
             rel = float(np.abs(mine - ref).max() / max(1.0, np.abs(ref).max()))
             rows.append(f"{rel:.1e}"); worst = max(worst, rel)
         perr = float(np.abs(got[0].cpu().numpy().astype(np.float64) - want).max())
-        print(f"{name} math={os.environ.get('CT_CONV_MATH', 'bf16x6')}: worst block rel err {worst:.2e}, prob map max abs err {perr:.2e}  [{' '.join(rows)}]")
+        print(f"{name} math={os.environ.get('CT_CONV_MATH', 'f16x3')}: worst block rel err {worst:.2e}, prob map max abs err {perr:.2e}  [{' '.join(rows)}]")
         return
     for name in (args or ["unet3_a"]):
-        for math in ("f32", "bf16x6"):
+        for math in ("f32", "bf16x6", "f16x3"):
             out = subprocess.run([sys.executable, __file__, "accuracy", "child", name], env=dict(os.environ, CT_CONV_MATH=math),
                                  capture_output=True, text=True)
             print(out.stdout.strip() or out.stderr[-800:])

@@ -1,4 +1,5 @@
-"""The conv kernel families must agree with each other: f32-input MFMA vs split-bf16, decoder tap folding on/off, Z8 tiles on/off.
+"""The conv kernel families must agree with each other: f32-input MFMA vs split-bf16 (bf16x6) vs split-fp16 (f16x3, the default),
+decoder tap folding on/off, Z8 tiles on/off.
 
 The family is chosen when the model is created (CT_CONV_MATH / CT_CONV_FOLD, read once per process), so every mode runs in
 its own child process on the same seeded patches (CT_CONV_MATH / CT_CONV_FOLD / CT_CONV_Z8); the default mode is additionally held to the oracle in test_gpu_unet.py."""
@@ -34,7 +35,8 @@ np.savez(out, prob=both.cpu().numpy(), dump=dump.cpu().numpy())
 def test_kernel_families_agree(name, tmp_path):
     res = {}
     # (math, fold, z8): z8 = the 8 x 8 x 8 tile geometry of levels with Z <= 8 (split-bf16 kernels only)
-    for math, fold, z8 in (("f32", "0", "1"), ("f32", "1", "1"), ("bf16x6", "0", "1"), ("bf16x6", "1", "1"), ("bf16x6", "1", "0")):
+    for math, fold, z8 in (("f32", "0", "1"), ("f32", "1", "1"), ("bf16x6", "0", "1"), ("bf16x6", "1", "1"), ("bf16x6", "1", "0"),
+                           ("f16x3", "0", "1"), ("f16x3", "1", "1"), ("f16x3", "1", "0")):
         out = tmp_path / f"{name}_{math}_{fold}_{z8}.npz"
         env = dict(os.environ, CT_CONV_MATH=math, CT_CONV_FOLD=fold, CT_CONV_Z8=z8)
         r = subprocess.run([sys.executable, "-c", CHILD, str(REPO), name, str(out)], env=env, capture_output=True, text=True,
