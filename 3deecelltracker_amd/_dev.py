@@ -115,6 +115,33 @@ def prgls_two_ref(prior_d, tgt_d, ref_d, tracked_d, beta, lambda_, max_iteration
     return out_l, out_n, post, iters.value
 
 
+def prgls_two_ref_batched(problems, beta, lambda_, max_iteration, want_posterior=False, want_ref=False):
+    """B independent prgls_with_two_ref problems in one chain of launches (ct_prgls_two_ref_batched).
+    problems: list of (prior fp64 [m][n], tgt [m][3], ref [n][3], tracked [l][3] or None) device tensors (ragged sizes allowed).
+    -> list of (out_tracked | None, out_ref | None, posterior | None, iterations), bit-identical to separate prgls_two_ref calls."""
+    t = torch(); L = _lib.lib()
+    B = len(problems)
+    if B == 0:
+        return []
+    dev = problems[0][0].device
+    ms = [int(p[0].shape[0]) for p in problems]; ns = [int(p[0].shape[1]) for p in problems]
+    ls = [0 if p[3] is None else int(p[3].shape[0]) for p in problems]
+    if max(ns) > PRGLS_MAX_POINTS:
+        raise ValueError(f"PR-GLS: {max(ns)} reference points exceed the dense M-step limit of {PRGLS_MAX_POINTS}")
+    out_l = [empty((l, 3), t.float64, dev) if l else None for l in ls]
+    out_n = [empty((n, 3), t.float64, dev) if want_ref else None for n in ns]
+    post = [empty((m, n), t.float64, dev) if want_posterior else None for m, n in zip(ms, ns)]
+    ptrs = lambda xs: (C.c_void_p * B)(*[None if x is None else x.data_ptr() for x in xs])
+    im, in_, il = _lib.ivec(ms), _lib.ivec(ns), _lib.ivec(ls)
+    ws = workspace(L.ct_prgls_batched_workspace_bytes(B, im, in_, il), dev)
+    iters = (C.c_int * B)()
+    _lib.check(L.ct_prgls_two_ref_batched(B, ptrs([p[0] for p in problems]), ptrs([p[1] for p in problems]), im,
+                                          ptrs([p[2] for p in problems]), in_, ptrs([p[3] for p in problems]), il, float(beta),
+                                          float(lambda_), int(max_iteration), ptrs(out_l), ptrs(out_n), ptrs(post), iters,
+                                          ws.data_ptr(), ws.numel(), stream(dev)), "ct_prgls_two_ref_batched")
+    return [(out_l[b], out_n[b], post[b], int(iters[b])) for b in range(B)]
+
+
 def prgls_legacy(X_d, Y_d, corr_d, BETA, max_iteration, LAMBDA, vol, want_P=True):
     t = torch(); L = _lib.lib()
     n, m = X_d.shape[0], Y_d.shape[0]

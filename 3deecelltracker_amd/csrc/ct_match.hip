@@ -490,6 +490,12 @@ __global__ void row_match_set_kernel(int* __restrict__ row_match, const int32_t*
 // ------------------------------------------------------------------------------------------------
 // scalars block (device): [0] sigma2  [1] gamma  [2] sumP  [3] move_norm2  [4] c = lambda*sigma2  [5] iteration
 enum { S_SIGMA2 = 0, S_GAMMA = 1, S_SUMP = 2, S_NORM2 = 3, S_C = 4, S_IT = 5, S_DONE = 6, S_RES = 7, S_NUM = 8 };
+
+// Batched EM (ct_prgls_two_ref_batched): problem b = blockIdx.z works on the same workspace layout shifted by b * stride
+// doubles (inputs are copied into the workspace first, so EVERY pointer of a launch shifts alike); dims[4 b ..] = m, n, l of
+// problem b (the grid is sized for the largest).  A single-problem launch has gridDim.z = 1: zero shift, dims == null.
+struct Bt { size_t stride; const int* dims; };
+#define BT_SHIFT(T, p) p = (T)((const double*)(p) + (size_t)blockIdx.z * bt.stride)
 // Low-rank M-step (see "Low-rank fast path" below): tolerances of the nested pivoted-Cholesky factorisation |G - U^T U|_max
 // (diag(G) = 1) and the relative residuals of the exact system at which the rank is raised / the step is rejected.
 constexpr double kLowRankTol = 1e-10;              // coarse rank (~40): enough while c = lambda sigma2 is large
@@ -511,7 +517,12 @@ __global__ __launch_bounds__(256) void gauss_kernel(const double* __restrict__ a
 // sum over all (t, r) of |ref_r - tgt_t|^2  -> per-row partial sums rowpart[m]
 __global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restrict__ ref, int n, const double* __restrict__ tgt, int m,
                                                            const double* __restrict__ P /* weights or null */,
-                                                           double* __restrict__ rowpart, const double* __restrict__ sc = nullptr) {
+                                                           double* __restrict__ rowpart, const double* __restrict__ sc = nullptr,
+                                                           Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, ref); BT_SHIFT(const double*, tgt); BT_SHIFT(double*, rowpart);
+    if (P) BT_SHIFT(const double*, P);
+    if (sc) BT_SHIFT(const double*, sc);
+    if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
     if (sc && sc[S_DONE] != 0.0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wave;
@@ -532,10 +543,16 @@ __global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restr
 // mode 2 (legacy, track.py:103-112):      gamma = 1 - sumP/m;            sigma2 = max(sum / (3 sumP), 1)
 __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ rowpart, int m, int n, int mode,
                                                       double* __restrict__ sc, const double* __restrict__ normpart = nullptr,
-                                                      const double* __restrict__ respart = nullptr, int* __restrict__ rank_p = nullptr) {
+                                                      const double* __restrict__ respart = nullptr, int* __restrict__ rank_p = nullptr,
+                                                      Bt bt = Bt{0, nullptr}) {
     __shared__ double red[4];
     __shared__ double red2[4];
     __shared__ double red3[4], red4[4];
+    BT_SHIFT(const double*, rowpart); BT_SHIFT(double*, sc);
+    if (normpart) BT_SHIFT(const double*, normpart);
+    if (respart) BT_SHIFT(const double*, respart);
+    if (rank_p) BT_SHIFT(int*, rank_p);
+    if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
     if (mode != 0 && sc[S_DONE] != 0.0) return;
     if (respart) {
         double r1 = 0.0, r2 = 0.0;
@@ -591,7 +608,11 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
 __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict__ prior, const double* __restrict__ pred,
                                                         int n, const double* __restrict__ tgt, int m,
                                                         const double* __restrict__ sc, int legacy, double vol,
-                                                        double* __restrict__ P, double s2v = 0.0, double gammav = 0.0) {
+                                                        double* __restrict__ P, double s2v = 0.0, double gammav = 0.0,
+                                                        Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, prior); BT_SHIFT(const double*, pred); BT_SHIFT(const double*, tgt); BT_SHIFT(double*, P);
+    if (sc) BT_SHIFT(const double*, sc);
+    if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
     if (sc && sc[S_DONE] != 0.0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wave;
@@ -618,7 +639,11 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
 // column statistics, stage 1: block (x: 64 columns, y: row segment) -> part[seg][4][n] = colsum, Y^T P
 constexpr int CS_SEG = 32;
 __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict__ P, const double* __restrict__ tgt, int m, int n,
-                                                       double* __restrict__ part, const double* __restrict__ sc = nullptr) {
+                                                       double* __restrict__ part, const double* __restrict__ sc = nullptr,
+                                                       Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, P); BT_SHIFT(const double*, tgt); BT_SHIFT(double*, part);
+    if (sc) BT_SHIFT(const double*, sc);
+    if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
     if (sc && sc[S_DONE] != 0.0) return;
     __shared__ double red[4][64][4];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -728,7 +753,12 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
                                                          double* __restrict__ predl, double* __restrict__ norm_part,
                                                          const double* __restrict__ sc, const double* __restrict__ dvec,
                                                          const double* __restrict__ sqd, const double* __restrict__ rhs,
-                                                         double* __restrict__ res_part) {
+                                                         double* __restrict__ res_part, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, C); BT_SHIFT(const double*, G); BT_SHIFT(double*, predn); BT_SHIFT(const double*, Gln);
+    BT_SHIFT(double*, predl); BT_SHIFT(double*, norm_part); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
+    BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs);
+    if (res_part) BT_SHIFT(double*, res_part);
+    if (bt.dims) { n = bt.dims[4 * blockIdx.z + 1]; l = bt.dims[4 * blockIdx.z + 2]; }
     if (sc[S_DONE] != 0.0) return;
     const bool add = sc[S_IT] >= 1.0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -776,7 +806,9 @@ constexpr int LR_RMAX = 128;
 // rank_out[1] = rows computed (tol_fine reached, or LR_RMAX).
 __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __restrict__ G, int n, double tol_coarse, double tol,
                                                               double* __restrict__ U, double* __restrict__ resid,
-                                                              int* __restrict__ rank_out) {
+                                                              int* __restrict__ rank_out, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, G); BT_SHIFT(double*, U); BT_SHIFT(double*, resid); BT_SHIFT(int*, rank_out);
+    if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
     __shared__ double redv[16];
     __shared__ int redi[16];
     __shared__ double pivv; __shared__ int pivi;
@@ -822,7 +854,10 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
 // 4 waves; writes d_i, sqrt d_i and the scaled right-hand side b~_i = (Y^T P[:, i] - x_i d_i) / sqrt d_i.
 __global__ __launch_bounds__(256) void colstats_finish_par_kernel(const double* __restrict__ part, int n, const double* __restrict__ xref,
                                                                   const double* __restrict__ sc, double* __restrict__ dvec,
-                                                                  double* __restrict__ sqd, double* __restrict__ rhs) {
+                                                                  double* __restrict__ sqd, double* __restrict__ rhs, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, part); BT_SHIFT(const double*, xref); BT_SHIFT(const double*, sc); BT_SHIFT(double*, dvec);
+    BT_SHIFT(double*, sqd); BT_SHIFT(double*, rhs);
+    if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
     if (sc[S_DONE] != 0.0) return;
     __shared__ double red[4][64][4];
     const int cl = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -853,7 +888,11 @@ __global__ __launch_bounds__(256) void colstats_finish_par_kernel(const double* 
 __global__ __launch_bounds__(256) void lr_gram_kernel(int n, const double* __restrict__ U, const int* __restrict__ rank_p,
                                                       const double* __restrict__ sc, const double* __restrict__ dvec,
                                                       const double* __restrict__ sqd, const double* __restrict__ rhs,
-                                                      double* __restrict__ Sout /* [LR_RMAX][LR_RMAX] */, double* __restrict__ yout /* [LR_RMAX][3] */) {
+                                                      double* __restrict__ Sout /* [LR_RMAX][LR_RMAX] */, double* __restrict__ yout /* [LR_RMAX][3] */,
+                                                      Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, U); BT_SHIFT(const int*, rank_p); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
+    BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs); BT_SHIFT(double*, Sout); BT_SHIFT(double*, yout);
+    if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
     if (sc[S_DONE] != 0.0) return;
     const int r = *rank_p;
     const int ntri = r * (r + 1) / 2;
@@ -1282,7 +1321,10 @@ __global__ __launch_bounds__(256) void chol_backward_kernel(const double* __rest
 __global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict__ Sin, const double* __restrict__ yin,
                                                        int n, const int* __restrict__ rank_p, double lambda,
                                                        const double* __restrict__ dvec, double* __restrict__ sc,
-                                                       double* __restrict__ qout) {
+                                                       double* __restrict__ qout, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, Sin); BT_SHIFT(const double*, yin); BT_SHIFT(const int*, rank_p); BT_SHIFT(const double*, dvec);
+    BT_SHIFT(double*, sc); BT_SHIFT(double*, qout);
+    if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
     if (sc[S_DONE] != 0.0) return;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int r = *rank_p;
@@ -1388,7 +1430,10 @@ __global__ __launch_bounds__(256) void dense_small_solve_kernel(const double* __
 __global__ __launch_bounds__(256) void lr_coeff_kernel(const double* __restrict__ U, int n, const int* __restrict__ rank_p,
                                                        const double* __restrict__ q, const double* __restrict__ sqd,
                                                        const double* __restrict__ rhs, const double* __restrict__ sc,
-                                                       double* __restrict__ C) {
+                                                       double* __restrict__ C, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, U); BT_SHIFT(const int*, rank_p); BT_SHIFT(const double*, q); BT_SHIFT(const double*, sqd);
+    BT_SHIFT(const double*, rhs); BT_SHIFT(const double*, sc); BT_SHIFT(double*, C);
+    if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
     if (sc[S_DONE] != 0.0) return;
     __shared__ double ps[4][64][3];
     __shared__ double qs[LR_RMAX * 3];
@@ -1712,6 +1757,58 @@ int lowrank_prepare(const PrglsWs& w, int n, hipStream_t st, int* rank_coarse, i
     *rank_coarse = r[0]; *rank_fine = r[1];
     return CT_OK;
 }
+
+// Batched initialisation (one launch for all problems): G = gauss(ref, ref), Gln = gauss(ref, tracked) stored [l][n], T(X) = X,
+// tracked copy, scalar block {sigma2 0, gamma 0.05, ...} -- the arithmetic of gauss_kernel / the host-side init of
+// ct_prgls_two_ref (trackerlite.py:319-325).
+__global__ __launch_bounds__(256) void prgls_init_batch_kernel(const double* __restrict__ ref, const double* __restrict__ tracked,
+                                                               double two_b2, double* __restrict__ G, double* __restrict__ Gln,
+                                                               double* __restrict__ predn, double* __restrict__ predl,
+                                                               double* __restrict__ sc, Bt bt) {
+    BT_SHIFT(const double*, ref); BT_SHIFT(const double*, tracked); BT_SHIFT(double*, G); BT_SHIFT(double*, Gln);
+    BT_SHIFT(double*, predn); BT_SHIFT(double*, predl); BT_SHIFT(double*, sc);
+    const int n = bt.dims[4 * blockIdx.z + 1], l = bt.dims[4 * blockIdx.z + 2];
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid < (size_t)n * n) {
+        const int i = (int)(gid / n), j = (int)(gid - (size_t)i * n);
+        const double dx = ref[3 * j] - ref[3 * i], dy = ref[3 * j + 1] - ref[3 * i + 1], dz = ref[3 * j + 2] - ref[3 * i + 2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        G[gid] = exp(-d2 / two_b2);
+    }
+    if (gid < (size_t)n * l) {
+        const int i = (int)(gid / n), j = (int)(gid - (size_t)i * n);
+        const double dx = ref[3 * j] - tracked[3 * i], dy = ref[3 * j + 1] - tracked[3 * i + 1], dz = ref[3 * j + 2] - tracked[3 * i + 2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        Gln[gid] = exp(-d2 / two_b2);
+    }
+    if (gid < 3 * (size_t)n) predn[gid] = ref[gid];
+    if (gid < 3 * (size_t)l) predl[gid] = tracked[gid];
+    if (gid < S_NUM) sc[gid] = gid == S_GAMMA ? 0.05 : 0.0;
+}
+__global__ void prgls_stop_kernel(double* __restrict__ sc, size_t stride, int b) { sc[(size_t)b * stride + S_DONE] = 1.0; }
+// scalar blocks / ranks of all problems -> one contiguous buffer (a strided hipMemcpy2DAsync to the host was observed to
+// serialise with every other stream of the process: 15 instead of 65 volumes/s in the pipelined benchmark)
+__global__ void prgls_gather_kernel(const double* __restrict__ sc, const int* __restrict__ rank, size_t stride, int B,
+                                    double* __restrict__ out_sc, int* __restrict__ out_rank) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (out_sc && i < B * S_NUM) out_sc[i] = sc[(size_t)(i / S_NUM) * stride + i % S_NUM];
+    if (out_rank && i < 2 * B) out_rank[i] = reinterpret_cast<const int*>(reinterpret_cast<const double*>(rank) + (size_t)(i / 2) * stride)[i % 2];
+}
+
+struct BatchLayout { size_t per_bytes, in_prior, in_tgt, in_ref, in_trk, dims_off, tail_off, total; };
+BatchLayout batch_layout(int B, int mm, int nn, int ll) {
+    BatchLayout L{};
+    size_t off = prgls_layout(mm, nn, ll, nullptr, nullptr);
+    L.in_prior = off; off += align_up((size_t)mm * nn * sizeof(double), 256);
+    L.in_tgt = off; off += align_up(3 * (size_t)mm * sizeof(double), 256);
+    L.in_ref = off; off += align_up(3 * (size_t)nn * sizeof(double), 256);
+    L.in_trk = off; off += align_up(3 * (size_t)(ll > 0 ? ll : 1) * sizeof(double), 256);
+    L.per_bytes = off;
+    L.dims_off = (size_t)B * L.per_bytes;
+    L.tail_off = L.dims_off + align_up((size_t)B * 4 * sizeof(int), 256) + align_up((size_t)B * (S_NUM * sizeof(double) + 2 * sizeof(int)), 256);
+    L.total = L.tail_off + ct_prgls_workspace_bytes(mm, nn, ll) + 512;
+    return L;
+}
 }  // namespace
 
 size_t ct_prgls_workspace_bytes(int m, int n, int l) {
@@ -1826,6 +1923,150 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
     if (l > 0) HIPCHK(hipMemcpyAsync(out_tracked, w.predl, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (out_ref) HIPCHK(hipMemcpyAsync(out_ref, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (posterior) HIPCHK(hipMemcpyAsync(posterior, w.P, (size_t)m * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return CT_OK;
+}
+
+size_t ct_prgls_batched_workspace_bytes(int B, const int* m, const int* n, const int* l) {
+    if (B <= 0 || !m || !n || !l) return 0;
+    int mm = 0, nn = 0, ll = 0;
+    for (int b = 0; b < B; ++b) {
+        if (m[b] <= 0 || n[b] <= 0 || l[b] < 0) return 0;
+        mm = m[b] > mm ? m[b] : mm; nn = n[b] > nn ? n[b] : nn; ll = l[b] > ll ? l[b] : ll;
+    }
+    return batch_layout(B, mm, nn, ll).total;
+}
+
+int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* const* tgt, const int* m, const double* const* ref,
+                             const int* n, const double* const* tracked, const int* l, double beta, double lambda, int max_iteration,
+                             double* const* out_tracked, double* const* out_ref, double* const* posterior, int* iters,
+                             void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (B <= 0 || !prior || !tgt || !m || !ref || !n || !l || !workspace) return CT_EINVAL;
+    int mm = 0, nn = 0, ll = 0;
+    for (int b = 0; b < B; ++b) {
+        if (!prior[b] || !tgt[b] || !ref[b] || m[b] <= 0 || n[b] <= 0 || l[b] < 0 ||
+            (l[b] > 0 && (!tracked || !tracked[b] || !out_tracked || !out_tracked[b]))) return CT_EINVAL;
+        mm = m[b] > mm ? m[b] : mm; nn = n[b] > nn ? n[b] : nn; ll = l[b] > ll ? l[b] : ll;
+    }
+    const BatchLayout L = batch_layout(B, mm, nn, ll);
+    if (workspace_bytes < L.total) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    PrglsWs w;
+    prgls_layout(mm, nn, ll, base, &w);                      // problem 0's arrays; problem b's are `stride` doubles further
+    const size_t stride = L.per_bytes / sizeof(double);
+    double* in_prior = (double*)(base + L.in_prior); double* in_tgt = (double*)(base + L.in_tgt);
+    double* in_ref = (double*)(base + L.in_ref); double* in_trk = (double*)(base + L.in_trk);
+    int* d_dims = (int*)(base + L.dims_off);
+    double* d_gsc = (double*)(base + L.dims_off + align_up((size_t)B * 4 * sizeof(int), 256));      // gathered scalar blocks
+    int* d_grank = (int*)(d_gsc + (size_t)B * S_NUM);                                                // gathered ranks
+    std::vector<int> hdims(4 * (size_t)B, 0);
+    for (int b = 0; b < B; ++b) {
+        hdims[4 * b] = m[b]; hdims[4 * b + 1] = n[b]; hdims[4 * b + 2] = l[b];
+        HIPCHK(hipMemcpyAsync(in_prior + b * stride, prior[b], (size_t)m[b] * n[b] * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(in_tgt + b * stride, tgt[b], 3 * (size_t)m[b] * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(in_ref + b * stride, ref[b], 3 * (size_t)n[b] * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (l[b] > 0) HIPCHK(hipMemcpyAsync(in_trk + b * stride, tracked[b], 3 * (size_t)l[b] * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(d_dims, hdims.data(), hdims.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                        // hdims is a host temporary
+    const Bt bt{stride, d_dims};
+    const unsigned zB = (unsigned)B;
+    {
+        const size_t tot = (size_t)nn * (nn > ll ? nn : ll);
+        const size_t cover = tot > 3 * (size_t)(nn > ll ? nn : ll) ? tot : 3 * (size_t)(nn > ll ? nn : ll);
+        hipLaunchKernelGGL(prgls_init_batch_kernel, dim3((unsigned)((cover + 255) / 256), 1, zB), dim3(256), 0, st, in_ref, in_trk,
+                           2.0 * beta * beta, w.G, w.Gln, w.predn, w.predl, w.sc, bt);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_ref, nn, in_tgt, mm, (const double*)nullptr,
+                       w.rowpart0, (const double*)nullptr, bt);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(scalars_kernel, dim3(1, 1, zB), dim3(256), 0, st, w.rowpart0, mm, nn, 0, w.sc, (const double*)nullptr,
+                       (const double*)nullptr, (int*)nullptr, bt);
+    LAUNCH_CHECK();
+    ENSURE_BIG_LDS(lr_solve_kernel);
+    hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1, 1, zB), dim3(1024), 0, st, w.G, nn, kLowRankTol, kLowRankTolTight, w.U, w.resid, w.rank, bt);
+    LAUNCH_CHECK();
+    std::vector<int> hrank(2 * (size_t)B, 0);
+    hipLaunchKernelGGL(prgls_gather_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, st, (const double*)nullptr, w.rank, stride, B, (double*)nullptr, d_grank);
+    LAUNCH_CHECK();
+    HIPCHK(hipMemcpyAsync(hrank.data(), d_grank, 2 * (size_t)B * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // problems whose Gram matrix does not factorise to the coarse tolerance (or CT_PRGLS_DENSE) and problems whose low-rank
+    // M-step the residual monitor rejects are finished by the single-problem routine (its retry / dense logic) afterwards
+    std::vector<char> fallback(B, 0), finished(B, 0);
+    int rank = 0, live = 0;
+    for (int b = 0; b < B; ++b) {
+        if (hrank[2 * b] <= 0 || getenv("CT_PRGLS_DENSE")) {
+            fallback[b] = 1;
+            hipLaunchKernelGGL(prgls_stop_kernel, dim3(1), dim3(1), 0, st, w.sc, stride, b);
+            LAUNCH_CHECK();
+        } else { rank = hrank[2 * b + 1] > rank ? hrank[2 * b + 1] : rank; ++live; }
+    }
+    const int total = max_iteration - 1;
+    std::vector<double> hsc((size_t)B * S_NUM, 0.0);
+    for (int enq = 0; enq < total && live > 0;) {
+        const int chunk = (total - enq) < 16 ? (total - enq) : 16;
+        for (int k = 0; k < chunk; ++k) {
+            hipLaunchKernelGGL(posterior_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_prior, w.predn, nn, in_tgt, mm, w.sc, 0, 1.0,
+                               w.P, 0.0, 0.0, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(colstats_kernel, dim3((nn + 63) / 64, CS_SEG, zB), dim3(256), 0, st, w.P, in_tgt, mm, nn, w.part, w.sc, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((nn + 63) / 64, 1, zB), dim3(256), 0, st, w.part, nn, w.predn, w.sc, w.dvec,
+                               w.sqd, w.rhs, bt);
+            LAUNCH_CHECK();
+            const int nent = rank * (rank + 1) / 2 + 3 * rank;
+            hipLaunchKernelGGL(lr_gram_kernel, dim3((nent + 3) / 4, 1, zB), dim3(256), 0, st, nn, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs,
+                               w.Spart, w.ypart, bt);
+            LAUNCH_CHECK();
+            const size_t lds = (size_t)(rank + 3) * (rank | 1) * sizeof(double);
+            hipLaunchKernelGGL(lr_solve_kernel, dim3(1, 1, zB), dim3(256), lds, st, w.Spart, w.ypart, nn, w.rank, lambda, w.dvec, w.sc, w.q, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(lr_coeff_kernel, dim3((nn + 63) / 64, 1, zB), dim3(256), 0, st, w.U, nn, w.rank, w.q, w.sqd, w.rhs, w.sc, w.C, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(apply_dual_kernel, dim3((nn + ll + 3) / 4, 1, zB), dim3(256), 0, st, w.C, w.G, nn, w.predn, w.Gln, ll, w.predl,
+                               w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, w.predn, nn, in_tgt, mm, w.P, w.rowpart, w.sc, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(scalars_kernel, dim3(1, 1, zB), dim3(256), 0, st, w.rowpart, mm, nn, 1, w.sc, w.normpart, w.respart, w.rank, bt);
+            LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(prgls_gather_kernel, dim3((B * S_NUM + 63) / 64), dim3(64), 0, st, w.sc, (const int*)nullptr, stride, B, d_gsc, (int*)nullptr);
+        LAUNCH_CHECK();
+        HIPCHK(hipMemcpyAsync(hsc.data(), d_gsc, (size_t)B * S_NUM * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        enq += chunk;
+        live = 0;
+        for (int b = 0; b < B; ++b) {
+            if (fallback[b] || finished[b]) continue;
+            const double* h = &hsc[(size_t)b * S_NUM];
+            if (!(h[S_RES] <= kLowRankMaxResidual)) {
+                fallback[b] = 1;
+                hipLaunchKernelGGL(prgls_stop_kernel, dim3(1), dim3(1), 0, st, w.sc, stride, b);
+                LAUNCH_CHECK();
+                continue;
+            }
+            if (iters) iters[b] = (int)h[S_IT];
+            if (h[S_DONE] != 0.0) finished[b] = 1; else ++live;
+        }
+    }
+    for (int b = 0; b < B; ++b) {
+        if (fallback[b]) {
+            int it = 0;
+            const int rc = ct_prgls_two_ref(prior[b], tgt[b], m[b], ref[b], n[b], l[b] > 0 ? tracked[b] : nullptr, l[b], beta, lambda, max_iteration,
+                                            l[b] > 0 ? out_tracked[b] : nullptr, out_ref ? out_ref[b] : nullptr,
+                                            posterior ? posterior[b] : nullptr, &it, base + L.tail_off, ct_prgls_workspace_bytes(mm, nn, ll) + 256,
+                                            stream);
+            if (rc) return rc;
+            if (iters) iters[b] = it;
+            continue;
+        }
+        if (l[b] > 0) HIPCHK(hipMemcpyAsync(out_tracked[b], w.predl + b * stride, 3 * (size_t)l[b] * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (out_ref && out_ref[b]) HIPCHK(hipMemcpyAsync(out_ref[b], w.predn + b * stride, 3 * (size_t)n[b] * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (posterior && posterior[b]) HIPCHK(hipMemcpyAsync(posterior[b], w.P + b * stride, (size_t)m[b] * n[b] * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
     return CT_OK;
 }
 

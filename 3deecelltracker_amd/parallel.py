@@ -133,7 +133,7 @@ def _agree_on_tail(local, tail_shape, dtype, device):
     return tuple(int(v) for v in m[2:2 + int(m[1])]), getattr(torch, _DTYPES[int(m[7])]), dev
 
 
-def sharded_map_gather(fn: Callable, items: Sequence, tail_shape=None, dtype=None, device=None, chains: int = 1):
+def sharded_map_gather(fn: Callable, items: Sequence, tail_shape=None, dtype=None, device=None, chains: int = 1, batch_fn=None):
     """Apply `fn(item) -> tensor` to this rank's share of `items` and all-gather the stacked results
     in item order: [len(items), ...] on every rank.  chains > 1: the rank's own items run `chains` at a time
     (chain_map).  Ranks whose share is empty take part in the collective with a zero-length contribution whose
@@ -142,7 +142,8 @@ def sharded_map_gather(fn: Callable, items: Sequence, tail_shape=None, dtype=Non
     rank, world = dist_info()
     items = list(items)
     b, e = shard_range(len(items), rank, world)
-    mine = chain_map(fn, items[b:e], chains)
+    # batch_fn(list of items) -> list of tensors: the rank's whole share at once (e.g. one batched chain of launches)
+    mine = (batch_fn(items[b:e]) if e > b else []) if batch_fn is not None else chain_map(fn, items[b:e], chains)
     local = torch.stack(mine) if mine else None
     if world == 1:
         if local is None:

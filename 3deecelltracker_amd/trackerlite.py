@@ -144,10 +144,25 @@ def match_device(ffn_model: FFN, seg_t1_n, seg_t2_m, confirmed_l, beta, lambda_,
     return out_l, iters
 
 
+def match_device_batched(ffn_model: FFN, problems, beta, lambda_, max_iteration=MAX_ITERATION, k=K_POINTS, threshold=0.1):
+    """match_device for a list of independent (seg_t1_n, seg_t2_m, confirmed_l) problems: FFN scores and the greedy prior one
+    problem after the other, then ALL PR-GLS runs in one chain of launches (ct_prgls_two_ref_batched; the GPU retires the ~10
+    tiny dependent kernels of an EM iteration at the same rate for one problem as for twenty).  Results are bit-identical to
+    [match_device(...) for ...].  -> list of ((l, 3) device tensor, iterations)."""
+    batch = []
+    for seg_t1_n, seg_t2_m, confirmed_l in problems:
+        _dev.check_match_sizes(seg_t1_n.shape[0], seg_t2_m.shape[0], k, "match_device_batched")
+        corr = initial_matching_device(ffn_model, seg_t1_n, seg_t2_m, k)
+        _, _, prior = _dev.greedy_match(corr, threshold, 0)
+        batch.append((prior, seg_t2_m, seg_t1_n, confirmed_l))
+    res = _dev.prgls_two_ref_batched(batch, beta, lambda_, max_iteration)
+    return [(r[0], r[3]) for r in res]
+
+
 class TrackerLite:
     """Tracks cells from pre-computed segmentations with a trained FFN (reference :33-150)."""
 
-    ensemble_chains = 4      # matches of one ensemble prediction in flight on this GPU (parallel.chain_map); 1 = one by one
+    ensemble_batched = True  # the PR-GLS runs of one ensemble prediction share one chain of launches (False: one by one)
 
     def __init__(self, results_dir: str, ffn_model_name: str, proofed_coords_vol1: Coordinates,
                  miss_frame: List[int] = None, basedir: str = "ffn_models"):
@@ -204,13 +219,30 @@ class TrackerLite:
         vols = get_volumes_list(current_vol=t2, skip_volumes=skipped_volumes, sampling_number=sampling_number,
                                 adjacent=adjacent, start_vol=t_start)
 
-        def one(t1):
-            loaded = np.load(str(self.results_dir / TRACK_RESULTS / COORDS_REAL / f"coords{str(t1).zfill(6)}.npy"))
-            c = Coordinates(loaded, coord_t1.interpolation_factor, coord_t1.voxel_size, dtype="real")
-            return _dev.to_dev(self.predict_cell_positions(t1=t1, t2=t2, confirmed_coord_t1=c, beta=beta, lambda_=lambda_).real,
-                               t.float64)
-        stack = parallel.sharded_map_gather(one, vols, tail_shape=(coord_t1.cell_num, 3), dtype=t.float64,
-                                            chains=self.ensemble_chains)                        # [k][l][3] fp64 device
+        def members(t1_list):
+            """This rank's share of the source volumes: every member normalised with its own confirmed set (reference :88-93),
+            FFN + greedy one by one, all PR-GLS runs batched into one chain of launches, de-normalised; the Coordinates round
+            trip of the reference (float32 raw storage, :103-105 then .real at :123) is reproduced on the way out."""
+            assert t2 not in self.miss_frame
+            seg2 = _dev.points_dev(self._get_segmented_pos(t2).real)
+            probs, paras = [], []
+            for t1 in t1_list:
+                loaded = np.load(str(self.results_dir / TRACK_RESULTS / COORDS_REAL / f"coords{str(t1).zfill(6)}.npy"))
+                c = Coordinates(loaded, coord_t1.interpolation_factor, coord_t1.voxel_size, dtype="real")
+                conf_n, para = _dev.normalize_points(_dev.points_dev(c.real))
+                s2, _ = _dev.normalize_points(seg2, apply_para=para)
+                s1, _ = _dev.normalize_points(_dev.points_dev(self._get_segmented_pos(t1).real), apply_para=para)
+                probs.append((s1, s2, conf_n)); paras.append(para)
+            outs = match_device_batched(self.ffn_model, probs, beta, lambda_) if self.ensemble_batched else \
+                [match_device(self.ffn_model, *p, beta, lambda_) for p in probs]
+            res = []
+            for (tracked_n, _), para in zip(outs, paras):
+                real = _dev.denormalize_points(tracked_n, para).cpu().numpy()
+                res.append(_dev.to_dev(Coordinates(real, self.proofed_coords_vol1.interpolation_factor,
+                                                   self.proofed_coords_vol1.voxel_size, dtype="real").real, t.float64))
+            return res
+        stack = parallel.sharded_map_gather(None, vols, tail_shape=(coord_t1.cell_num, 3), dtype=t.float64,
+                                            batch_fn=members)                                   # [k][l][3] fp64 device
         mean = _dev.trim_mean(stack, 0.1).cpu().numpy()
         return Coordinates(mean, interpolation_factor=self.proofed_coords_vol1.interpolation_factor,
                            voxel_size=self.proofed_coords_vol1.voxel_size, dtype="real")

@@ -88,27 +88,38 @@ def make_frames_mode(ctx, args):
     comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
     pending = []
 
-    def match_job():
-        tracked, iters = tl.match_device(ctx.active["ffn"], ctx.seg1, ctx.seg2, ctx.conf, beta=3, lambda_=3)
-        ctx.iters_log.append(iters)
-        return tracked
+    waiting = [0]                                            # frames whose match has not been submitted yet
+
+    def match_job(nframes):
+        # the matches of `nframes` consecutive frames as ONE chain of launches (trackerlite.match_device_batched)
+        outs = tl.match_device_batched(ctx.active["ffn"], [(ctx.seg1, ctx.seg2, ctx.conf)] * nframes, beta=3, lambda_=3)
+        ctx.iters_log.extend(it for _, it in outs)
+        return [o for o, _ in outs]
 
     def collect(fut):
-        tracked = fut.result()                               # the worker has synchronised its stream: `tracked` is complete
+        tracked = fut.result()                               # the worker has synchronised its stream: the results are complete
         if ctx.world > 1:
-            with torch.cuda.stream(comm):                    # "gather of centroid sets" (14 KB / rank) on its own stream
-                dist.all_gather(gather_buf, tracked)
+            with torch.cuda.stream(comm):                    # "gather of centroid sets" (14 KB / rank and frame) on its own stream
+                for tr in tracked:
+                    dist.all_gather(gather_buf, tr)
         return tracked
+
+    def submit(nframes):
+        pending.append(ctx.pipe.submit_match(match_job, nframes))
+        while len(pending) > args.match_workers:
+            collect(pending.pop(0))
 
     def step():
         with torch.cuda.stream(ctx.pipe.seg_stream):
             norm = pre.normalize_image_device(ctx.raw, NOISE_LEVEL, (27, 27, 1), mode=0, subtract_median=True)
             ctx.model.predict_volume_device(norm, out=ctx.prob)
-        pending.append(ctx.pipe.submit_match(match_job))
-        while len(pending) > args.match_workers:
-            collect(pending.pop(0))
+        waiting[0] += 1
+        if waiting[0] >= args.match_batch:
+            submit(waiting[0]); waiting[0] = 0
 
     def finish():
+        if waiting[0]:
+            submit(waiting[0]); waiting[0] = 0
         while pending:
             collect(pending.pop(0))
         if comm is not None:
@@ -342,9 +353,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run: all ranks on cuda:0 (needs --backend gloo)")
-    ap.add_argument("--match-cus", type=int, default=64, help="CUs reserved for the matching chains (rest: U-Net)")
+    ap.add_argument("--match-cus", type=int, default=96, help="CUs reserved for the matching chains (rest: U-Net)")
     ap.add_argument("--disjoint-match-cus", action="store_true", help="give every match chain its own CU slice (measured: worse)")
-    ap.add_argument("--match-workers", type=int, default=3, help="frames whose match chains are in flight concurrently")
+    ap.add_argument("--match-workers", type=int, default=2, help="match chains in flight concurrently")
+    ap.add_argument("--match-batch", type=int, default=4, help="frames whose matches share one chain of launches (ct_prgls_two_ref_batched)")
     ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
     ap.add_argument("--cpu-patches", type=int, default=20, help="U-Net patches timed by the CPU baseline sample")
     args = ap.parse_args()
@@ -472,7 +484,8 @@ def main():
             "config": dict({"workload": workload, "mode": args.mode, "patches_per_volume": n_patches, "cells": args.cells,
                             "prgls_iterations": int(np.median(iters_main)) if iters_main else None,
                             "cu_partition": {"unet": ctx.pipe.n_cu - ctx.pipe.match_cus, "match": ctx.pipe.match_cus},
-                            "match_chains_in_flight": args.match_workers, "parallelism": parallelism}, **extra),
+                            "match_chains_in_flight": args.match_workers, "frames_per_match_chain": args.match_batch,
+                            "parallelism": parallelism}, **extra),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "layers": layers,

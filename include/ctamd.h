@@ -191,6 +191,19 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
                      double* out_tracked, double* out_ref, double* posterior, int* iters,
                      void* workspace, size_t workspace_bytes, ct_stream_t stream);
 
+/* B independent prgls_with_two_ref problems (ragged sizes) in ONE chain of launches: problem b = blockIdx.z of every EM kernel.
+ * A match is a chain of ~10 tiny dependent kernels per EM iteration and the GPU retires such kernels at a few hundred
+ * thousand per second however many streams issue them, so the matches of independent frames (or of one ensemble prediction,
+ * trackerlite.py:115-122) are cheaper batched than concurrent.  Arguments as ct_prgls_two_ref, as HOST arrays of B device
+ * pointers / sizes; results are bit-identical to B separate calls (same kernels, same per-problem rank steering; a problem
+ * whose low-rank M-step is rejected is finished by the single-problem routine).  Synchronous like ct_prgls_two_ref.        */
+size_t ct_prgls_batched_workspace_bytes(int B, const int* m, const int* n, const int* l);
+int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* const* tgt, const int* m,
+                             const double* const* ref, const int* n, const double* const* tracked, const int* l,
+                             double beta, double lambda, int max_iteration, double* const* out_tracked,
+                             double* const* out_ref, double* const* posterior, int* iters,
+                             void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
 /* pr_gls_quick (track.py:11-114): X [dev] fp64 [n][3], Y [dev] fp64 [m][3], corr [dev] fp32 [m][n].
  * Runs max_iteration-1 EM iterations.  P [dev] fp64 [m][n], TX [dev] fp64 [n][3], C [dev] fp64 [3][n]. */
 int ct_prgls_legacy(const double* X, int n, const double* Y, int m, const float* corr,

@@ -8,6 +8,7 @@
     python scripts/microbench.py segment               ct_segment_centroids
     python scripts/microbench.py correction            ct_accurate_correction (600 cells)
     python scripts/microbench.py match [n gain shift]  FFN + greedy + PR-GLS, per-iteration time
+    python scripts/microbench.py batched [n]           B matches as one batched PR-GLS chain vs separate calls
     python scripts/microbench.py goodprior [n]         PR-GLS with a prior as a trained FFN gives it
     python scripts/microbench.py legacy [n ...]        legacy Tracker._predict_pos_once
     python scripts/microbench.py ensemble              20 x 600-cell matches, 1..8 chains in flight
@@ -164,6 +165,48 @@ def cmd_match(args):
     t_gr, _ = timeit(lambda: _dev.greedy_match(corr, 0.1, 0), warm=0)
     print(f"n={n}: match {dt*1e3:.2f} ms total, {it} PR-GLS iterations -> {(dt - t_ffn - t_gr)/max(it,1)*1e6:.1f} us/iter; "
           f"ffn {t_ffn*1e3:.2f} ms, greedy {t_gr*1e3:.2f} ms")
+
+
+def cmd_batched(args):
+    """B x 600-cell PR-GLS (noise prior) as one batched chain vs B separate calls."""
+    synth, ffn_mod, tl, _dev = mod("synth"), mod("ffn"), mod("trackerlite"), mod("_dev")
+    ffn = ffn_mod.FFN().set_weights_dict(synth.make_ffn_weights(0))
+    a, b = norm_pair(int(args[0]) if args else 600)
+    corr = ffn_mod.initial_matching_device(ffn, a, b, 20)
+    _, _, prior = _dev.greedy_match(corr, 0.1, 0)
+    t1, out = timeit(lambda: _dev.prgls_two_ref(prior, b, a, a, 3.0, 3.0, 2000, want_posterior=False), reps=2, warm=1)
+    print(f"single: {t1*1e3:.1f} ms, {out[-1]} iterations -> {t1/out[-1]*1e6:.1f} us/iteration")
+    for B in (1, 2, 4, 8):
+        tb, res = timeit(lambda: _dev.prgls_two_ref_batched([(prior, b, a, a)] * B, 3.0, 3.0, 2000), reps=2, warm=1)
+        print(f"batched B={B}: {tb*1e3:.1f} ms = {tb/B*1e3:.1f} ms per match, {tb/res[0][3]*1e6:.1f} us/iteration")
+
+
+def cmd_pipebatch(args):
+    """Batched match jobs on the CU-masked match partition, alone and next to the U-Net stream (what bench.py's frames mode does)."""
+    synth, unet3d, ffn_mod, tl, par = mod("synth"), mod("unet3d"), mod("ffn"), mod("trackerlite"), mod("parallel")
+    ffn = ffn_mod.FFN().set_weights_dict(synth.make_ffn_weights(0))
+    model = unet3d.unet3_a().set_weights_dict(synth.make_unet_weights("unet3_a", 0))
+    vol = torch.randn(512, 512, 32, device="cuda"); out = torch.zeros_like(vol)
+    a, b = norm_pair(600)
+    for cus in (64, 32):
+        for B in (1, 4, 8):
+            pipe = par.FramePipeline(device=0, match_cus=cus, workers=1)
+
+            def job():
+                t0 = time.perf_counter()
+                tl.match_device_batched(ffn, [(a, b, a)] * B, 3, 3)
+                torch.cuda.current_stream().synchronize()
+                return time.perf_counter() - t0
+            for with_unet in (False, True):
+                f = pipe.submit_match(job)
+                if with_unet:
+                    while not f.done():
+                        with torch.cuda.stream(pipe.seg_stream):
+                            model.predict_volume_device(vol, out=out)
+                        pipe.seg_stream.synchronize()
+                dt = f.result()
+                print(f"match partition {cus} CUs, batch {B}, U-Net running: {with_unet}: {dt*1e3:.1f} ms per job = {dt/B*1e3:.1f} ms per match")
+            pipe.close()
 
 
 def cmd_goodprior(args):

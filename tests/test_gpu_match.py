@@ -267,9 +267,9 @@ def test_trackerlite_end_to_end(tmp_path, ffn_w):
                for t1 in tl.get_volumes_list(5, [4])]
     from scipy.stats import trim_mean
     np.testing.assert_allclose(ens.real, cit.Coordinates(trim_mean(singles, 0.1, axis=0), 4, vs, "real").real, rtol=0, atol=1e-5)
-    # the ensemble members run four at a time on their own streams (parallel.chain_map): same bits as one by one
-    assert trk.ensemble_chains == 4
-    trk.ensemble_chains = 1
+    # the PR-GLS runs of the ensemble members share one chain of launches (ct_prgls_two_ref_batched): same bits as one by one
+    assert trk.ensemble_batched is True
+    trk.ensemble_batched = False
     ens1 = trk.predict_cell_positions_ensemble([4], 5, proof, beta=3, lambda_=3, sampling_number=20)
     assert np.array_equal(ens1.real, ens.real)
 
@@ -499,3 +499,41 @@ def test_trackerlite_ensemble_20_volumes_113_cells_against_oracle(tmp_path, ffn_
     # trimmed mean absorbs at most 2 outliers per coordinate, so compare robustly and require near-total agreement
     close = np.abs(ens.real - want).max(axis=1) <= 1e-3
     assert close.mean() >= 0.97, f"only {close.mean():.3f} of the cells agree with the oracle ensemble"
+
+
+def test_prgls_batched_is_bit_identical_to_separate_calls(ffn):
+    """ct_prgls_two_ref_batched on ragged problems (different m, n, l; a noise prior that runs hundreds of iterations next to
+    converging ones; one problem without a tracked set) == separate ct_prgls_two_ref calls, bit for bit, iteration counts too."""
+    import torch
+    probs = []
+    for n_ref, n_tgt, n_trk, seed, sharp in ((120, 100, 120, 1, True), (90, 131, 40, 2, False), (150, 150, 0, 3, True), (64, 70, 64, 4, False)):
+        rng = np.random.default_rng(seed)
+        x, y = synth.make_point_pair(max(n_ref, n_tgt), seed=seed, box=(168, 401, 32))
+        xn, (mean, scale) = mr.normalize_points(x[:n_ref], return_para=True); yn = ((y - mean) / scale)[:n_tgt]
+        if sharp:                                     # a prior as a trained FFN gives it: converges in a few iterations
+            corr = rng.uniform(0, 0.05, (n_tgt, n_ref)).astype(np.float32)
+            k = min(n_ref, n_tgt); corr[np.arange(k), rng.permutation(n_ref)[:k]] = rng.uniform(0.7, 0.99, k).astype(np.float32)
+        else:
+            corr = ffn_mod.initial_matching_ffn(ffn, xn, yn, 20)
+        prior, _ = tl.simple_match(corr)
+        trk = None if n_trk == 0 else dev.points_dev(xn[:n_trk] + rng.normal(0, 0.002, (n_trk, 3)))
+        probs.append((dev.to_dev(prior.astype(np.float64), torch.float64), dev.points_dev(yn), dev.points_dev(xn), trk))
+    batched = dev.prgls_two_ref_batched(probs, 3.0, 3.0, 2000, want_posterior=True, want_ref=True)
+    its = []
+    for (prior, tgt, ref, trk), (bl, bn, bp, bit) in zip(probs, batched):
+        sl, sn, sp, sit = dev.prgls_two_ref(prior, tgt, ref, trk, 3.0, 3.0, 2000, want_posterior=True, want_ref=True)
+        assert bit == sit
+        assert torch.equal(bn, sn) and torch.equal(bp, sp)
+        assert (bl is None and sl is None) or torch.equal(bl, sl)
+        its.append(sit)
+    assert len(set(its)) > 1                          # the problems really stop at different iterations
+    # a bounded run (max_iteration) and the batched TrackerLite step
+    b4 = dev.prgls_two_ref_batched(probs, 3.0, 3.0, 4)
+    for (prior, tgt, ref, trk), (bl, _, _, bit) in zip(probs, b4):
+        sl, _, _, sit = dev.prgls_two_ref(prior, tgt, ref, trk, 3.0, 3.0, 4, want_posterior=False)
+        assert bit == sit == 3 and ((bl is None and sl is None) or torch.equal(bl, sl))
+    xs = [(p[2], p[1], p[2]) for p in probs[:2]]
+    got = tl.match_device_batched(ffn, xs, 3, 3)
+    for (s1, s2, c), (out, it) in zip(xs, got):
+        ref_out, ref_it = tl.match_device(ffn, s1, s2, c, 3, 3)
+        assert it == ref_it and torch.equal(out, ref_out)
