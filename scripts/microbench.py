@@ -251,14 +251,22 @@ def cmd_ensemble(args):
 
     def one(j):
         return tl.match_device(ffn, j[0], j[1], j[0], 3, 3)[0]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    outb = tl.match_device_batched(ffn, [(j[0], j[1], j[0]) for j in jobs], 3, 3); torch.cuda.synchronize()
+    dtb = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    outb = tl.match_device_batched(ffn, [(j[0], j[1], j[0]) for j in jobs], 3, 3); torch.cuda.synchronize()
+    dtb = time.perf_counter() - t0
     ref = None
-    for chains in (1, 3, 4, 5, 6, 8):
+    for chains in (1, 4):
         par.chain_map(one, jobs[:chains], chains); torch.cuda.synchronize()
         t0 = time.perf_counter(); out = par.chain_map(one, jobs, chains); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         same = True if ref is None else all(torch.equal(a, b) for a, b in zip(ref, out))
         ref = ref or out
         print(f"ensemble of 20 matches, {chains} chain(s): {dt*1e3:.0f} ms ({dt/20*1e3:.1f} ms per match), identical to sequential: {same}")
+    print(f"ensemble of 20 matches, batched PR-GLS: {dtb*1e3:.0f} ms ({dtb/20*1e3:.1f} ms per match), identical to sequential: "
+          f"{all(torch.equal(a, b[0]) for a, b in zip(ref, outb))}")
 
 
 def cmd_chains(args):
