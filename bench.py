@@ -301,6 +301,9 @@ def roofline_from_timing(ctx, args, n_patches, steps):
                 "math": ("f16x3 split (2 fp16 components per operand, 3 MFMA products per fp32 product, per-patch power-of-two scaling, fp32 accumulate)" if dom.get("f16") else
                          "bf16x6 split (6 bf16 MFMA products per fp32 product, fp32 accumulate)") if dom["bf"] else "f32-input MFMA",
                 "fp32_equivalent_tflops": round(dom_fp32_equiv, 2),
+                "frac_of_cu_share": round(achieved / peak_tf * ctx.pipe.n_cu / max(ctx.pipe.n_cu - ctx.pipe.match_cus, 1), 4),
+                "note": "the U-Net stream owns cu_partition.unet of the chip's CUs (the rest runs the match chains); frac is against the "
+                        "FULL-chip peak, frac_of_cu_share against the peak of the CUs this kernel may use",
                 "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4), "launches": dom["launches"],
                 "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                 "executed_gflop_per_launch": round(dom["issued"] / max(dom["launches"], 1) / 1e9, 2),

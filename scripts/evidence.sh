@@ -1,10 +1,22 @@
+# Round evidence on the GPU box (run through gpurun): GPU tests, smoke, rocprofv3 kernel stats of the benchmark command and of
+# the U-Net alone, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate PMC passes), SQ counters, the match chain, the bench line.
+#   usage: bash scripts/evidence.sh r02
 set -u
+R=${1:-r02}
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash scripts/prof.sh bench_r1 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-realistic-pass | head -12
-bash scripts/prof.sh unet_r1 $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -12
-bash scripts/prof_pmc.sh unet_r1 FETCH_SIZE $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -5
-bash scripts/prof_pmc.sh unet_r1 WRITE_SIZE $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -5
+mkdir -p gpurun_out/prof
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+bash scripts/prof.sh bench_$R $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-realistic-pass | head -4
+bash scripts/prof.sh unet_$R $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -4
+bash scripts/prof_pmc.sh unet_$R FETCH_SIZE $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -3
+bash scripts/prof_pmc.sh unet_$R WRITE_SIZE $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -3
+bash scripts/prof_sq.sh unet_$R "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" $GRAFT_REPO_ROOT/scripts/microbench.py unet | tail -12
+bash scripts/prof_sq.sh unet2_$R "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_INSTS_VALU" $GRAFT_REPO_ROOT/scripts/microbench.py unet | tail -12
+bash scripts/prof.sh match600_$R $GRAFT_REPO_ROOT/scripts/microbench.py match 600 | head -3
+bash scripts/prof.sh batched_$R $GRAFT_REPO_ROOT/scripts/microbench.py batched 600 | head -3
 cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py > gpurun_out/bench_r1_bf.json 2> gpurun_out/bench_r1_bf.err; tail -c 1500 gpurun_out/bench_r1_bf.json
+python scripts/hbm_traffic.py gpurun_out/prof/unet_${R}_FETCH_SIZE.csv gpurun_out/prof/unet_${R}_WRITE_SIZE.csv gpurun_out/prof/${R}_unet_hbm_traffic.json "python scripts/microbench.py unet" | head -30
+for s in unet "unet --layers" lcn segment correction "match 600" "goodprior 600" legacy ensemble frame pcie; do timeout 300 python scripts/microbench.py $s 2>&1 | grep -v amdgpu.ids | tail -16; done > gpurun_out/microbench_$R.txt 2>&1
+tail -60 gpurun_out/microbench_$R.txt
+timeout 900 python bench.py > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err; tail -c 400 gpurun_out/bench_$R.err; head -c 1500 gpurun_out/bench_$R.json
