@@ -210,3 +210,73 @@ def test_device_full_chain_against_oracle(g, ffn_w, tmp_path):
     trk.save_coordinates()
     tab = np.loadtxt(tmp_path / "track_information" / "tracked_coordinates.csv", delimiter=",", skiprows=1)
     assert tab.shape == (2 * trk.cell_num_t0, 5)
+
+
+def test_interpolate_seg_host_logic_cpu():
+    """interpolate_seg (tracker.py:1046-1075) is one-off host set-up (scipy): z-interpolation by repetition, per-cell Gaussian
+    smoothing, the reference's crop, re-labelling; overlapping smoothed cells raise instead of silently skipping the watershed."""
+    tracker = importlib.import_module("3deecelltracker_amd.tracker")
+    trk = tracker.Tracker.for_matching(None, siz_xyz=(40, 44, 6), z_xy_ratio=3.0, z_scaling=4)
+    lab = np.zeros((40, 44, 6), dtype=np.int64)
+    gx, gy, gz = np.meshgrid(np.arange(40), np.arange(44), np.arange(6), indexing="ij")
+    for i, c in enumerate(((10, 10, 2), (28, 12, 3), (18, 32, 2.5)), start=1):
+        lab[((gx - c[0]) / 4.0) ** 2 + ((gy - c[1]) / 4.0) ** 2 + ((gz - c[2]) / 1.2) ** 2 <= 1.0] = i
+    trk.segmentation_manual_relabels = lab
+    trk.interpolate_seg()
+    seg = trk.seg_cells_interpolated_corrected
+    assert seg.shape == (40, 44, 24) and set(np.unique(seg)) == {0, 1, 2, 3}
+    assert list(trk.Z_RANGE_INTERP) == [2, 6, 10, 14, 18, 22] and trk.segmentation_manual_relabels.shape == (40, 44, 6)
+    assert trk.cell_num_t0 == 3 and trk.r_coordinates_tracked_t0.shape == (3, 3)
+    # centres stay where the cells were drawn (z in real units = layer * z_xy_ratio); labels are renumbered in raster order of
+    # their first voxel, like skimage.measure.label in _relabel_separated_cells (:1077-1085): x = 10, 18, 28
+    np.testing.assert_allclose(trk.r_coordinates_tracked_t0[:, :2], [(10, 10), (18, 32), (28, 12)], atol=0.6)
+    np.testing.assert_allclose(trk.r_coordinates_tracked_t0[:, 2] / 3.0, [2, 2.5, 3], atol=0.6)
+    # the smoothed volume of a cell is close to the original's (percentile threshold, track.py:352-356)
+    for i, j in ((1, 1), (2, 3), (3, 2)):
+        assert 0.8 < (seg == i).sum() / (4.0 * (lab == j).sum()) < 1.25
+    lab2 = lab.copy(); lab2[((gx - 13) / 4.0) ** 2 + ((gy - 13) / 4.0) ** 2 + ((gz - 2) / 1.2) ** 2 <= 1.0] = 4     # touches cell 1
+    trk.segmentation_manual_relabels = lab2
+    with pytest.raises(NotImplementedError, match="watershed"):
+        trk.interpolate_seg()
+
+
+@pytest.mark.gpu
+def test_device_notebook_flow_from_tiff_folders(ffn_w, tmp_path):
+    """The legacy notebook's call sequence on a folder tree of TIFF layers: segment_vol1 -> (manual correction = the automatic
+    result) -> load_manual_seg -> interpolate_seg -> cal_subregions -> initiate_tracking -> match -> track -> save_coordinates."""
+    from PIL import Image
+    tracker = importlib.import_module("3deecelltracker_amd.tracker")
+    ffn_mod = importlib.import_module("3deecelltracker_amd.ffn")
+    unet3d = importlib.import_module("3deecelltracker_amd.unet3d")
+    siz, zs, ratio = (120, 136, 14), 2, 4.0
+    (tmp_path / "models").mkdir()
+    ffn_mod.FFN().set_weights_dict(ffn_w).save_weights(tmp_path / "models" / "ffn.npz")
+    unet3d.unet3_a().set_weights_dict(synth.make_passthrough_unet_weights("unet3_a", 0)).save_weights(tmp_path / "models" / "unet.npz")
+    trk = tracker.Tracker(volume_num=3, siz_xyz=siz, z_xy_ratio=ratio, z_scaling=zs, noise_level=100, min_size=20, beta_tk=300,
+                          lambda_tk=0.1, maxiter_tk=20, folder_path=str(tmp_path), image_name="img_t%04i_z%04i.tif",
+                          unet_model_file="unet.npz", ffn_model_file="ffn.npz")
+    frames = {}
+    for vol, move in ((1, 0.0), (2, 1.5), (3, 3.0)):
+        frames[vol] = synth.make_legacy_frame_case(0, siz, zs, ratio, 40, move=move)["raw"]
+        for z in range(siz[2]):
+            Image.fromarray(frames[vol][:, :, z]).save(tmp_path / "data" / ("img_t%04i_z%04i.tif" % (vol, z + 1)))
+    trk.load_unet(); trk.load_ffn()
+    trk.segment_vol1()
+    n_auto = int(trk.segresult.segmentation_auto.max())
+    assert n_auto >= 25 and len(list((tmp_path / "auto_vol1").glob("auto_vol1_z*.tif"))) == siz[2]
+    assert (tmp_path / "unet_cache" / "t000001.npy").exists()
+    for f in (tmp_path / "auto_vol1").glob("*.tif"):                       # "manual correction": accept the automatic result
+        Image.open(f).save(tmp_path / "manual_vol1" / f.name.replace("auto", "manual"))
+    trk.load_manual_seg()
+    assert trk.segmentation_manual_relabels.shape == siz and int(trk.segmentation_manual_relabels.max()) == n_auto
+    trk.interpolate_seg(); trk.cal_subregions(); trk._check_multicells(); trk.initiate_tracking()
+    assert trk.cell_num_t0 == n_auto and len(trk.region_list) == n_auto
+    anim, (bd, vol, i_disp, pred) = trk.match(2, "min_size")
+    assert vol == 2 and i_disp.shape == (n_auto, 3) and pred.shape == (n_auto, 3) and i_disp.dtype.kind == "i"
+    # the cells moved by about (1.5, -0.9, ~0) voxels between volume 1 and 2: the corrected displacement sees it
+    med = np.median(i_disp[bd == 0], axis=0)
+    assert 0.5 <= med[0] <= 2.5 and -2.0 <= med[1] <= 0.0
+    trk.track(None, None, from_volume=2)
+    assert len(trk.history.r_tracked_coordinates) == 3
+    trk.save_coordinates()
+    assert (tmp_path / "track_information" / "tracked_coordinates.csv").exists()
