@@ -354,43 +354,48 @@ __global__ __launch_bounds__(64) void ffn_rows_finish_kernel(const float* __rest
 // generic inputs.  The threshold test of the reference (stop at the first maximum below it) == never accept an
 // edge below it.  A final sort by the same order recovers the reference's pick sequence.
 constexpr int GD_ROWLANES = 16;
-enum { GD_COUNT = 0, GD_NEW = 1, GD_DONE = 2 };
+enum { GD_COUNT = 0, GD_NEW = 1 /* and 2: one counter per round parity */, GD_DONE = 3 };
 
-__global__ __launch_bounds__(256) void gd_rowbest_kernel(const float* __restrict__ corr, int m, int n,
-                                                         const unsigned char* __restrict__ row_used,
-                                                         const unsigned char* __restrict__ col_used,
-                                                         float* __restrict__ rowval, int* __restrict__ rowcol,
-                                                         int* __restrict__ ctr) {
+// One round = two launches.  gd_best_kernel: blocks [0, nrb) find every free row's best free column (16 rows per block, one wave
+// each), blocks [nrb, nrb + ncb) every free column's best free row (64 columns x 16 row lanes); gd_accept_kernel accepts the
+// locally dominant edges.  Termination without a separate launch: accept of round k counts into NEW[k & 1]; round k + 1 starts by
+// looking at that counter (zero -> nothing was accepted -> done, every block leaves) and re-arms NEW[(k + 1) & 1], which nobody
+// touches in between.  (Round 1: four launches per round -- row best, column best, accept, round end.)
+__global__ __launch_bounds__(64 * GD_ROWLANES) void gd_best_kernel(const float* __restrict__ corr, int m, int n,
+                                                                   const unsigned char* __restrict__ row_used,
+                                                                   const unsigned char* __restrict__ col_used,
+                                                                   float* __restrict__ rowval, int* __restrict__ rowcol,
+                                                                   int* __restrict__ colrow, int* __restrict__ ctr, int round, int nrb) {
     if (ctr[GD_DONE]) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wave;
-    if (t >= m) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr[GD_NEW] = 0;      // reset for this round's accept kernel
-    if (row_used[t]) { if (lane == 0) rowcol[t] = -1; return; }
-    const float* row = corr + (size_t)t * n;
-    float best = -1.f; int bi = 0x7fffffff;
-    for (int c = lane; c < n; c += 64) {
-        if (col_used[c]) continue;
-        const float v = row[c];
-        if (v > best) { best = v; bi = c; }                           // ascending c => lowest column on ties
+    if (round > 0 && ctr[GD_NEW + ((round - 1) & 1)] == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctr[GD_DONE] = 1;
+        return;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr[GD_NEW + (round & 1)] = 0;      // re-arm this round's counter
+    if ((int)blockIdx.x < nrb) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int t = blockIdx.x * GD_ROWLANES + wave;
+        if (t >= m) return;
+        if (row_used[t]) { if (lane == 0) rowcol[t] = -1; return; }
+        const float* row = corr + (size_t)t * n;
+        float best = -1.f; int bi = 0x7fffffff;
+        for (int c = lane; c < n; c += 64) {
+            if (col_used[c]) continue;
+            const float v = row[c];
+            if (v > best) { best = v; bi = c; }                           // ascending c => lowest column on ties
+        }
 #pragma unroll
-    for (int mk = 32; mk >= 1; mk >>= 1) {
-        const float ov = __shfl_xor(best, mk); const int oi = __shfl_xor(bi, mk);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        for (int mk = 32; mk >= 1; mk >>= 1) {
+            const float ov = __shfl_xor(best, mk); const int oi = __shfl_xor(bi, mk);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { rowval[t] = best; rowcol[t] = (bi == 0x7fffffff) ? -1 : bi; }
+        return;
     }
-    if (lane == 0) { rowval[t] = best; rowcol[t] = (bi == 0x7fffffff) ? -1 : bi; }
-}
-
-__global__ __launch_bounds__(64 * GD_ROWLANES) void gd_colbest_kernel(const float* __restrict__ corr, int m, int n,
-                                                                      const unsigned char* __restrict__ row_used,
-                                                                      const unsigned char* __restrict__ col_used,
-                                                                      int* __restrict__ colrow, const int* __restrict__ ctr) {
-    if (ctr[GD_DONE]) return;
     __shared__ float sv[GD_ROWLANES][64];
     __shared__ int si[GD_ROWLANES][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int r = blockIdx.x * 64 + cl;
+    const int r = ((int)blockIdx.x - nrb) * 64 + cl;
     float best = -1.f; int bt = 0x7fffffff;
     if (r < n && !col_used[r])
         for (int t = rl; t < m; t += GD_ROWLANES) {
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(64 * GD_ROWLANES) void gd_colbest_kernel(const floa
 __global__ __launch_bounds__(256) void gd_accept_kernel(int m, int n, float thr, const float* __restrict__ rowval,
                                                         const int* __restrict__ rowcol, const int* __restrict__ colrow,
                                                         unsigned char* __restrict__ row_used, unsigned char* __restrict__ col_used,
-                                                        unsigned long long* __restrict__ keys, int* __restrict__ ctr) {
+                                                        unsigned long long* __restrict__ keys, int* __restrict__ ctr, int round) {
     if (ctr[GD_DONE]) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= m || row_used[t]) return;
@@ -421,12 +426,10 @@ __global__ __launch_bounds__(256) void gd_accept_kernel(int m, int n, float thr,
     if (r < 0 || !(v >= thr) || colrow[r] != t) return;
     row_used[t] = 1; col_used[r] = 1;
     const int k = atomicAdd(&ctr[GD_COUNT], 1);
-    atomicAdd(&ctr[GD_NEW], 1);
+    atomicAdd(&ctr[GD_NEW + (round & 1)], 1);
     const unsigned flat = (unsigned)t * (unsigned)n + (unsigned)r;
     keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
 }
-
-__global__ void gd_round_end_kernel(int* __restrict__ ctr) { if (ctr[GD_NEW] == 0) ctr[GD_DONE] = 1; }
 
 // single workgroup: bitonic sort of the accepted keys (descending) -> pairs in the reference's pick order
 __global__ __launch_bounds__(1024) void gd_finalize_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ ctr,
@@ -1635,21 +1638,20 @@ int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, 
     int hctr[4] = {0, 0, 0, 0};
     for (int done_rounds = 0; done_rounds < max_rounds;) {
         const int chunk = done_rounds == 0 ? 12 : 8;
+        const int nrb = (m + GD_ROWLANES - 1) / GD_ROWLANES, ncb = (n + 63) / 64;
         for (int k = 0; k < chunk; ++k) {
-            hipLaunchKernelGGL(gd_rowbest_kernel, dim3((m + 3) / 4), dim3(256), 0, st, corr, m, n, row_used, col_used, rowval, rowcol, ctr);
-            LAUNCH_CHECK();
-            hipLaunchKernelGGL(gd_colbest_kernel, dim3((n + 63) / 64), dim3(64 * GD_ROWLANES), 0, st, corr, m, n, row_used, col_used, colrow, ctr);
+            const int round = done_rounds + k;
+            hipLaunchKernelGGL(gd_best_kernel, dim3(nrb + ncb), dim3(64 * GD_ROWLANES), 0, st, corr, m, n, row_used, col_used, rowval, rowcol,
+                               colrow, ctr, round, nrb);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(gd_accept_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, n, threshold, rowval, rowcol, colrow,
-                               row_used, col_used, keys, ctr);
-            LAUNCH_CHECK();
-            hipLaunchKernelGGL(gd_round_end_kernel, dim3(1), dim3(1), 0, st, ctr);
+                               row_used, col_used, keys, ctr, round);
             LAUNCH_CHECK();
         }
         done_rounds += chunk;
         HIPCHK(hipMemcpyAsync(hctr, ctr, sizeof(hctr), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (hctr[GD_DONE]) break;
+        if (hctr[GD_DONE] || hctr[GD_NEW + ((done_rounds - 1) & 1)] == 0) break;      // the last round accepted nothing
     }
     if (getenv("CT_DEBUG")) fprintf(stderr, "[ct_greedy_match] m %d n %d pairs %d\n", m, n, hctr[GD_COUNT]);
     {
