@@ -1267,6 +1267,114 @@ __global__ __launch_bounds__(256, 8) void conv_first_mfma_kernel(const float* __
     if (amax_out) amax_publish(vmax, amax_out + lp * AMAX_STRIDE, tid, amax_red);
 }
 
+// ------------------------------------------------------------------------------------------------
+// First conv on the fp16 matrix pipe (split-fp16 family).  Same tile, gather and row mapping as conv_first_mfma_kernel; what
+// changes is the arithmetic: the 1-channel halo tile is converted once to packed (hi, lo) fp16 pairs (4 B per voxel, the size
+// of the fp32 value) with a power-of-two scale taken from the TILE's own maximum (Cin = 1: a single chunk, so every workgroup
+// can scale by itself), and the three products hi*hi + lo*hi + hi*lo of a tap sit in three K slots of ONE MFMA:
+//   K = 32 = 4 lane groups x 2 taps x [a_hi, a_lo, a_hi, 0] . [w_hi, w_hi, w_lo, 0]
+// so 36 taps = 5 v_mfma_f32_16x16x32_f16 (80 cycles) instead of 9 v_mfma_f32_16x16x4_f32 (288 cycles) per 32 voxels, fed by two
+// ds_read_b32 + two v_and per MFMA.  The layer is HBM-bound; this takes the matrix phase out of its critical path.
+// ------------------------------------------------------------------------------------------------
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_first_f16_kernel(const float* __restrict__ vol, TileGeom q, int p_begin,
+                                                             const u32x4* __restrict__ wf16 /* [5][64] */, float wscale_inv,
+                                                             const float* __restrict__ epi /* [3][8] */,
+                                                             float* __restrict__ out, int act, uint32_t* __restrict__ amax_out) {
+    constexpr int HX1 = F1X + 2, HY1 = F1Y + 2, HZ1 = F1Z + 2, NV = HX1 * HY1 * HZ1;
+    __shared__ uint32_t tile[NV];
+    __shared__ int mapx[HX1], mapy[HY1], mapz[HZ1];
+    __shared__ float amax_red[4], tmax_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tilesX = (q.nx + F1X - 1) / F1X, tilesY = (q.ny + F1Y - 1) / F1Y, tilesZ = (q.nz + F1Z - 1) / F1Z;
+    int b = blockIdx.x;
+    const int tz = b % tilesZ; b /= tilesZ;
+    const int ty = b % tilesY; b /= tilesY;
+    const int tx = b % tilesX; const int lp = b / tilesX;
+    const int pg = p_begin + lp;
+    const int pk = pg % q.gz, pj = (pg / q.gz) % q.gy, pi = pg / (q.gz * q.gy);
+    const int x0 = tx * F1X, y0 = ty * F1Y, z0 = tz * F1Z;
+    if (tid < HX1) { const int l = x0 - 1 + tid; mapx[tid] = (l >= 0 && l < q.nx) ? reflect_idx(pi * q.cx + l - q.bx, q.vx) : -1; }
+    else if (tid >= 64 && tid < 64 + HY1) { const int t = tid - 64, l = y0 - 1 + t; mapy[t] = (l >= 0 && l < q.ny) ? reflect_idx(pj * q.cy + l - q.by, q.vy) : -1; }
+    else if (tid >= 128 && tid < 128 + HZ1) { const int t = tid - 128, l = z0 - 1 + t; mapz[t] = (l >= 0 && l < q.nz) ? reflect_idx(pk * q.cz + l - q.bz, q.vz) : -1; }
+    const int g = lane >> 4, zl = lane & 15;
+    __syncthreads();
+    // gather: thread t < 2 * HX1 * HY1 takes half a z column (HZ1 / 2 values) of halo column t >> 1 -- the (x, y) reflect
+    // look-ups and the row base address are computed once per thread, each element costs one add and one load
+    constexpr int HALF = HZ1 / 2;
+    static_assert(HZ1 % 2 == 0 && 2 * HX1 * HY1 <= 256, "gather mapping");
+    float vals[HALF]; float tmax = 0.f;
+    const int gcol = tid >> 1, gz0 = (tid & 1) * HALF;
+    const bool gact = tid < 2 * HX1 * HY1;
+    {
+        const int hx = gcol / HY1, hy = gcol - hx * HY1;
+        const int sx = gact ? mapx[hx] : -1, sy = gact ? mapy[hy] : -1;
+        const float* rowp = vol + ((size_t)(sx < 0 ? 0 : sx) * q.vy + (sy < 0 ? 0 : sy)) * q.vz;
+        const bool rowok = sx >= 0 && sy >= 0;
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const int sz = mapz[gz0 + i];
+            const float v = (rowok && sz >= 0) ? rowp[sz] : 0.f;
+            vals[i] = v; tmax = fmaxf(tmax, fabsf(v));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+    if (lane == 0) tmax_red[wave] = tmax;
+    __syncthreads();
+    const int kexp = amax_exponent(__float_as_uint(fmaxf(fmaxf(tmax_red[0], tmax_red[1]), fmaxf(tmax_red[2], tmax_red[3]))));
+    const float in_scale = pow2f(-kexp), out_mul = pow2f(kexp) * wscale_inv;
+    if (gact) {
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const float x = vals[i] * in_scale;
+            const float hi = __uint_as_float(__float_as_uint(x) & 0xffffe000u);
+            tile[gcol * HZ1 + gz0 + i] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(hi, x - hi));   // [15:0] hi, [31:16] lo
+        }
+    }
+    // tap' = (dx' * 3 + dy) * 3 + dz (dx' in 0..3) of MFMA j, lane group g, sub-slot s = 8 j + 2 g + s; slots beyond 36 carry zero weights
+    __syncthreads();
+    f32x4 acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int px0 = (wave >> 1) * 2, py0 = (wave & 1) * 4;
+    const int wbase = ((2 * px0) * HY1 + py0) * HZ1 + zl;
+    u32x4 wcur = wf16[lane];                                        // weights stream from L1/L2 one K-block ahead (20 VGPRs if all were held)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const u32x4 wj = wcur;
+        if (j + 1 < 5) wcur = wf16[(j + 1) * 64 + lane];
+        const int k0 = 8 * j + 2 * g, k1 = k0 + 1;
+        const int o0 = wbase + (k0 < 36 ? ((k0 / 9) * HY1 + (k0 / 3) % 3) * HZ1 + k0 % 3 : 0);
+        const int o1 = wbase + (k1 < 36 ? ((k1 / 9) * HY1 + (k1 / 3) % 3) * HZ1 + k1 % 3 : 0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            constexpr int dummy = 0; (void)dummy;
+            const int cm = ((2 * (m >> 2)) * HY1 + (m & 3)) * HZ1;          // compile-time column offset
+            const uint32_t a0 = tile[o0 + cm], a1 = tile[o1 + cm];
+            const u32x4 av = u32x4{a0, a0 & 0xffffu, a1, a1 & 0xffffu};
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wj), __builtin_bit_cast(f16x8, av), acc[m], 0, 0, 0);
+        }
+    }
+    const float alpha = act == 0 ? kLeakyAlpha : 0.f;
+    const int cb = 4 * (g & 1);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(epi + cb);
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(epi + 8 + cb);
+    const f32x4 shift = *reinterpret_cast<const f32x4*>(epi + 16 + cb);
+    const int z = z0 + zl;
+    float vmax = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int x = x0 + 2 * (px0 + (m >> 2)) + (g >> 1), y = y0 + py0 + (m & 3);
+        if (x >= q.nx || y >= q.ny || z >= q.nz) continue;
+        f32x4 r = acc[m] * out_mul + bias;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = r[e]; r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e]; vmax = fmaxf(vmax, fabsf(r[e])); }
+        *reinterpret_cast<f32x4*>(out + (((size_t)(lp * q.nx + x) * q.ny + y) * q.nz + z) * 8 + cb) = r;
+    }
+    if (amax_out) amax_publish(vmax, amax_out + lp * AMAX_STRIDE, tid, amax_red);
+}
+
 // blocked [X][Y][C/8][Z][8] (patch 0) -> Keras NDHWC [X][Y][Z][C]   (parity tests only)
 __global__ __launch_bounds__(256) void unblock_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       int X, int Y, int Z, int C) {
@@ -1335,6 +1443,9 @@ struct ct_unet {
     float* d_weights;                // device arena
     size_t first_w_off, head_off;    // float offsets
     size_t first_mfma_off;           // packed weights of conv_first_mfma_kernel (Cout == 8)
+    size_t first_f16_off;            // packed (hi, hi, lo, 0) fp16 weights of conv_first_f16_kernel
+    float first_wscale_inv;          // 1 / their power-of-two scale
+    bool first_f16;                  // the split-fp16 first conv is in use
     size_t arena_floats;
     // optional per-launch HIP-event timing (bench.py roofline): pairs recorded on the launch stream
     bool timing;
@@ -1720,6 +1831,7 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
     ct_unet* h = new (std::nothrow) ct_unet();
     if (!h) return CT_EINVAL;
     h->timing = false;
+    h->first_f16 = false; h->first_f16_off = 0; h->first_wscale_inv = 1.f;
     h->arch_id = arch_id; h->device = device; h->ad = kArch[arch_id];
     const ArchDesc& ad = h->ad;
     h->nlevels = ad.ndown + 1;
@@ -1809,6 +1921,29 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
                         const int kk = 4 * t + g, dxp = kk / 9, dy = (kk / 3) % 3, dz = kk % 3, dx = dxp - xs;
                         if (dx >= 0 && dx <= 2) arena[h->first_mfma_off + t * 64 + lane] = kern[((dx * 3 + dy) * 3 + dz) * 8 + co];
                     }
+                // split-fp16 packing: wf16[j][lane = g*16 + n][4 dwords] = [w_hi, w_hi | w_lo, 0] of tap' 8j + 2g + s (s = 0, 1), row n
+                float wmax = 0.f;
+                for (int e = 0; e < 27 * 8; ++e) wmax = fmaxf(wmax, fabsf(kern[e]));
+                float wscale = 1.f;
+                if (wmax > 0.f && std::isfinite(wmax)) { int ex; frexpf(wmax, &ex); int sh = 14 - ex; sh = sh < -100 ? -100 : (sh > 100 ? 100 : sh); wscale = ldexpf(1.f, sh); }
+                h->first_wscale_inv = 1.f / wscale;
+                h->first_f16_off = arena.size();
+                arena.resize(arena.size() + 5 * 64 * 4, 0.f);
+                uint16_t* wf = reinterpret_cast<uint16_t*>(arena.data() + h->first_f16_off);
+                for (int j = 0; j < 5; ++j)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = lane >> 4, n = lane & 15, xs = n >> 3, co = n & 7;
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int kk = 8 * j + 2 * g + s2, dxp = kk / 9, dy = (kk / 3) % 3, dz = kk % 3, dx = dxp - xs;
+                            uint16_t hl[2] = {0, 0};
+                            if (kk < 36 && dx >= 0 && dx <= 2) h_split_host(kern[((dx * 3 + dy) * 3 + dz) * 8 + co] * wscale, hl);
+                            uint16_t* d = wf + ((size_t)(j * 64 + lane) * 4 + 2 * s2) * 2;      // two dwords per sub-slot
+                            d[0] = hl[0]; d[1] = hl[0]; d[2] = hl[1]; d[3] = 0;
+                        }
+                    }
+                static const bool first_f16_on = !(getenv("CT_FIRST_F16") && atoi(getenv("CT_FIRST_F16")) == 0);
+                const char* mathenv = getenv("CT_CONV_MATH");
+                h->first_f16 = first_f16_on && !(mathenv && (strcmp(mathenv, "f32") == 0 || strcmp(mathenv, "bf16x6") == 0));
             }
             c.epi_off = push_epi(bias, gamma, beta, mean, var, c.cout, c.cout);
             arena.resize(align_up(arena.size(), 4), 0.f);
@@ -1909,6 +2044,15 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             const float* epi = h->d_weights + c.epi_off;
             if (vsrc && c.cout == 8) {
                 const int nb1 = P * ((d[0] + F1X - 1) / F1X) * ((d[1] + F1Y - 1) / F1Y) * ((d[2] + F1Z - 1) / F1Z);
+                if (h->first_f16) {
+                    static const int occ = getenv("CT_FIRST_OCC") ? atoi(getenv("CT_FIRST_OCC")) : 5;
+                    const u32x4* wf = reinterpret_cast<const u32x4*>(h->d_weights + h->first_f16_off);
+                    uint32_t* am = any_f16 ? aptr(c.dst) : nullptr;
+                    if (occ >= 8) hipLaunchKernelGGL(conv_first_f16_kernel<8>, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin, wf, h->first_wscale_inv, epi, tptr(c.dst), ad.act, am);
+                    else if (occ == 5) hipLaunchKernelGGL(conv_first_f16_kernel<5>, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin, wf, h->first_wscale_inv, epi, tptr(c.dst), ad.act, am);
+                    else if (occ >= 6) hipLaunchKernelGGL(conv_first_f16_kernel<6>, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin, wf, h->first_wscale_inv, epi, tptr(c.dst), ad.act, am);
+                    else hipLaunchKernelGGL(conv_first_f16_kernel<4>, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin, wf, h->first_wscale_inv, epi, tptr(c.dst), ad.act, am);
+                } else
                 hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(nb1), dim3(256), 0, st, vsrc->vol, vsrc->q, vsrc->p_begin,
                                    h->d_weights + h->first_mfma_off, epi, tptr(c.dst), ad.act, any_f16 ? aptr(c.dst) : nullptr);
             } else if (c.cout == 8)
