@@ -48,7 +48,7 @@ def workspace(nbytes, device=None):
 KNN_MAX_POINTS = 4096        # knn_features_kernel keeps one point set's distances per wave in LDS
 KNN_MAX_K = 31
 GREEDY_MAX_SIDE = 16384      # min(m, n): one bitonic sort of the accepted pairs in LDS
-PRGLS_MAX_POINTS = 5461      # dense M-step scratch: 3 n <= 128^2 doubles
+PRGLS_MAX_POINTS = 16384     # practical bound (the n x n fp64 Gram / posterior matrices: 2 GB each at 16384); no kernel limit
 TRIM_MEAN_MAX_K = 64
 
 

@@ -1681,20 +1681,20 @@ struct PrglsWs {
 size_t prgls_layout(int m, int n, int l, unsigned char* base, PrglsWs* w) {
     size_t off = 0;
     auto take = [&](size_t count) { double* p = base ? (double*)(base + off) : nullptr; off += align_up(count * sizeof(double), 256); return p; };
-    const int nblk = (n + 31) / 32;
     PrglsWs t{};
     t.G = take((size_t)n * n); t.Gln = take((size_t)n * (l > 0 ? l : 1)); t.M = take((size_t)n * n);
     t.P = take((size_t)m * n); t.part = take((size_t)CS_SEG * 4 * n); t.dvec = take(n); t.sqd = take(n);
     t.rhs = take(3 * (size_t)n); t.C = take(3 * (size_t)n); t.predn = take(3 * (size_t)n);
     t.predl = take(3 * (size_t)(l > 0 ? l : 1)); t.rowpart = take(m); t.rowpart0 = take(m); t.normpart = take(n); t.sc = take(S_NUM);
-    t.U = take((size_t)LR_RMAX * n); t.Spart = take((size_t)LR_RMAX * LR_RMAX); t.ypart = take((size_t)LR_RMAX * 3); (void)nblk;
+    t.U = take((size_t)LR_RMAX * n); t.ypart = take((size_t)LR_RMAX * 3);
+    t.Spart = take((size_t)LR_RMAX * LR_RMAX > 3 * (size_t)n ? (size_t)LR_RMAX * LR_RMAX : 3 * (size_t)n);   // also the dense path's [3][n] right-hand sides
     t.q = take(LR_RMAX * 3); t.resid = take(n); t.respart = take(2 * (size_t)n); t.rank = (int*)take(8);
     if (w) *w = t;
     return off;
 }
 
 int cholesky_solve(const PrglsWs& w, int n, hipStream_t st) {
-    double* W = w.Spart;                       // [3][n]: idle low-rank buffer (>= 128 * 128 doubles >= 3 n for n <= 5461)
+    double* W = w.Spart;                       // [3][n]: the low-rank path's S buffer is idle here and sized max(128 * 128, 3 n)
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int nb = n - k0 < NB ? n - k0 : NB;
         const int rem = n - k0 - nb;
@@ -1742,7 +1742,6 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
     hipLaunchKernelGGL(colstats_finish_kernel, dim3(1), dim3(256), 0, st, w.part, n, xref, lambda, w.sc, w.dvec, w.sqd, w.rhs);
     LAUNCH_CHECK();
     const size_t nn = (size_t)n * n;
-    if (3 * (size_t)n > (size_t)LR_RMAX * LR_RMAX) return CT_ESHAPE;
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, w.G, w.sqd, w.sc, n, w.M, w.rhs, w.Spart);
     LAUNCH_CHECK();
     return cholesky_solve(w, n, st);

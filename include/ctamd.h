@@ -21,7 +21,7 @@
  *   - size limits of the kernels (CT_ESHAPE beyond them; the Python mirrors check them up front, _dev.check_match_sizes):
  *       ct_knn_features        n <= 4096 points, k <= 31 neighbours
  *       ct_greedy_match        min(m, n) <= 16384, m * n < 2^32
- *       ct_prgls_two_ref / ct_prgls_legacy / ct_solve_movements   n <= 5461 reference points (dense M-step: 3 n <= 128^2)
+ *       ct_prgls_two_ref / ct_prgls_legacy / ct_solve_movements   no kernel limit (workspace ~ 5 n^2 doubles; the mirrors stop at 16384)
  *       ct_trim_mean           k <= 64 predictions
  *   - collectives: there are no ct_comm_* entry points.  The path's only inter-GPU exchange is a gather of results
  *     (centre crops, centroid sets, ensemble predictions), issued by the host layer through
