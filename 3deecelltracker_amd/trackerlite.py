@@ -96,6 +96,29 @@ def estimate_posterior(prior_p_mxn, initial_sigma_square: float, predicted_ref_n
     return P.cpu().numpy()
 
 
+def softmax_normalize(similarity_matrix_mxn: np.ndarray) -> np.ndarray:
+    """reference :385-386 (unused upstream; host one-liner)."""
+    a = np.asarray(similarity_matrix_mxn)
+    e = np.exp(a - a.max(axis=1, keepdims=True))
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def row_wise_normalize(similarity_matrix_mxn: np.ndarray) -> np.ndarray:
+    """reference :389-390"""
+    a = np.asarray(similarity_matrix_mxn)
+    return a / np.sum(a, axis=1, keepdims=True)
+
+
+def non_max_suppression_normalize(similarity_matrix_mxn: np.ndarray, threshold=0.5) -> np.ndarray:
+    """reference :393-406: the greedy one-to-one prior in its legacy form (1/n everywhere, matched rows 0.1/(n-1) with 0.9 at the
+    pair) -- ct_greedy_match mode 1, the same kernel the legacy PR-GLS uses."""
+    t = _dev.torch()
+    mat = np.asarray(similarity_matrix_mxn)
+    corr_d = _dev.to_dev(mat.astype(np.float32, copy=False), t.float32)
+    _, _, prior_d = _dev.greedy_match(corr_d, threshold, 1)
+    return prior_d.cpu().numpy().astype(mat.dtype, copy=False)
+
+
 def solve_movements_ref(initial_sigma_square, lambda_, posterior_mxn, ptrs_ref_nx3, ptrs_tgt_mx3, scaling_factors_nxn):
     """reference :409-417 -> movements basis C (3, n).  `scaling_factors_nxn` is the (symmetric) Gram matrix."""
     t = _dev.torch(); L = _lib.lib()

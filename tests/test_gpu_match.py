@@ -537,3 +537,14 @@ def test_prgls_batched_is_bit_identical_to_separate_calls(ffn):
     for (s1, s2, c), (out, it) in zip(xs, got):
         ref_out, ref_it = tl.match_device(ffn, s1, s2, c, 3, 3)
         assert it == ref_it and torch.equal(out, ref_out)
+
+
+def test_unused_normalisation_helpers_of_the_reference(g):
+    """trackerlite.py:385-406 (dead code upstream, kept for the import surface): non_max_suppression_normalize == the legacy
+    greedy prior (oracle legacy_prior, track.py:58-70 formulation), softmax / row-wise by their definitions."""
+    from scipy.special import softmax
+    corr = g["corr_113"]
+    got = tl.non_max_suppression_normalize(corr, threshold=0.5)
+    assert np.array_equal(got, mr.legacy_prior(corr, 0.5).astype(corr.dtype))
+    np.testing.assert_allclose(tl.softmax_normalize(corr), softmax(corr, axis=1), rtol=1e-6)
+    np.testing.assert_allclose(tl.row_wise_normalize(corr), corr / corr.sum(1, keepdims=True), rtol=0)
