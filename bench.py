@@ -79,40 +79,29 @@ def timed(ctx, step, finish, steps, warmup):
     return dt
 
 
-def make_frames_mode(ctx, args):
-    """frames sharded: each rank its own frame (LCN -> U-Net on the big CU partition, match chains on the small one)."""
-    import torch
-    import torch.distributed as dist
-    tl = mod("trackerlite"); pre = mod("preprocess")
-    gather_buf = [torch.empty((args.cells, 3), dtype=torch.float64, device=ctx.dev) for _ in range(ctx.world)] if ctx.world > 1 else None
-    comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
+def _match_batcher(ctx, args, on_results=None):
+    """The matches of `--match-batch` consecutive frames go out as ONE chain of launches (trackerlite.match_device_batched) on the
+    match partition; at most `--match-workers` chains are in flight.  Returns (frame_done, finish)."""
+    tl = mod("trackerlite")
     pending = []
-
     waiting = [0]                                            # frames whose match has not been submitted yet
 
     def match_job(nframes):
-        # the matches of `nframes` consecutive frames as ONE chain of launches (trackerlite.match_device_batched)
         outs = tl.match_device_batched(ctx.active["ffn"], [(ctx.seg1, ctx.seg2, ctx.conf)] * nframes, beta=3, lambda_=3)
         ctx.iters_log.extend(it for _, it in outs)
         return [o for o, _ in outs]
 
     def collect(fut):
         tracked = fut.result()                               # the worker has synchronised its stream: the results are complete
-        if ctx.world > 1:
-            with torch.cuda.stream(comm):                    # "gather of centroid sets" (14 KB / rank and frame) on its own stream
-                for tr in tracked:
-                    dist.all_gather(gather_buf, tr)
-        return tracked
+        if on_results is not None:
+            on_results(tracked)
 
     def submit(nframes):
         pending.append(ctx.pipe.submit_match(match_job, nframes))
         while len(pending) > args.match_workers:
             collect(pending.pop(0))
 
-    def step():
-        with torch.cuda.stream(ctx.pipe.seg_stream):
-            norm = pre.normalize_image_device(ctx.raw, NOISE_LEVEL, (27, 27, 1), mode=0, subtract_median=True)
-            ctx.model.predict_volume_device(norm, out=ctx.prob)
+    def frame_done():
         waiting[0] += 1
         if waiting[0] >= args.match_batch:
             submit(waiting[0]); waiting[0] = 0
@@ -122,23 +111,46 @@ def make_frames_mode(ctx, args):
             submit(waiting[0]); waiting[0] = 0
         while pending:
             collect(pending.pop(0))
+    return frame_done, finish
+
+
+def make_frames_mode(ctx, args):
+    """frames sharded: each rank its own frame (LCN -> U-Net on the big CU partition, match chains on the small one)."""
+    import torch
+    import torch.distributed as dist
+    pre = mod("preprocess")
+    gather_buf = [torch.empty((args.cells, 3), dtype=torch.float64, device=ctx.dev) for _ in range(ctx.world)] if ctx.world > 1 else None
+    comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
+
+    def gather(tracked):
+        if ctx.world > 1:
+            with torch.cuda.stream(comm):                    # "gather of centroid sets" (14 KB / rank and frame) on its own stream
+                for tr in tracked:
+                    dist.all_gather(gather_buf, tr)
+
+    frame_done, finish_matches = _match_batcher(ctx, args, gather)
+
+    def step():
+        with torch.cuda.stream(ctx.pipe.seg_stream):
+            norm = pre.normalize_image_device(ctx.raw, NOISE_LEVEL, (27, 27, 1), mode=0, subtract_median=True)
+            ctx.model.predict_volume_device(norm, out=ctx.prob)
+        frame_done()
+
+    def finish():
+        finish_matches()
         if comm is not None:
             comm.synchronize()
     return step, finish
 
 
 def make_patches_mode(ctx, args):
-    """config 3: one frame per step, patches sharded over the ranks (parallel.predict_volume_sharded), match on rank 0."""
+    """config 3: one frame per step, patches sharded over the ranks (parallel.predict_volume_sharded), matches on rank 0 (batched
+    like the frames mode's)."""
     import torch
     import torch.distributed as dist
-    tl = mod("trackerlite"); pre = mod("preprocess"); par = mod("parallel")
+    pre = mod("preprocess"); par = mod("parallel")
     comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
-    pending = []
-
-    def match_job():
-        tracked, iters = tl.match_device(ctx.active["ffn"], ctx.seg1, ctx.seg2, ctx.conf, beta=3, lambda_=3)
-        ctx.iters_log.append(iters)
-        return tracked
+    frame_done, finish_matches = _match_batcher(ctx, args)
 
     def step():
         with torch.cuda.stream(ctx.pipe.seg_stream):
@@ -147,13 +159,11 @@ def make_patches_mode(ctx, args):
             norm = pre.normalize_image_device(ctx.raw, NOISE_LEVEL, (27, 27, 1), mode=0, subtract_median=True)
             ctx.prob = par.predict_volume_sharded(ctx.model, norm, src=None, comm_stream=comm)
         if ctx.rank == 0:
-            pending.append(ctx.pipe.submit_match(match_job))
-            while len(pending) > args.match_workers:
-                pending.pop(0).result()
+            frame_done()
 
     def finish():
-        while pending:
-            pending.pop(0).result()
+        if ctx.rank == 0:
+            finish_matches()
     return step, finish
 
 
