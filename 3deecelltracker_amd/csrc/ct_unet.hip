@@ -639,6 +639,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KB_STD = 7, KB_FOLD = 3, KB_C8 = 9, KB_C8F = 5;
 
+
 // ------------------------------------------------------------------------------------------------
 // Split-fp16 ("f16x3") family: the same kernels with TWO fp16 components per operand and THREE products.
 //
@@ -656,17 +657,13 @@ constexpr int KB_STD = 7, KB_FOLD = 3, KB_C8 = 9, KB_C8F = 5;
 template <bool F16> struct SplitMath { static constexpr int NC = F16 ? 2 : 3, NP = F16 ? 3 : 6; };
 
 __device__ __forceinline__ void h_split4(const f32x4 v, float s, uint2& h, uint2& l) {
-    float hs[4], ls[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = v[e] * s;
-        hs[e] = __uint_as_float(__float_as_uint(x) & 0xffffe000u);     // top 11 significant bits: exact in fp16
-        ls[e] = x - hs[e];                                             // exact; <= 13 significant bits, cut to 11 below
-    }
-    h = uint2{__builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(hs[0], hs[1])),
-              __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(hs[2], hs[3]))};
-    l = uint2{__builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(ls[0], ls[1])),
-              __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(ls[2], ls[3]))};
+    // hi = the scaled value cut to fp16 (round toward zero: its top 11 significant bits), lo = fp16(x - hi); x - hi is exact in fp32
+    const float x0 = v[0] * s, x1 = v[1] * s, x2 = v[2] * s, x3 = v[3] * s;
+    const auto h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+    const float l0 = x0 - (float)h01[0], l1 = x1 - (float)h01[1], l2 = x2 - (float)h23[0], l3 = x3 - (float)h23[1];
+    h = uint2{__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+    l = uint2{__builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l0, l1)),
+              __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l2, l3))};
 }
 
 // exponent k such that m * 2^-k lies in [2^13, 2^14); 0 for m == 0 / inf / nan; clamped so that 2^+-k stay normal floats
@@ -738,53 +735,109 @@ __device__ __forceinline__ void bf_split4(const f32x4 v, uint2& h, uint2& m, uin
     l = uint2{__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u)};
 }
 
-// One 8-channel halo tile -> three bf16 planes in LDS (see stage_halo_tile for the addressing).
-template <bool Z8, bool F16>
-__device__ __forceinline__ void bf_stage_tile(const ConvArgs& a, int c0, int p, int x0, int y0, int z0, int tid, char* lds, float in_scale) {
+// Staging of one 8-channel halo tile, global -> registers -> LDS component planes (position p = (hx * HY + hy) * HZ + hz at
+// 16 B per plane).  The staging used to be most of the VALU work of the thin layers (and those layers are VALU-issue bound: ~60
+// instructions per float4, three quarters of them 64-bit index arithmetic repeated for every channel chunk).  Now:
+//   * a thread owns one (z, channel half) of the tile's interior z range and walks the halo columns NCG at a time, so its LDS
+//     address and its z offset are per-thread constants and the column part of the address is the same for every thread of a
+//     column: it comes from a table in LDS (byte offset of the column in channel group 0 of its patch, -1 = outside the volume =
+//     zero padding) built once per workgroup and source tensor;
+//   * the two z-halo planes are separate slots, read only when the layer has more than one z block (otherwise they are the 'same'
+//     padding: written as zeros with the first chunk and never touched again).
+template <bool Z8> struct StageGeom {
     using G = BfGeom<Z8>;
-    f32x4 v[G::NSTAGEv];
-    const float* src; int CQ, SX, SY, SZ, sux, suy, suz, cq;
-    if (c0 < a.CA) { src = a.srcA; CQ = a.CA >> 3; SX = a.AX; SY = a.AY; SZ = a.AZ;
-                     sux = a.ux; suy = a.uy; suz = a.uz; cq = c0 >> 3; }
-    else           { src = a.srcB; CQ = a.CB >> 3; SX = a.X; SY = a.Y; SZ = a.Z;
-                     sux = suy = suz = 0; cq = (c0 - a.CA) >> 3; }
+    static constexpr int ZS = G::ZB * 2;                      // float4 slots of one column's interior: (z, channel half)
+    static constexpr int NCG = 256 / ZS;                      // columns per iteration
+    static constexpr int NCOLS = G::HXv * G::HYv;
+    static constexpr int NIT = (NCOLS + NCG - 1) / NCG;
+    static constexpr int NHS = NCOLS * 4;                     // z-halo slots: (column, plane, channel half)
+    static constexpr int NHIT = (NHS + 255) / 256;
+};
+
+template <bool Z8>
+__device__ __forceinline__ void stage_table(const ConvArgs& a, bool from_a, int x0, int y0, int tid, int* tab) {
+    using G = BfGeom<Z8>;
+    if (tid < StageGeom<Z8>::NCOLS) {
+        const int CQ = from_a ? (a.CA >> 3) : (a.CB >> 3), SY = from_a ? a.AY : a.Y, SZ = from_a ? a.AZ : a.Z;
+        const int sux = from_a ? a.ux : 0, suy = from_a ? a.uy : 0;
+        const int hx = tid / G::HYv, hy = tid - hx * G::HYv;
+        const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
+        tab[tid] = (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y) ? (((gx >> sux) * SY + (gy >> suy)) * CQ * SZ) * 32 : -1;
+    }
+}
+
+// channel group c0 / 8 of patch p in its source tensor (uniform)
+__device__ __forceinline__ const char* stage_base(const ConvArgs& a, int c0, int p) {
+    if (c0 < a.CA) return reinterpret_cast<const char*>(a.srcA + ((size_t)p * a.AX * a.AY * (a.CA >> 3) + (c0 >> 3)) * a.AZ * 8);
+    return reinterpret_cast<const char*>(a.srcB + ((size_t)p * a.X * a.Y * (a.CB >> 3) + ((c0 - a.CA) >> 3)) * a.Z * 8);
+}
+
+template <bool Z8>
+__device__ __forceinline__ void stage_load(const ConvArgs& a, const char* base, const int* tab, int suz, int z0, int tid, bool with_zhalo,
+                                           f32x4 (&v)[StageGeom<Z8>::NIT], f32x4 (&vh)[StageGeom<Z8>::NHIT]) {
+    using S = StageGeom<Z8>; using G = BfGeom<Z8>;
+    const int zs = tid % S::ZS, cgp = tid / S::ZS;
+    const int gz = z0 + (zs >> 1);
+    const int zb = gz < a.Z ? ((gz >> suz) * 8 + (zs & 1) * 4) * 4 : -1;
 #pragma unroll
-    for (int i = 0; i < G::NSTAGEv; ++i) {
-        const int f = tid + 256 * i;
+    for (int i = 0; i < S::NIT; ++i) {
+        const int c = cgp + S::NCG * i;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (f < G::NF4v) {
-            const int col = f / (G::HZv * 2), w = f - col * (G::HZv * 2);
-            const int hz = w >> 1, half = w & 1;
-            const int hx = col / G::HYv, hy = col - hx * G::HYv;
-            const int gx = x0 - 1 + hx, gy = y0 - 1 + hy, gz = z0 - 1 + hz;
-            if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
-                const size_t idx = ((((size_t)(p * SX + (gx >> sux)) * SY + (gy >> suy)) * CQ + cq) * SZ
-                                    + (gz >> suz)) * 8 + half * 4;
-                v[i] = *reinterpret_cast<const f32x4*>(src + idx);
-            }
+        if ((i + 1) * S::NCG <= S::NCOLS || c < S::NCOLS) {
+            const int t = tab[c];
+            if ((t | zb) >= 0) v[i] = *reinterpret_cast<const f32x4*>(base + (uint32_t)(t + zb));
         }
     }
-    __syncthreads();                                          // every wave is done reading the previous tile
+    if (with_zhalo) {
 #pragma unroll
-    for (int i = 0; i < G::NSTAGEv; ++i) {
-        const int f = tid + 256 * i;                          // slot f = position f >> 1, channel half f & 1
-        if (f < G::NF4v) {
-            char* d = lds + f * 8;
-            if constexpr (F16) {
-                uint2 h, l;
-                h_split4(v[i], in_scale, h, l);
-                *reinterpret_cast<uint2*>(d) = h;
-                *reinterpret_cast<uint2*>(d + G::PLANE) = l;
-            } else {
-                uint2 h, m, l;
-                bf_split4(v[i], h, m, l);
-                *reinterpret_cast<uint2*>(d) = h;
-                *reinterpret_cast<uint2*>(d + G::PLANE) = m;
-                *reinterpret_cast<uint2*>(d + 2 * G::PLANE) = l;
+        for (int i = 0; i < S::NHIT; ++i) {
+            const int idx = tid + 256 * i;
+            vh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < S::NHS) {
+                const int gzh = (idx & 2) ? z0 + G::ZB : z0 - 1;
+                const int t = tab[idx >> 2];
+                if (t >= 0 && gzh >= 0 && gzh < a.Z)
+                    vh[i] = *reinterpret_cast<const f32x4*>(base + (uint32_t)(t + ((gzh >> suz) * 8 + (idx & 1) * 4) * 4));
             }
         }
     }
-    __syncthreads();
+}
+
+template <bool Z8, bool F16>
+__device__ __forceinline__ void stage_put(const f32x4 v, char* d, float in_scale) {
+    using G = BfGeom<Z8>;
+    if constexpr (F16) {
+        uint2 h, l;
+        h_split4(v, in_scale, h, l);
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + G::PLANE) = l;
+    } else {
+        uint2 h, m, l;
+        bf_split4(v, h, m, l);
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + G::PLANE) = m;
+        *reinterpret_cast<uint2*>(d + 2 * G::PLANE) = l;
+    }
+}
+
+template <bool Z8, bool F16>
+__device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8>::NIT], const f32x4 (&vh)[StageGeom<Z8>::NHIT], int tid,
+                                            bool with_zhalo, char* lds, float in_scale) {
+    using S = StageGeom<Z8>; using G = BfGeom<Z8>;
+    const int zs = tid % S::ZS, cgp = tid / S::ZS;
+    char* d0 = lds + ((cgp * G::HZv + 1 + (zs >> 1)) * 2 + (zs & 1)) * 8;
+#pragma unroll
+    for (int i = 0; i < S::NIT; ++i)
+        if ((i + 1) * S::NCG <= S::NCOLS || cgp + S::NCG * i < S::NCOLS)
+            stage_put<Z8, F16>(v[i], d0 + i * (S::NCG * G::HZv * 16), in_scale);
+    if (with_zhalo) {
+#pragma unroll
+        for (int i = 0; i < S::NHIT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < S::NHS)
+                stage_put<Z8, F16>(vh[i], lds + (((idx >> 2) * G::HZv + ((idx & 2) ? G::HZv - 1 : 0)) * 2 + (idx & 1)) * 8, in_scale);
+        }
+    }
 }
 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
@@ -868,6 +921,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
     constexpr int HYg = G::HYv, HZg = G::HZv;
     __shared__ __attribute__((aligned(16))) char lds[SplitMath<F16>::NC * G::PLANE];
     __shared__ float amax_red[4];
+    __shared__ int coltab[2][StageGeom<Z8>::NCOLS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Consecutive workgroup ids go to different XCDs (round-robin), each with its own L2: give every XCD a CONTIGUOUS range of
     // tiles so that neighbouring tiles -- which share their halos -- meet in one L2 instead of fetching them from HBM 8 times
@@ -922,17 +976,31 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
     constexpr int KBS = C8 ? KB_C8 : KB_STD;                  // skip / ordinary chunks
     constexpr int KBF = C8 ? KB_C8F : KB_FOLD;                // folded chunks
     constexpr int NCLS = C8 ? 2 : 4;
-    const int nA = FOLD ? (a.CA >> 3) : 0;
+    using S = StageGeom<Z8>;
+    const int nA = FOLD ? (a.CA >> 3) : 0;                    // folded chunks
+    const int nFromA = a.CA >> 3;                             // chunks read from srcA (the decoder's low-res tensor)
+    const int cls = C8 ? wy : (wx * 2 + wy);
+    if (nFromA > 0) stage_table<Z8>(a, true, x0, y0, tid, coltab[0]);
+    if (nFromA < a.nchunks) stage_table<Z8>(a, false, x0, y0, tid, coltab[1]);
+    __syncthreads();
+    auto stage = [&](int chunk) {
+        f32x4 v[S::NIT], vh[S::NHIT];
+        const bool from_a = chunk < nFromA;
+        const bool zhalo = a.zblocks > 1 || chunk == 0;       // one z block: the z halo is zero padding, written once
+        stage_load<Z8>(a, stage_base(a, chunk * 8, p), coltab[from_a ? 0 : 1], from_a ? a.uz : 0, z0, tid, zhalo, v, vh);
+        __syncthreads();                                      // every wave is done reading the previous tile
+        stage_store<Z8, F16>(v, vh, tid, zhalo, lds, in_scale);
+        __syncthreads();
+    };
     if constexpr (FOLD) {
-        const int cls = C8 ? wy : (wx * 2 + wy);
         for (int chunk = 0; chunk < nA; ++chunk) {
-            bf_stage_tile<Z8, F16>(a, chunk * 8, p, x0, y0, z0, tid, lds, in_scale);
+            stage(chunk);
             const uint4* wp = wbase + (((size_t)chunk * NCLS + cls) * KBF * a.nt_total + ntb) * NC * 64;
             bf_chunk_mma<F16, NT, NCOL, KBF, C8, true, FOLD, Z8>(acc, lds, foldpos, g, wp, a.nt_total);
         }
     }
     for (int chunk = nA; chunk < a.nchunks; ++chunk) {
-        bf_stage_tile<Z8, F16>(a, chunk * 8, p, x0, y0, z0, tid, lds, in_scale);
+        stage(chunk);
         const uint4* wp = wbase + (((size_t)nA * NCLS * KBF + (size_t)(chunk - nA) * KBS) * a.nt_total + ntb) * NC * 64;
         bf_chunk_mma<F16, NT, NCOL, KBS, C8, false, FOLD, Z8>(acc, lds, lanepos, g, wp, a.nt_total);
     }
