@@ -66,12 +66,26 @@ struct ConvArgs {
     int nt_total;           // cout tiles of 16 in the packed weights (a block computes NT of them)
     int ngroups;            // nt_total / NT  (blocks along the cout dimension; 1 unless Cout > 64)
     // split-fp16 kernels: per-patch absolute maxima of the tensors (uint32 bit patterns of non-negative floats)
-    const uint32_t* amaxA;  // srcA's tensor [P] (or null)
+    const uint32_t* amaxA;  // srcA's tensor [P] (= amaxB when there is no srcA)
     const uint32_t* amaxB;  // srcB's tensor [P]
     uint32_t* amax_out;     // this conv's output tensor [P] (null for the head layer)
     float wscale_inv;       // 1 / (power-of-two scale applied to the packed fp16 weights)
     int nxcd;               // XCDs the launch stream may use (workgroups are dealt to them round-robin); 0/1 = no remapping
+    // split kernels: workgroup id -> tile without integer divisions (set by launch_conv_split from the grid)
+    uint32_t xper, xrem;    // grid / nxcd, grid % nxcd
+    uint32_t mdiv[5];       // floor(2^32 / d) for d = ngroups, zblocks, tilesY, tilesX, nxcd
+#ifdef CT_TRACE
+    unsigned long long* trace;   // [workgroups][8] phase timestamps (s_memtime) + hw id, scripts/microbench.py trace
+#endif
 };
+
+#ifdef CT_TRACE
+extern "C" { __attribute__((visibility("default"))) unsigned long long* ct_trace_buf = nullptr;
+             __attribute__((visibility("default"))) int ct_trace_layer = -1; }
+#define CT_TR(k) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CT_TR(k) do {} while (0)
+#endif
 
 namespace {
 
@@ -754,15 +768,18 @@ template <bool Z8> struct StageGeom {
     static constexpr int NHIT = (NHS + 255) / 256;
 };
 
+// Every wave builds its own copy of the table (its lanes write it and read it back: LDS keeps one wave's requests in order, so no
+// workgroup barrier stands between the kernel's entry and its first global loads).
 template <bool Z8>
-__device__ __forceinline__ void stage_table(const ConvArgs& a, bool from_a, int x0, int y0, int tid, int* tab) {
+__device__ __forceinline__ void stage_table(const ConvArgs& a, bool from_a, int x0, int y0, int lane, int* tab) {
     using G = BfGeom<Z8>;
-    if (tid < StageGeom<Z8>::NCOLS) {
-        const int CQ = from_a ? (a.CA >> 3) : (a.CB >> 3), SY = from_a ? a.AY : a.Y, SZ = from_a ? a.AZ : a.Z;
-        const int sux = from_a ? a.ux : 0, suy = from_a ? a.uy : 0;
-        const int hx = tid / G::HYv, hy = tid - hx * G::HYv;
+    const int CQ = from_a ? (a.CA >> 3) : (a.CB >> 3), SY = from_a ? a.AY : a.Y, SZ = from_a ? a.AZ : a.Z;
+    const int sux = from_a ? a.ux : 0, suy = from_a ? a.uy : 0;
+#pragma unroll
+    for (int c = lane; c < StageGeom<Z8>::NCOLS; c += 64) {
+        const int hx = c / G::HYv, hy = c - hx * G::HYv;
         const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
-        tab[tid] = (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y) ? (((gx >> sux) * SY + (gy >> suy)) * CQ * SZ) * 32 : -1;
+        tab[c] = (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y) ? (((gx >> sux) * SY + (gy >> suy)) * CQ * SZ) * 32 : -1;
     }
 }
 
@@ -779,14 +796,16 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, const char* base, 
     const int zs = tid % S::ZS, cgp = tid / S::ZS;
     const int gz = z0 + (zs >> 1);
     const int zb = gz < a.Z ? ((gz >> suz) * 8 + (zs & 1) * 4) * 4 : -1;
+    int t[S::NIT];
+#pragma unroll
+    for (int i = 0; i < S::NIT; ++i) {                        // all table reads go out before the first (conditional) global load
+        const int c = cgp + S::NCG * i;
+        t[i] = ((i + 1) * S::NCG <= S::NCOLS || c < S::NCOLS) ? tab[c] : -1;
+    }
 #pragma unroll
     for (int i = 0; i < S::NIT; ++i) {
-        const int c = cgp + S::NCG * i;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if ((i + 1) * S::NCG <= S::NCOLS || c < S::NCOLS) {
-            const int t = tab[c];
-            if ((t | zb) >= 0) v[i] = *reinterpret_cast<const f32x4*>(base + (uint32_t)(t + zb));
-        }
+        if ((t[i] | zb) >= 0) v[i] = *reinterpret_cast<const f32x4*>(base + (uint32_t)(t[i] + zb));
     }
     if (with_zhalo) {
 #pragma unroll
@@ -854,6 +873,9 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 #pragma unroll
         for (int c = 0; c < NC; ++c) wnext[0][c] = *reinterpret_cast<const u32x4*>(wp + (size_t)c * 64);
     }
+#ifdef CT_EXP_REUSE
+    u32x4 avs[2][4][NC];
+#endif
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb, G::HYv, G::HZv), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1, G::HYv, G::HZv),
@@ -881,7 +903,13 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
         }
 #pragma unroll
         for (int cg = 0; cg < NCOL; cg += 4) {
+#ifdef CT_EXP_REUSE
+            static_assert(NCOL <= 8, "");
+            u32x4 (&av)[4][NC] = avs[cg >> 2];
+            if (kb % CT_EXP_REUSE == 0)
+#else
             u32x4 av[4][NC];
+#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int mt = cg + q;
@@ -913,7 +941,7 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 }
 
 template <bool F16, int NT, bool C8, bool FOLD, bool Z8>
-__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const ConvArgs a_in) {
     static_assert(!C8 || NT == 1, "the Cout = 8 kernel has one row tile");
     static_assert(!(C8 && Z8), "Cout = 8 layers sit at the full-resolution level");
     using G = BfGeom<Z8>;
@@ -921,23 +949,39 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
     constexpr int HYg = G::HYv, HZg = G::HZv;
     __shared__ __attribute__((aligned(16))) char lds[SplitMath<F16>::NC * G::PLANE];
     __shared__ float amax_red[4];
-    __shared__ int coltab[2][StageGeom<Z8>::NCOLS];
+    __shared__ int coltab[4][2][StageGeom<Z8>::NCOLS];       // per wave: column tables of the two source tensors
+    __shared__ __attribute__((aligned(16))) float epi_s[4 * NT * 16];   // this block's bias | scale | shift | head weights
+    // All kernel arguments are fetched in one go: left alone, the compiler loads each where it is first used, and the ~20 dependent
+    // scalar-load round trips (200-300 cycles apiece with every workgroup hitting the same lines) were a third of a thin layer's
+    // workgroup lifetime, all of it in front of the first global load.
+    ConvArgs a = a_in;
+    asm volatile("" : "+s"(a.CA), "+s"(a.CB), "+s"(a.AX), "+s"(a.AY), "+s"(a.AZ), "+s"(a.ux), "+s"(a.uy), "+s"(a.uz),
+                      "+s"(a.nchunks), "+s"(a.tilesX), "+s"(a.tilesY), "+s"(a.zblocks), "+s"(a.ngroups),
+                      "+s"(a.nxcd), "+s"(a.xper), "+s"(a.xrem), "+s"(a.mdiv[0]), "+s"(a.mdiv[1]), "+s"(a.mdiv[2]), "+s"(a.mdiv[3]), "+s"(a.mdiv[4])
+                    : "s"(a_in.X), "s"(a_in.Y), "s"(a_in.Z),       // (X, Y, Z as in-out operands trip the backend: inputs only;
+                      "s"(a_in.srcA), "s"(a_in.srcB), "s"(a_in.epi), "s"(a_in.head), "s"(a_in.amaxA), "s"(a_in.amaxB));   // pointers would lose their address space)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    CT_TR(0);
+#ifdef CT_TRACE
+    if (a.trace && tid == 0) a.trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 | (0 << 6) | (31 << 11))) << 32) | __builtin_amdgcn_s_getreg((4 | (0 << 6) | (31 << 11)));
+#endif
     // Consecutive workgroup ids go to different XCDs (round-robin), each with its own L2: give every XCD a CONTIGUOUS range of
     // tiles so that neighbouring tiles -- which share their halos -- meet in one L2 instead of fetching them from HBM 8 times
     // (the full-resolution layers moved 1.6-1.8x their algorithmic bytes before this).
-    int b = blockIdx.x;
-    if (a.nxcd > 1) {
-        const int nb = (int)gridDim.x, per = nb / a.nxcd, rem = nb - per * a.nxcd;
-        const int xcd = b % a.nxcd, idx = b / a.nxcd;
-        b = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    uint32_t b = blockIdx.x;
+    // n -> n / d, returns n % d, with the host's floor(2^32 / d): the quotient estimate is short by at most one
+    auto divmod = [](uint32_t& n, uint32_t d, uint32_t m) { uint32_t q = __umulhi(n, m), r = n - q * d; if (r >= d) { ++q; r -= d; }
+                                                             n = q; return (int)r; };
+    {
+        const uint32_t xcd = (uint32_t)divmod(b, (uint32_t)a.nxcd, a.mdiv[4]);     // b is now the index inside the XCD's range
+        b += xcd * a.xper + (xcd < a.xrem ? xcd : a.xrem);
     }
-    const int cg = b % a.ngroups; b /= a.ngroups;
+    const int cg = divmod(b, (uint32_t)a.ngroups, a.mdiv[0]);
     const int ntb = cg * NT;
-    const int zb = b % a.zblocks; b /= a.zblocks;
-    const int ty = b % a.tilesY;  b /= a.tilesY;
-    const int tx = b % a.tilesX;
-    const int p = b / a.tilesX;
+    const int zb = divmod(b, (uint32_t)a.zblocks, a.mdiv[1]);
+    const int ty = divmod(b, (uint32_t)a.tilesY, a.mdiv[2]);
+    const int tx = divmod(b, (uint32_t)a.tilesX, a.mdiv[3]);
+    const int p = (int)b;
     const int x0 = tx * G::TXv, y0 = ty * G::TYv, z0 = zb * G::ZB;
     const int g = lane >> 4;
     const int zl = Z8 ? (lane & 7) : (lane & 15);
@@ -964,13 +1008,23 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // split-fp16: one power-of-two scale for all input channels of this patch (the larger of the two source tensors' maxima)
-    float in_scale = 1.f, out_mul = 1.f;
+    // (vector loads on purpose -- threadIdx.y is 0, but the compiler cannot know: a scalar load's return is only waitable as
+    //  "everything", and that wait would land in front of the first LDS read, i.e. in front of the tile's global loads)
+    uint32_t amax_bits = 0, amax_bits_a = 0;
     if constexpr (F16) {
-        uint32_t mb = a.amaxB[p * AMAX_STRIDE];
-        if (a.amaxA) { const uint32_t ma = a.amaxA[p * AMAX_STRIDE]; mb = ma > mb ? ma : mb; }
-        const int k = amax_exponent(mb);
-        in_scale = pow2f(-k); out_mul = pow2f(k) * a.wscale_inv;
+        amax_bits = a.amaxB[p * AMAX_STRIDE + threadIdx.y];
+        amax_bits_a = a.amaxA[p * AMAX_STRIDE + threadIdx.y];     // (the host passes amaxB again when there is no second source)
     }
+    // epilogue constants of this block's NT * 16 output channels: fetched now, parked in LDS with the first tile
+    constexpr int ECH = NT * 16;
+    const int ECP = C8 ? 16 : a.nt_total * 16;                // channel stride of the packed epilogue arrays
+    float epi_reg = 0.f;
+    {
+        const int k = tid / ECH, j = tid - k * ECH;
+        if (k < 3) epi_reg = a.epi[k * ECP + ntb * 16 + j];
+        else if (k == 3 && a.head) epi_reg = a.head[ntb * 16 + j];
+    }
+    const float head_bias = a.head ? a.head[ECP + threadIdx.y] : 0.f;
     constexpr int NC = SplitMath<F16>::NC;
     const uint4* wbase = reinterpret_cast<const uint4*>(a.wpack) + lane;
     constexpr int KBS = C8 ? KB_C8 : KB_STD;                  // skip / ordinary chunks
@@ -980,17 +1034,27 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
     const int nA = FOLD ? (a.CA >> 3) : 0;                    // folded chunks
     const int nFromA = a.CA >> 3;                             // chunks read from srcA (the decoder's low-res tensor)
     const int cls = C8 ? wy : (wx * 2 + wy);
-    if (nFromA > 0) stage_table<Z8>(a, true, x0, y0, tid, coltab[0]);
-    if (nFromA < a.nchunks) stage_table<Z8>(a, false, x0, y0, tid, coltab[1]);
-    __syncthreads();
+    if (nFromA > 0) stage_table<Z8>(a, true, x0, y0, lane, coltab[wave][0]);
+    if (nFromA < a.nchunks) stage_table<Z8>(a, false, x0, y0, lane, coltab[wave][1]);
+    float in_scale = 1.f, out_mul = 1.f;
     auto stage = [&](int chunk) {
         f32x4 v[S::NIT], vh[S::NHIT];
         const bool from_a = chunk < nFromA;
         const bool zhalo = a.zblocks > 1 || chunk == 0;       // one z block: the z halo is zero padding, written once
-        stage_load<Z8>(a, stage_base(a, chunk * 8, p), coltab[from_a ? 0 : 1], from_a ? a.uz : 0, z0, tid, zhalo, v, vh);
+        stage_load<Z8>(a, stage_base(a, chunk * 8, p), coltab[wave][from_a ? 0 : 1], from_a ? a.uz : 0, z0, tid, zhalo, v, vh);
+        if (chunk == 0) CT_TR(1);
         __syncthreads();                                      // every wave is done reading the previous tile
+        if (chunk == 0) {
+            CT_TR(2);
+            if (tid < 4 * ECH) epi_s[tid] = epi_reg;
+            if constexpr (F16) {                              // one power-of-two scale for all input channels of this patch
+                const int k = amax_exponent(amax_bits_a > amax_bits ? amax_bits_a : amax_bits);
+                in_scale = pow2f(-k); out_mul = pow2f(k) * a.wscale_inv;
+            }
+        }
         stage_store<Z8, F16>(v, vh, tid, zhalo, lds, in_scale);
         __syncthreads();
+        if (chunk == 0) CT_TR(3);
     };
     if constexpr (FOLD) {
         for (int chunk = 0; chunk < nA; ++chunk) {
@@ -1005,6 +1069,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
         bf_chunk_mma<F16, NT, NCOL, KBS, C8, false, FOLD, Z8>(acc, lds, lanepos, g, wp, a.nt_total);
     }
 
+    CT_TR(4);
     // ---- epilogue: (un-scale) -> bias -> activation -> BatchNorm affine; stores / fused pool / fused head as in the fp32 kernels
     const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
     const int z = z0 + zl;
@@ -1012,9 +1077,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
     if constexpr (C8) {
         // lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx + (g>>1), y = y0 + col_y(mt)
         const int cb = 4 * (g & 1);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
-        const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + 16 + cb);
-        const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 32 + cb);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(epi_s + cb);
+        const f32x4 scale = *reinterpret_cast<const f32x4*>(epi_s + ECH + cb);
+        const f32x4 shift = *reinterpret_cast<const f32x4*>(epi_s + 2 * ECH + cb);
         const int x = x0 + wx + (g >> 1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -1030,22 +1095,21 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
             if (a.out && ok)
                 *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
             if (a.head) {
-                const f32x4 hw = *reinterpret_cast<const f32x4*>(a.head + cb);
+                const f32x4 hw = *reinterpret_cast<const f32x4*>(epi_s + 3 * ECH + cb);
                 float part = r[0] * hw[0] + r[1] * hw[1] + r[2] * hw[2] + r[3] * hw[3];
                 part += __shfl_xor(part, 16);                    // the other channel half of the same voxel
                 if ((g & 1) == 0 && ok)
-                    a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + a.head[16])));
+                    a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + head_bias)));
             }
         }
         if constexpr (F16) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
     } else {
-        const int CP = a.nt_total * 16;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int cb = 16 * (ntb + nt) + 4 * g;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(a.epi + cb);
-            const f32x4 scale = *reinterpret_cast<const f32x4*>(a.epi + CP + cb);
-            const f32x4 shift = *reinterpret_cast<const f32x4*>(a.epi + 2 * CP + cb);
+            const int cbl = 16 * nt + 4 * g;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(epi_s + cbl);
+            const f32x4 scale = *reinterpret_cast<const f32x4*>(epi_s + ECH + cbl);
+            const f32x4 shift = *reinterpret_cast<const f32x4*>(epi_s + 2 * ECH + cbl);
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 f32x4 r = F16 ? acc[mt][nt] * out_mul + bias : acc[mt][nt] + bias;
@@ -1113,13 +1177,13 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
             }
         }
         if (a.head) {      // Conv3D(1, 1, activation='sigmoid') fused: dot over channels, then sigmoid
-            const float hb = a.head[CP];
+            const float hb = head_bias;
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 float part = 0.f;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const f32x4 hw = *reinterpret_cast<const f32x4*>(a.head + 16 * (ntb + nt) + 4 * g);
+                    const f32x4 hw = *reinterpret_cast<const f32x4*>(epi_s + 3 * ECH + 16 * nt + 4 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) part += acc[mt][nt][e] * hw[e];
                 }
@@ -1131,6 +1195,10 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(ConvA
             }
         }
     }
+    CT_TR(5);
+#ifdef CT_TRACE
+    __builtin_amdgcn_s_waitcnt(0); CT_TR(6);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1793,7 +1861,16 @@ int launch_conv_bf(const ConvArgs& a, int P, bool fold, bool z8, hipStream_t st)
     return (int)hipGetLastError();
 }
 template <bool F16>
-int launch_conv_split(const ConvArgs& a, int P, int NTsel, bool c8, bool fold, bool z8, hipStream_t st) {
+int launch_conv_split(const ConvArgs& a_in, int P, int NTsel, bool c8, bool fold, bool z8, hipStream_t st) {
+    ConvArgs a = a_in;
+    {
+        const uint32_t nblk = (uint32_t)P * a.tilesX * a.tilesY * a.zblocks * (c8 ? 1 : a.ngroups);
+        if (c8) a.ngroups = 1;
+        if (a.nxcd < 1) a.nxcd = 1;
+        a.xper = nblk / (uint32_t)a.nxcd; a.xrem = nblk - a.xper * (uint32_t)a.nxcd;
+        const int d[5] = {a.ngroups, a.zblocks, a.tilesY, a.tilesX, a.nxcd};
+        for (int i = 0; i < 5; ++i) a.mdiv[i] = d[i] <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)d[i]);
+    }
     if (c8) {
         const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
         if (fold) hipLaunchKernelGGL((conv3_split_kernel<F16, 1, true, true, false>), dim3(nblk), dim3(256), 0, st, a);
@@ -2175,8 +2252,11 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             if (c.head) { a.head = h->d_weights + h->head_off; a.head_out = prob_out; }
             a.act = ad.act;
             a.nxcd = nxcd;
+#ifdef CT_TRACE
+            a.trace = ((int)i == ct_trace_layer) ? ct_trace_buf : nullptr;
+#endif
             if (c.f16) {
-                a.amaxB = aptr(c.srcB); a.amaxA = c.srcA >= 0 ? aptr(c.srcA) : nullptr;
+                a.amaxB = aptr(c.srcB); a.amaxA = c.srcA >= 0 ? aptr(c.srcA) : a.amaxB;
                 a.amax_out = c.head ? nullptr : aptr(c.dst);
                 a.wscale_inv = c.wscale_inv;
             }
