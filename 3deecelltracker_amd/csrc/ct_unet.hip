@@ -860,56 +860,50 @@ __device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8>::NIT]
 }
 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
+#ifndef CT_WPF1
+#define CT_WPF1 2          // K-blocks of weight fragments in flight ahead of the MFMAs, NT = 1 / 2 / 4
+#endif
+#ifndef CT_WPF2
+#define CT_WPF2 1
+#endif
+#ifndef CT_WPF4
+#define CT_WPF4 0
+#endif
 template <bool F16, int NT, int NCOL, int KB, bool C8, bool FOLDED, bool KFOLD, bool Z8>
 __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char* lds, int lanepos, int g,
                                              const uint4* wp, int nt_total) {          // (no __restrict__: see the prefetch)
-    // NT == 1: a K-block is only 12-48 MFMAs, less than the L2 round trip of its weight fragments, so the next block's
-    // fragments are requested before this block's MFMAs.  Wider tiles hide it by themselves.
+    // A K-block is 12-96 MFMAs (200-1600 cycles); the L2 round trip of its weight fragments is 200+ cycles and nothing else in the
+    // wave's stream covers it, so the fragments of the next PFD blocks are requested ahead of this block's MFMAs (registers permitting).
     using G = BfGeom<Z8>;
     constexpr int NC = SplitMath<F16>::NC, NP = SplitMath<F16>::NP;
-    constexpr bool PREFETCH = NT == 1;
-    u32x4 wnext[NT][NC];
-    if constexpr (PREFETCH) {
+    constexpr int PFD0 = NT == 1 ? (CT_WPF1) : (NT == 2 ? (CT_WPF2) : (CT_WPF4));
+    constexpr int PFD = PFD0 < KB ? PFD0 : KB - 1;
+    u32x4 wbuf[PFD + 1][NT][NC];
+    auto wload = [&](int kb, u32x4 (&dst)[NT][NC]) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) wnext[0][c] = *reinterpret_cast<const u32x4*>(wp + (size_t)c * 64);
-    }
-#ifdef CT_EXP_REUSE
-    u32x4 avs[2][4][NC];
-#endif
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                dst[nt][c] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(kb * nt_total + nt) * NC + c) * 64);
+    };
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) wload(k, wbuf[k]);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb, G::HYv, G::HZv), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1, G::HYv, G::HZv),
                   t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2, G::HYv, G::HZv), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3, G::HYv, G::HZv);
         const int tp = g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
         const char* ab = lds + (lanepos + tp) * 16;
-        u32x4 wv[NT][NC];
-        if constexpr (PREFETCH) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) wv[0][c] = wnext[0][c];
-            if (kb + 1 < KB) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    wnext[0][c] = *reinterpret_cast<const u32x4*>(wp + ((size_t)((kb + 1) * nt_total) * NC + c) * 64);
-            }
+        if (kb + PFD < KB) wload(kb + PFD, wbuf[(kb + PFD) % (PFD + 1)]);
+        u32x4 (&wv)[NT][NC] = wbuf[kb % (PFD + 1)];
+        if constexpr (PFD > 0) {
             // keep the prefetch up here: instruction selection and the scheduler sink a plain load to its first use
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    wv[nt][c] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(kb * nt_total + nt) * NC + c) * 64);
         }
 #pragma unroll
         for (int cg = 0; cg < NCOL; cg += 4) {
-#ifdef CT_EXP_REUSE
-            static_assert(NCOL <= 8, "");
-            u32x4 (&av)[4][NC] = avs[cg >> 2];
-            if (kb % CT_EXP_REUSE == 0)
-#else
             u32x4 av[4][NC];
-#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int mt = cg + q;
@@ -920,7 +914,7 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
             }
             // all fragment reads of the column group go out before its first MFMA (left alone, the scheduler issues them just in
             // time to save registers and every pair of MFMAs then eats a full LDS round trip)
-            if constexpr (PREFETCH) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (NT == 1) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
             // (weight component, activation component), smallest terms first: bf16 hh, hm, mh, mm, hl, lh; fp16 hh, hl, lh
             constexpr int WI[6] = {0, 0, 1, F16 ? 0 : 1, 0, 2}, AI[6] = {0, 1, 0, F16 ? 0 : 1, 2, 0};
 #pragma unroll
