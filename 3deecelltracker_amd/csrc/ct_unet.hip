@@ -696,9 +696,18 @@ constexpr int AMAX_STRIDE = 32;        // uint32 words between the slots of cons
 
 // block-wide max of non-negative floats (256 threads = 4 waves) -> one atomicMax on the tensor's per-patch slot
 __device__ __forceinline__ void amax_publish(float m, uint32_t* slot, int tid, float* red /* [4] LDS */) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((tid & 63) == 0) red[tid >> 6] = m;
+    // wave maximum by DPP (six 2-cycle VALU ops; __shfl_xor is a chain of six LDS-crossbar round trips): non-negative floats
+    // order like their bit patterns, lane 63 ends up with the maximum of all rows
+    int v = __builtin_bit_cast(int, m);
+#define CT_DPPMAX(ctrl, rmask) { const int t = __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false); v = v > t ? v : t; }
+    CT_DPPMAX(0xB1, 0xf)      // quad_perm [1,0,3,2]
+    CT_DPPMAX(0x4E, 0xf)      // quad_perm [2,3,0,1]
+    CT_DPPMAX(0x141, 0xf)     // row_half_mirror
+    CT_DPPMAX(0x140, 0xf)     // row_mirror
+    CT_DPPMAX(0x142, 0xa)     // row_bcast:15 into rows 1, 3
+    CT_DPPMAX(0x143, 0xc)     // row_bcast:31 into rows 2, 3
+#undef CT_DPPMAX
+    if ((tid & 63) == 63) red[tid >> 6] = __builtin_bit_cast(float, v);
     __syncthreads();
     if (tid == 0)
         (void)__hip_atomic_fetch_max(slot, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))), __ATOMIC_RELAXED,
@@ -859,6 +868,19 @@ __device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8>::NIT]
     }
 }
 
+// byte offset (inside one component plane) of the lane's B fragment for every K-block of a tap set: lane group g supplies tap slot
+// 4 kb + g.  Built once per kernel -- inside the K loop the four-way select cost a dozen instructions per K-block.
+template <int KB, bool C8, bool FOLDED, bool Z8>
+__device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)[KB]) {
+    using G = BfGeom<Z8>;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb, G::HYv, G::HZv), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1, G::HYv, G::HZv),
+                  t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2, G::HYv, G::HZv), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3, G::HYv, G::HZv);
+        tapoff[kb] = (lanepos + (g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3)))) * 16;
+    }
+}
+
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
 #ifndef CT_WPF1
 #define CT_WPF1 2          // K-blocks of weight fragments in flight ahead of the MFMAs, NT = 1 / 2 / 4
@@ -870,8 +892,8 @@ __device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8>::NIT]
 #define CT_WPF4 0
 #endif
 template <bool F16, int NT, int NCOL, int KB, bool C8, bool FOLDED, bool KFOLD, bool Z8>
-__device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char* lds, int lanepos, int g,
-                                             const uint4* wp, int nt_total) {          // (no __restrict__: see the prefetch)
+__device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char* lds, const int (&tapoff)[KB],
+                                             const uint4* wp /* uniform */, uint32_t lane16, int nt_total) {   // (no __restrict__: see the prefetch)
     // A K-block is 12-96 MFMAs (200-1600 cycles); the L2 round trip of its weight fragments is 200+ cycles and nothing else in the
     // wave's stream covers it, so the fragments of the next PFD blocks are requested ahead of this block's MFMAs (registers permitting).
     using G = BfGeom<Z8>;
@@ -884,16 +906,13 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                dst[nt][c] = *reinterpret_cast<const u32x4*>(wp + ((size_t)(kb * nt_total + nt) * NC + c) * 64);
+                dst[nt][c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(wp + ((size_t)(kb * nt_total + nt) * NC + c) * 64) + lane16);
     };
 #pragma unroll
     for (int k = 0; k < PFD; ++k) wload(k, wbuf[k]);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-        const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb, G::HYv, G::HZv), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1, G::HYv, G::HZv),
-                  t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2, G::HYv, G::HZv), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3, G::HYv, G::HZv);
-        const int tp = g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3));
-        const char* ab = lds + (lanepos + tp) * 16;
+        const char* ab = lds + tapoff[kb];
         if (kb + PFD < KB) wload(kb + PFD, wbuf[(kb + PFD) % (PFD + 1)]);
         u32x4 (&wv)[NT][NC] = wbuf[kb % (PFD + 1)];
         if constexpr (PFD > 0) {
@@ -1020,7 +1039,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
     }
     const float head_bias = a.head ? a.head[ECP + threadIdx.y] : 0.f;
     constexpr int NC = SplitMath<F16>::NC;
-    const uint4* wbase = reinterpret_cast<const uint4*>(a.wpack) + lane;
+    const uint4* wbase = reinterpret_cast<const uint4*>(a.wpack);
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     constexpr int KBS = C8 ? KB_C8 : KB_STD;                  // skip / ordinary chunks
     constexpr int KBF = C8 ? KB_C8F : KB_FOLD;                // folded chunks
     constexpr int NCLS = C8 ? 2 : 4;
@@ -1051,16 +1071,22 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
         if (chunk == 0) CT_TR(3);
     };
     if constexpr (FOLD) {
+        int tapoff[KBF];
+        bf_tap_offsets<KBF, C8, true, Z8>(foldpos, g, tapoff);
         for (int chunk = 0; chunk < nA; ++chunk) {
             stage(chunk);
             const uint4* wp = wbase + (((size_t)chunk * NCLS + cls) * KBF * a.nt_total + ntb) * NC * 64;
-            bf_chunk_mma<F16, NT, NCOL, KBF, C8, true, FOLD, Z8>(acc, lds, foldpos, g, wp, a.nt_total);
+            bf_chunk_mma<F16, NT, NCOL, KBF, C8, true, FOLD, Z8>(acc, lds, tapoff, wp, lane16, a.nt_total);
         }
     }
-    for (int chunk = nA; chunk < a.nchunks; ++chunk) {
-        stage(chunk);
-        const uint4* wp = wbase + (((size_t)nA * NCLS * KBF + (size_t)(chunk - nA) * KBS) * a.nt_total + ntb) * NC * 64;
-        bf_chunk_mma<F16, NT, NCOL, KBS, C8, false, FOLD, Z8>(acc, lds, lanepos, g, wp, a.nt_total);
+    {
+        int tapoff[KBS];
+        bf_tap_offsets<KBS, C8, false, Z8>(lanepos, g, tapoff);
+        for (int chunk = nA; chunk < a.nchunks; ++chunk) {
+            stage(chunk);
+            const uint4* wp = wbase + (((size_t)nA * NCLS * KBF + (size_t)(chunk - nA) * KBS) * a.nt_total + ntb) * NC * 64;
+            bf_chunk_mma<F16, NT, NCOL, KBS, C8, false, FOLD, Z8>(acc, lds, tapoff, wp, lane16, a.nt_total);
+        }
     }
 
     CT_TR(4);
