@@ -201,13 +201,13 @@ def measure_pcie(ctx):
         norm = pre.normalize_image_device(d, NOISE_LEVEL, (27, 27, 1), mode=0, subtract_median=True)
         ctx.model.predict_volume_device(norm, out=ctx.prob)
         out_h.copy_(ctx.prob, non_blocking=True)
-    for _ in range(2):
+    for _ in range(3):
         frame()
     torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(10):
         frame()
     torch.cuda.synchronize(ctx.dev)
-    dt = (time.perf_counter() - t0) / 5
+    dt = (time.perf_counter() - t0) / 10
     return {"segment_ms_per_frame": round(dt * 1e3, 3), "segment_volumes_per_s": round(1.0 / dt, 2),
             "what": "pinned H2D of the raw uint16 stack + LCN + U-Net + pinned D2H of the fp32 probability map, full chip, one frame at a time"}
 

@@ -11,8 +11,11 @@ bash scripts/prof.sh bench_$R $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-r
 bash scripts/prof.sh unet_$R $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -4
 bash scripts/prof_pmc.sh unet_$R FETCH_SIZE $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -3
 bash scripts/prof_pmc.sh unet_$R WRITE_SIZE $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -3
-bash scripts/prof_sq.sh unet_$R "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" $GRAFT_REPO_ROOT/scripts/microbench.py unet | tail -12
-bash scripts/prof_sq.sh unet2_$R "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_INSTS_VALU" $GRAFT_REPO_ROOT/scripts/microbench.py unet | tail -12
+bash scripts/prof_sq.sh unetA_$R "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" $GRAFT_REPO_ROOT/scripts/microbench.py unet | tail -1
+bash scripts/prof_sq.sh unetB_$R "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" $GRAFT_REPO_ROOT/scripts/microbench.py unet | tail -1
+bash scripts/prof_sq.sh unetC_$R "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" $GRAFT_REPO_ROOT/scripts/microbench.py unet | tail -1
+cd $GRAFT_REPO_ROOT
+python scripts/sq_summary.py gpurun_out/prof/unet_${R}_kernel_stats.csv gpurun_out/prof/${R}_unet_sq_summary.json gpurun_out/prof/unetA_${R}_sq.csv gpurun_out/prof/unetB_${R}_sq.csv gpurun_out/prof/unetC_${R}_sq.csv
 bash scripts/prof.sh match600_$R $GRAFT_REPO_ROOT/scripts/microbench.py match 600 | head -3
 bash scripts/prof.sh batched_$R $GRAFT_REPO_ROOT/scripts/microbench.py batched 600 | head -3
 cd $GRAFT_REPO_ROOT
