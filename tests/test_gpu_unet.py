@@ -216,3 +216,34 @@ def test_config2_512x512x32_against_oracle_patches():
         sl = got[i * 112:(i + 1) * 112, j * 112:(j + 1) * 112, k * 12:(k + 1) * 12]
         want = want[:sl.shape[0], :sl.shape[1], :sl.shape[2]]
         assert sl.size > 0 and float(np.abs(sl - want).max()) <= 1e-4, p
+
+
+def test_split_fp16_scaling_over_the_dynamic_range():
+    """The default conv family splits fp32 operands into fp16 pairs after an exact per-patch power-of-two scaling by the input
+    tensor's maximum.  One batch with patches of very different magnitude (x 1e-4, x 1, x 1e4), an all-zero patch and a patch with
+    a single 1e5 outlier: every conv block of every patch stays within 2e-5 of ITS OWN scale vs the fp64-accumulating oracle, the
+    patches do not influence each other (bit-identical to running them alone), nothing overflows."""
+    import torch
+    arch = arch_mod.UNET3_A
+    w = synth.make_unet_weights("unet3_a", seed=5)
+    model = unet3d.unet3_a().set_weights_dict(w)
+    rng = np.random.default_rng(6)
+    base = rng.normal(size=arch.input_shape).astype(np.float32)
+    outlier = (0.01 * rng.normal(size=arch.input_shape)).astype(np.float32); outlier[80, 80, 8] = 1e5
+    batch = np.stack([base * 1e-4, base, base * 1e4, np.zeros_like(base), outlier]).astype(np.float32)
+    got = model.predict_device(torch.from_numpy(batch).cuda()).cpu().numpy()
+    assert np.isfinite(got).all()
+    for p in range(len(batch)):
+        collect = []
+        want = ur.unet_forward(batch[p], w, arch, dtype=np.float32, collect=collect)
+        alone, dump = model.predict_device(torch.from_numpy(batch[p:p + 1]).cuda(), layer_dump=True)
+        assert np.array_equal(alone[0].cpu().numpy(), got[p]), f"patch {p}: result depends on its batch neighbours"
+        dump = dump.cpu().numpy(); off = 0
+        for i, ref in enumerate(collect):
+            mine = dump[off:off + ref.size].reshape(ref.shape); off += ref.size
+            scale = max(float(np.abs(ref).max()), 1e-30)
+            err = float(np.abs(mine - ref).max())
+            assert err <= 2e-5 * scale, f"patch {p} conv block {i}: max abs err {err} at scale {scale}"
+        # the head is a sigmoid of a logit whose error scales with the last block's magnitude (slope <= 1/4): 1e-4 at ordinary scale
+        tol = max(1e-4, 0.25 * 2e-5 * float(np.abs(collect[-1]).max()) * float(np.abs(w["head"]["kernel"]).sum()))
+        assert float(np.abs(got[p] - want).max()) <= tol, f"patch {p}: probability map (tolerance {tol})"
