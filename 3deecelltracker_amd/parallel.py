@@ -236,9 +236,10 @@ class FramePipeline:
     `n_cu - match_cus` CUs, and `workers` host threads each drive the match chain of a *different* frame on their
     own stream inside the remaining `match_cus` CUs (ctypes releases the GIL while a chain runs).  Frames are
     independent units, so results are identical to processing them one after another.
+    `priority=True` replaces the partition by stream priorities (light matches only, see below).
     """
 
-    def __init__(self, device: int = 0, match_cus: int = 32, workers: int = 3, disjoint: bool = False):
+    def __init__(self, device: int = 0, match_cus: int = 32, workers: int = 3, disjoint: bool = False, priority: bool = False):
         import ctypes as C
         from concurrent.futures import ThreadPoolExecutor
         import threading
@@ -258,8 +259,18 @@ class FramePipeline:
             _lib.check(L.ct_stream_create_cu_range(device, first, count, C.byref(h)), "ct_stream_create_cu_range")
             self._handles.append(h)
             return torch.cuda.ExternalStream(h.value, device=f"cuda:{device}")
-        self.seg_stream = cu_stream(self.match_cus, self.n_cu - self.match_cus)
-        if disjoint and self.match_cus >= 2 * self.workers:
+        if priority:
+            # no CU partition: the U-Net on a normal-priority full-chip stream, the match chains on high-priority streams.  Every
+            # tiny kernel of a chain then waits for a workgroup slot to drain (~10 us), which a 10-iteration match can afford
+            # (121 vs 116 volumes/s in bench.py's discriminating-FFN pass) and a 364-iteration one cannot (63 vs 89).
+            self.seg_stream = torch.cuda.Stream(device=f"cuda:{device}", priority=0)
+            self._match_streams = [torch.cuda.Stream(device=f"cuda:{device}", priority=-1) for _ in range(self.workers)]
+            self.match_cus = 0
+        else:
+            self.seg_stream = cu_stream(self.match_cus, self.n_cu - self.match_cus)
+        if priority:
+            pass
+        elif disjoint and self.match_cus >= 2 * self.workers:
             # every chain gets its own slice of the match partition (streams sharing one CU mask were observed to
             # advance in lock-step, i.e. serialised)
             per = self.match_cus // self.workers

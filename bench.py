@@ -375,6 +375,8 @@ def main():
     ap.add_argument("--disjoint-match-cus", action="store_true", help="give every match chain its own CU slice (measured: worse)")
     ap.add_argument("--match-workers", type=int, default=2, help="match chains in flight concurrently")
     ap.add_argument("--realistic-match-cus", type=int, default=32, help="match partition of the informative pass with the discriminating FFN")
+    ap.add_argument("--priority-streams", action="store_true", help="headline pass without a CU partition: U-Net on a normal-priority full-chip stream, match chains on high-priority streams (loses with the 364-iteration matches of the random-init FFN: 63 vs 89 volumes/s)")
+    ap.add_argument("--realistic-partition", action="store_true", help="discriminating-FFN pass on a CU partition (--realistic-match-cus) instead of priority streams (116 vs 121 volumes/s)")
     ap.add_argument("--match-batch", type=int, default=8, help="frames whose matches share one chain of launches (ct_prgls_two_ref_batched); capped at steps // 4 so that a short run still overlaps its matches with the U-Net")
     ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
     ap.add_argument("--cpu-patches", type=int, default=20, help="U-Net patches timed by the CPU baseline sample")
@@ -425,7 +427,7 @@ def main():
     # dependent chain of tiny matching kernels only advances between conv launches: measured step = sum, not max), and one
     # PR-GLS chain is latency-bound.  FramePipeline splits the CUs with masked streams and lets `--match-workers` host threads
     # each drive the match of a different frame (frames are independent units).
-    ctx.pipe = par.FramePipeline(device=ctx.local, match_cus=args.match_cus, workers=args.match_workers, disjoint=args.disjoint_match_cus)
+    ctx.pipe = par.FramePipeline(device=ctx.local, match_cus=args.match_cus, workers=args.match_workers, disjoint=args.disjoint_match_cus, priority=args.priority_streams)
     ctx.iters_log = []
     ctx.active = {"ffn": ctx.ffn}
     ctx.on_timed_start = None
@@ -457,15 +459,16 @@ def main():
             ctx.active["ffn"] = ctx.ffn_trained
             ctx.iters_log.clear()
             headline_pipe = ctx.pipe
-            ctx.pipe = par.FramePipeline(device=ctx.local, match_cus=args.realistic_match_cus, workers=args.match_workers)
+            ctx.pipe = par.FramePipeline(device=ctx.local, match_cus=args.realistic_match_cus, workers=args.match_workers, priority=not args.realistic_partition)
             step2, finish2 = makers[args.mode](ctx, args)
             dt2 = timed(ctx, step2, finish2, args.steps, args.warmup)
             extra["with_discriminating_ffn"] = {
                 "volumes_per_s": round(units / dt2, 3), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
                 "prgls_iterations": int(np.median(ctx.iters_log)) if ctx.iters_log else None,
-                "cu_partition": {"unet": ctx.pipe.n_cu - ctx.pipe.match_cus, "match": ctx.pipe.match_cus},
+                "cu_partition": ({"unet": ctx.pipe.n_cu - ctx.pipe.match_cus, "match": ctx.pipe.match_cus} if ctx.pipe.match_cus else
+                                 {"unet": ctx.pipe.n_cu, "match": "no partition: match chains on high-priority streams"}),
                 "ffn": "tests/golden/ffn_synthetic_trained.npz (synthetic-pair training, 84 % of the true pairs found at 600 cells)",
-                "note": "same inputs as the headline run; the FFN weights differ, and with them the CU partition that balances the two halves"}
+                "note": "same inputs as the headline run; the FFN weights differ, and with them the way the two halves share the chip (a 10-iteration match is light enough to ride on high-priority streams beside a full-chip U-Net)"}
             ctx.pipe.close(); ctx.pipe = headline_pipe
             ctx.active["ffn"] = ctx.ffn
         if world == 1 and args.mode == "frames":
