@@ -45,11 +45,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const void* __restrict_
     __syncthreads();
     const uint32_t p0 = st[0].prefix, p1 = st[1].prefix, mask = st[0].mask;      // the masks are always equal
     const bool same = p0 == p1;
-    const size_t nround = (n + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
-    for (size_t rnd = 0; rnd < nround; ++rnd) {
-        const size_t i = (rnd * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        const bool live = i < n;
-        const uint32_t k = live ? key_of(data, dtype, i) : 0u;
+    auto count = [&](bool live, uint32_t k) {
         const int d = (int)((k >> shift) & 0xFF);
         const bool m0 = live && (k & mask) == p0, m1 = live && !same && (k & mask) == p1;
         const unsigned long long b0 = __ballot(m0);
@@ -60,6 +56,29 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const void* __restrict_
             else if (m0) atomicAdd(&h[0][d], 1u);
         }
         if (m1) atomicAdd(&h[1][d], 1u);
+    };
+    // 16 bytes per thread and load (8 uint16 or 4 float keys): a 2-byte load per key left the pass at 0.4 TB/s
+    const int kpv = dtype == 0 ? 8 : 4;
+    const size_t nvec = ((uintptr_t)data & 15) == 0 ? n / kpv : 0;            // (an unaligned view takes the key-by-key loop below)
+    const size_t nround = (nvec + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
+    for (size_t rnd = 0; rnd < nround; ++rnd) {
+        const size_t v = (rnd * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        const bool live = v < nvec;
+        uint4 q = live ? reinterpret_cast<const uint4*>(data)[v] : uint4{0u, 0u, 0u, 0u};
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (dtype == 0) { count(live, w[e] & 0xFFFFu); count(live, w[e] >> 16); }
+            else count(live, w[e] ^ ((w[e] >> 31) ? 0xFFFFFFFFu : 0x80000000u));
+        }
+    }
+    {                                                         // the keys behind the last full vector
+        const size_t first = nvec * kpv, rest = n - first;
+        const size_t rounds = (rest + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
+        for (size_t rnd = 0; rnd < rounds; ++rnd) {
+            const size_t i = first + (rnd * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+            count(i < n, i < n ? key_of(data, dtype, i) : 0u);
+        }
     }
     __syncthreads();
     if (h[0][threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[0][threadIdx.x]);
@@ -88,19 +107,38 @@ __global__ void median_finish_kernel(const SelState* __restrict__ lo, const SelS
     *median = 0.5 * (value_of_key(lo->prefix, dtype) + value_of_key(hi->prefix, dtype));      // np.median: mean of the two middles
 }
 
-// x = max(img - median, 0)   (preprocess.py:186-187)   or plain conversion when median == nullptr
-__global__ __launch_bounds__(256) void prep_kernel(const void* __restrict__ img, int dtype, size_t n, const double* __restrict__ median,
-                                                   float* __restrict__ x) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double v = dtype == 0 ? (double)reinterpret_cast<const uint16_t*>(img)[i] : (double)reinterpret_cast<const float*>(img)[i];
-    if (median) { v -= *median; if (v < 0.0) v = 0.0; }
-    x[i] = (float)v;
+// Source / epilogue plumbing of the box passes.  SRC 0: a float array; SRC 1: the raw image, x = max(img - median, 0) formed on
+// the fly (the fp32 copy of x is never written).  EPI 0: store the sum; EPI 1 (last pass of the first box): a = sum / vol ->
+// A, (x - a)^2 -> out; EPI 2 (last pass of the second box): (x - A) / (sqrt(sum / vol) + noise) -> out  (preprocess.py:150-167).
+struct LcnIO {
+    const void* img; int dtype; const double* median;      // the raw image (x is derived from it)
+    float* A;                                               // local mean (written by EPI 1, read by EPI 2)
+    float inv_vol, noise;
+};
+__device__ __forceinline__ float lcn_x(const LcnIO& io, size_t i) {
+    double v = io.dtype == 0 ? (double)reinterpret_cast<const uint16_t*>(io.img)[i] : (double)reinterpret_cast<const float*>(io.img)[i];
+    if (io.median) { v -= *io.median; if (v < 0.0) v = 0.0; }
+    return (float)v;
+}
+template <int SRC> __device__ __forceinline__ float box_src(const float* __restrict__ in, const LcnIO& io, size_t i) {
+    if constexpr (SRC == 0) return in[i]; else return lcn_x(io, i);
+}
+template <int EPI> __device__ __forceinline__ void box_emit(float* __restrict__ out, const LcnIO& io, size_t i, double sum) {
+    if constexpr (EPI == 0) out[i] = (float)sum;
+    else if constexpr (EPI == 1) { const float av = (float)sum * io.inv_vol; const float df = lcn_x(io, i) - av; io.A[i] = av; out[i] = df * df; }
+    else out[i] = (lcn_x(io, i) - io.A[i]) / (sqrtf((float)sum * io.inv_vol) + io.noise);
+}
+__device__ __forceinline__ int box_fold(int q, int len, int mode) {      // index of tap q, -1 = zero padding
+    if (mode == 0) return (q < 0 || q >= len) ? -1 : q;
+    const int period = 2 * len;                      // d c b a | a b c d | d c b a
+    q %= period; if (q < 0) q += period;
+    return q >= len ? period - 1 - q : q;
 }
 
 // 1-D centred box sum along `axis` of a [X][Y][Z] array (z fastest); mode 0 = zero padding, 1 = scipy 'reflect'
+template <int SRC, int EPI>
 __global__ __launch_bounds__(256) void box1d_kernel(const float* __restrict__ in, float* __restrict__ out, int X, int Y, int Z,
-                                                    int axis, int half, int mode) {
+                                                    int axis, int half, int mode, LcnIO io) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t n = (size_t)X * Y * Z;
     if (i >= n) return;
@@ -111,34 +149,30 @@ __global__ __launch_bounds__(256) void box1d_kernel(const float* __restrict__ in
     const size_t base = i - (size_t)pos * stride;
     double acc = 0.0;
     for (int d = -half; d <= half; ++d) {
-        int q = pos + d;
-        if (mode == 0) { if (q < 0 || q >= len) continue; }
-        else {                                       // d c b a | a b c d | d c b a
-            const int period = 2 * len;
-            q %= period; if (q < 0) q += period;
-            if (q >= len) q = period - 1 - q;
-        }
-        acc += (double)in[base + (size_t)q * stride];
+        const int q = box_fold(pos + d, len, mode);
+        if (q >= 0) acc += (double)box_src<SRC>(in, io, base + (size_t)q * stride);
     }
-    out[i] = (float)acc;
+    box_emit<EPI>(out, io, i, acc);
 }
 
 // Sliding-window form of box1d_kernel for the x and y axes (stride >= Z): one thread walks a segment of one line, so an
-// output costs ~2.4 reads instead of `2 half + 1` (27 by default).  The window sum is carried in double with an
-// error-free TwoSum compensation term, i.e. it equals the directly accumulated double sum to ~2^-100 of the largest
-// partial sum; consecutive threads own consecutive lines (z fastest) so every read and write is a coalesced row.
-constexpr int BOX_SEG = 64;
-__device__ __forceinline__ float box_val(const float* __restrict__ in, size_t base, size_t stride, int q, int len, int mode) {
-    if (mode == 0) { if (q < 0 || q >= len) return 0.f; }
-    else {                                           // d c b a | a b c d | d c b a
-        const int period = 2 * len;
-        q %= period; if (q < 0) q += period;
-        if (q >= len) q = period - 1 - q;
-    }
-    return in[base + (size_t)q * stride];
+// output costs ~2.7 reads instead of `2 half + 1` (27 by default).  The window sum is carried in double: over a segment of
+// BOX_SEG steps it drifts by < BOX_SEG * 2^-53 of the largest partial sum from the directly accumulated double sum -- eleven
+// orders of magnitude below the fp32 value that is stored (an error-free TwoSum compensation used to ride along; its dependent
+// fp64 chain made the pass latency-bound: 65 us per pass instead of 30); consecutive threads own consecutive lines (z fastest)
+// so every read and write is a coalesced row.
+#ifndef CT_BOX_SEG
+#define CT_BOX_SEG 32
+#endif
+constexpr int BOX_SEG = CT_BOX_SEG;
+template <int SRC>
+__device__ __forceinline__ float box_val(const float* __restrict__ in, const LcnIO& io, size_t base, size_t stride, int q, int len, int mode) {
+    q = box_fold(q, len, mode);
+    return q < 0 ? 0.f : box_src<SRC>(in, io, base + (size_t)q * stride);
 }
+template <int SRC, int EPI>
 __global__ __launch_bounds__(256) void box1d_run_kernel(const float* __restrict__ in, float* __restrict__ out, int X, int Y, int Z,
-                                                        int axis, int half, int mode) {
+                                                        int axis, int half, int mode, LcnIO io) {
     const int len = axis == 0 ? X : Y;
     const size_t nlines = axis == 0 ? (size_t)Y * Z : (size_t)X * Z;
     const int nseg = (len + BOX_SEG - 1) / BOX_SEG;
@@ -148,35 +182,37 @@ __global__ __launch_bounds__(256) void box1d_run_kernel(const float* __restrict_
     const size_t stride = axis == 0 ? (size_t)Y * Z : (size_t)Z;
     const size_t base = axis == 0 ? line : (line / Z) * (size_t)Y * Z + (line % Z);
     const int p0 = seg * BOX_SEG, p1 = min(p0 + BOX_SEG, len);
-    double acc = 0.0, comp = 0.0;
-    for (int d = -half; d <= half; ++d) acc += (double)box_val(in, base, stride, p0 + d, len, mode);
-    out[base + (size_t)p0 * stride] = (float)acc;
+    double acc = 0.0;
+    for (int d = -half; d <= half; ++d) acc += (double)box_val<SRC>(in, io, base, stride, p0 + d, len, mode);
+    box_emit<EPI>(out, io, base + (size_t)p0 * stride, acc);
     for (int p = p0 + 1; p < p1; ++p) {
-        const double v = (double)box_val(in, base, stride, p + half, len, mode) - (double)box_val(in, base, stride, p - 1 - half, len, mode);
-        const double s = acc + v;                    // TwoSum: s + e == acc + v exactly
-        const double bb = s - acc;
-        comp += (acc - (s - bb)) + (v - bb);
-        acc = s;
-        out[base + (size_t)p * stride] = (float)(acc + comp);
+        acc += (double)box_val<SRC>(in, io, base, stride, p + half, len, mode) - (double)box_val<SRC>(in, io, base, stride, p - 1 - half, len, mode);
+        box_emit<EPI>(out, io, base + (size_t)p * stride, acc);
     }
 }
 
-// a = s / vol ; d = (x - a)^2
-__global__ __launch_bounds__(256) void avgdiff_kernel(const float* __restrict__ x, const float* __restrict__ s, float inv_vol, size_t n,
-                                                      float* __restrict__ a, float* __restrict__ d) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float av = s[i] * inv_vol;
-    const float df = x[i] - av;
-    a[i] = av; d[i] = df * df;
+template <int SRC, int EPI>
+int launch_box_pass(bool run, const float* in, float* out, const int dims[3], int ax, int half, int mode, const LcnIO& io, hipStream_t s) {
+    const size_t n = (size_t)dims[0] * dims[1] * dims[2];
+    if (run) {
+        const size_t nthreads = (n / dims[ax]) * (size_t)((dims[ax] + BOX_SEG - 1) / BOX_SEG);
+        hipLaunchKernelGGL((box1d_run_kernel<SRC, EPI>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, in, out, dims[0], dims[1],
+                           dims[2], ax, half, mode, io);
+    } else
+        hipLaunchKernelGGL((box1d_kernel<SRC, EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, dims[0], dims[1], dims[2], ax,
+                           half, mode, io);
+    LAUNCH_CHECK();
+    return CT_OK;
 }
-
-// out = (x - a) / (sqrt(s2 / vol) + noise)
-__global__ __launch_bounds__(256) void lcn_final_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ s2,
-                                                        float inv_vol, float noise, size_t n, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    out[i] = (x[i] - a[i]) / (sqrtf(s2[i] * inv_vol) + noise);
+int box_pass(int src, int epi, bool run, const float* in, float* out, const int dims[3], int ax, int half, int mode, const LcnIO& io, hipStream_t s) {
+    switch (src * 3 + epi) {
+        case 0: return launch_box_pass<0, 0>(run, in, out, dims, ax, half, mode, io, s);
+        case 1: return launch_box_pass<0, 1>(run, in, out, dims, ax, half, mode, io, s);
+        case 2: return launch_box_pass<0, 2>(run, in, out, dims, ax, half, mode, io, s);
+        case 3: return launch_box_pass<1, 0>(run, in, out, dims, ax, half, mode, io, s);
+        case 4: return launch_box_pass<1, 1>(run, in, out, dims, ax, half, mode, io, s);
+        default: return launch_box_pass<1, 2>(run, in, out, dims, ax, half, mode, io, s);
+    }
 }
 
 int select_two_ranks(const void* data, int dtype, size_t n, unsigned long long rank_lo, unsigned long long rank_hi, SelState* st,
@@ -184,7 +220,7 @@ int select_two_ranks(const void* data, int dtype, size_t n, unsigned long long r
     SelState init[2] = {{0u, 0u, rank_lo}, {0u, 0u, rank_hi}};
     HIPCHK(hipMemcpyAsync(st, init, sizeof(init), hipMemcpyHostToDevice, s));
     const int top = dtype == 0 ? 8 : 24;
-    const unsigned nblk = (unsigned)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
+    const unsigned nblk = (unsigned)((n + 256 * 32 - 1) / (256 * 32) < 2048 ? (n + 256 * 32 - 1) / (256 * 32) : 2048);
     for (int shift = top; shift >= 0; shift -= 8) {
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk ? nblk : 1), dim3(256), 0, s, data, dtype, n, shift, st, hist);
         LAUNCH_CHECK();
@@ -228,43 +264,34 @@ int ct_normalize_image(const void* img, int dtype, const int dims[3], double noi
     const size_t n = (size_t)dims[0] * dims[1] * dims[2];
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const size_t slab = align_up(n * sizeof(float), 256);
-    float* X = (float*)ws; float* A = (float*)(ws + slab); float* T1 = (float*)(ws + 2 * slab); float* T2 = (float*)(ws + 3 * slab);
+    float* A = (float*)(ws + slab); float* T1 = (float*)(ws + 2 * slab); float* T2 = (float*)(ws + 3 * slab);   // (slab 0: spare)
     unsigned char* tail = ws + 4 * slab;
     double* median = (double*)(tail + 3072);
-    const unsigned nb = (unsigned)((n + 255) / 256);
     if (subtract_median) {
         int rc = ct_median(img, dtype, n, median, tail, 4096, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(prep_kernel, dim3(nb), dim3(256), 0, s, img, dtype, n, subtract_median ? median : (const double*)nullptr, X);
-    LAUNCH_CHECK();
-    const float inv_vol = 1.0f / (float)(filter[0] * filter[1] * filter[2]);
-    auto box = [&](const float* src, float* dst, float* tmp) -> int {   // separable: result ends in dst
-        const float* cur = src; float* bufs[2] = {dst, tmp}; int w = 0; int passes = 0;
-        for (int ax = 0; ax < 3; ++ax) if (filter[ax] > 1) ++passes;
-        if (passes == 0) { HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s)); return CT_OK; }
-        w = (passes & 1) ? 0 : 1;                         // so that the last pass writes dst
-        for (int ax = 0; ax < 3; ++ax) {
-            if (filter[ax] == 1) continue;
-            if (ax < 2 && filter[ax] > 3) {                    // sliding window along x / y
-                const int len = dims[ax];
-                const size_t nthreads = (n / len) * (size_t)((len + BOX_SEG - 1) / BOX_SEG);
-                hipLaunchKernelGGL(box1d_run_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, cur, bufs[w], dims[0], dims[1],
-                                   dims[2], ax, filter[ax] / 2, mode);
-            } else
-                hipLaunchKernelGGL(box1d_kernel, dim3(nb), dim3(256), 0, s, cur, bufs[w], dims[0], dims[1], dims[2], ax, filter[ax] / 2, mode);
-            LAUNCH_CHECK();
+    LcnIO io{img, dtype, subtract_median ? median : (const double*)nullptr, A, 1.0f / (float)(filter[0] * filter[1] * filter[2]), (float)noise_level};
+    // One separable box: up to three 1-D passes; the first reads `src` (or x formed from the raw image when src is null), the
+    // last one applies the epilogue and writes dst; intermediate sums ping-pong between dst and tmp.
+    auto box = [&](const float* src, float* dst, float* tmp, int epi) -> int {
+        int axes[3], passes = 0;
+        for (int ax = 0; ax < 3; ++ax) if (filter[ax] > 1) axes[passes++] = ax;
+        if (passes == 0) axes[passes++] = 2;                  // 1 x 1 x 1: a single pass of width 1 carries source and epilogue
+        const float* cur = src; float* bufs[2] = {dst, tmp};
+        int w = (passes & 1) ? 0 : 1;                         // so that the last pass writes dst
+        for (int k = 0; k < passes; ++k) {
+            const int ax = axes[k];
+            const bool run = ax < 2 && filter[ax] > 3;        // sliding window along x / y
+            const int rc = box_pass(cur == nullptr ? 1 : 0, k == passes - 1 ? epi : 0, run, cur, bufs[w], dims, ax, filter[ax] / 2, mode, io, s);
+            if (rc) return rc;
             cur = bufs[w]; w ^= 1;
         }
         return CT_OK;
     };
     int rc;
-    if ((rc = box(X, T1, T2))) return rc;
-    hipLaunchKernelGGL(avgdiff_kernel, dim3(nb), dim3(256), 0, s, X, T1, inv_vol, n, A, T2);
-    LAUNCH_CHECK();
-    if ((rc = box(T2, T1, out))) return rc;               // `out` doubles as scratch before the final kernel writes it
-    hipLaunchKernelGGL(lcn_final_kernel, dim3(nb), dim3(256), 0, s, X, A, T1, inv_vol, (float)noise_level, n, out);
-    LAUNCH_CHECK();
+    if ((rc = box(nullptr, T2, T1, 1))) return rc;            // A = local mean, T2 = (x - A)^2
+    if ((rc = box(T2, out, T1, 2))) return rc;                // out = (x - A) / (sqrt(box(T2) / vol) + noise)
     return CT_OK;
 }
 

@@ -63,6 +63,12 @@ def test_device_median_is_exact():
     assert pre.median_device(torch.from_numpy(f).cuda()) == float(np.median(f.astype(np.float64)))
     f = np.array([-1.0, 1.0, -2.0, 2.0], np.float32)
     assert pre.median_device(torch.from_numpy(f).cuda()) == 0.0
+    # views that do not start on a 16-byte boundary (the vectorised histogram pass falls back to key-by-key loads)
+    a = rng.integers(0, 5000, 40003).astype(np.uint16); d = torch.from_numpy(a).cuda()
+    for off in (1, 3, 8):
+        assert pre.median_device(d[off:]) == float(np.median(a[off:]))
+    f = rng.normal(0, 100, 9001).astype(np.float32); d = torch.from_numpy(f).cuda()
+    assert pre.median_device(d[1:]) == float(np.median(f[1:].astype(np.float64)))
 
 
 @pytest.mark.gpu
