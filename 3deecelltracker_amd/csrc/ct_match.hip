@@ -802,6 +802,7 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
 // direct factorisation's).  The truncation |G - U^T U| <= tol perturbs the solution by ~ tol/c.
 // ------------------------------------------------------------------------------------------------
 constexpr int LR_RMAX = 128;
+constexpr int LR_PF = 8;                       // rows of U fetched together in lowrank_factor_kernel's update loop
 
 // pivoted Cholesky of the symmetric PSD matrix G (n x n); single workgroup.
 // U [LR_RMAX][n] (row k contiguous).  The factorisation is nested (row k does not depend on later rows), so one run to the fine
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
     __shared__ double redv[16];
     __shared__ int redi[16];
     __shared__ double pivv; __shared__ int pivi;
-    __shared__ double urow[LR_RMAX];            // U[0..k-1][p]
+    __shared__ double urow[LR_RMAX + LR_PF];    // U[0..k-1][p], zero padded
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < n; i += 1024) resid[i] = G[(size_t)i * n + i];
     __syncthreads();
@@ -839,11 +840,19 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
         if (k_coarse < 0 && !(pivv > tol_coarse)) k_coarse = k;
         if (!(pivv > tol)) break;
         const int p = pivi; const double piv = sqrt(pivv);
-        if (tid < k) urow[tid] = U[(size_t)tid * n + p];
+        if (tid < LR_RMAX + LR_PF) urow[tid] = tid < k ? U[(size_t)tid * n + p] : 0.0;      // zeros behind row k - 1
         __syncthreads();
         for (int i = tid; i < n; i += 1024) {
             double u = G[(size_t)i * n + p];
-            for (int j = 0; j < k; ++j) u -= U[(size_t)j * n + i] * urow[j];
+            // same subtraction order as the plain loop, but LR_PF loads are in flight together: the plain loop waited one L2 round
+            // trip per previous row (k x ~400 cycles, the whole cost of a step); rows past k - 1 are re-reads times the zero padding
+            for (int j0 = 0; j0 < k; j0 += LR_PF) {
+                double t[LR_PF];
+#pragma unroll
+                for (int q = 0; q < LR_PF; ++q) t[q] = U[(size_t)min(j0 + q, k - 1) * n + i];
+#pragma unroll
+                for (int q = 0; q < LR_PF; ++q) u -= t[q] * urow[j0 + q];
+            }
             u /= piv;
             U[(size_t)k * n + i] = u;
             resid[i] = (i == p) ? 0.0 : resid[i] - u * u;
