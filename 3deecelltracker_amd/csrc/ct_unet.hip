@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float t = r[e];
-                r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+                r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e];       // LeakyReLU / ReLU (0 <= alpha < 1) without a select
                 if constexpr (F16) vmax = fmaxf(vmax, fabsf(r[e]));
             }
             const int y = y0 + col_y(mt);
@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = r[e];
-                    r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e];
+                    r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e];       // LeakyReLU / ReLU (0 <= alpha < 1) without a select
                     if constexpr (F16) vmax = fmaxf(vmax, fabsf(r[e]));
                 }
                 acc[mt][nt] = r;
@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(256, 8) void conv_first_mfma_kernel(const float* __
         if (x >= q.nx || y >= q.ny || z >= q.nz) continue;
         f32x4 r = acc[m] + bias;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float t = r[e]; r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e]; vmax = fmaxf(vmax, fabsf(r[e])); }
+        for (int e = 0; e < 4; ++e) { const float t = r[e]; r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e]; vmax = fmaxf(vmax, fabsf(r[e])); }
         *reinterpret_cast<f32x4*>(out + (((size_t)(lp * q.nx + x) * q.ny + y) * q.nz + z) * 8 + cb) = r;
     }
     if (amax_out) amax_publish(vmax, amax_out + lp * AMAX_STRIDE, tid, amax_red);
@@ -1534,7 +1534,7 @@ __global__ __launch_bounds__(256, OCC) void conv_first_f16_kernel(const float* _
         if (x >= q.nx || y >= q.ny || z >= q.nz) continue;
         f32x4 r = acc[m] * out_mul + bias;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float t = r[e]; r[e] = (t >= 0.f ? t : t * alpha) * scale[e] + shift[e]; vmax = fmaxf(vmax, fabsf(r[e])); }
+        for (int e = 0; e < 4; ++e) { const float t = r[e]; r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e]; vmax = fmaxf(vmax, fabsf(r[e])); }
         *reinterpret_cast<f32x4*>(out + (((size_t)(lp * q.nx + x) * q.ny + y) * q.nz + z) * 8 + cb) = r;
     }
     if (amax_out) amax_publish(vmax, amax_out + lp * AMAX_STRIDE, tid, amax_red);
