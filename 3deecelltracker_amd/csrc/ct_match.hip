@@ -801,6 +801,10 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
 // (Woodbury on the symmetrically scaled system; its cancellation error is cond * eps, the same as a
 // direct factorisation's).  The truncation |G - U^T U| <= tol perturbs the solution by ~ tol/c.
 // ------------------------------------------------------------------------------------------------
+// EM iterations enqueued before the host looks at the convergence flags again: a first short chunk (matches with a good prior converge in
+// 6-11 iterations; the rest of a 16-iteration chunk would be ~90 launches that return at once): 8, 8, then 16 at a time
+static inline int prgls_chunk(int enq, int total) { const int c = enq < 16 ? 8 : 16; return (total - enq) < c ? (total - enq) : c; }
+
 constexpr int LR_RMAX = 128;
 constexpr int LR_PF = 8;                       // rows of U fetched together in lowrank_factor_kernel's update loop
 
@@ -1873,7 +1877,7 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
     double* ck_sc = w.M + 3 * (size_t)(n + (l > 0 ? l : 1));
     const bool ck_fits = (size_t)3 * (n + (l > 0 ? l : 1)) + S_NUM <= (size_t)n * n;
     for (int enq = 0; enq < total;) {
-        const int chunk = (total - enq) < 16 ? (total - enq) : 16;
+        const int chunk = prgls_chunk(enq, total);
         if (rank > 0 && ck_fits) {
             HIPCHK(hipMemcpyAsync(ck_n, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
             if (l > 0) HIPCHK(hipMemcpyAsync(ck_l, w.predl, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -2016,7 +2020,7 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
     const int total = max_iteration - 1;
     std::vector<double> hsc((size_t)B * S_NUM, 0.0);
     for (int enq = 0; enq < total && live > 0;) {
-        const int chunk = (total - enq) < 16 ? (total - enq) : 16;
+        const int chunk = prgls_chunk(enq, total);
         for (int k = 0; k < chunk; ++k) {
             hipLaunchKernelGGL(posterior_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_prior, w.predn, nn, in_tgt, mm, w.sc, 0, 1.0,
                                w.P, 0.0, 0.0, bt);
