@@ -3,7 +3,6 @@
     python scripts/microbench.py unet [X Y Z]          U-Net volume path (default 512 512 32)
     python scripts/microbench.py arch [name ...]       patch throughput of unet3_a / unet3_c / unet3_b
     python scripts/microbench.py families              A/B of the conv kernel families (CT_CONV_MATH x CT_CONV_FOLD)
-    python scripts/microbench.py accuracy [name ...]   conv families vs an fp64 evaluation (uses the oracle: test infra)
     python scripts/microbench.py lcn                   ct_normalize_image on a 512x512x32 uint16 frame
     python scripts/microbench.py segment               ct_segment_centroids
     python scripts/microbench.py correction            ct_accurate_correction (600 cells)
@@ -90,39 +89,6 @@ def cmd_families(args):
         env = dict(os.environ, CT_CONV_FOLD=fold, CT_CONV_MATH=math)
         out = subprocess.run([sys.executable, __file__, "unet"], env=env, capture_output=True, text=True)
         print(f"CT_CONV_MATH={math} CT_CONV_FOLD={fold}:", out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-600:])
-
-
-def cmd_accuracy(args):
-    if args and args[0] == "child":
-        from oracle import unet_ref as ur
-        name = args[1]
-        synth, unet3d, arch = mod("synth"), mod("unet3d"), mod("arch").ARCHS[name]
-        w = synth.make_unet_weights(name, seed=1)
-        patch = np.random.default_rng(2).normal(size=arch.input_shape).astype(np.float32)
-        ref_path = f"/tmp/conv_acc_ref_{name}.npz"
-        if os.path.exists(ref_path):
-            z = np.load(ref_path); want = z["want"]; collect = [z[f"l{i}"] for i in range(int(z["n"]))]
-        else:
-            collect = []
-            want = ur.unet_forward(patch, w, arch, dtype=np.float64, collect=collect)
-            np.savez(ref_path, want=want, n=len(collect), **{f"l{i}": c for i, c in enumerate(collect)})
-        model = getattr(unet3d, name)().set_weights_dict(w)
-        got, dump = model.predict_device(torch.from_numpy(patch[None]).cuda(), layer_dump=True)
-        torch.cuda.synchronize()
-        dump = dump.cpu().numpy().astype(np.float64)
-        off = 0; worst = 0.0; rows = []
-        for ref in collect:
-            mine = dump[off:off + ref.size].reshape(ref.shape); off += ref.size
-            rel = float(np.abs(mine - ref).max() / max(1.0, np.abs(ref).max()))
-            rows.append(f"{rel:.1e}"); worst = max(worst, rel)
-        perr = float(np.abs(got[0].cpu().numpy().astype(np.float64) - want).max())
-        print(f"{name} math={os.environ.get('CT_CONV_MATH', 'f16x3')}: worst block rel err {worst:.2e}, prob map max abs err {perr:.2e}  [{' '.join(rows)}]")
-        return
-    for name in (args or ["unet3_a"]):
-        for math in ("f32", "bf16x6", "f16x3"):
-            out = subprocess.run([sys.executable, __file__, "accuracy", "child", name], env=dict(os.environ, CT_CONV_MATH=math),
-                                 capture_output=True, text=True)
-            print(out.stdout.strip() or out.stderr[-800:])
 
 
 def cmd_lcn(args):
