@@ -331,9 +331,10 @@ def cmd_frame(args):
 
 def cmd_trace(args):
     """Per-workgroup phase timeline of one conv layer (needs a -DCT_TRACE build: scripts/build_variants.sh trace "-DCT_TRACE";
-    CTAMD_LIB=.../libctamd_trace.so python scripts/microbench.py trace <layer> ...).  Marks (s_memtime, 100 MHz): 0 kernel entry,
-    1 first tile's loads issued, 2 first barrier passed, 3 tile staged (loads arrived, split, written), 4 last MFMA issued,
-    5 epilogue stores issued, 6 stores complete."""
+    CTAMD_LIB=.../libctamd_trace.so python scripts/microbench.py trace <layer> ...).  Marks are s_memtime stamps (shader cycles; the
+    counters of different XCDs are not aligned, so only differences inside one workgroup are used): 0 kernel entry, 1 first tile's
+    loads issued, 2 first barrier passed, 3 tile staged (loads arrived, split, written), 4 last MFMA issued, 5 epilogue stores
+    issued, 6 stores complete."""
     import ctypes
     synth, unet3d = mod("synth"), mod("unet3d")
     L = mod("_lib").lib()
@@ -351,23 +352,15 @@ def cmd_trace(args):
         ctypes.c_int.in_dll(L, "ct_trace_layer").value = -1
         t = buf.cpu().numpy().reshape(-1, 8)
         t = t[t[:, 0] != 0]
-        t0 = t[:, 0].min(); span = (t[:, 6].max() - t0)
-        tick = 10.0   # ns per s_memtime tick (100 MHz)
-        print(f"L{layer}: {len(t)} workgroups, kernel span {span*tick/1e3:.1f} us")
-        names = ["entry->loads issued", "loads issued->barrier", "barrier->tile staged", "staged->last MFMA (all chunks)", "MFMA->stores issued", "stores issued->complete"]
+        print(f"L{layer}: {len(t)} workgroups; cycles between marks")
+        names = ["entry->loads issued", "loads issued->barrier", "barrier->tile staged", "staged->last MFMA (all chunks)", "MFMA->stores issued",
+                 "stores issued->complete"]
         for k in range(6):
-            d = (t[:, k + 1] - t[:, k]) * tick
-            print(f"   {names[k]:32s} mean {d.mean():8.0f} ns   p10 {np.percentile(d,10):7.0f}  p50 {np.percentile(d,50):7.0f}  p90 {np.percentile(d,90):7.0f}")
-        life = (t[:, 6] - t[:, 0]) * tick
-        print(f"   workgroup lifetime mean {life.mean():.0f} ns; sum of lifetimes / span = {life.sum()/(span*tick):.1f} workgroups resident on average "
-              f"({life.sum()/(span*tick)/256:.2f} per CU)")
+            d = (t[:, k + 1] - t[:, k]).astype(np.float64)
+            print(f"   {names[k]:32s} mean {d.mean():8.0f}   p10 {np.percentile(d,10):7.0f}  p50 {np.percentile(d,50):7.0f}  p90 {np.percentile(d,90):7.0f}")
+        life = (t[:, 6] - t[:, 0]).astype(np.float64)
         hw = t[:, 7]; cu = ((hw >> 32) & 0xf) * 1000 + ((hw >> 13) & 0x7) * 100 + ((hw >> 8) & 0xf)       # xcc, se, cu
-        ucu = np.unique(cu)
-        print(f"   distinct (xcc, se, cu) ids seen: {len(ucu)}")
-        # launch rate: workgroup entries per microsecond over the middle of the kernel
-        ent = np.sort(t[:, 0] - t0) * tick / 1e3
-        mid = ent[(ent > span*tick/1e3*0.2) & (ent < span*tick/1e3*0.8)]
-        print(f"   entries per us in the middle 60 %: {len(mid)/(span*tick/1e3*0.6):.1f}")
+        print(f"   workgroup lifetime mean {life.mean():.0f} cycles; distinct (xcc, se, cu) ids seen: {len(np.unique(cu))}")
 
 
 if __name__ == "__main__":
