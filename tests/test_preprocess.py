@@ -95,3 +95,22 @@ def test_device_normalize_full_size_properties():
     assert torch.equal(a, b)
     with pytest.raises(ValueError):
         pre.normalize_image_device(d, 100.0, filter_size=(26, 27, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs", [(1, 1, 1), (3, 1, 1), (1, 1, 5), (9, 3, 3), (1, 27, 1)])
+def test_device_lcn_filter_shapes_against_oracle(fs):
+    """Every pass structure of ct_normalize_image: no pass at all (1x1x1: source and epilogue meet in one width-1 pass), a single
+    short pass, z only, three passes, y only -- zero and reflect borders, float32 images and uint16 images with the median."""
+    rng = np.random.default_rng(11)
+    img = (rng.normal(200.0, 30.0, (37, 29, 9)) + 500.0 * (rng.uniform(size=(37, 29, 9)) > 0.97)).astype(np.float32)
+    for mode, fn in (("constant", pre.lcn_gpu), ("reflect", pre.lcn_cpu)):
+        got = fn(img, noise_level=7.0, filter_size=fs)
+        want = pr.lcn(img.astype(np.float64), 7.0, fs, mode)
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-4)
+    if fs[2] == 1:
+        import torch
+        raw = np.clip(img, 0, 65535).astype(np.uint16)
+        got = pre.normalize_image_device(torch.from_numpy(raw).cuda(), 7.0, filter_size=fs).cpu().numpy()
+        x = np.maximum(raw.astype(np.float64) - np.median(raw), 0.0)
+        np.testing.assert_allclose(got, pr.lcn(x, 7.0, fs, "constant"), rtol=0, atol=3e-4)
