@@ -165,6 +165,24 @@ def gram_apply(pred_d, inter_d, C_d, beta):
     return pred_d
 
 
+def legacy_predict_pos(ffn_handle, seg_pre_d, seg_tgt_d, tracked_pre_d, beta, lambda_, max_iteration, reps, k_ptrs=20, want_fit=False):
+    """Tracker._predict_pos_once for one source volume as ONE native call (ct_legacy_predict_pos) -> pred [l][3]
+    (+ C [reps][3][n], inter [reps][n][3] with want_fit).  The call releases the interpreter lock for the whole chain."""
+    t = torch(); L = _lib.lib()
+    n, m = seg_pre_d.shape[0], seg_tgt_d.shape[0]
+    l = 0 if tracked_pre_d is None else tracked_pre_d.shape[0]
+    dev = seg_pre_d.device
+    pred = empty((l, 3), t.float64, dev) if l else None
+    Cs = empty((reps, 3, n), t.float64, dev) if want_fit else None
+    inter = empty((reps, n, 3), t.float64, dev) if want_fit else None
+    ws = workspace(L.ct_legacy_predict_workspace_bytes(n, m, int(reps), int(k_ptrs)), dev)
+    _lib.check(L.ct_legacy_predict_pos(ffn_handle, seg_pre_d.data_ptr(), n, seg_tgt_d.data_ptr(), m,
+                                       tracked_pre_d.data_ptr() if l else None, l, float(beta), float(lambda_), int(max_iteration), int(reps),
+                                       int(k_ptrs), pred.data_ptr() if l else None, Cs.data_ptr() if want_fit else None,
+                                       inter.data_ptr() if want_fit else None, ws.data_ptr(), ws.numel(), stream(dev)), "ct_legacy_predict_pos")
+    return (pred, Cs, inter) if want_fit else pred
+
+
 def trim_mean(stack_d, cut=0.1):
     """stack_d fp64 [k][n][3] -> [n][3]  (scipy.stats.trim_mean(..., cut, axis=0))"""
     t = torch(); L = _lib.lib()

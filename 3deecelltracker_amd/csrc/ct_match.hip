@@ -2187,6 +2187,66 @@ int ct_gram_apply(double* pred, int l, const double* inter, int n, const double*
     return CT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ legacy prediction chain
+// Tracker._predict_pos_once (tracker.py:1193-1222) = _fit_ffn_prgls (:1224-1254: `reps` x [initial_matching_quick -> pr_gls_quick with
+// BETA * 0.8^i, each repetition starting from the previous one's transformed points]) followed by _predict_one_rep (:1269-1289) for
+// every repetition.  One call per source volume: the ~500 launches of the chain are enqueued from C, so the host threads that drive the
+// <= 20 independent source volumes of an ensemble prediction (tracker.py:1499-1506) are not serialised by the Python interpreter lock
+// (composed from Python the ensemble saturated at ~3 ms per source volume whatever the number of chains).
+static size_t legacy_predict_layout(int n, int m, int reps, int k, size_t off[8]) {
+    size_t o = 0;
+    const size_t fw = (size_t)(3 * k + 1);
+    off[0] = o; o += align_up((size_t)n * fw * sizeof(float), 256);                 // feat_ref
+    off[1] = o; o += align_up((size_t)m * fw * sizeof(float), 256);                 // feat_tgt
+    off[2] = o; o += align_up((size_t)m * n * sizeof(float), 256);                  // corr
+    off[3] = o; o += align_up((size_t)(reps + 1) * n * 3 * sizeof(double), 256);    // inter[0..reps]
+    off[4] = o; o += align_up((size_t)reps * 3 * n * sizeof(double), 256);          // C[0..reps-1]
+    off[5] = o; o += align_up(ct_ffn_workspace_bytes(n, m), 256);                   // FFN scratch
+    off[6] = o; o += align_up(ct_prgls_workspace_bytes(m, n, 0), 256);              // PR-GLS scratch
+    return o;
+}
+
+size_t ct_legacy_predict_workspace_bytes(int n, int m, int reps, int k_ptrs) {
+    if (n <= 0 || m <= 0 || reps <= 0 || k_ptrs <= 0) return 0;
+    size_t off[8];
+    return legacy_predict_layout(n, m, reps, k_ptrs, off) + 512;
+}
+
+int ct_legacy_predict_pos(ct_ffn_t* ffn, const double* seg_pre, int n, const double* seg_tgt, int m, const double* tracked_pre, int l,
+                          double beta, double lambda, int max_iteration, int reps, int k_ptrs, double* pred_out, double* C_out,
+                          double* inter_out, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (!ffn || !seg_pre || !seg_tgt || !workspace || n <= 0 || m <= 0 || reps <= 0 || k_ptrs <= 0 || l < 0 || (l > 0 && (!tracked_pre || !pred_out)))
+        return CT_EINVAL;
+    if (workspace_bytes < ct_legacy_predict_workspace_bytes(n, m, reps, k_ptrs)) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    size_t off[8];
+    legacy_predict_layout(n, m, reps, k_ptrs, off);
+    float* feat_ref = (float*)(base + off[0]); float* feat_tgt = (float*)(base + off[1]); float* corr = (float*)(base + off[2]);
+    double* inter = (double*)(base + off[3]); double* Cs = (double*)(base + off[4]);
+    void* fws = base + off[5]; void* pws = base + off[6];
+    const size_t n3 = (size_t)n * 3;
+    int rc;
+    HIPCHK(hipMemcpyAsync(inter, seg_pre, n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = ct_knn_features(seg_tgt, m, k_ptrs, feat_tgt, stream))) return rc;      // the target's features are the same in every repetition
+    for (int i = 0; i < reps; ++i) {
+        const double b = beta * pow(0.8, (double)i);
+        if ((rc = ct_knn_features(inter + i * n3, n, k_ptrs, feat_ref, stream))) return rc;
+        if ((rc = ct_ffn_pairgrid(ffn, feat_ref, n, feat_tgt, m, corr, fws, ct_ffn_workspace_bytes(n, m), stream))) return rc;
+        if ((rc = ct_prgls_legacy(inter + i * n3, n, seg_tgt, m, corr, b, max_iteration, lambda, 1e8, nullptr, inter + (i + 1) * n3,
+                                  Cs + (size_t)i * n3, pws, ct_prgls_workspace_bytes(m, n, 0), stream)))
+            return rc;
+    }
+    if (l > 0) {
+        HIPCHK(hipMemcpyAsync(pred_out, tracked_pre, (size_t)l * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        for (int i = 0; i < reps; ++i)
+            if ((rc = ct_gram_apply(pred_out, l, inter + i * n3, n, Cs + (size_t)i * n3, beta * pow(0.8, (double)i), stream))) return rc;
+    }
+    if (C_out) HIPCHK(hipMemcpyAsync(C_out, Cs, (size_t)reps * n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (inter_out) HIPCHK(hipMemcpyAsync(inter_out, inter, (size_t)reps * n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return CT_OK;
+}
+
 int ct_trim_mean(const double* stack, int k, int n3, double cut, double* out, ct_stream_t stream) {
     if (!stack || !out || k <= 0 || n3 <= 0 || cut < 0.0 || cut >= 0.5) return CT_EINVAL;
     if (k > TM_MAXK) return CT_ESHAPE;

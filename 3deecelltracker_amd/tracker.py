@@ -167,7 +167,7 @@ def _not_accelerated(name):
 class Tracker:
     """reference :779-1551.  Constructor and public method names follow the reference (:854-859)."""
 
-    ensemble_chains = 4      # source-volume predictions of one ensemble step in flight on this GPU (parallel.chain_map)
+    ensemble_chains = 8      # source-volume predictions of one ensemble step in flight on this GPU (parallel.chain_map)
     connectivity = 1         # region step: 6-connected components (scipy.ndimage.label default)
 
     def __init__(self, volume_num, siz_xyz: tuple, z_xy_ratio, z_scaling, noise_level, min_size, beta_tk, lambda_tk, maxiter_tk,
@@ -582,8 +582,19 @@ class Tracker:
     def _predict_pos_device(self, source_volume):
         seg_pre = _dev.points_dev(self.history.r_segmented_coordinates[source_volume - 1])
         seg_tgt = _dev.points_dev(self.segresult.r_coordinates_segment)
+        tracked_pre = _dev.points_dev(self.history.r_tracked_coordinates[source_volume - 1])
+        if isinstance(self.ffn_model, FFN) and self.ffn_model._handle is not None:
+            # the whole chain (5 x [features, FFN, PR-GLS] + 5 x Gram application) as one native call: the threads that drive the
+            # independent source volumes of an ensemble prediction then run without the interpreter lock
+            _dev.check_match_sizes(seg_pre.shape[0], seg_tgt.shape[0], 20, "Tracker._fit_ffn_prgls")
+            return _dev.legacy_predict_pos(self.ffn_model._handle, seg_pre, seg_tgt, tracked_pre, self.beta_tk, self.lambda_tk,
+                                           self.max_iteration, REP_NUM_PRGLS, 20)
+        return self._predict_pos_composed(seg_pre, seg_tgt, tracked_pre)
+
+    def _predict_pos_composed(self, seg_pre, seg_tgt, tracked_pre):
+        """The same chain call by call (foreign FFN objects; the parity test of the fused entry point)."""
         C_t, beta_t, inter_t = self._fit_device(seg_pre, seg_tgt, REP_NUM_PRGLS)
-        pred = _dev.points_dev(self.history.r_tracked_coordinates[source_volume - 1]).clone()
+        pred = tracked_pre.clone()
         for Cm, b, inter in zip(C_t, beta_t, inter_t):
             _dev.gram_apply(pred, inter, Cm, b)
         return pred

@@ -230,6 +230,18 @@ int ct_solve_movements(double sigma_square, double lambda, const double* P, cons
 int ct_gram_apply(double* pred, int l, const double* inter, int n, const double* C, double beta,
                   ct_stream_t stream);
 
+/* Tracker._predict_pos_once (tracker.py:1193-1222) for one source volume in ONE call: `reps` x [kNN features -> FFN pair grid ->
+ * pr_gls_quick with beta * 0.8^i, every repetition starting from the previous one's transformed points] (_fit_ffn_prgls :1224-1254),
+ * then _predict_one_rep (:1269-1289) for every repetition on the tracked points.  seg_pre [dev] fp64 [n][3], seg_tgt [m][3],
+ * tracked_pre [l][3] (l may be 0) -> pred_out [l][3]; optional C_out [reps][3][n], inter_out [reps][n][3] (the list the reference
+ * returns).  Same arithmetic as calling ct_knn_features / ct_ffn_pairgrid / ct_prgls_legacy / ct_gram_apply one by one; exists so that
+ * the host threads driving the independent source volumes of an ensemble prediction (:1499-1506) are not serialised by the caller's
+ * interpreter.  Synchronises `stream` (the greedy prior inside ct_prgls_legacy reads its round counter).                           */
+size_t ct_legacy_predict_workspace_bytes(int n, int m, int reps, int k_ptrs);
+int ct_legacy_predict_pos(ct_ffn_t* ffn, const double* seg_pre, int n, const double* seg_tgt, int m, const double* tracked_pre, int l,
+                          double beta, double lambda, int max_iteration, int reps, int k_ptrs, double* pred_out, double* C_out,
+                          double* inter_out, void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
 /* trim_mean(stack, 0.1, axis=0) of k predictions (trackerlite.py:123, tracker.py:1508):
  * stack [dev] fp64 [k][n3] -> out [dev] fp64 [n3].                                               */
 int ct_trim_mean(const double* stack, int k, int n3, double cut, double* out, ct_stream_t stream);

@@ -548,3 +548,35 @@ def test_unused_normalisation_helpers_of_the_reference(g):
     assert np.array_equal(got, mr.legacy_prior(corr, 0.5).astype(corr.dtype))
     np.testing.assert_allclose(tl.softmax_normalize(corr), softmax(corr, axis=1), rtol=1e-6)
     np.testing.assert_allclose(tl.row_wise_normalize(corr), corr / corr.sum(1, keepdims=True), rtol=0)
+
+
+def test_legacy_predict_pos_native_chain_equals_the_composed_calls(ffn):
+    """ct_legacy_predict_pos (one native call per source volume: 5 x [kNN features, FFN pair grid, pr_gls_quick] + 5 x Gram
+    application, tracker.py:1193-1289) against the same chain issued call by call: bit-identical predictions, C matrices and
+    intermediate point sets; and an ensemble of source volumes run on 8 concurrent host threads equals the sequential one."""
+    import torch
+    tracker_mod = importlib.import_module("3deecelltracker_amd.tracker")
+    rng = np.random.default_rng(21)
+    n, nvol = 113, 9
+    base = rng.uniform(0, 1, (n, 3)) * np.array([168, 401, 128])
+    segs, trks = [], []
+    for _ in range(nvol):
+        a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.04
+        pts = (base - base.mean(0)) @ a + base.mean(0) + rng.normal(0, 0.5, base.shape)
+        segs.append(pts[rng.permutation(n)][: n - int(rng.integers(0, 6))]); trks.append(base + rng.normal(0, 0.3, base.shape))
+    trk = tracker_mod.Tracker.for_matching(ffn, beta_tk=1000.0, lambda_tk=1e-5, maxiter_tk=10, ensemble=nvol - 1)
+    trk.history.r_segmented_coordinates = segs[:-1]; trk.history.r_tracked_coordinates = trks[:-1]
+    trk.cell_num_t0 = n
+    trk.inject_segmentation(segs[-1])
+    for v in (1, 4):
+        seg_pre = dev.points_dev(segs[v - 1]); seg_tgt = dev.points_dev(segs[-1]); trk_pre = dev.points_dev(trks[v - 1])
+        want = trk._predict_pos_composed(seg_pre, seg_tgt, trk_pre)
+        C_t, beta_t, inter_t = trk._fit_device(seg_pre, seg_tgt, 5)
+        got, Cs, inter = dev.legacy_predict_pos(ffn._handle, seg_pre, seg_tgt, trk_pre, 1000.0, 1e-5, 10, 5, 20, want_fit=True)
+        assert torch.equal(got, want) and torch.equal(got, trk._predict_pos_device(v))
+        for i in range(5):
+            assert torch.equal(Cs[i], C_t[i]) and torch.equal(inter[i], inter_t[i]) and beta_t[i] == 1000.0 * 0.8 ** i
+    trk.ensemble_chains = 1
+    seq = trk.predict_ensemble(nvol)
+    trk.ensemble_chains = 8
+    assert np.array_equal(trk.predict_ensemble(nvol), seq)
