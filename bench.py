@@ -246,8 +246,11 @@ def roofline_from_timing(ctx, args, n_patches, steps):
     for i in range(nl):
         cin, cout, nt = C.c_int(), C.c_int(), C.c_int(); d = (C.c_int * 3)()
         L.ct_unet_layer_info(model._handle, i, C.byref(cin), C.byref(cout), d, C.byref(nt))
-        flops = 2.0 * d[0] * d[1] * d[2] * 27 * cin.value * cout.value * n_patches       # per launch (one volume)
-        abytes = 4.0 * d[0] * d[1] * d[2] * (cin.value + cout.value) * n_patches
+        reg = (C.c_int * 4)()
+        L.ct_unet_layer_region(model._handle, i, reg)            # volume path: decoder convs compute only what the centre crops depend on
+        part = (reg[1] - reg[0]) * (reg[3] - reg[2]) / float(d[0] * d[1]) if d[0] * d[1] else 1.0
+        flops = 2.0 * d[0] * d[1] * d[2] * 27 * cin.value * cout.value * n_patches * part       # per launch (one volume), computed part
+        abytes = 4.0 * d[0] * d[1] * d[2] * (cin.value + cout.value) * n_patches * part
         code = nt.value
         bf = abs(code) >= 1000
         f16 = abs(code) >= 2000
@@ -277,7 +280,7 @@ def roofline_from_timing(ctx, args, n_patches, steps):
         t_ms = ms[i] / max(cnt[i], 1)
         hbm_frac = abytes / max(t_ms * 1e-3, 1e-12) / 1e12 / HBM_PEAK_TBS
         mfma_frac = issued * (nprod if bf else 1.0) / max(t_ms * 1e-3, 1e-12) / 1e12 / (BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF)
-        layers.append({"layer": i, "cin": cin.value, "cout": cout.value, "dims": [d[0], d[1], d[2]], "kernel": name,
+        layers.append({"layer": i, "cin": cin.value, "cout": cout.value, "dims": [d[0], d[1], d[2]], "computed_fraction": round(part, 4), "kernel": name,
                        "ms": round(t_ms, 4),
                        "tflops": round(flops * cnt[i] / max(ms[i], 1e-9) / 1e9, 2),
                        "issued_tflops": round(issued * cnt[i] / max(ms[i], 1e-9) / 1e9, 2),

@@ -102,6 +102,10 @@ int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int d
  * MFMA kernels when the model is created) report the same codes offset by 1000 (Cout = 8: -1008 / -1009).  Levels with
  * Z <= 8 run that kernel's 8 x 8 x 8 tile instantiation (CT_CONV_Z8=0: the 4 x 8 x 16 one).                            */
 int ct_unet_layer_fold_channels(const ct_unet_t* h, int layer);
+/* Output extent {x0, x1, y0, y1} (voxels of the layer's level, z always whole) that `layer` computed in the last run.  The patch
+ * entry point computes every layer in full; ct_unet_predict_volume keeps only the centre crop of every patch (unet3d.py:246-254),
+ * so its decoder convs compute only the tiles some kept voxel depends on (CT_CONV_CROP=0: everything, as the reference does).  */
+int ct_unet_layer_region(const ct_unet_t* h, int layer, int region[4]);
 int ct_unet_set_timing(ct_unet_t* h, int enable);
 int ct_unet_get_timing(ct_unet_t* h, float* ms_per_layer, int* launches_per_layer, int n_layers);
 
