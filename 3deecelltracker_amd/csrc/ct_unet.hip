@@ -63,6 +63,8 @@ struct ConvArgs {
     int act;                // 0 LeakyReLU(0.3), 1 ReLU
     int tilesX, tilesY, zblocks;
     int tx0, ty0;           // first tile of the launch (volume path: only the tiles the centre crops depend on are computed)
+    int nx0, nx1, ny0, ny1; // outputs some kept voxel depends on: only they enter the tensor's per-patch maximum (the rest of a computed
+                            // tile may have been fed from voxels nobody computed)
     int cout;
     int nt_total;           // cout tiles of 16 in the packed weights (a block computes NT of them)
     int ngroups;            // nt_total / NT  (blocks along the cout dimension; 1 unless Cout > 64)
@@ -1105,13 +1107,15 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             f32x4 r = F16 ? acc[mt][0] * out_mul + bias : acc[mt][0] + bias;
+            float cmax = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float t = r[e];
                 r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e];       // LeakyReLU / ReLU (0 <= alpha < 1) without a select
-                if constexpr (F16) vmax = fmaxf(vmax, fabsf(r[e]));
+                if constexpr (F16) cmax = fmaxf(cmax, fabsf(r[e]));
             }
             const int y = y0 + col_y(mt);
+            if constexpr (F16) { if (x >= a.nx0 && x < a.nx1 && y >= a.ny0 && y < a.ny1) vmax = fmaxf(vmax, cmax); }
             const bool ok = x < a.X && y < a.Y && z < a.Z;
             if (a.out && ok)
                 *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
@@ -1134,11 +1138,16 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 f32x4 r = F16 ? acc[mt][nt] * out_mul + bias : acc[mt][nt] + bias;
+                float cmax = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = r[e];
                     r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e];       // LeakyReLU / ReLU (0 <= alpha < 1) without a select
-                    if constexpr (F16) vmax = fmaxf(vmax, fabsf(r[e]));
+                    if constexpr (F16) cmax = fmaxf(cmax, fabsf(r[e]));
+                }
+                if constexpr (F16) {
+                    const int x = x0 + col_x(mt), y = y0 + col_y(mt);
+                    if (x >= a.nx0 && x < a.nx1 && y >= a.ny0 && y < a.ny1) vmax = fmaxf(vmax, cmax);
                 }
                 acc[mt][nt] = r;
             }
@@ -1581,6 +1590,7 @@ struct ConvPlan {
     float wscale_inv;     // f16x3: 1 / power-of-two scale of the packed weights
     int nt_used;          // instantiation launched by the last run (small grids split NT = 4 into 2 x NT = 2)
     int region[4];        // x0, x1, y0, y1 computed by the last run (volume path: the part the centre crops depend on)
+    int needed[4];        // the part of it some kept voxel really depends on (region = needed rounded out to whole tiles)
     size_t wpack_off;     // float4 offset into the device weight arena
     size_t epi_off;       // float offset
 };
@@ -2230,13 +2240,16 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
         }
     }
     // Volume path: unet3_prediction keeps only the centre crop of every patch (unet3d.py:246-254), so decoder outputs that no kept voxel
-    // depends on are dead work.  Walk the layers backwards: a conv computes the tiles that cover what its consumers read (its own
-    // kept/consumed region grown by the 3x3x3 footprint, halved through an upsampling, doubled through a pool; z is never cut).
-    // Every computed tile has all of its inputs computed, so the kept voxels are what the full evaluation gives (the per-patch scale
-    // exponents are then maxima over the computed part of a tensor -- still exact power-of-two scalings).  unet3_a, shrink (24,24,2):
-    // L13 49 %, L12 60 %, L11 80 %, L10 90 % of their tiles, everything above in full.
+    // depends on are dead work.  Walk the layers backwards: a conv NEEDS what its consumers read of its output (their needed region
+    // grown by the 3x3x3 footprint, halved through an upsampling, doubled through a pool; z is never cut) and COMPUTES the whole
+    // tiles covering that.  Every needed output has all of its inputs needed -- hence computed -- upstream, so the kept voxels are what
+    // the full evaluation gives.  The rest of a computed tile may be fed from voxels nobody computed: it is written but never read
+    // by a needed output (an MFMA column is one voxel, so nothing mixes), and only needed outputs enter the per-patch maxima that
+    // scale the next layer.  unet3_a, shrink (24,24,2): L13 49 %, L12 60 %, L11 64 %, L10 64 %, L9 80 % of their tiles, the rest in
+    // full.  CT_CONV_CROP=1: inputs derived from the computed tiles instead (no computed output ever sees an uncomputed input;
+    // L11 80 %, L10 90 %), CT_CONV_CROP=0: everything, as the reference does.
     static const bool z8_on = !(getenv("CT_CONV_Z8") && atoi(getenv("CT_CONV_Z8")) == 0);
-    static const bool crop_on = !(getenv("CT_CONV_CROP") && atoi(getenv("CT_CONV_CROP")) == 0);
+    static const int crop_mode = getenv("CT_CONV_CROP") ? atoi(getenv("CT_CONV_CROP")) : 2;
     {
         struct Reg { int lo[2], hi[2]; bool any; };
         const size_t nc = h->convs.size();
@@ -2248,12 +2261,12 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             }
             r.any = true;
         };
-        const bool cut = crop_on && vsrc && !layer_dump;
+        const bool cut = crop_mode > 0 && vsrc && !layer_dump;
         for (size_t ii = nc; ii-- > 0;) {
             ConvPlan& c = h->convs[ii];
             const int* d = h->dims[c.level];
             Reg n{{0, 0}, {0, 0}, false};
-            if (cut && c.bf && ii > 0) {
+            if (cut && c.f16 && ii > 0) {
                 if (c.head) { const int lo[2] = {vsrc->q.bx, vsrc->q.by}, hi[2] = {vsrc->q.bx + vsrc->q.cx, vsrc->q.by + vsrc->q.cy}; join(n, lo, hi); }
                 if (c.dst >= 0 && !c.head && need[c.dst].any) join(n, need[c.dst].lo, need[c.dst].hi);
                 if (c.pool_dst >= 0 && need[c.pool_dst].any) {
@@ -2267,15 +2280,17 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             for (int ax = 0; ax < 2; ++ax) {
                 int lo = n.any ? n.lo[ax] : 0, hi = n.any ? n.hi[ax] : d[ax];
                 lo = lo < 0 ? 0 : lo; hi = hi > d[ax] ? d[ax] : hi;
+                c.needed[2 * ax] = lo; c.needed[2 * ax + 1] = hi;
                 lo = lo / tile[ax] * tile[ax];
                 hi = (hi + tile[ax] - 1) / tile[ax] * tile[ax]; hi = hi > d[ax] ? d[ax] : hi;
                 c.region[2 * ax] = lo; c.region[2 * ax + 1] = hi;
             }
+            if (crop_mode == 1) for (int k = 0; k < 4; ++k) c.needed[k] = c.region[k];   // conservative: whatever is computed counts as needed
             if (ii == 0) continue;
             int ilo[2], ihi[2];
             for (int ax = 0; ax < 2; ++ax) {
-                ilo[ax] = c.region[2 * ax] - 1 < 0 ? 0 : c.region[2 * ax] - 1;
-                ihi[ax] = c.region[2 * ax + 1] + 1 > d[ax] ? d[ax] : c.region[2 * ax + 1] + 1;
+                ilo[ax] = c.needed[2 * ax] - 1 < 0 ? 0 : c.needed[2 * ax] - 1;
+                ihi[ax] = c.needed[2 * ax + 1] + 1 > d[ax] ? d[ax] : c.needed[2 * ax + 1] + 1;
             }
             join(need[c.srcB], ilo, ihi);
             if (c.srcA >= 0) {
@@ -2351,6 +2366,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 const int tw = z8 ? 8 : TX;
                 a.tx0 = c.region[0] / tw; a.ty0 = c.region[2] / TY;
                 a.tilesX = (c.region[1] - c.region[0] + tw - 1) / tw; a.tilesY = (c.region[3] - c.region[2] + TY - 1) / TY;
+                a.nx0 = c.needed[0]; a.nx1 = c.needed[1]; a.ny0 = c.needed[2]; a.ny1 = c.needed[3];
             }
             a.zblocks = z8 ? (d[2] + 7) / 8 : (d[2] + 15) / 16;
             // small grids: a wide layer whose NT = 4 grid is only a few "waves" of workgroups loses up to a third to the

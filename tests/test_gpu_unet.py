@@ -247,3 +247,42 @@ def test_split_fp16_scaling_over_the_dynamic_range():
         # the head is a sigmoid of a logit whose error scales with the last block's magnitude (slope <= 1/4): 1e-4 at ordinary scale
         tol = max(1e-4, 0.25 * 2e-5 * float(np.abs(collect[-1]).max()) * float(np.abs(w["head"]["kernel"]).sum()))
         assert float(np.abs(got[p] - want).max()) <= tol, f"patch {p}: probability map (tolerance {tol})"
+
+
+def test_volume_path_computes_only_what_the_centre_crops_need():
+    """ct_unet_predict_volume evaluates decoder tiles only where a kept (centre-crop) voxel depends on them; the rest of its
+    workspace is never read by a kept voxel.  (1) The stitched map equals -- within the arithmetic's own noise -- the one
+    assembled from fully evaluated patches; (2) it does not change when the workspace is filled with NaN / huge values
+    beforehand (uncomputed regions must not leak into kept voxels, nor into the per-patch scale exponents); (3) the computed
+    fractions are what the dependency walk predicts for unet3_a with shrink (24, 24, 2)."""
+    import ctypes as C
+    import torch
+    arch = arch_mod.UNET3_A
+    model = unet3d.unet3_a().set_weights_dict(synth.make_unet_weights("unet3_a", seed=7))
+    vol = torch.randn(200, 230, 20, device="cuda")
+    ref_out = model.predict_volume_device(vol)
+    # (1) against patch-by-patch full evaluation + the reference's stitching
+    plan = ur.tile_plan(tuple(vol.shape), arch.input_shape, arch.input_shape, (24, 24, 2))
+    patches = ur.gather_patches(vol.cpu().numpy(), plan)
+    full = model.predict_device(torch.from_numpy(np.ascontiguousarray(patches)).cuda()).cpu().numpy()
+    want = ur.scatter_centres(full, plan, tuple(vol.shape))
+    assert float(np.abs(ref_out.cpu().numpy() - want).max()) <= 5e-6
+    # (2) poison the cached workspace, run again: bit-identical
+    _lib = importlib.import_module("3deecelltracker_amd._lib")
+    ws = model._workspace(_lib.lib().ct_unet_workspace_bytes(model._handle, 128))
+    for poison in (float("nan"), 3.0e38, -1.0e30):
+        ws.view(torch.float32).fill_(poison)
+        assert torch.equal(model.predict_volume_device(vol), ref_out)
+    # (3) the dependency walk
+    L = _lib.lib()
+    nl = L.ct_unet_num_conv_layers(model._handle)
+    frac = []
+    for i in range(nl):
+        reg = (C.c_int * 4)(); d = (C.c_int * 3)()
+        L.ct_unet_layer_region(model._handle, i, reg); L.ct_unet_layer_info(model._handle, i, None, None, d, None)
+        frac.append((reg[1] - reg[0]) * (reg[3] - reg[2]) / float(d[0] * d[1]))
+    assert all(f == 1.0 for f in frac[:9]) and frac[13] == (112 * 112) / (160 * 160) and frac[12] == (120 * 128) / (160 * 160)
+    assert frac[9] <= 1.0 and frac[10] < 0.7 and frac[11] < 0.7
+    model.predict_device(torch.from_numpy(np.ascontiguousarray(patches[:1])).cuda())        # the patch entry point computes everything
+    L.ct_unet_layer_region(model._handle, 13, reg)
+    assert tuple(reg) == (0, 160, 0, 160)
