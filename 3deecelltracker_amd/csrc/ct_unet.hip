@@ -63,6 +63,11 @@ struct ConvArgs {
     int act;                // 0 LeakyReLU(0.3), 1 ReLU
     int tilesX, tilesY, zblocks;
     int tx0, ty0;           // first tile of the launch (volume path: only the tiles the centre crops depend on are computed)
+    // patches on the volume's far faces keep a shorter crop: their needed / computed extents end earlier (x: patches with grid index
+    // i == gx1, y: j == gy1; gx1 < 0: no such patches); workgroups of tiles such a patch does not need return at once
+    int p_first, pg_yz, pg_z, gx1, gy1;
+    int cx1e, cy1e, nx1e, ny1e;
+    uint32_t mdivp[2];      // floor(2^32 / d) for d = pg_yz, pg_z
     int nx0, nx1, ny0, ny1; // outputs some kept voxel depends on: only they enter the tensor's per-patch maximum (the rest of a computed
                             // tile may have been fed from voxels nobody computed)
     int cout;
@@ -999,6 +1004,16 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
     const int tx = divmod(b, (uint32_t)a.tilesX, a.mdiv[3]);
     const int p = (int)b;
     const int x0 = (tx + a.tx0) * G::TXv, y0 = (ty + a.ty0) * G::TYv, z0 = zb * G::ZB;
+    int nx1 = a.nx1, ny1 = a.ny1;
+    if (a.gx1 >= 0) {                                          // volume path: is this a patch on a far face of the volume?
+        uint32_t pg = (uint32_t)(a.p_first + p);
+        const int rem = divmod(pg, (uint32_t)a.pg_yz, a.mdivp[0]);         // pg = i
+        uint32_t jq = (uint32_t)rem;
+        (void)divmod(jq, (uint32_t)a.pg_z, a.mdivp[1]);                    // jq = j
+        const bool xe = (int)pg == a.gx1, ye = (int)jq == a.gy1;
+        if ((xe && x0 >= a.cx1e) || (ye && y0 >= a.cy1e)) return;          // (uniform, before any barrier) nothing kept depends on this tile
+        nx1 = xe ? a.nx1e : nx1; ny1 = ye ? a.ny1e : ny1;
+    }
     const int g = lane >> 4;
     const int zl = Z8 ? (lane & 7) : (lane & 15);
     const int csel = Z8 ? ((lane >> 3) & 1) : 0;              // Z8: which of the MFMA column's two y-adjacent columns
@@ -1115,7 +1130,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
                 if constexpr (F16) cmax = fmaxf(cmax, fabsf(r[e]));
             }
             const int y = y0 + col_y(mt);
-            if constexpr (F16) { if (x >= a.nx0 && x < a.nx1 && y >= a.ny0 && y < a.ny1) vmax = fmaxf(vmax, cmax); }
+            if constexpr (F16) { if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax); }
             const bool ok = x < a.X && y < a.Y && z < a.Z;
             if (a.out && ok)
                 *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
@@ -1147,7 +1162,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
                 }
                 if constexpr (F16) {
                     const int x = x0 + col_x(mt), y = y0 + col_y(mt);
-                    if (x >= a.nx0 && x < a.nx1 && y >= a.ny0 && y < a.ny1) vmax = fmaxf(vmax, cmax);
+                    if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax);
                 }
                 acc[mt][nt] = r;
             }
@@ -1591,6 +1606,7 @@ struct ConvPlan {
     int nt_used;          // instantiation launched by the last run (small grids split NT = 4 into 2 x NT = 2)
     int region[4];        // x0, x1, y0, y1 computed by the last run (volume path: the part the centre crops depend on)
     int needed[4];        // the part of it some kept voxel really depends on (region = needed rounded out to whole tiles)
+    int region_e[4], needed_e[4];   // the same for patches on the volume's far faces (their kept crop is shorter)
     size_t wpack_off;     // float4 offset into the device weight arena
     size_t epi_off;       // float offset
 };
@@ -2250,7 +2266,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
     // L11 80 %, L10 90 %), CT_CONV_CROP=0: everything, as the reference does.
     static const bool z8_on = !(getenv("CT_CONV_Z8") && atoi(getenv("CT_CONV_Z8")) == 0);
     static const int crop_mode = getenv("CT_CONV_CROP") ? atoi(getenv("CT_CONV_CROP")) : 2;
-    {
+    for (int edge = 0; edge < 2; ++edge) {                  // 0: ordinary patches, 1: patches on the far x / y faces of the volume (shorter kept crop)
         struct Reg { int lo[2], hi[2]; bool any; };
         const size_t nc = h->convs.size();
         std::vector<Reg> need(h->tensors.size(), Reg{{0, 0}, {0, 0}, false});
@@ -2267,7 +2283,11 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             const int* d = h->dims[c.level];
             Reg n{{0, 0}, {0, 0}, false};
             if (cut && c.f16 && ii > 0) {
-                if (c.head) { const int lo[2] = {vsrc->q.bx, vsrc->q.by}, hi[2] = {vsrc->q.bx + vsrc->q.cx, vsrc->q.by + vsrc->q.cy}; join(n, lo, hi); }
+                if (c.head) {
+                    const int keepx = edge ? vsrc->q.vx - (vsrc->q.gx - 1) * vsrc->q.cx : vsrc->q.cx, keepy = edge ? vsrc->q.vy - (vsrc->q.gy - 1) * vsrc->q.cy : vsrc->q.cy;
+                    const int lo[2] = {vsrc->q.bx, vsrc->q.by}, hi[2] = {vsrc->q.bx + keepx, vsrc->q.by + keepy};
+                    join(n, lo, hi);
+                }
                 if (c.dst >= 0 && !c.head && need[c.dst].any) join(n, need[c.dst].lo, need[c.dst].hi);
                 if (c.pool_dst >= 0 && need[c.pool_dst].any) {
                     const int lo[2] = {need[c.pool_dst].lo[0] * ad.pool[0], need[c.pool_dst].lo[1] * ad.pool[1]};
@@ -2280,17 +2300,19 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             for (int ax = 0; ax < 2; ++ax) {
                 int lo = n.any ? n.lo[ax] : 0, hi = n.any ? n.hi[ax] : d[ax];
                 lo = lo < 0 ? 0 : lo; hi = hi > d[ax] ? d[ax] : hi;
-                c.needed[2 * ax] = lo; c.needed[2 * ax + 1] = hi;
+                int* needed = edge ? c.needed_e : c.needed; int* region = edge ? c.region_e : c.region;
+                needed[2 * ax] = lo; needed[2 * ax + 1] = hi;
                 lo = lo / tile[ax] * tile[ax];
                 hi = (hi + tile[ax] - 1) / tile[ax] * tile[ax]; hi = hi > d[ax] ? d[ax] : hi;
-                c.region[2 * ax] = lo; c.region[2 * ax + 1] = hi;
+                region[2 * ax] = lo; region[2 * ax + 1] = hi;
             }
-            if (crop_mode == 1) for (int k = 0; k < 4; ++k) c.needed[k] = c.region[k];   // conservative: whatever is computed counts as needed
+            int* needed = edge ? c.needed_e : c.needed; const int* region = edge ? c.region_e : c.region;
+            if (crop_mode == 1) for (int k = 0; k < 4; ++k) needed[k] = region[k];   // conservative: whatever is computed counts as needed
             if (ii == 0) continue;
             int ilo[2], ihi[2];
             for (int ax = 0; ax < 2; ++ax) {
-                ilo[ax] = c.needed[2 * ax] - 1 < 0 ? 0 : c.needed[2 * ax] - 1;
-                ihi[ax] = c.needed[2 * ax + 1] + 1 > d[ax] ? d[ax] : c.needed[2 * ax + 1] + 1;
+                ilo[ax] = needed[2 * ax] - 1 < 0 ? 0 : needed[2 * ax] - 1;
+                ihi[ax] = needed[2 * ax + 1] + 1 > d[ax] ? d[ax] : needed[2 * ax + 1] + 1;
             }
             join(need[c.srcB], ilo, ihi);
             if (c.srcA >= 0) {
@@ -2367,6 +2389,16 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 a.tx0 = c.region[0] / tw; a.ty0 = c.region[2] / TY;
                 a.tilesX = (c.region[1] - c.region[0] + tw - 1) / tw; a.tilesY = (c.region[3] - c.region[2] + TY - 1) / TY;
                 a.nx0 = c.needed[0]; a.nx1 = c.needed[1]; a.ny0 = c.needed[2]; a.ny1 = c.needed[3];
+                a.gx1 = a.gy1 = -1;
+                const bool edges = crop_mode > 0 && vsrc && !layer_dump && c.f16 &&
+                                   (c.region_e[1] < c.region[1] || c.region_e[3] < c.region[3] || c.needed_e[1] < c.needed[1] || c.needed_e[3] < c.needed[3]);
+                if (edges) {
+                    a.p_first = vsrc->p_begin; a.pg_yz = vsrc->q.gy * vsrc->q.gz; a.pg_z = vsrc->q.gz;
+                    a.gx1 = vsrc->q.gx - 1; a.gy1 = vsrc->q.gy - 1;
+                    a.cx1e = c.region_e[1]; a.cy1e = c.region_e[3]; a.nx1e = c.needed_e[1]; a.ny1e = c.needed_e[3];
+                    const int dd[2] = {a.pg_yz, a.pg_z};
+                    for (int k = 0; k < 2; ++k) a.mdivp[k] = dd[k] <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)dd[k]);
+                }
             }
             a.zblocks = z8 ? (d[2] + 7) / 8 : (d[2] + 15) / 16;
             // small grids: a wide layer whose NT = 4 grid is only a few "waves" of workgroups loses up to a third to the
