@@ -183,6 +183,27 @@ def legacy_predict_pos(ffn_handle, seg_pre_d, seg_tgt_d, tracked_pre_d, beta, la
     return (pred, Cs, inter) if want_fit else pred
 
 
+LEGACY_BATCH_MAX_POINTS = 132      # ct_legacy_predict_pos_batched: one workgroup solves a problem's dense M-step
+
+
+def legacy_predict_pos_batched(ffn_handle, seg_pre_list, seg_tgt_d, tracked_pre_list, beta, lambda_, max_iteration, reps, k_ptrs=20):
+    """B source volumes of one ensemble prediction as ONE chain of launches -> pred fp64 [B][l][3] (ct_legacy_predict_pos_batched)."""
+    import ctypes as C
+    t = torch(); L = _lib.lib()
+    B = len(seg_pre_list)
+    m, l = seg_tgt_d.shape[0], tracked_pre_list[0].shape[0]
+    ns = [int(x.shape[0]) for x in seg_pre_list]
+    dev = seg_tgt_d.device
+    out = empty((B, l, 3), t.float64, dev)
+    ws = workspace(L.ct_legacy_predict_batched_workspace_bytes(B, max(ns), m, l, int(reps), int(k_ptrs)), dev)
+    pre = (C.c_void_p * B)(*[x.data_ptr() for x in seg_pre_list]); trk = (C.c_void_p * B)(*[x.data_ptr() for x in tracked_pre_list])
+    nn = (C.c_int * B)(*ns)
+    _lib.check(L.ct_legacy_predict_pos_batched(ffn_handle, B, pre, nn, seg_tgt_d.data_ptr(), m, trk, l, float(beta), float(lambda_),
+                                               int(max_iteration), int(reps), int(k_ptrs), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               stream(dev)), "ct_legacy_predict_pos_batched")
+    return out
+
+
 def trim_mean(stack_d, cut=0.1):
     """stack_d fp64 [k][n][3] -> [n][3]  (scipy.stats.trim_mean(..., cut, axis=0))"""
     t = torch(); L = _lib.lib()

@@ -71,6 +71,8 @@ SIGNATURES = {
     "ct_gram_apply": (_i, [_vp, _i, _vp, _i, _vp, _d, _vp]),
     "ct_legacy_predict_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ct_legacy_predict_pos": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ct_legacy_predict_batched_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "ct_legacy_predict_pos_batched": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _d, _d, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ct_normalize_workspace_bytes": (_sz, [_ip]),
     "ct_median": (_i, [_vp, _i, _sz, _vp, _vp, _sz, _vp]),
     "ct_normalize_image": (_i, [_vp, _i, _ip, _d, _ip, _i, _i, _vp, _vp, _sz, _vp]),

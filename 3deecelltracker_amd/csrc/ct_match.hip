@@ -89,12 +89,24 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_MAXN = 4096;
 
+// Batched EM (ct_prgls_two_ref_batched): problem b = blockIdx.z works on the same workspace layout shifted by b * stride
+// doubles (inputs are copied into the workspace first, so EVERY pointer of a launch shifts alike); dims[4 b ..] = m, n, l of
+// problem b (the grid is sized for the largest).  A single-problem launch has gridDim.z = 1: zero shift, dims == null.
+struct Bt { size_t stride; const int* dims; };
+#define BT_SHIFT(T, p) p = (T)((const double*)(p) + (size_t)blockIdx.z * bt.stride)
+// (the legacy prediction chain batches its other kernels the same way: BT_DIM_N / BT_DIM_M read a problem's own sizes)
+#define BT_DIM_M(v) do { if (bt.dims) v = bt.dims[4 * blockIdx.z + 0]; } while (0)
+#define BT_DIM_N(v) do { if (bt.dims) v = bt.dims[4 * blockIdx.z + 1]; } while (0)
+#define BT_DIM_L(v) do { if (bt.dims) v = bt.dims[4 * blockIdx.z + 2]; } while (0)
+
 __global__ __launch_bounds__(64) void knn_features_kernel(const double* __restrict__ pts, int n, int k,
-                                                          float* __restrict__ feat) {
+                                                          float* __restrict__ feat, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, pts); BT_SHIFT(float*, feat); BT_DIM_N(n);
     __shared__ double dist[KNN_MAXN];
     __shared__ double sel_d[32];
     __shared__ int sel_i[32];
     const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
     const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
     for (int j = lane; j < n; j += 64) {
         const double dx = pts[3 * j] - px, dy = pts[3 * j + 1] - py, dz = pts[3 * j + 2] - pz;
@@ -222,7 +234,10 @@ __global__ void denormalize_points_kernel(const double* __restrict__ pts, int n,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                        float* __restrict__ C, int M, int N, int K,
-                                                       const float* __restrict__ bn /* [4][N] gamma,beta,mean,var or null */) {
+                                                       const float* __restrict__ bn /* [4][N] gamma,beta,mean,var or null */,
+                                                       Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const float*, A); BT_SHIFT(float*, C); BT_DIM_N(M);         // batched: rows = the problem's reference points
+    if ((int)blockIdx.y * 64 >= M) return;
     __shared__ float As[16][64 + 1];
     __shared__ float Bs[16][64 + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -279,7 +294,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ffn_pair_kernel(const float* __restrict__ U, int n, const float* __restrict__ V, int m,
                                                        const float* __restrict__ bn2, const float* __restrict__ w3,
-                                                       float b3, float* __restrict__ corr) {
+                                                       float b3, float* __restrict__ corr, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const float*, U); BT_SHIFT(float*, corr); BT_DIM_N(n);      // (V: the target half is shared by the batch)
+    if ((int)blockIdx.x * 32 >= n) return;
     constexpr int KC = 64;
     __shared__ float Us[32][KC + 1];
     __shared__ float Vs[32][KC + 1];
@@ -365,7 +382,10 @@ __global__ __launch_bounds__(64 * GD_ROWLANES) void gd_best_kernel(const float* 
                                                                    const unsigned char* __restrict__ row_used,
                                                                    const unsigned char* __restrict__ col_used,
                                                                    float* __restrict__ rowval, int* __restrict__ rowcol,
-                                                                   int* __restrict__ colrow, int* __restrict__ ctr, int round, int nrb) {
+                                                                   int* __restrict__ colrow, int* __restrict__ ctr, int round, int nrb,
+                                                                   Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const float*, corr); BT_SHIFT(const unsigned char*, row_used); BT_SHIFT(const unsigned char*, col_used);
+    BT_SHIFT(float*, rowval); BT_SHIFT(int*, rowcol); BT_SHIFT(int*, colrow); BT_SHIFT(int*, ctr); BT_DIM_N(n);
     if (ctr[GD_DONE]) return;
     if (round > 0 && ctr[GD_NEW + ((round - 1) & 1)] == 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) ctr[GD_DONE] = 1;
@@ -396,28 +416,31 @@ __global__ __launch_bounds__(64 * GD_ROWLANES) void gd_best_kernel(const float* 
     __shared__ int si[GD_ROWLANES][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int r = ((int)blockIdx.x - nrb) * 64 + cl;
-    float best = -1.f; int bt = 0x7fffffff;
+    float best = -1.f; int btg = 0x7fffffff;
     if (r < n && !col_used[r])
         for (int t = rl; t < m; t += GD_ROWLANES) {
             if (row_used[t]) continue;
             const float v = corr[(size_t)t * n + r];
-            if (v > best) { best = v; bt = t; }                       // ascending t => lowest row on ties
+            if (v > best) { best = v; btg = t; }                       // ascending t => lowest row on ties
         }
-    sv[rl][cl] = best; si[rl][cl] = bt;
+    sv[rl][cl] = best; si[rl][cl] = btg;
     __syncthreads();
     if (rl == 0 && r < n) {
         for (int q = 1; q < GD_ROWLANES; ++q) {
             const float ov = sv[q][cl]; const int oi = si[q][cl];
-            if (ov > best || (ov == best && oi < bt)) { best = ov; bt = oi; }
+            if (ov > best || (ov == best && oi < btg)) { best = ov; btg = oi; }
         }
-        colrow[r] = (bt == 0x7fffffff) ? -1 : bt;
+        colrow[r] = (btg == 0x7fffffff) ? -1 : btg;
     }
 }
 
 __global__ __launch_bounds__(256) void gd_accept_kernel(int m, int n, float thr, const float* __restrict__ rowval,
                                                         const int* __restrict__ rowcol, const int* __restrict__ colrow,
                                                         unsigned char* __restrict__ row_used, unsigned char* __restrict__ col_used,
-                                                        unsigned long long* __restrict__ keys, int* __restrict__ ctr, int round) {
+                                                        unsigned long long* __restrict__ keys, int* __restrict__ ctr, int round,
+                                                        Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const float*, rowval); BT_SHIFT(const int*, rowcol); BT_SHIFT(const int*, colrow); BT_SHIFT(unsigned char*, row_used);
+    BT_SHIFT(unsigned char*, col_used); BT_SHIFT(unsigned long long*, keys); BT_SHIFT(int*, ctr); BT_DIM_N(n);
     if (ctr[GD_DONE]) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= m || row_used[t]) return;
@@ -433,7 +456,9 @@ __global__ __launch_bounds__(256) void gd_accept_kernel(int m, int n, float thr,
 
 // single workgroup: bitonic sort of the accepted keys (descending) -> pairs in the reference's pick order
 __global__ __launch_bounds__(1024) void gd_finalize_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ ctr,
-                                                           int n, int32_t* __restrict__ pairs, int32_t* __restrict__ n_pairs) {
+                                                           int n, int32_t* __restrict__ pairs, int32_t* __restrict__ n_pairs,
+                                                           Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const unsigned long long*, keys); BT_SHIFT(const int*, ctr); BT_SHIFT(int32_t*, pairs); BT_SHIFT(int32_t*, n_pairs); BT_DIM_N(n);
     extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
     const int cnt = ctr[GD_COUNT];
     int p2 = 1; while (p2 < cnt) p2 <<= 1;
@@ -460,7 +485,8 @@ __global__ __launch_bounds__(1024) void gd_finalize_kernel(const unsigned long l
 
 __global__ __launch_bounds__(256) void prior_fill_kernel(double* __restrict__ prior, int m, int n, int mode,
                                                          const int32_t* __restrict__ pairs, const int32_t* __restrict__ n_pairs,
-                                                         int* __restrict__ row_match /* [m] scratch */) {
+                                                         int* __restrict__ row_match /* [m] scratch */, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(double*, prior); BT_SHIFT(const int32_t*, pairs); BT_SHIFT(const int32_t*, n_pairs); BT_SHIFT(int*, row_match); BT_DIM_N(n);
     // pass A (blockIdx.y == 0): row_match[t] = matched ref or -1
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t tot = (size_t)m * n;
@@ -478,12 +504,14 @@ __global__ __launch_bounds__(256) void prior_fill_kernel(double* __restrict__ pr
     prior[gid] = v;
 }
 
-__global__ void row_match_kernel(int* __restrict__ row_match, int m) {
+__global__ void row_match_kernel(int* __restrict__ row_match, int m, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(int*, row_match);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid < m) row_match[tid] = -1;
 }
 __global__ void row_match_set_kernel(int* __restrict__ row_match, const int32_t* __restrict__ pairs,
-                                     const int32_t* __restrict__ n_pairs) {
+                                     const int32_t* __restrict__ n_pairs, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(int*, row_match); BT_SHIFT(const int32_t*, pairs); BT_SHIFT(const int32_t*, n_pairs);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid < *n_pairs) row_match[pairs[2 * tid + 1]] = pairs[2 * tid];
 }
@@ -494,11 +522,6 @@ __global__ void row_match_set_kernel(int* __restrict__ row_match, const int32_t*
 // scalars block (device): [0] sigma2  [1] gamma  [2] sumP  [3] move_norm2  [4] c = lambda*sigma2  [5] iteration
 enum { S_SIGMA2 = 0, S_GAMMA = 1, S_SUMP = 2, S_NORM2 = 3, S_C = 4, S_IT = 5, S_DONE = 6, S_RES = 7, S_NUM = 8 };
 
-// Batched EM (ct_prgls_two_ref_batched): problem b = blockIdx.z works on the same workspace layout shifted by b * stride
-// doubles (inputs are copied into the workspace first, so EVERY pointer of a launch shifts alike); dims[4 b ..] = m, n, l of
-// problem b (the grid is sized for the largest).  A single-problem launch has gridDim.z = 1: zero shift, dims == null.
-struct Bt { size_t stride; const int* dims; };
-#define BT_SHIFT(T, p) p = (T)((const double*)(p) + (size_t)blockIdx.z * bt.stride)
 // Low-rank M-step (see "Low-rank fast path" below): tolerances of the nested pivoted-Cholesky factorisation |G - U^T U|_max
 // (diag(G) = 1) and the relative residuals of the exact system at which the rank is raised / the step is rejected.
 constexpr double kLowRankTol = 1e-10;              // coarse rank (~40): enough while c = lambda sigma2 is large
@@ -508,7 +531,9 @@ constexpr double kLowRankMaxResidual = 1e-6;       // host-side: the chunk is re
 
 // out[i][j] = exp(-|a_j - b_i|^2 / (2 s2)),  i < nb, j < na      (trackerlite.py:368-372)
 __global__ __launch_bounds__(256) void gauss_kernel(const double* __restrict__ a, int na, const double* __restrict__ b, int nb,
-                                                    double two_s2, double* __restrict__ out, int raw = 0) {
+                                                    double two_s2, double* __restrict__ out, int raw = 0, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, a); BT_SHIFT(const double*, b); BT_SHIFT(double*, out);
+    if (bt.dims) { na = nb = bt.dims[4 * blockIdx.z + 1]; }               // batched use: the Gram matrix of a problem's own reference set
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)na * nb) return;
     const int i = (int)(gid / na), j = (int)(gid - (size_t)i * na);
@@ -721,7 +746,12 @@ __global__ __launch_bounds__(256) void apply_field_kernel(const double* __restri
                                                           double* __restrict__ norm_part /* [cols] or null */,
                                                           const double* __restrict__ sc = nullptr,
                                                           const double* __restrict__ dvec = nullptr, const double* __restrict__ sqd = nullptr,
-                                                          const double* __restrict__ rhs = nullptr, double* __restrict__ res_part = nullptr) {
+                                                          const double* __restrict__ rhs = nullptr, double* __restrict__ res_part = nullptr,
+                                                          Bt bt = Bt{0, nullptr}) {
+    if (bt.dims) {                                                         // batched legacy chain: square field on the problem's own reference set
+        BT_SHIFT(const double*, C); BT_SHIFT(const double*, Gt); BT_SHIFT(double*, pts); BT_SHIFT(const double*, base);
+        n = cols = bt.dims[4 * blockIdx.z + 1];
+    }
     if (sc && sc[S_DONE] != 0.0) return;
     if (mode == 3) mode = (sc[S_IT] >= 1.0) ? 1 : 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1393,7 +1423,9 @@ constexpr int DS_MAXN = 132;
 __global__ __launch_bounds__(256) void dense_small_solve_kernel(const double* __restrict__ part, int n, const double* __restrict__ xref,
                                                                 const double* __restrict__ G, double lambda, double* __restrict__ sc,
                                                                 double* __restrict__ dvec, double* __restrict__ sqd_g,
-                                                                double* __restrict__ rhs_g, double* __restrict__ C) {
+                                                                double* __restrict__ rhs_g, double* __restrict__ C, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, part); BT_SHIFT(const double*, xref); BT_SHIFT(const double*, G); BT_SHIFT(double*, sc); BT_SHIFT(double*, dvec);
+    BT_SHIFT(double*, sqd_g); BT_SHIFT(double*, rhs_g); BT_SHIFT(double*, C); BT_DIM_N(n);
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double sq[DS_MAXN];
     __shared__ double idiag[DS_MAXN];
@@ -1479,7 +1511,8 @@ __global__ __launch_bounds__(256) void lr_coeff_kernel(const double* __restrict_
 
 // tracker.py:1269-1289: pred[j] += sum_i C[:, i] exp(-|pred_j - inter_i|^2 / 2 beta^2); one wave per j
 __global__ __launch_bounds__(256) void gram_apply_kernel(double* __restrict__ pred, int l, const double* __restrict__ inter, int n,
-                                                         const double* __restrict__ C, double two_b2) {
+                                                         const double* __restrict__ C, double two_b2, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(double*, pred); BT_SHIFT(const double*, inter); BT_SHIFT(const double*, C); BT_DIM_N(n);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + wave;
     if (j >= l) return;
@@ -1513,6 +1546,32 @@ __global__ __launch_bounds__(256) void trim_mean_kernel(const double* __restrict
 }
 
 }  // namespace
+
+// ---- helpers of the batched legacy chain (problem = blockIdx.z, everything at a fixed slab stride)
+__global__ __launch_bounds__(256) void bt_copy3_kernel(double* __restrict__ dst, const double* __restrict__ src, int which /* 1: n, 2: l */, Bt bt) {
+    BT_SHIFT(double*, dst); BT_SHIFT(const double*, src);
+    const int cnt = 3 * bt.dims[4 * blockIdx.z + which];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void bt_zero_kernel(unsigned char* __restrict__ p, int nwords, Bt bt) {
+    BT_SHIFT(unsigned char*, p);
+    uint32_t* w = reinterpret_cast<uint32_t*>(p);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nwords; i += gridDim.x * 256) w[i] = 0u;
+}
+__global__ void bt_legacy_init_kernel(double* __restrict__ sc, double* __restrict__ C, Bt bt) {       // gamma0 = 0.1 (track.py:41), C = 0
+    BT_SHIFT(double*, sc); BT_SHIFT(double*, C);
+    const int n = bt.dims[4 * blockIdx.z + 1];
+    if (threadIdx.x < S_NUM) sc[threadIdx.x] = threadIdx.x == S_GAMMA ? 0.1 : 0.0;
+    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) C[i] = 0.0;
+}
+__global__ void bt_gather_ctr_kernel(const int* __restrict__ ctr, size_t stride, int B, int* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { const int* c = (const int*)((const double*)ctr + (size_t)b * stride); for (int k = 0; k < 4; ++k) out[4 * b + k] = c[k]; }
+}
+__global__ __launch_bounds__(256) void bt_pack_kernel(const double* __restrict__ src, size_t stride, int cnt, double* __restrict__ dst) {
+    const double* sp = src + (size_t)blockIdx.z * stride;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256) dst[(size_t)blockIdx.z * cnt + i] = sp[i];
+}
 
 struct ct_ffn {
     int device;
@@ -2244,6 +2303,198 @@ int ct_legacy_predict_pos(ct_ffn_t* ffn, const double* seg_pre, int n, const dou
     }
     if (C_out) HIPCHK(hipMemcpyAsync(C_out, Cs, (size_t)reps * n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (inter_out) HIPCHK(hipMemcpyAsync(inter_out, inter, (size_t)reps * n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return CT_OK;
+}
+
+// The same chain for B source volumes at once: problem b = blockIdx.z of every kernel, its buffers one slab further (ragged n[b]; the
+// target set, the tracked-point count and all parameters are shared).  Requires max n <= 132 (the single-workgroup dense M-step; the
+// caller falls back to ct_legacy_predict_pos per volume otherwise).  ~500 launches per ensemble step instead of ~500 per source volume:
+// the chain is bound by the dispatch rate of dependent tiny kernels, not by their work.  Bit-identical to B separate calls.
+struct LegacySlab {
+    size_t inter, Cs, feat, Hr, U, corr, prior, pairs, gd, G, P, part, dvec, sqd, rhs, C, predn, rowpart, sc, tgt, pred, size;
+    size_t gd_keys, gd_ctr, gd_words;
+};
+static LegacySlab legacy_slab(int nmax, int m, int l, int reps, int k) {
+    LegacySlab L{}; size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
+    const size_t n = (size_t)nmax, fw = (size_t)(3 * k + 1);
+    L.inter = take((size_t)(reps + 1) * n * 3 * 8); L.Cs = take((size_t)reps * 3 * n * 8);
+    L.feat = take(n * fw * 4); L.Hr = take(n * HID * 4); L.U = take(n * HID * 4); L.corr = take((size_t)m * n * 4);
+    L.prior = take((size_t)m * n * 8); L.pairs = take(n * 8 + 8);
+    L.gd = o;                                                  // greedy scratch, zeroed per repetition: flags, tables, keys, counters
+    take((size_t)m); take(n); take((size_t)m * 4); take((size_t)m * 4); take((size_t)m * 4); take(n * 4);
+    L.gd_keys = take((size_t)(m > nmax ? m : nmax) * 8); L.gd_ctr = take(256);
+    L.gd_words = (o - L.gd) / 4;
+    L.G = take(n * n * 8); L.P = take((size_t)m * n * 8); L.part = take((size_t)CS_SEG * 4 * n * 8); L.dvec = take(n * 8); L.sqd = take(n * 8);
+    L.rhs = take(3 * n * 8); L.C = take(3 * n * 8); L.predn = take(3 * n * 8); L.rowpart = take((size_t)m * 8); L.sc = take(S_NUM * 8);
+    L.tgt = take((size_t)m * 3 * 8); L.pred = take((size_t)(l > 0 ? l : 1) * 3 * 8);
+    L.size = o;
+    return L;
+}
+static size_t legacy_shared_bytes(int B, int m, int k) {
+    return align_up((size_t)m * (3 * k + 1) * 4, 256) + 2 * align_up((size_t)m * HID * 4, 256) + align_up((size_t)B * 16, 256) + align_up((size_t)B * 16, 256);
+}
+
+size_t ct_legacy_predict_batched_workspace_bytes(int B, int nmax, int m, int l, int reps, int k_ptrs) {
+    if (B <= 0 || nmax <= 0 || m <= 0 || reps <= 0 || k_ptrs <= 0 || l < 0) return 0;
+    return (size_t)B * legacy_slab(nmax, m, l, reps, k_ptrs).size + legacy_shared_bytes(B, m, k_ptrs) + 512;
+}
+
+int ct_legacy_predict_pos_batched(ct_ffn_t* ffn, int B, const double* const* seg_pre, const int* n, const double* seg_tgt, int m,
+                                  const double* const* tracked_pre, int l, double beta, double lambda, int max_iteration, int reps,
+                                  int k_ptrs, double* pred_out, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (!ffn || B <= 0 || !seg_pre || !n || !seg_tgt || m <= 0 || !workspace || reps <= 0 || k_ptrs <= 0 || l <= 0 || !tracked_pre || !pred_out)
+        return CT_EINVAL;
+    int nmax = 0;
+    for (int b = 0; b < B; ++b) { if (n[b] <= k_ptrs || !seg_pre[b] || !tracked_pre[b]) return CT_EINVAL; nmax = n[b] > nmax ? n[b] : nmax; }
+    if (nmax > DS_MAXN || m <= k_ptrs) return CT_ESHAPE;
+    if (workspace_bytes < ct_legacy_predict_batched_workspace_bytes(B, nmax, m, l, reps, k_ptrs)) return CT_EWORKSPACE;
+    DeviceGuard dg(ffn->device);
+    if (dg.err != hipSuccess) return (int)dg.err;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const LegacySlab L = legacy_slab(nmax, m, l, reps, k_ptrs);
+    unsigned char* shared = base + (size_t)B * L.size;
+    float* feat_tgt = (float*)shared; shared += align_up((size_t)m * (3 * k_ptrs + 1) * 4, 256);
+    float* Ht = (float*)shared; shared += align_up((size_t)m * HID * 4, 256);
+    float* V = (float*)shared; shared += align_up((size_t)m * HID * 4, 256);
+    int* d_dims = (int*)shared; shared += align_up((size_t)B * 16, 256);
+    int* d_ctr = (int*)shared;
+    std::vector<int> hdims((size_t)B * 4, 0), hctr((size_t)B * 4, 0);
+    for (int b = 0; b < B; ++b) { hdims[4 * b] = m; hdims[4 * b + 1] = n[b]; hdims[4 * b + 2] = l; }
+    HIPCHK(hipMemcpyAsync(d_dims, hdims.data(), hdims.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    const Bt bt{L.size / sizeof(double), d_dims};
+    const unsigned zB = (unsigned)B;
+    auto at = [&](size_t off) { return base + off; };        // problem 0's copy of a slab member
+    const size_t n3max = (size_t)nmax * 3;
+    for (int b = 0; b < B; ++b) {
+        unsigned char* sb = base + (size_t)b * L.size;
+        HIPCHK(hipMemcpyAsync(sb + L.inter, seg_pre[b], (size_t)n[b] * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(sb + L.pred, tracked_pre[b], (size_t)l * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(sb + L.tgt, seg_tgt, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    ENSURE_BIG_LDS(gd_finalize_kernel);
+    ENSURE_BIG_LDS(dense_small_solve_kernel);
+    const float* W = ffn->d_w;
+    // target half of the FFN: once for the whole batch
+    hipLaunchKernelGGL(knn_features_kernel, dim3(m), dim3(64), 0, st, seg_tgt, m, k_ptrs, feat_tgt, Bt{0, nullptr});
+    LAUNCH_CHECK();
+    int rc;
+    if ((rc = gemm(feat_tgt, FEAT, W + ffn->o_w1, Ht, m, HID, FEAT, W + ffn->o_bn1, st))) return rc;
+    if ((rc = gemm(Ht, HID, W + ffn->o_w2 + (size_t)HID * HID, V, m, HID, HID, nullptr, st))) return rc;
+    const int nrb = (m + GD_ROWLANES - 1) / GD_ROWLANES, ncb = (nmax + 63) / 64;
+    for (int i = 0; i < reps; ++i) {
+        const double bi = beta * pow(0.8, (double)i);
+        double* X = (double*)at(L.inter) + (size_t)i * n3max;               // this repetition's reference points (slab-relative)
+        float* feat = (float*)at(L.feat); float* Hr = (float*)at(L.Hr); float* U = (float*)at(L.U); float* corr = (float*)at(L.corr);
+        // initial_matching_quick (track.py:117-178): features -> FFN on all pairs
+        hipLaunchKernelGGL(knn_features_kernel, dim3(nmax, 1, zB), dim3(64), 0, st, X, nmax, k_ptrs, feat, bt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, feat, FEAT, W + ffn->o_w1, Hr, nmax, HID, FEAT,
+                           W + ffn->o_bn1, bt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, Hr, HID, W + ffn->o_w2, U, nmax, HID, HID,
+                           (const float*)nullptr, bt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(ffn_pair_kernel, dim3((nmax + 31) / 32, (m + 31) / 32, zB), dim3(256), 0, st, U, nmax, V, m, W + ffn->o_bn2, W + ffn->o_w3,
+                           ffn->b3, corr, bt);
+        LAUNCH_CHECK();
+        // pr_gls_quick (track.py:11-114): greedy prior with threshold 0.5 ...
+        unsigned char* gd = at(L.gd);
+        unsigned char* row_used = gd; size_t go = align_up((size_t)m, 256);
+        unsigned char* col_used = gd + go; go += align_up((size_t)nmax, 256);
+        float* rowval = (float*)(gd + go); go += align_up((size_t)m * 4, 256);
+        int* rowcol = (int*)(gd + go); go += align_up((size_t)m * 4, 256);
+        int* row_match = (int*)(gd + go); go += align_up((size_t)m * 4, 256);
+        int* colrow = (int*)(gd + go);
+        unsigned long long* keys = (unsigned long long*)at(L.gd_keys); int* ctr = (int*)at(L.gd_ctr);
+        int32_t* pairs = (int32_t*)at(L.pairs); int32_t* npairs = pairs + 2 * nmax;
+        double* prior = (double*)at(L.prior);
+        hipLaunchKernelGGL(bt_zero_kernel, dim3(8, 1, zB), dim3(256), 0, st, gd, (int)L.gd_words, bt);
+        LAUNCH_CHECK();
+        const int max_rounds = (m < nmax ? m : nmax) + 1;
+        int maxcnt = 0;
+        for (int done_rounds = 0; done_rounds < max_rounds;) {
+            const int chunk = done_rounds == 0 ? 12 : 8;
+            for (int k = 0; k < chunk; ++k) {
+                const int round = done_rounds + k;
+                hipLaunchKernelGGL(gd_best_kernel, dim3(nrb + ncb, 1, zB), dim3(64 * GD_ROWLANES), 0, st, corr, m, nmax, row_used, col_used, rowval, rowcol,
+                                   colrow, ctr, round, nrb, bt);
+                LAUNCH_CHECK();
+                hipLaunchKernelGGL(gd_accept_kernel, dim3((m + 255) / 256, 1, zB), dim3(256), 0, st, m, nmax, 0.5f, rowval, rowcol, colrow, row_used,
+                                   col_used, keys, ctr, round, bt);
+                LAUNCH_CHECK();
+            }
+            done_rounds += chunk;
+            hipLaunchKernelGGL(bt_gather_ctr_kernel, dim3((B + 63) / 64), dim3(64), 0, st, ctr, bt.stride, B, d_ctr);
+            LAUNCH_CHECK();
+            HIPCHK(hipMemcpyAsync(hctr.data(), d_ctr, hctr.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            bool all_done = true; maxcnt = 0;
+            for (int b = 0; b < B; ++b) {
+                if (!(hctr[4 * b + GD_DONE] || hctr[4 * b + GD_NEW + ((done_rounds - 1) & 1)] == 0)) all_done = false;
+                maxcnt = hctr[4 * b + GD_COUNT] > maxcnt ? hctr[4 * b + GD_COUNT] : maxcnt;
+            }
+            if (all_done) break;
+        }
+        {
+            int p2 = 1; while (p2 < maxcnt) p2 <<= 1;
+            hipLaunchKernelGGL(gd_finalize_kernel, dim3(1, 1, zB), dim3(1024), (size_t)p2 * 8, st, keys, ctr, nmax, pairs, npairs, bt);
+            LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(row_match_kernel, dim3((m + 255) / 256, 1, zB), dim3(256), 0, st, row_match, m, bt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(row_match_set_kernel, dim3((nmax + 255) / 256, 1, zB), dim3(256), 0, st, row_match, pairs, npairs, bt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(prior_fill_kernel, dim3((unsigned)(((size_t)m * nmax + 255) / 256), 1, zB), dim3(256), 0, st, prior, m, nmax, 1, pairs, npairs,
+                           row_match, bt);
+        LAUNCH_CHECK();
+        // ... then max_iteration - 1 EM iterations with the dense M-step
+        double* G = (double*)at(L.G); double* P = (double*)at(L.P); double* part = (double*)at(L.part); double* dvec = (double*)at(L.dvec);
+        double* sqd = (double*)at(L.sqd); double* rhs = (double*)at(L.rhs); double* Cc = (double*)at(L.C); double* predn = (double*)at(L.predn);
+        double* rowpart = (double*)at(L.rowpart); double* sc = (double*)at(L.sc); double* Y = (double*)at(L.tgt);
+        hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)(((size_t)nmax * nmax + 255) / 256), 1, zB), dim3(256), 0, st, X, nmax, X, nmax, 2.0 * bi * bi, G, 0, bt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(bt_copy3_kernel, dim3(2, 1, zB), dim3(256), 0, st, predn, X, 1, bt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(bt_legacy_init_kernel, dim3(1, 1, zB), dim3(256), 0, st, sc, Cc, bt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4, 1, zB), dim3(256), 0, st, X, nmax, Y, m, (const double*)nullptr, rowpart,
+                           (const double*)nullptr, bt);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(scalars_kernel, dim3(1, 1, zB), dim3(256), 0, st, rowpart, m, nmax, 0, sc, (const double*)nullptr, (const double*)nullptr,
+                           (int*)nullptr, bt);
+        LAUNCH_CHECK();
+        const size_t lds = (size_t)(nmax + 3) * (nmax | 1) * sizeof(double);
+        for (int it = 1; it < max_iteration; ++it) {
+            hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4, 1, zB), dim3(256), 0, st, prior, predn, nmax, Y, m, sc, 1, 1e8, P, 0.0, 0.0, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(colstats_kernel, dim3((nmax + 63) / 64, CS_SEG, zB), dim3(256), 0, st, P, Y, m, nmax, part, sc, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(dense_small_solve_kernel, dim3(1, 1, zB), dim3(256), lds, st, part, nmax, X, G, lambda, sc, dvec, sqd, rhs, Cc, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(apply_field_kernel, dim3((nmax + 3) / 4, 1, zB), dim3(256), 0, st, Cc, G, nmax, nmax, predn, X, 2, (double*)nullptr,
+                               (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (double*)nullptr, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4, 1, zB), dim3(256), 0, st, predn, nmax, Y, m, P, rowpart, (const double*)nullptr, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(scalars_kernel, dim3(1, 1, zB), dim3(256), 0, st, rowpart, m, nmax, 2, sc, (const double*)nullptr, (const double*)nullptr,
+                               (int*)nullptr, bt);
+            LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(bt_copy3_kernel, dim3(2, 1, zB), dim3(256), 0, st, X + n3max, predn, 1, bt);                    // next repetition starts from T_X
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(bt_copy3_kernel, dim3(2, 1, zB), dim3(256), 0, st, (double*)at(L.Cs) + (size_t)i * n3max, Cc, 1, bt);
+        LAUNCH_CHECK();
+    }
+    // _predict_one_rep (tracker.py:1269-1289) for every repetition
+    for (int i = 0; i < reps; ++i) {
+        hipLaunchKernelGGL(gram_apply_kernel, dim3((l + 3) / 4, 1, zB), dim3(256), 0, st, (double*)at(L.pred), l, (double*)at(L.inter) + (size_t)i * n3max, nmax,
+                           (double*)at(L.Cs) + (size_t)i * n3max, 2.0 * (beta * pow(0.8, (double)i)) * (beta * pow(0.8, (double)i)), bt);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bt_pack_kernel, dim3(2, 1, zB), dim3(256), 0, st, (const double*)at(L.pred), bt.stride, 3 * l, pred_out);
+    LAUNCH_CHECK();
     return CT_OK;
 }
 

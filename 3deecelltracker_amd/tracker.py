@@ -168,6 +168,7 @@ class Tracker:
     """reference :779-1551.  Constructor and public method names follow the reference (:854-859)."""
 
     ensemble_chains = 8      # source-volume predictions of one ensemble step in flight on this GPU (parallel.chain_map)
+    ensemble_batched = True  # ... or, when the point sets are small enough, all of them as one batched chain of launches
     connectivity = 1         # region step: 6-connected components (scipy.ndimage.label default)
 
     def __init__(self, volume_num, siz_xyz: tuple, z_xy_ratio, z_scaling, noise_level, min_size, beta_tk, lambda_tk, maxiter_tk,
@@ -639,8 +640,27 @@ class Tracker:
         t = _dev.torch()
         vols = get_reference_vols(self.ensemble, vol, adjacent=self.adjacent) if source_vols is None else source_vols
         stack = parallel.sharded_map_gather(lambda v: self._predict_pos_device(v), vols, tail_shape=(int(self.cell_num_t0), 3),
-                                            dtype=t.float64, chains=self.ensemble_chains)
+                                            dtype=t.float64, chains=self.ensemble_chains, batch_fn=self._ensemble_batch_fn())
         return _dev.trim_mean(stack, 0.1).cpu().numpy()
+
+    def _ensemble_batch_fn(self):
+        """This rank's source volumes as ONE chain of launches (ct_legacy_predict_pos_batched) when the native FFN is in use and every
+        point set is small enough for the single-workgroup dense M-step; None -> concurrent per-volume chains."""
+        if not (isinstance(self.ffn_model, FFN) and self.ffn_model._handle is not None and self.ensemble_batched):
+            return None
+        seg_tgt_np = self.segresult.r_coordinates_segment
+        sizes = [len(x) for x in self.history.r_segmented_coordinates] + [len(seg_tgt_np)]
+        if not sizes or max(sizes) > _dev.LEGACY_BATCH_MAX_POINTS or min(sizes) <= 20:
+            return None
+
+        def run(vols):
+            seg_tgt = _dev.points_dev(seg_tgt_np)
+            pre = [_dev.points_dev(self.history.r_segmented_coordinates[v - 1]) for v in vols]
+            trk = [_dev.points_dev(self.history.r_tracked_coordinates[v - 1]) for v in vols]
+            out = _dev.legacy_predict_pos_batched(self.ffn_model._handle, pre, seg_tgt, trk, self.beta_tk, self.lambda_tk, self.max_iteration,
+                                                  REP_NUM_PRGLS, 20)
+            return [out[i] for i in range(len(vols))]
+        return run
 
     # ------------------------------------------------------------------ tracking loop (reference :1415-1551)
     def track(self, fig=None, ax=None, from_volume=2):

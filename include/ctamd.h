@@ -246,6 +246,16 @@ int ct_legacy_predict_pos(ct_ffn_t* ffn, const double* seg_pre, int n, const dou
                           double beta, double lambda, int max_iteration, int reps, int k_ptrs, double* pred_out, double* C_out,
                           double* inter_out, void* workspace, size_t workspace_bytes, ct_stream_t stream);
 
+/* The same chain for the B independent source volumes of one ensemble prediction (tracker.py:1499-1506) as ONE chain of launches:
+ * problem b = blockIdx.z of every kernel (ragged n[b]; target set, tracked-point count l and all parameters shared).  seg_pre[b]
+ * [dev] fp64 [n[b]][3], tracked_pre[b] [dev] fp64 [l][3] (host arrays of device pointers) -> pred_out [dev] fp64 [B][l][3].
+ * Bit-identical to B calls of ct_legacy_predict_pos.  max n[b] <= 132 (the dense M-step of such a problem is one workgroup);
+ * CT_ESHAPE otherwise -- call ct_legacy_predict_pos per volume then.  Synchronises `stream`.                                    */
+size_t ct_legacy_predict_batched_workspace_bytes(int B, int nmax, int m, int l, int reps, int k_ptrs);
+int ct_legacy_predict_pos_batched(ct_ffn_t* ffn, int B, const double* const* seg_pre, const int* n, const double* seg_tgt, int m,
+                                  const double* const* tracked_pre, int l, double beta, double lambda, int max_iteration, int reps,
+                                  int k_ptrs, double* pred_out, void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
 /* trim_mean(stack, 0.1, axis=0) of k predictions (trackerlite.py:123, tracker.py:1508):
  * stack [dev] fp64 [k][n3] -> out [dev] fp64 [n3].                                               */
 int ct_trim_mean(const double* stack, int k, int n3, double cut, double* out, ct_stream_t stream);

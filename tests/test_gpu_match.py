@@ -580,3 +580,29 @@ def test_legacy_predict_pos_native_chain_equals_the_composed_calls(ffn):
     seq = trk.predict_ensemble(nvol)
     trk.ensemble_chains = 8
     assert np.array_equal(trk.predict_ensemble(nvol), seq)
+
+
+def test_legacy_predict_pos_batched_is_bit_identical_to_per_volume_calls(ffn):
+    """ct_legacy_predict_pos_batched: the source volumes of an ensemble prediction as ONE chain of launches (problem = blockIdx.z,
+    ragged reference sets) -- every prediction bit-identical to its own ct_legacy_predict_pos call, for 1, 3 and 20 problems."""
+    import torch
+    rng = np.random.default_rng(31)
+    n0, l = 113, 97
+    base = rng.uniform(0, 1, (n0, 3)) * np.array([168, 401, 128])
+    tgt = dev.points_dev(base[rng.permutation(n0)][:109] + rng.normal(0, 0.5, (109, 3)))
+    pre, trk = [], []
+    for b in range(20):
+        a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.04
+        pts = (base - base.mean(0)) @ a + base.mean(0) + rng.normal(0, 0.5, base.shape)
+        nb = n0 - int(rng.integers(0, 9)) if b else 132                     # ragged; one problem at the kernel's size limit
+        if nb > n0:
+            pts = np.concatenate([pts, rng.uniform(0, 1, (nb - n0, 3)) * np.array([168, 401, 128])])
+        pre.append(dev.points_dev(pts[rng.permutation(len(pts))][:nb])); trk.append(dev.points_dev(base[:l] + rng.normal(0, 0.3, (l, 3))))
+    single = [dev.legacy_predict_pos(ffn._handle, pre[b], tgt, trk[b], 1000.0, 1e-5, 10, 5, 20) for b in range(20)]
+    for B in (1, 3, 20):
+        got = dev.legacy_predict_pos_batched(ffn._handle, pre[:B], tgt, trk[:B], 1000.0, 1e-5, 10, 5, 20)
+        for b in range(B):
+            assert torch.equal(got[b], single[b]), f"B = {B}: problem {b} differs by {float((got[b] - single[b]).abs().max())}"
+    big = [dev.points_dev(rng.uniform(0, 1, (140, 3)) * 100)]
+    with pytest.raises(Exception):
+        dev.legacy_predict_pos_batched(ffn._handle, big, tgt, trk[:1], 1000.0, 1e-5, 10, 5, 20)      # 140 > 132: CT_ESHAPE
