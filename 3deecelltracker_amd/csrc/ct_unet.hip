@@ -62,7 +62,7 @@ struct ConvArgs {
     float* head_out;        // [P][X][Y][Z]
     int act;                // 0 LeakyReLU(0.3), 1 ReLU
     int tilesX, tilesY, zblocks;
-    int tx0, ty0;           // first tile of the launch (volume path: only the tiles the centre crops depend on are computed)
+    int tx0, ty0;           // origin (voxels, even) of the launch's tile grid (volume path: only the tiles the centre crops depend on are computed)
     // patches on the volume's far faces keep a shorter crop: their needed / computed extents end earlier (x: patches with grid index
     // i == gx1, y: j == gy1; gx1 < 0: no such patches); workgroups of tiles such a patch does not need return at once
     int p_first, pg_yz, pg_z, gx1, gy1;
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
     const int ty = divmod(b, (uint32_t)a.tilesY, a.mdiv[2]);
     const int tx = divmod(b, (uint32_t)a.tilesX, a.mdiv[3]);
     const int p = (int)b;
-    const int x0 = (tx + a.tx0) * G::TXv, y0 = (ty + a.ty0) * G::TYv, z0 = zb * G::ZB;
+    const int x0 = a.tx0 + tx * G::TXv, y0 = a.ty0 + ty * G::TYv, z0 = zb * G::ZB;
     int nx1 = a.nx1, ny1 = a.ny1;
     if (a.gx1 >= 0) {                                          // volume path: is this a patch on a far face of the volume?
         uint32_t pg = (uint32_t)(a.p_first + p);
@@ -2302,22 +2302,33 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 lo = lo < 0 ? 0 : lo; hi = hi > d[ax] ? d[ax] : hi;
                 int* needed = edge ? c.needed_e : c.needed; int* region = edge ? c.region_e : c.region;
                 needed[2 * ax] = lo; needed[2 * ax + 1] = hi;
-                lo = lo / tile[ax] * tile[ax];
-                hi = (hi + tile[ax] - 1) / tile[ax] * tile[ax]; hi = hi > d[ax] ? d[ax] : hi;
+                lo &= ~1;                                              // the tile grid starts at an even voxel (2 x 2 pools, parity classes of
+                hi = lo + (hi - lo + tile[ax] - 1) / tile[ax] * tile[ax];   // the folded taps, x pairs of the Cout = 8 kernels), not at a tile multiple
+                hi = hi > d[ax] ? d[ax] : hi;
                 region[2 * ax] = lo; region[2 * ax + 1] = hi;
             }
             int* needed = edge ? c.needed_e : c.needed; const int* region = edge ? c.region_e : c.region;
             if (crop_mode == 1) for (int k = 0; k < 4; ++k) needed[k] = region[k];   // conservative: whatever is computed counts as needed
             if (ii == 0) continue;
+            // What the kernel READS for its needed outputs.  Ordinary kernels: the 3 x 3 footprint.  The Cout = 8 kernels compute two
+            // x-adjacent voxels per MFMA column over their common 4 x 3 footprint: each voxel also multiplies the neighbour's extra column
+            // by a zero weight -- and 0 x (a NaN from a voxel nobody computed) is NaN, so that column has to hold computed values too.
+            int nlo[2] = {needed[0], needed[2]}, nhi[2] = {needed[1], needed[3]};
+            if (c.c8) { nlo[0] &= ~1; nhi[0] = (nhi[0] + 1) & ~1; }
             int ilo[2], ihi[2];
             for (int ax = 0; ax < 2; ++ax) {
-                ilo[ax] = needed[2 * ax] - 1 < 0 ? 0 : needed[2 * ax] - 1;
-                ihi[ax] = needed[2 * ax + 1] + 1 > d[ax] ? d[ax] : needed[2 * ax + 1] + 1;
+                ilo[ax] = nlo[ax] - 1 < 0 ? 0 : nlo[ax] - 1;
+                ihi[ax] = nhi[ax] + 1 > d[ax] ? d[ax] : nhi[ax] + 1;
             }
             join(need[c.srcB], ilo, ihi);
             if (c.srcA >= 0) {
+                const int* da = h->dims[c.level + 1];
                 const int u[2] = {ad.pool[0] == 2 ? 1 : 0, ad.pool[1] == 2 ? 1 : 0};
-                const int lo[2] = {ilo[0] >> u[0], ilo[1] >> u[1]}, hi[2] = {(ihi[0] + u[0]) >> u[0], (ihi[1] + u[1]) >> u[1]};
+                int lo[2] = {ilo[0] >> u[0], ilo[1] >> u[1]}, hi[2] = {(ihi[0] + u[0]) >> u[0], (ihi[1] + u[1]) >> u[1]};
+                if (c.c8 && u[0]) {                                // folded pairs: low-res offsets {-1, 0, +1} around the pair's own low-res voxel
+                    lo[0] = (nlo[0] >> 1) - 1 < 0 ? 0 : (nlo[0] >> 1) - 1;
+                    hi[0] = (nhi[0] >> 1) + 1 > da[0] ? da[0] : (nhi[0] >> 1) + 1;
+                }
                 join(need[c.srcA], lo, hi);
             }
         }
@@ -2386,7 +2397,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             const bool z8 = z8_on && c.bf && !c.c8 && d[2] <= 8;
             {
                 const int tw = z8 ? 8 : TX;
-                a.tx0 = c.region[0] / tw; a.ty0 = c.region[2] / TY;
+                a.tx0 = c.region[0]; a.ty0 = c.region[2];
                 a.tilesX = (c.region[1] - c.region[0] + tw - 1) / tw; a.tilesY = (c.region[3] - c.region[2] + TY - 1) / TY;
                 a.nx0 = c.needed[0]; a.nx1 = c.needed[1]; a.ny0 = c.needed[2]; a.ny1 = c.needed[3];
                 a.gx1 = a.gy1 = -1;

@@ -281,8 +281,8 @@ def test_volume_path_computes_only_what_the_centre_crops_need():
         reg = (C.c_int * 4)(); d = (C.c_int * 3)()
         L.ct_unet_layer_region(model._handle, i, reg); L.ct_unet_layer_info(model._handle, i, None, None, d, None)
         frac.append((reg[1] - reg[0]) * (reg[3] - reg[2]) / float(d[0] * d[1]))
-    assert all(f == 1.0 for f in frac[:9]) and frac[13] == (112 * 112) / (160 * 160) and frac[12] == (120 * 128) / (160 * 160)
-    assert frac[9] <= 1.0 and frac[10] < 0.7 and frac[11] < 0.7
+    assert all(f == 1.0 for f in frac[:8]) and frac[13] == (112 * 112) / (160 * 160) and frac[12] == (116 * 120) / (160 * 160)
+    assert frac[8] <= 1.0 and frac[9] < 1.0 and frac[10] < 0.7 and frac[11] < 0.7, frac
     model.predict_device(torch.from_numpy(np.ascontiguousarray(patches[:1])).cuda())        # the patch entry point computes everything
     L.ct_unet_layer_region(model._handle, 13, reg)
     assert tuple(reg) == (0, 160, 0, 160)
