@@ -286,3 +286,22 @@ def test_volume_path_computes_only_what_the_centre_crops_need():
     model.predict_device(torch.from_numpy(np.ascontiguousarray(patches[:1])).cuda())        # the patch entry point computes everything
     L.ct_unet_layer_region(model._handle, 13, reg)
     assert tuple(reg) == (0, 160, 0, 160)
+
+
+@pytest.mark.parametrize("name,shape,shrink", [("unet3_a", (112, 112, 12), (24, 24, 2)), ("unet3_a", (224, 250, 12), (24, 24, 2)),
+                                               ("unet3_a", (300, 120, 30), (16, 8, 2)), ("unet3_c", (100, 90, 70), (12, 12, 12)),
+                                               ("unet3_c", (64, 64, 64), (8, 10, 6))])
+def test_volume_path_ignores_uncomputed_workspace(name, shape, shrink):
+    """The crop-aware decoder leaves parts of its tensors unwritten; nothing a kept voxel depends on may read them -- not even
+    through a zero weight (0 x NaN).  Workspace filled with NaN / Inf / huge values before the run: bit-identical output, for volumes
+    with and without partial crops on their far faces, other shrink values, and the net with (2, 2, 2) pools and several z blocks."""
+    import torch
+    model = getattr(unet3d, name)().set_weights_dict(synth.make_unet_weights(name, seed=8))
+    vol = torch.randn(*shape, device="cuda")
+    ref_out = model.predict_volume_device(vol, shrink=shrink).clone()
+    assert bool(torch.isfinite(ref_out).all())
+    _lib = importlib.import_module("3deecelltracker_amd._lib")
+    ws = model._workspace(_lib.lib().ct_unet_workspace_bytes(model._handle, 128))
+    for poison in (float("nan"), float("inf"), -3.0e38):
+        ws.view(torch.float32).fill_(poison)
+        assert torch.equal(model.predict_volume_device(vol, shrink=shrink), ref_out), f"{name} {shape} {shrink}: poison {poison} leaked"
