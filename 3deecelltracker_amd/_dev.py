@@ -183,6 +183,23 @@ def legacy_predict_pos(ffn_handle, seg_pre_d, seg_tgt_d, tracked_pre_d, beta, la
     return (pred, Cs, inter) if want_fit else pred
 
 
+def match_front_batched(ffn_handle, refs, tgts, k, threshold, mode=0):
+    """FFN scores + greedy prior of B independent problems as ONE chain of launches (ct_match_front_batched)
+    -> list of prior tensors fp64 [m_b][n_b]."""
+    import ctypes as C
+    t = torch(); L = _lib.lib()
+    B = len(refs)
+    ns = [int(x.shape[0]) for x in refs]; ms = [int(x.shape[0]) for x in tgts]
+    dev = refs[0].device
+    priors = [empty((ms[b], ns[b]), t.float64, dev) for b in range(B)]
+    ws = workspace(L.ct_match_front_batched_workspace_bytes(B, max(ns), max(ms), int(k)), dev)
+    rp = (C.c_void_p * B)(*[x.data_ptr() for x in refs]); tp = (C.c_void_p * B)(*[x.data_ptr() for x in tgts])
+    pp = (C.c_void_p * B)(*[x.data_ptr() for x in priors])
+    _lib.check(L.ct_match_front_batched(ffn_handle, B, rp, (C.c_int * B)(*ns), tp, (C.c_int * B)(*ms), int(k), float(threshold), int(mode), pp,
+                                        ws.data_ptr(), ws.numel(), stream(dev)), "ct_match_front_batched")
+    return priors
+
+
 LEGACY_BATCH_MAX_POINTS = 132      # ct_legacy_predict_pos_batched: one workgroup solves a problem's dense M-step
 
 

@@ -69,6 +69,8 @@ SIGNATURES = {
     "ct_estimate_posterior": (_i, [_vp, _d, _vp, _i, _vp, _i, _d, _d, _vp, _vp]),
     "ct_solve_movements": (_i, [_d, _d, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "ct_gram_apply": (_i, [_vp, _i, _vp, _i, _vp, _d, _vp]),
+    "ct_match_front_batched_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ct_match_front_batched": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "ct_legacy_predict_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ct_legacy_predict_pos": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ct_legacy_predict_batched_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

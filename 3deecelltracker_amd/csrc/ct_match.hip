@@ -295,8 +295,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void ffn_pair_kernel(const float* __restrict__ U, int n, const float* __restrict__ V, int m,
                                                        const float* __restrict__ bn2, const float* __restrict__ w3,
                                                        float b3, float* __restrict__ corr, Bt bt = Bt{0, nullptr}) {
-    BT_SHIFT(const float*, U); BT_SHIFT(float*, corr); BT_DIM_N(n);      // (V: the target half is shared by the batch)
-    if ((int)blockIdx.x * 32 >= n) return;
+    BT_SHIFT(const float*, U); BT_SHIFT(float*, corr); BT_DIM_N(n);      // V: shared by the batch (legacy chain) unless dims[3] != 0
+    if (bt.dims && bt.dims[4 * blockIdx.z + 3]) { BT_SHIFT(const float*, V); BT_DIM_M(m); }
+    if ((int)blockIdx.x * 32 >= n || (int)blockIdx.y * 32 >= m) return;
     constexpr int KC = 64;
     __shared__ float Us[32][KC + 1];
     __shared__ float Vs[32][KC + 1];
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(64 * GD_ROWLANES) void gd_best_kernel(const float* 
                                                                    int* __restrict__ colrow, int* __restrict__ ctr, int round, int nrb,
                                                                    Bt bt = Bt{0, nullptr}) {
     BT_SHIFT(const float*, corr); BT_SHIFT(const unsigned char*, row_used); BT_SHIFT(const unsigned char*, col_used);
-    BT_SHIFT(float*, rowval); BT_SHIFT(int*, rowcol); BT_SHIFT(int*, colrow); BT_SHIFT(int*, ctr); BT_DIM_N(n);
+    BT_SHIFT(float*, rowval); BT_SHIFT(int*, rowcol); BT_SHIFT(int*, colrow); BT_SHIFT(int*, ctr); BT_DIM_N(n); BT_DIM_M(m);
     if (ctr[GD_DONE]) return;
     if (round > 0 && ctr[GD_NEW + ((round - 1) & 1)] == 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) ctr[GD_DONE] = 1;
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void gd_accept_kernel(int m, int n, float thr,
                                                         unsigned long long* __restrict__ keys, int* __restrict__ ctr, int round,
                                                         Bt bt = Bt{0, nullptr}) {
     BT_SHIFT(const float*, rowval); BT_SHIFT(const int*, rowcol); BT_SHIFT(const int*, colrow); BT_SHIFT(unsigned char*, row_used);
-    BT_SHIFT(unsigned char*, col_used); BT_SHIFT(unsigned long long*, keys); BT_SHIFT(int*, ctr); BT_DIM_N(n);
+    BT_SHIFT(unsigned char*, col_used); BT_SHIFT(unsigned long long*, keys); BT_SHIFT(int*, ctr); BT_DIM_N(n); BT_DIM_M(m);
     if (ctr[GD_DONE]) return;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= m || row_used[t]) return;
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(1024) void gd_finalize_kernel(const unsigned long l
 __global__ __launch_bounds__(256) void prior_fill_kernel(double* __restrict__ prior, int m, int n, int mode,
                                                          const int32_t* __restrict__ pairs, const int32_t* __restrict__ n_pairs,
                                                          int* __restrict__ row_match /* [m] scratch */, Bt bt = Bt{0, nullptr}) {
-    BT_SHIFT(double*, prior); BT_SHIFT(const int32_t*, pairs); BT_SHIFT(const int32_t*, n_pairs); BT_SHIFT(int*, row_match); BT_DIM_N(n);
+    BT_SHIFT(double*, prior); BT_SHIFT(const int32_t*, pairs); BT_SHIFT(const int32_t*, n_pairs); BT_SHIFT(int*, row_match); BT_DIM_N(n); BT_DIM_M(m);
     // pass A (blockIdx.y == 0): row_match[t] = matched ref or -1
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t tot = (size_t)m * n;
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void prior_fill_kernel(double* __restrict__ pr
 }
 
 __global__ void row_match_kernel(int* __restrict__ row_match, int m, Bt bt = Bt{0, nullptr}) {
-    BT_SHIFT(int*, row_match);
+    BT_SHIFT(int*, row_match); BT_DIM_M(m);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid < m) row_match[tid] = -1;
 }
@@ -2303,6 +2304,134 @@ int ct_legacy_predict_pos(ct_ffn_t* ffn, const double* seg_pre, int n, const dou
     }
     if (C_out) HIPCHK(hipMemcpyAsync(C_out, Cs, (size_t)reps * n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (inter_out) HIPCHK(hipMemcpyAsync(inter_out, inter, (size_t)reps * n3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return CT_OK;
+}
+
+// FFN scores + greedy prior (the front half of TrackerLite.predict_cell_positions, trackerlite.py:83-91: initial_matching_ffn ->
+// simple_match) for B independent problems as one chain of launches; ragged reference AND target sets.  prior_out[b] [dev] fp64
+// [m[b]][n[b]].  Bit-identical to ct_knn_features x 2 + ct_ffn_pairgrid + ct_greedy_match per problem.  Synchronises `stream`.
+struct MatchFrontSlab { size_t ref, tgt, featr, featt, Hr, Ht, U, V, corr, pairs, gd, gd_keys, gd_ctr, gd_words, prior, size; };
+static MatchFrontSlab match_front_slab(int nmax, int mmax, int k) {
+    MatchFrontSlab L{}; size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
+    const size_t n = (size_t)nmax, m = (size_t)mmax, fw = (size_t)(3 * k + 1);
+    L.ref = take(n * 24); L.tgt = take(m * 24); L.featr = take(n * fw * 4); L.featt = take(m * fw * 4);
+    L.Hr = take(n * HID * 4); L.Ht = take(m * HID * 4); L.U = take(n * HID * 4); L.V = take(m * HID * 4); L.corr = take(m * n * 4);
+    L.pairs = take(n * 8 + 8);
+    L.gd = o;
+    take(m); take(n); take(m * 4); take(m * 4); take(m * 4); take(n * 4);
+    L.gd_keys = take((m > n ? m : n) * 8); L.gd_ctr = take(256);
+    L.gd_words = (o - L.gd) / 4;
+    L.prior = take(m * n * 8);
+    L.size = o;
+    return L;
+}
+size_t ct_match_front_batched_workspace_bytes(int B, int nmax, int mmax, int k_ptrs) {
+    if (B <= 0 || nmax <= 0 || mmax <= 0 || k_ptrs <= 0) return 0;
+    return (size_t)B * match_front_slab(nmax, mmax, k_ptrs).size + 3 * align_up((size_t)B * 16, 256) + 512;
+}
+int ct_match_front_batched(ct_ffn_t* ffn, int B, const double* const* ref, const int* n, const double* const* tgt, const int* m, int k_ptrs,
+                           float threshold, int mode, double* const* prior_out, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (!ffn || B <= 0 || !ref || !n || !tgt || !m || !prior_out || !workspace || k_ptrs <= 0 || (mode != 0 && mode != 1)) return CT_EINVAL;
+    int nmax = 0, mmax = 0;
+    for (int b = 0; b < B; ++b) {
+        if (!ref[b] || !tgt[b] || !prior_out[b] || n[b] <= k_ptrs || m[b] <= k_ptrs) return CT_EINVAL;
+        nmax = n[b] > nmax ? n[b] : nmax; mmax = m[b] > mmax ? m[b] : mmax;
+    }
+    if (nmax > KNN_MAXN || mmax > KNN_MAXN || (nmax < mmax ? nmax : mmax) > 16384) return CT_ESHAPE;
+    if (workspace_bytes < ct_match_front_batched_workspace_bytes(B, nmax, mmax, k_ptrs)) return CT_EWORKSPACE;
+    DeviceGuard dg(ffn->device);
+    if (dg.err != hipSuccess) return (int)dg.err;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* base = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const MatchFrontSlab L = match_front_slab(nmax, mmax, k_ptrs);
+    unsigned char* shared = base + (size_t)B * L.size;
+    int* d_dims = (int*)shared; shared += align_up((size_t)B * 16, 256);      // {m, n, 0, 1}: problem sizes; [3] = 1: per-problem target half
+    int* d_dimsT = (int*)shared; shared += align_up((size_t)B * 16, 256);     // {n, m, ..}: the same table seen from the target set
+    int* d_ctr = (int*)shared;
+    std::vector<int> hd((size_t)B * 8, 0), hctr((size_t)B * 4, 0);
+    for (int b = 0; b < B; ++b) { hd[4 * b] = m[b]; hd[4 * b + 1] = n[b]; hd[4 * b + 3] = 1; hd[4 * B + 4 * b] = n[b]; hd[4 * B + 4 * b + 1] = m[b]; }
+    HIPCHK(hipMemcpyAsync(d_dims, hd.data(), (size_t)B * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_dimsT, hd.data() + 4 * B, (size_t)B * 16, hipMemcpyHostToDevice, st));
+    const Bt bt{L.size / sizeof(double), d_dims}, btT{L.size / sizeof(double), d_dimsT};
+    const unsigned zB = (unsigned)B;
+    auto at = [&](size_t off) { return base + off; };
+    for (int b = 0; b < B; ++b) {
+        unsigned char* sb = base + (size_t)b * L.size;
+        HIPCHK(hipMemcpyAsync(sb + L.ref, ref[b], (size_t)n[b] * 24, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(sb + L.tgt, tgt[b], (size_t)m[b] * 24, hipMemcpyDeviceToDevice, st));
+    }
+    ENSURE_BIG_LDS(gd_finalize_kernel);
+    const float* W = ffn->d_w;
+    float* featr = (float*)at(L.featr); float* featt = (float*)at(L.featt); float* Hr = (float*)at(L.Hr); float* Ht = (float*)at(L.Ht);
+    float* U = (float*)at(L.U); float* V = (float*)at(L.V); float* corr = (float*)at(L.corr);
+    hipLaunchKernelGGL(knn_features_kernel, dim3(nmax, 1, zB), dim3(64), 0, st, (const double*)at(L.ref), nmax, k_ptrs, featr, bt);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn_features_kernel, dim3(mmax, 1, zB), dim3(64), 0, st, (const double*)at(L.tgt), mmax, k_ptrs, featt, btT);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, featr, FEAT, W + ffn->o_w1, Hr, nmax, HID, FEAT, W + ffn->o_bn1, bt);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (mmax + 63) / 64, zB), dim3(256), 0, st, featt, FEAT, W + ffn->o_w1, Ht, mmax, HID, FEAT, W + ffn->o_bn1, btT);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, Hr, HID, W + ffn->o_w2, U, nmax, HID, HID, (const float*)nullptr, bt);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (mmax + 63) / 64, zB), dim3(256), 0, st, Ht, HID, W + ffn->o_w2 + (size_t)HID * HID, V, mmax, HID, HID,
+                       (const float*)nullptr, btT);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(ffn_pair_kernel, dim3((nmax + 31) / 32, (mmax + 31) / 32, zB), dim3(256), 0, st, U, nmax, V, mmax, W + ffn->o_bn2, W + ffn->o_w3, ffn->b3, corr, bt);
+    LAUNCH_CHECK();
+    unsigned char* gd = at(L.gd);
+    unsigned char* row_used = gd; size_t go = align_up((size_t)mmax, 256);
+    unsigned char* col_used = gd + go; go += align_up((size_t)nmax, 256);
+    float* rowval = (float*)(gd + go); go += align_up((size_t)mmax * 4, 256);
+    int* rowcol = (int*)(gd + go); go += align_up((size_t)mmax * 4, 256);
+    int* row_match = (int*)(gd + go); go += align_up((size_t)mmax * 4, 256);
+    int* colrow = (int*)(gd + go);
+    unsigned long long* keys = (unsigned long long*)at(L.gd_keys); int* ctr = (int*)at(L.gd_ctr);
+    int32_t* pairs = (int32_t*)at(L.pairs); int32_t* npairs = pairs + 2 * nmax;
+    double* prior = (double*)at(L.prior);
+    hipLaunchKernelGGL(bt_zero_kernel, dim3(8, 1, zB), dim3(256), 0, st, gd, (int)L.gd_words, bt);
+    LAUNCH_CHECK();
+    const int nrb = (mmax + GD_ROWLANES - 1) / GD_ROWLANES, ncb = (nmax + 63) / 64;
+    const int max_rounds = (mmax < nmax ? mmax : nmax) + 1;
+    int maxcnt = 0;
+    for (int done_rounds = 0; done_rounds < max_rounds;) {
+        const int chunk = done_rounds == 0 ? 12 : 8;
+        for (int k = 0; k < chunk; ++k) {
+            const int round = done_rounds + k;
+            hipLaunchKernelGGL(gd_best_kernel, dim3(nrb + ncb, 1, zB), dim3(64 * GD_ROWLANES), 0, st, corr, mmax, nmax, row_used, col_used, rowval, rowcol, colrow,
+                               ctr, round, nrb, bt);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(gd_accept_kernel, dim3((mmax + 255) / 256, 1, zB), dim3(256), 0, st, mmax, nmax, threshold, rowval, rowcol, colrow, row_used,
+                               col_used, keys, ctr, round, bt);
+            LAUNCH_CHECK();
+        }
+        done_rounds += chunk;
+        hipLaunchKernelGGL(bt_gather_ctr_kernel, dim3((B + 63) / 64), dim3(64), 0, st, ctr, bt.stride, B, d_ctr);
+        LAUNCH_CHECK();
+        HIPCHK(hipMemcpyAsync(hctr.data(), d_ctr, hctr.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        bool all_done = true; maxcnt = 0;
+        for (int b = 0; b < B; ++b) {
+            if (!(hctr[4 * b + GD_DONE] || hctr[4 * b + GD_NEW + ((done_rounds - 1) & 1)] == 0)) all_done = false;
+            maxcnt = hctr[4 * b + GD_COUNT] > maxcnt ? hctr[4 * b + GD_COUNT] : maxcnt;
+        }
+        if (all_done) break;
+    }
+    {
+        int p2 = 1; while (p2 < maxcnt) p2 <<= 1;
+        hipLaunchKernelGGL(gd_finalize_kernel, dim3(1, 1, zB), dim3(1024), (size_t)p2 * 8, st, keys, ctr, nmax, pairs, npairs, bt);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(row_match_kernel, dim3((mmax + 255) / 256, 1, zB), dim3(256), 0, st, row_match, mmax, bt);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(row_match_set_kernel, dim3((nmax + 255) / 256, 1, zB), dim3(256), 0, st, row_match, pairs, npairs, bt);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(prior_fill_kernel, dim3((unsigned)(((size_t)mmax * nmax + 255) / 256), 1, zB), dim3(256), 0, st, prior, mmax, nmax, mode, pairs, npairs,
+                       row_match, bt);
+    LAUNCH_CHECK();
+    for (int b = 0; b < B; ++b)
+        HIPCHK(hipMemcpyAsync(prior_out[b], base + (size_t)b * L.size + L.prior, (size_t)m[b] * n[b] * sizeof(double), hipMemcpyDeviceToDevice, st));
     return CT_OK;
 }
 

@@ -168,16 +168,22 @@ def match_device(ffn_model: FFN, seg_t1_n, seg_t2_m, confirmed_l, beta, lambda_,
 
 
 def match_device_batched(ffn_model: FFN, problems, beta, lambda_, max_iteration=MAX_ITERATION, k=K_POINTS, threshold=0.1):
-    """match_device for a list of independent (seg_t1_n, seg_t2_m, confirmed_l) problems: FFN scores and the greedy prior one
-    problem after the other, then ALL PR-GLS runs in one chain of launches (ct_prgls_two_ref_batched; the GPU retires the ~10
+    """match_device for a list of independent (seg_t1_n, seg_t2_m, confirmed_l) problems: FFN scores and the greedy priors of all
+    problems in one chain of launches, then ALL PR-GLS runs in another (ct_prgls_two_ref_batched; the GPU retires the ~10
     tiny dependent kernels of an EM iteration at the same rate for one problem as for twenty).  Results are bit-identical to
     [match_device(...) for ...].  -> list of ((l, 3) device tensor, iterations)."""
     batch = []
     for seg_t1_n, seg_t2_m, confirmed_l in problems:
         _dev.check_match_sizes(seg_t1_n.shape[0], seg_t2_m.shape[0], k, "match_device_batched")
-        corr = initial_matching_device(ffn_model, seg_t1_n, seg_t2_m, k)
-        _, _, prior = _dev.greedy_match(corr, threshold, 0)
-        batch.append((prior, seg_t2_m, seg_t1_n, confirmed_l))
+    if isinstance(ffn_model, FFN) and ffn_model._handle is not None and len(problems) > 1:
+        # FFN scores and greedy priors of all problems as one chain of launches too (ct_match_front_batched)
+        priors = _dev.match_front_batched(ffn_model._handle, [p[0] for p in problems], [p[1] for p in problems], k, threshold, 0)
+        batch = [(priors[i], p[1], p[0], p[2]) for i, p in enumerate(problems)]
+    else:
+        for seg_t1_n, seg_t2_m, confirmed_l in problems:
+            corr = initial_matching_device(ffn_model, seg_t1_n, seg_t2_m, k)
+            _, _, prior = _dev.greedy_match(corr, threshold, 0)
+            batch.append((prior, seg_t2_m, seg_t1_n, confirmed_l))
     res = _dev.prgls_two_ref_batched(batch, beta, lambda_, max_iteration)
     return [(r[0], r[3]) for r in res]
 

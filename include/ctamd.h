@@ -234,6 +234,15 @@ int ct_solve_movements(double sigma_square, double lambda, const double* P, cons
 int ct_gram_apply(double* pred, int l, const double* inter, int n, const double* C, double beta,
                   ct_stream_t stream);
 
+/* The front half of TrackerLite.predict_cell_positions (trackerlite.py:83-91: initial_matching_ffn -> simple_match) for B independent
+ * problems as ONE chain of launches (problem b = blockIdx.z; ragged reference and target sets): ref[b] [dev] fp64 [n[b]][3], tgt[b] [dev]
+ * fp64 [m[b]][3] (host arrays of device pointers) -> prior_out[b] [dev] fp64 [m[b]][n[b]] (mode 0: simple_match's prior, 1: the legacy one).
+ * Bit-identical to ct_knn_features x 2 + ct_ffn_pairgrid + ct_greedy_match per problem; feeds ct_prgls_two_ref_batched.
+ * Synchronises `stream` (greedy round counters).                                                                                 */
+size_t ct_match_front_batched_workspace_bytes(int B, int nmax, int mmax, int k_ptrs);
+int ct_match_front_batched(ct_ffn_t* ffn, int B, const double* const* ref, const int* n, const double* const* tgt, const int* m, int k_ptrs,
+                           float threshold, int mode, double* const* prior_out, void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
 /* Tracker._predict_pos_once (tracker.py:1193-1222) for one source volume in ONE call: `reps` x [kNN features -> FFN pair grid ->
  * pr_gls_quick with beta * 0.8^i, every repetition starting from the previous one's transformed points] (_fit_ffn_prgls :1224-1254),
  * then _predict_one_rep (:1269-1289) for every repetition on the tracked points.  seg_pre [dev] fp64 [n][3], seg_tgt [m][3],

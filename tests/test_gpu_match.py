@@ -606,3 +606,30 @@ def test_legacy_predict_pos_batched_is_bit_identical_to_per_volume_calls(ffn):
     big = [dev.points_dev(rng.uniform(0, 1, (140, 3)) * 100)]
     with pytest.raises(Exception):
         dev.legacy_predict_pos_batched(ffn._handle, big, tgt, trk[:1], 1000.0, 1e-5, 10, 5, 20)      # 140 > 132: CT_ESHAPE
+
+
+def test_match_front_batched_is_bit_identical_to_per_problem_calls(ffn):
+    """ct_match_front_batched (FFN scores + greedy prior of B problems in one chain of launches, ragged reference and target sets)
+    against initial_matching_device + greedy_match per problem: priors bit-identical for noise scores (many greedy rounds) and both
+    prior dialects; match_device_batched (which now uses it) still equals match_device problem by problem."""
+    import torch
+    rng = np.random.default_rng(41)
+    refs, tgts = [], []
+    for b in range(6):
+        n, m = int(rng.integers(40, 200)), int(rng.integers(40, 200))
+        refs.append(dev.points_dev(rng.normal(size=(n, 3)))); tgts.append(dev.points_dev(rng.normal(size=(m, 3))))
+    for mode, thr in ((0, 0.1), (1, 0.5)):
+        got = dev.match_front_batched(ffn._handle, refs, tgts, 20, thr, mode)
+        for b in range(6):
+            corr = ffn_mod.initial_matching_device(ffn, refs[b], tgts[b], 20)
+            _, _, want = dev.greedy_match(corr, thr, mode)
+            assert torch.equal(got[b], want), f"mode {mode} problem {b}"
+    problems = []
+    for b in range(3):
+        x, y = synth.make_point_pair(150 + 10 * b, seed=60 + b)
+        xn, (mean, scale) = mr.normalize_points(x, return_para=True); yn = (y - mean) / scale
+        problems.append((dev.points_dev(xn), dev.points_dev(yn), dev.points_dev(xn[:100])))
+    single = [tl.match_device(ffn, *p, beta=3, lambda_=3) for p in problems]
+    batched = tl.match_device_batched(ffn, problems, beta=3, lambda_=3)
+    for (a, ia), (b_, ib) in zip(single, batched):
+        assert torch.equal(a, b_) and ia == ib
