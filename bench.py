@@ -380,14 +380,11 @@ def main():
     ap.add_argument("--realistic-match-cus", type=int, default=32, help="match partition of the informative pass with the discriminating FFN")
     ap.add_argument("--priority-streams", action="store_true", help="headline pass without a CU partition: U-Net on a normal-priority full-chip stream, match chains on high-priority streams (loses with the 364-iteration matches of the random-init FFN: 63 vs 89 volumes/s)")
     ap.add_argument("--realistic-partition", action="store_true", help="discriminating-FFN pass on a CU partition (--realistic-match-cus) instead of priority streams (116 vs 121 volumes/s)")
-    ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval for the run (0: leave the default 5 ms)")
     ap.add_argument("--match-batch", type=int, default=16, help="frames whose matches share one chain of launches (ct_prgls_two_ref_batched); capped at steps // 4 so that a short run still overlaps its matches with the U-Net")
     ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
     ap.add_argument("--cpu-patches", type=int, default=20, help="U-Net patches timed by the CPU baseline sample")
     args = ap.parse_args()
     args.match_batch = max(1, min(args.match_batch, max(1, args.steps // 4)))
-    if args.switch_interval > 0:
-        sys.setswitchinterval(args.switch_interval)
 
     import torch
     import torch.distributed as dist
