@@ -371,7 +371,11 @@ __global__ __launch_bounds__(64) void ffn_rows_finish_kernel(const float* __rest
 // sequential loop would pick.  Each round is three data-parallel kernels; the number of rounds is O(log n) for
 // generic inputs.  The threshold test of the reference (stop at the first maximum below it) == never accept an
 // edge below it.  A final sort by the same order recovers the reference's pick sequence.
-constexpr int GD_ROWLANES = 16;
+constexpr int GD_ROWLANES = 16;      // single match: 1024-thread workgroups keep the column pass short
+// batched chains share the chip with other streams: a 1024-thread workgroup needs 4 free wave slots on EVERY SIMD of one CU and
+// starves behind the 256-thread workgroups of the neighbouring chains (466 us per launch under the frame pipeline against 10 us
+// alone), so they use 256 threads.  Both reductions pick (max value, lowest index): the result does not depend on the split.
+constexpr int GD_ROWLANES_BATCH = 4;
 enum { GD_COUNT = 0, GD_NEW = 1 /* and 2: one counter per round parity */, GD_DONE = 3 };
 
 // One round = two launches.  gd_best_kernel: blocks [0, nrb) find every free row's best free column (16 rows per block, one wave
@@ -379,7 +383,8 @@ enum { GD_COUNT = 0, GD_NEW = 1 /* and 2: one counter per round parity */, GD_DO
 // locally dominant edges.  Termination without a separate launch: accept of round k counts into NEW[k & 1]; round k + 1 starts by
 // looking at that counter (zero -> nothing was accepted -> done, every block leaves) and re-arms NEW[(k + 1) & 1], which nobody
 // touches in between.  (Round 1: four launches per round -- row best, column best, accept, round end.)
-__global__ __launch_bounds__(64 * GD_ROWLANES) void gd_best_kernel(const float* __restrict__ corr, int m, int n,
+template <int RL>
+__global__ __launch_bounds__(64 * RL) void gd_best_kernel(const float* __restrict__ corr, int m, int n,
                                                                    const unsigned char* __restrict__ row_used,
                                                                    const unsigned char* __restrict__ col_used,
                                                                    float* __restrict__ rowval, int* __restrict__ rowcol,
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(64 * GD_ROWLANES) void gd_best_kernel(const float* 
     if (blockIdx.x == 0 && threadIdx.x == 0) ctr[GD_NEW + (round & 1)] = 0;      // re-arm this round's counter
     if ((int)blockIdx.x < nrb) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const int t = blockIdx.x * GD_ROWLANES + wave;
+        const int t = blockIdx.x * RL + wave;
         if (t >= m) return;
         if (row_used[t]) { if (lane == 0) rowcol[t] = -1; return; }
         const float* row = corr + (size_t)t * n;
@@ -413,13 +418,13 @@ __global__ __launch_bounds__(64 * GD_ROWLANES) void gd_best_kernel(const float* 
         if (lane == 0) { rowval[t] = best; rowcol[t] = (bi == 0x7fffffff) ? -1 : bi; }
         return;
     }
-    __shared__ float sv[GD_ROWLANES][64];
-    __shared__ int si[GD_ROWLANES][64];
+    __shared__ float sv[RL][64];
+    __shared__ int si[RL][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int r = ((int)blockIdx.x - nrb) * 64 + cl;
     float best = -1.f; int btg = 0x7fffffff;
     if (r < n && !col_used[r])
-        for (int t = rl; t < m; t += GD_ROWLANES) {
+        for (int t = rl; t < m; t += RL) {
             if (row_used[t]) continue;
             const float v = corr[(size_t)t * n + r];
             if (v > best) { best = v; btg = t; }                       // ascending t => lowest row on ties
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(64 * GD_ROWLANES) void gd_best_kernel(const float* 
     sv[rl][cl] = best; si[rl][cl] = btg;
     __syncthreads();
     if (rl == 0 && r < n) {
-        for (int q = 1; q < GD_ROWLANES; ++q) {
+        for (int q = 1; q < RL; ++q) {
             const float ov = sv[q][cl]; const int oi = si[q][cl];
             if (ov > best || (ov == best && oi < btg)) { best = ov; btg = oi; }
         }
@@ -1714,7 +1719,7 @@ int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, 
         const int nrb = (m + GD_ROWLANES - 1) / GD_ROWLANES, ncb = (n + 63) / 64;
         for (int k = 0; k < chunk; ++k) {
             const int round = done_rounds + k;
-            hipLaunchKernelGGL(gd_best_kernel, dim3(nrb + ncb), dim3(64 * GD_ROWLANES), 0, st, corr, m, n, row_used, col_used, rowval, rowcol,
+            hipLaunchKernelGGL(gd_best_kernel<GD_ROWLANES>, dim3(nrb + ncb), dim3(64 * GD_ROWLANES), 0, st, corr, m, n, row_used, col_used, rowval, rowcol,
                                colrow, ctr, round, nrb);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(gd_accept_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, n, threshold, rowval, rowcol, colrow,
@@ -2392,14 +2397,14 @@ int ct_match_front_batched(ct_ffn_t* ffn, int B, const double* const* ref, const
     double* prior = (double*)at(L.prior);
     hipLaunchKernelGGL(bt_zero_kernel, dim3(8, 1, zB), dim3(256), 0, st, gd, (int)L.gd_words, bt);
     LAUNCH_CHECK();
-    const int nrb = (mmax + GD_ROWLANES - 1) / GD_ROWLANES, ncb = (nmax + 63) / 64;
+    const int nrb = (mmax + GD_ROWLANES_BATCH - 1) / GD_ROWLANES_BATCH, ncb = (nmax + 63) / 64;
     const int max_rounds = (mmax < nmax ? mmax : nmax) + 1;
     int maxcnt = 0;
     for (int done_rounds = 0; done_rounds < max_rounds;) {
         const int chunk = done_rounds == 0 ? 12 : 8;
         for (int k = 0; k < chunk; ++k) {
             const int round = done_rounds + k;
-            hipLaunchKernelGGL(gd_best_kernel, dim3(nrb + ncb, 1, zB), dim3(64 * GD_ROWLANES), 0, st, corr, mmax, nmax, row_used, col_used, rowval, rowcol, colrow,
+            hipLaunchKernelGGL(gd_best_kernel<GD_ROWLANES_BATCH>, dim3(nrb + ncb, 1, zB), dim3(64 * GD_ROWLANES_BATCH), 0, st, corr, mmax, nmax, row_used, col_used, rowval, rowcol, colrow,
                                ctr, round, nrb, bt);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(gd_accept_kernel, dim3((mmax + 255) / 256, 1, zB), dim3(256), 0, st, mmax, nmax, threshold, rowval, rowcol, colrow, row_used,
@@ -2511,7 +2516,7 @@ int ct_legacy_predict_pos_batched(ct_ffn_t* ffn, int B, const double* const* seg
     int rc;
     if ((rc = gemm(feat_tgt, FEAT, W + ffn->o_w1, Ht, m, HID, FEAT, W + ffn->o_bn1, st))) return rc;
     if ((rc = gemm(Ht, HID, W + ffn->o_w2 + (size_t)HID * HID, V, m, HID, HID, nullptr, st))) return rc;
-    const int nrb = (m + GD_ROWLANES - 1) / GD_ROWLANES, ncb = (nmax + 63) / 64;
+    const int nrb = (m + GD_ROWLANES_BATCH - 1) / GD_ROWLANES_BATCH, ncb = (nmax + 63) / 64;
     for (int i = 0; i < reps; ++i) {
         const double bi = beta * pow(0.8, (double)i);
         double* X = (double*)at(L.inter) + (size_t)i * n3max;               // this repetition's reference points (slab-relative)
@@ -2547,7 +2552,7 @@ int ct_legacy_predict_pos_batched(ct_ffn_t* ffn, int B, const double* const* seg
             const int chunk = done_rounds == 0 ? 12 : 8;
             for (int k = 0; k < chunk; ++k) {
                 const int round = done_rounds + k;
-                hipLaunchKernelGGL(gd_best_kernel, dim3(nrb + ncb, 1, zB), dim3(64 * GD_ROWLANES), 0, st, corr, m, nmax, row_used, col_used, rowval, rowcol,
+                hipLaunchKernelGGL(gd_best_kernel<GD_ROWLANES_BATCH>, dim3(nrb + ncb, 1, zB), dim3(64 * GD_ROWLANES_BATCH), 0, st, corr, m, nmax, row_used, col_used, rowval, rowcol,
                                    colrow, ctr, round, nrb, bt);
                 LAUNCH_CHECK();
                 hipLaunchKernelGGL(gd_accept_kernel, dim3((m + 255) / 256, 1, zB), dim3(256), 0, st, m, nmax, 0.5f, rowval, rowcol, colrow, row_used,

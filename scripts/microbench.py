@@ -7,7 +7,7 @@
     python scripts/microbench.py segment               ct_segment_centroids
     python scripts/microbench.py correction            ct_accurate_correction (600 cells)
     python scripts/microbench.py match [n gain shift]  FFN + greedy + PR-GLS, per-iteration time
-    python scripts/microbench.py batched [n]           B matches as one batched PR-GLS chain vs separate calls
+    python scripts/microbench.py batched [n [B]]       B matches as one batched PR-GLS chain vs separate calls
     python scripts/microbench.py goodprior [n]         PR-GLS with a prior as a trained FFN gives it
     python scripts/microbench.py legacy [n ...]        legacy Tracker._predict_pos_once
     python scripts/microbench.py ensemble              20 x 600-cell matches, 1..8 chains in flight
@@ -142,7 +142,7 @@ def cmd_batched(args):
     _, _, prior = _dev.greedy_match(corr, 0.1, 0)
     t1, out = timeit(lambda: _dev.prgls_two_ref(prior, b, a, a, 3.0, 3.0, 2000, want_posterior=False), reps=2, warm=1)
     print(f"single: {t1*1e3:.1f} ms, {out[-1]} iterations -> {t1/out[-1]*1e6:.1f} us/iteration")
-    for B in (1, 2, 4, 8):
+    for B in ([int(args[1])] if len(args) > 1 else (1, 2, 4, 8, 16)):
         tb, res = timeit(lambda: _dev.prgls_two_ref_batched([(prior, b, a, a)] * B, 3.0, 3.0, 2000), reps=2, warm=1)
         print(f"batched B={B}: {tb*1e3:.1f} ms = {tb/B*1e3:.1f} ms per match, {tb/res[0][3]*1e6:.1f} us/iteration")
 
