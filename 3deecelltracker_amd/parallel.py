@@ -278,11 +278,22 @@ class FramePipeline:
                                    for i in range(self.workers)]
         else:
             self._match_streams = [cu_stream(0, self.match_cus) for _ in range(self.workers)]
+        # pre-processing of the NEXT frame (LCN: HBM-bound, 0.3 ms) can ride on the match partition while the U-Net of the current
+        # frame owns the big one: `with torch.cuda.stream(pipe.prep_stream)` + an event the seg stream waits on
+        # (created on first use: every extra stream takes a hardware queue, and an idle fifth one measurably slows the others)
+        self._prep_stream = None
+        self._make_prep = (lambda: torch.cuda.Stream(device=f"cuda:{device}", priority=-1)) if priority else (lambda: cu_stream(0, self.match_cus))
         self._tls = threading.local()
         self._free = list(range(self.workers))
         self._lock = threading.Lock()
         self._pool = ThreadPoolExecutor(max_workers=self.workers)
         self._inflight = []
+
+    @property
+    def prep_stream(self):
+        if self._prep_stream is None:
+            self._prep_stream = self._make_prep()
+        return self._prep_stream
 
     def _run(self, fn, args):
         import torch
