@@ -969,6 +969,112 @@ __global__ __launch_bounds__(256) void lr_gram_kernel(int n, const double* __res
     }
 }
 
+// The same sums, 4 x 4 entries per wave (lr_gram_kernel re-reads two rows of U per ENTRY: 31 MB through the caches per 600-point
+// problem and the third-largest kernel of a batched chain).  Bit-identical by construction: every lane accumulates the same
+// i = lane (mod 64) terms in the same order, and the 16 butterflies run "transposed" (at each step a lane keeps half of its
+// accumulators and hands the other half to its partner; fp add is commutative, so the kept sums equal wave_sum_d's bit for bit).
+constexpr int LG_T = 4;
+constexpr int LG_UN = 4;                       // i-steps whose loads are in flight together
+__device__ __forceinline__ void wave_sum16_d(double (&acc)[16], int lane) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int mk = 32 >> s;
+        const bool hi = (lane & mk) != 0;
+#pragma unroll
+        for (int k = 0; k < (8 >> s); ++k) {
+            const double a = acc[2 * k], b = acc[2 * k + 1];
+            const double send = hi ? a : b, keep = hi ? b : a;
+            acc[k] = keep + shfl_xor_d(send, mk);
+        }
+    }
+    acc[0] += shfl_xor_d(acc[0], 2);
+    acc[0] += shfl_xor_d(acc[0], 1);              // lane holds entry q = 8 bit2 + 4 bit3 + 2 bit4 + bit5 (bits of its lane number)
+}
+__global__ __launch_bounds__(256) void lr_gram_tiled_kernel(int n, const double* __restrict__ U, const int* __restrict__ rank_p,
+                                                            const double* __restrict__ sc, const double* __restrict__ dvec,
+                                                            const double* __restrict__ sqd, const double* __restrict__ rhs,
+                                                            double* __restrict__ Sout, double* __restrict__ yout, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, U); BT_SHIFT(const int*, rank_p); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
+    BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs); BT_SHIFT(double*, Sout); BT_SHIFT(double*, yout);
+    if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
+    if (sc[S_DONE] != 0.0) return;
+    const int r = *rank_p;
+    const int T = (r + LG_T - 1) / LG_T, ntri = T * (T + 1) / 2;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= ntri + T) return;
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    const int q_mine = ((lane >> 2) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+    if (w < ntri) {
+        int ta = (int)((sqrt(8.0 * w + 1.0) - 1.0) * 0.5);
+        while ((ta + 1) * (ta + 2) / 2 <= w) ++ta;
+        while (ta * (ta + 1) / 2 > w) --ta;
+        const int tb = w - ta * (ta + 1) / 2;
+        const int a0 = ta * LG_T, b0 = tb * LG_T;
+        const double* ua[LG_T]; const double* ub[LG_T];
+#pragma unroll
+        for (int k = 0; k < LG_T; ++k) { ua[k] = U + (size_t)min(a0 + k, r - 1) * n; ub[k] = U + (size_t)min(b0 + k, r - 1) * n; }
+        // LG_UN steps' operands are fetched together (the wave's time is its chain of load round trips, not its 160 fma);
+        // a step past the end loads a clamped index and skips its fma, so the terms and their order stay the same
+        for (int i0 = lane; i0 < n; i0 += 64 * LG_UN) {
+            double dd[LG_UN], va[LG_UN][LG_T], vb[LG_UN][LG_T];
+#pragma unroll
+            for (int u = 0; u < LG_UN; ++u) {
+                const int i = min(i0 + 64 * u, n - 1);
+                dd[u] = dvec[i];
+#pragma unroll
+                for (int k = 0; k < LG_T; ++k) { va[u][k] = ua[k][i]; vb[u][k] = ub[k][i]; }
+            }
+#pragma unroll
+            for (int u = 0; u < LG_UN; ++u) {
+                if (i0 + 64 * u < n) {
+#pragma unroll
+                    for (int k = 0; k < LG_T; ++k) {
+                        const double wa = va[u][k] * dd[u];
+#pragma unroll
+                        for (int j = 0; j < LG_T; ++j) acc[k * LG_T + j] = fma(wa, vb[u][j], acc[k * LG_T + j]);
+                    }
+                }
+            }
+        }
+        wave_sum16_d(acc, lane);
+        const int a2 = a0 + q_mine / LG_T, b2 = b0 + q_mine % LG_T;
+        if ((lane & 3) == 0 && a2 < r && b2 <= a2) Sout[a2 * LR_RMAX + b2] = acc[0];
+    } else {
+        const int a0 = (w - ntri) * LG_T;
+        const double* ua[LG_T];
+#pragma unroll
+        for (int k = 0; k < LG_T; ++k) ua[k] = U + (size_t)min(a0 + k, r - 1) * n;
+        for (int i0 = lane; i0 < n; i0 += 64 * LG_UN) {
+            double qq[LG_UN], bb[LG_UN][3], va[LG_UN][LG_T];
+#pragma unroll
+            for (int u = 0; u < LG_UN; ++u) {
+                const int i = min(i0 + 64 * u, n - 1);
+                qq[u] = sqd[i]; bb[u][0] = rhs[3 * i]; bb[u][1] = rhs[3 * i + 1]; bb[u][2] = rhs[3 * i + 2];
+#pragma unroll
+                for (int k = 0; k < LG_T; ++k) va[u][k] = ua[k][i];
+            }
+#pragma unroll
+            for (int u = 0; u < LG_UN; ++u) {
+                if (i0 + 64 * u < n) {
+#pragma unroll
+                    for (int k = 0; k < LG_T; ++k) {
+                        const double wa = va[u][k] * qq[u];
+                        acc[k * LG_T] = fma(wa, bb[u][0], acc[k * LG_T]); acc[k * LG_T + 1] = fma(wa, bb[u][1], acc[k * LG_T + 1]);
+                        acc[k * LG_T + 2] = fma(wa, bb[u][2], acc[k * LG_T + 2]);
+                    }
+                }
+            }
+        }
+        wave_sum16_d(acc, lane);
+        const int a2 = a0 + q_mine / LG_T, d = q_mine % LG_T;
+        if ((lane & 3) == 0 && a2 < r && d < 3) yout[a2 * 3 + d] = acc[0];
+    }
+}
+// CT_GRAM_TILED=0 selects the entry-per-wave kernel (A/B and the bit-identity test)
+static bool gram_tiled() { static const bool v = !(getenv("CT_GRAM_TILED") && getenv("CT_GRAM_TILED")[0] == '0'); return v; }
+
 constexpr int LS_B = 8;
 // In-LDS solve of the SPD system S q = y for 3 right-hand sides stored as rows r..r+2 of S (augmented Cholesky,
 // 8-column blocks, 2 barriers per block; then a blocked back-substitution).  256 threads.  On return rows r..r+2 hold q.
@@ -1801,7 +1907,11 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
         hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((n + 63) / 64), dim3(256), 0, st, w.part, n, xref, w.sc, w.dvec, w.sqd, w.rhs);
         LAUNCH_CHECK();
         const int nent = rank * (rank + 1) / 2 + 3 * rank;
-        hipLaunchKernelGGL(lr_gram_kernel, dim3((nent + 3) / 4), dim3(256), 0, st, n, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs, w.Spart, w.ypart);
+        const int ntile = (rank + LG_T - 1) / LG_T, nwave = ntile * (ntile + 1) / 2 + ntile;
+        if (gram_tiled())
+            hipLaunchKernelGGL(lr_gram_tiled_kernel, dim3((nwave + 3) / 4), dim3(256), 0, st, n, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs, w.Spart, w.ypart);
+        else
+            hipLaunchKernelGGL(lr_gram_kernel, dim3((nent + 3) / 4), dim3(256), 0, st, n, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs, w.Spart, w.ypart);
         LAUNCH_CHECK();
         const size_t lds = (size_t)(rank + 3) * (rank | 1) * sizeof(double);
         hipLaunchKernelGGL(lr_solve_kernel, dim3(1), dim3(256), lds, st, w.Spart, w.ypart, n, w.rank, lambda, w.dvec, w.sc, w.q);
@@ -2096,7 +2206,12 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
                                w.sqd, w.rhs, bt);
             LAUNCH_CHECK();
             const int nent = rank * (rank + 1) / 2 + 3 * rank;
-            hipLaunchKernelGGL(lr_gram_kernel, dim3((nent + 3) / 4, 1, zB), dim3(256), 0, st, nn, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs,
+            const int ntile = (rank + LG_T - 1) / LG_T, nwave = ntile * (ntile + 1) / 2 + ntile;
+            if (gram_tiled())
+                hipLaunchKernelGGL(lr_gram_tiled_kernel, dim3((nwave + 3) / 4, 1, zB), dim3(256), 0, st, nn, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs,
+                                   w.Spart, w.ypart, bt);
+            else
+                hipLaunchKernelGGL(lr_gram_kernel, dim3((nent + 3) / 4, 1, zB), dim3(256), 0, st, nn, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs,
                                w.Spart, w.ypart, bt);
             LAUNCH_CHECK();
             const size_t lds = (size_t)(rank + 3) * (rank | 1) * sizeof(double);

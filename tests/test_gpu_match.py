@@ -633,3 +633,43 @@ def test_match_front_batched_is_bit_identical_to_per_problem_calls(ffn):
     batched = tl.match_device_batched(ffn, problems, beta=3, lambda_=3)
     for (a, ia), (b_, ib) in zip(single, batched):
         assert torch.equal(a, b_) and ia == ib
+
+
+GRAM_CHILD = r"""
+import importlib, sys, hashlib
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+dev = importlib.import_module("3deecelltracker_amd._dev")
+h = hashlib.sha256()
+for n, seed in ((50, 0), (113, 1), (301, 2), (600, 3)):
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(n, 3)) * 0.3
+    b = a[rng.permutation(n)] * 1.05 + rng.normal(size=(n, 3)) * 0.01
+    prior = torch.from_numpy(rng.uniform(0.0, 1.0, (n, n))).cuda()
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    out = dev.prgls_two_ref(prior, tb, ta, ta, 3.0, 3.0, 60, want_posterior=True)
+    res = dev.prgls_two_ref_batched([(prior, tb, ta, ta)] * 3, 3.0, 3.0, 60)
+    torch.cuda.synchronize()
+    for t in list(out[:-1]) + [r[0] for r in res] + [r[1] for r in res]:
+        if torch.is_tensor(t):
+            h.update(t.cpu().numpy().tobytes())
+    h.update(str(out[-1]).encode()); h.update(str([r[3] for r in res]).encode())
+print("HASH", h.hexdigest())
+"""
+
+
+def test_tiled_gram_kernel_is_bit_identical_to_the_entry_per_wave_kernel():
+    """lr_gram_tiled_kernel (4 x 4 entries per wave, transposed butterflies) must reproduce lr_gram_kernel's sums bit for bit:
+    whole PR-GLS runs (single and batched, ranks that are and are not multiples of 4) hash equal with CT_GRAM_TILED=0 and 1."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    hashes = []
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", GRAM_CHILD, str(repo)], env=dict(os.environ, CT_GRAM_TILED=flag), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1])
+    assert hashes[0] == hashes[1]
