@@ -77,6 +77,11 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double shfl_d(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, src); hi = __shfl(hi, src);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
@@ -1074,6 +1079,82 @@ __global__ __launch_bounds__(256) void lr_gram_tiled_kernel(int n, const double*
 }
 // CT_GRAM_TILED=0 selects the entry-per-wave kernel (A/B and the bit-identity test)
 static bool gram_tiled() { static const bool v = !(getenv("CT_GRAM_TILED") && getenv("CT_GRAM_TILED")[0] == '0'); return v; }
+
+// ------------------------------------------------------------------------------------------------
+// Row-group variant of apply_dual_kernel for the batched TrackerLite chain (RG rows per wave).
+// The wave-per-row kernel re-reads the whole coefficient set (C: 14.4 KB at n = 600) for every 4.8-KB row of G it streams, i.e.
+// three quarters of its load instructions and of its L2 traffic are re-reads, and its three butterflies cost as much as its
+// loop.  With RG = 4 rows per wave the C loads are shared and the 12 reductions run transposed (wave_sum16_d).  Every lane still
+// accumulates the same terms in the same order and the butterfly tree is the same: results are bit-identical to the
+// wave-per-row kernel (tests/test_gpu_match.py; CT_ROW_GROUPS=0 selects that one).  B = 16 x 600 points: 29 -> 19 us per launch,
+// 150 -> 140 us per batched EM iteration.  (The same treatment of posterior / dist2_rowsum was measured and dropped: their exp /
+// distance chains need the occupancy of one row per wave - 36 -> 42 us and 18 -> 21 us.)  Single matches keep one row per wave.
+// ------------------------------------------------------------------------------------------------
+constexpr int RG = 4;
+static bool row_groups() { static const bool v = !(getenv("CT_ROW_GROUPS") && getenv("CT_ROW_GROUPS")[0] == '0'); return v; }
+constexpr int RG_MIN_BATCH = 4;                // fewer problems per launch: one row per wave fills the chip better
+// lane that holds entry q after wave_sum16_d
+__device__ __forceinline__ int sum16_lane(int q) { return (((q >> 3) & 1) << 2) | (((q >> 2) & 1) << 3) | (((q >> 1) & 1) << 4) | ((q & 1) << 5); }
+
+__global__ __launch_bounds__(256) void apply_dual_rg_kernel(const double* __restrict__ C, const double* __restrict__ G, int n,
+                                                            double* __restrict__ predn, const double* __restrict__ Gln, int l,
+                                                            double* __restrict__ predl, double* __restrict__ norm_part,
+                                                            const double* __restrict__ sc, const double* __restrict__ dvec,
+                                                            const double* __restrict__ sqd, const double* __restrict__ rhs,
+                                                            double* __restrict__ res_part, Bt bt) {
+    BT_SHIFT(const double*, C); BT_SHIFT(const double*, G); BT_SHIFT(double*, predn); BT_SHIFT(const double*, Gln);
+    BT_SHIFT(double*, predl); BT_SHIFT(double*, norm_part); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
+    BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs);
+    if (res_part) BT_SHIFT(double*, res_part);
+    if (bt.dims) { n = bt.dims[4 * blockIdx.z + 1]; l = bt.dims[4 * blockIdx.z + 2]; }
+    if (sc[S_DONE] != 0.0) return;
+    const bool add = sc[S_IT] >= 1.0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gn = (n + RG - 1) / RG, gl = (l + RG - 1) / RG;
+    int g = blockIdx.x * 4 + wave;
+    if (g >= gn + gl) return;
+    const bool second = g >= gn;
+    if (second) g -= gn;
+    const int rows = second ? l : n;
+    const int j0 = g * RG;
+    const double* base = second ? Gln : G;
+    const double* row[RG];
+#pragma unroll
+    for (int k = 0; k < RG; ++k) row[k] = base + (size_t)min(j0 + k, rows - 1) * n;
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double cx = C[i], cy = C[n + i], cz = C[2 * n + i];
+        double gv[RG];
+#pragma unroll
+        for (int k = 0; k < RG; ++k) gv[k] = row[k][i];
+#pragma unroll
+        for (int k = 0; k < RG; ++k) {
+            acc[4 * k] = fma(cx, gv[k], acc[4 * k]); acc[4 * k + 1] = fma(cy, gv[k], acc[4 * k + 1]);
+            acc[4 * k + 2] = fma(cz, gv[k], acc[4 * k + 2]);
+        }
+    }
+    wave_sum16_d(acc, lane);                       // lane sum16_lane(4 k + d) holds component d of row j0 + k
+    const int q_mine = ((lane >> 2) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+    const int k = q_mine >> 2;
+    const double ax = acc[0];
+    const double ay = shfl_d(acc[0], sum16_lane(4 * k + 1)), az = shfl_d(acc[0], sum16_lane(4 * k + 2));
+    const int j = j0 + k;
+    if ((lane & 3) != 0 || (q_mine & 3) != 0 || j >= rows) return;
+    double* pts = second ? predl : predn;
+    if (add) { pts[3 * j] += ax; pts[3 * j + 1] += ay; pts[3 * j + 2] += az; }
+    if (second) return;
+    norm_part[j] = ax * ax + ay * ay + az * az;
+    if (res_part) {
+        const double c = sc[S_C], d = dvec[j], q = sqd[j];
+        const double bx = q * rhs[3 * j], by = q * rhs[3 * j + 1], bz = q * rhs[3 * j + 2];
+        const double rx = d * ax + c * C[j] - bx, ry = d * ay + c * C[n + j] - by, rz = d * az + c * C[2 * n + j] - bz;
+        const double rr = fabs(rx) + fabs(ry) + fabs(rz);                 // NaN/Inf must not be swallowed by fmax
+        res_part[j] = isfinite(rr) ? fmax(fabs(rx), fmax(fabs(ry), fabs(rz))) : INFINITY;
+        res_part[n + j] = fmax(fabs(bx), fmax(fabs(by), fabs(bz)));
+    }
+}
 
 constexpr int LS_B = 8;
 // In-LDS solve of the SPD system S q = y for 3 right-hand sides stored as rows r..r+2 of S (augmented Cholesky,
@@ -2193,6 +2274,7 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
         } else { rank = hrank[2 * b + 1] > rank ? hrank[2 * b + 1] : rank; ++live; }
     }
     const int total = max_iteration - 1;
+    const bool rgm = B >= RG_MIN_BATCH && row_groups();
     std::vector<double> hsc((size_t)B * S_NUM, 0.0);
     for (int enq = 0; enq < total && live > 0;) {
         const int chunk = prgls_chunk(enq, total);
@@ -2219,8 +2301,12 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
             LAUNCH_CHECK();
             hipLaunchKernelGGL(lr_coeff_kernel, dim3((nn + 63) / 64, 1, zB), dim3(256), 0, st, w.U, nn, w.rank, w.q, w.sqd, w.rhs, w.sc, w.C, bt);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL(apply_dual_kernel, dim3((nn + ll + 3) / 4, 1, zB), dim3(256), 0, st, w.C, w.G, nn, w.predn, w.Gln, ll, w.predl,
-                               w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart, bt);
+            if (rgm)
+                hipLaunchKernelGGL(apply_dual_rg_kernel, dim3(((nn + RG - 1) / RG + (ll + RG - 1) / RG + 3) / 4, 1, zB), dim3(256), 0, st, w.C, w.G, nn,
+                                   w.predn, w.Gln, ll, w.predl, w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart, bt);
+            else
+                hipLaunchKernelGGL(apply_dual_kernel, dim3((nn + ll + 3) / 4, 1, zB), dim3(256), 0, st, w.C, w.G, nn, w.predn, w.Gln, ll, w.predl,
+                                   w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart, bt);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, w.predn, nn, in_tgt, mm, w.P, w.rowpart, w.sc, bt);
             LAUNCH_CHECK();

@@ -641,35 +641,45 @@ import numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 dev = importlib.import_module("3deecelltracker_amd._dev")
 h = hashlib.sha256()
-for n, seed in ((50, 0), (113, 1), (301, 2), (600, 3)):
+probs = []
+for n, seed in ((50, 0), (113, 1), (301, 2), (600, 3), (599, 4)):
     rng = np.random.default_rng(seed)
     a = rng.normal(size=(n, 3)) * 0.3
-    b = a[rng.permutation(n)] * 1.05 + rng.normal(size=(n, 3)) * 0.01
-    prior = torch.from_numpy(rng.uniform(0.0, 1.0, (n, n))).cuda()
+    m = n - (seed % 3)                                        # m != n, and sizes that are not multiples of 4
+    b = (a[rng.permutation(n)] * 1.05 + rng.normal(size=(n, 3)) * 0.01)[:m]
+    prior = torch.from_numpy(rng.uniform(0.0, 1.0, (m, n))).cuda()
     ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
-    out = dev.prgls_two_ref(prior, tb, ta, ta, 3.0, 3.0, 60, want_posterior=True)
-    res = dev.prgls_two_ref_batched([(prior, tb, ta, ta)] * 3, 3.0, 3.0, 60)
-    torch.cuda.synchronize()
-    for t in list(out[:-1]) + [r[0] for r in res] + [r[1] for r in res]:
+    trk = torch.from_numpy(a[: n - 7] + 0.001).cuda()         # tracked set != ref set, l != n
+    probs.append((prior, tb, ta, trk))
+    out = dev.prgls_two_ref(prior, tb, ta, trk, 3.0, 3.0, 60, want_posterior=True)
+    for t in out[:-1]:
         if torch.is_tensor(t):
             h.update(t.cpu().numpy().tobytes())
-    h.update(str(out[-1]).encode()); h.update(str([r[3] for r in res]).encode())
+    h.update(str(out[-1]).encode())
+res = dev.prgls_two_ref_batched(probs, 3.0, 3.0, 60)          # ragged batch of 5: the row-group kernels
+torch.cuda.synchronize()
+for r in res:
+    for t in r[:3]:
+        if torch.is_tensor(t):
+            h.update(t.cpu().numpy().tobytes())
+    h.update(str(r[3]).encode())
 print("HASH", h.hexdigest())
 """
 
 
-def test_tiled_gram_kernel_is_bit_identical_to_the_entry_per_wave_kernel():
-    """lr_gram_tiled_kernel (4 x 4 entries per wave, transposed butterflies) must reproduce lr_gram_kernel's sums bit for bit:
-    whole PR-GLS runs (single and batched, ranks that are and are not multiples of 4) hash equal with CT_GRAM_TILED=0 and 1."""
+def test_tiled_gram_and_row_group_kernels_are_bit_identical_to_the_simple_kernels():
+    """lr_gram_tiled_kernel (4 x 4 entries per wave, transposed butterflies) and the row-group variant of apply_dual (4 rows per
+    wave) must reproduce the entry-per-wave / wave-per-row kernels' sums bit for bit: whole PR-GLS runs
+    (single, and a ragged batch with m != n != l, sizes and ranks that are not multiples of 4) hash equal under every switch."""
     import os
     import subprocess
     import sys
     from pathlib import Path
     repo = Path(__file__).resolve().parent.parent
-    hashes = []
-    for flag in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", GRAM_CHILD, str(repo)], env=dict(os.environ, CT_GRAM_TILED=flag), capture_output=True,
-                           text=True, timeout=600)
+    hashes = {}
+    for gram, rg in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+        r = subprocess.run([sys.executable, "-c", GRAM_CHILD, str(repo)], env=dict(os.environ, CT_GRAM_TILED=gram, CT_ROW_GROUPS=rg),
+                           capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        hashes.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1])
-    assert hashes[0] == hashes[1]
+        hashes[(gram, rg)] = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1]
+    assert len(set(hashes.values())) == 1, hashes
