@@ -644,6 +644,7 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
 }
 
 // E-step: one wave per target row (trackerlite.py:375-382 / track.py:81-88)
+constexpr int PO_REG = 16;                      // posterior_kernel: rows of up to 64 * PO_REG columns are held in registers
 __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict__ prior, const double* __restrict__ pred,
                                                         int n, const double* __restrict__ tgt, int m,
                                                         const double* __restrict__ sc, int legacy, double vol,
@@ -663,6 +664,34 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
     const double* pr = prior + (size_t)t * n;
     double* po = P + (size_t)t * n;
     double acc = 0.0;
+    if (n <= 64 * PO_REG) {
+        // the row's numerators stay in registers until the row sum is known: P is written once (the two-pass form below writes
+        // every row twice and reads it back, which made this kernel the largest HBM consumer of an EM iteration).  Same values,
+        // same order of the sum.
+        double v[PO_REG];
+#pragma unroll
+        for (int q = 0; q < PO_REG; ++q) {
+            if (64 * q >= n) break;
+            const int r = lane + 64 * q;
+            v[q] = 0.0;
+            if (r < n) {
+                const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
+                const double k = exp(-(dx * dx + dy * dy + dz * dz) / two_s2);
+                const double num = legacy ? pr[r] * k : (1.0 - gamma) * pr[r] * k / norm;
+                v[q] = num;
+                acc += num;
+            }
+        }
+        acc = wave_sum_d(acc);
+        const double den = legacy ? acc + gamma * norm / ((1.0 - gamma) * vol) : acc + gamma / vol;
+#pragma unroll
+        for (int q = 0; q < PO_REG; ++q) {
+            if (64 * q >= n) break;
+            const int r = lane + 64 * q;
+            if (r < n) po[r] = v[q] / den;
+        }
+        return;
+    }
     for (int r = lane; r < n; r += 64) {
         const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
         const double k = exp(-(dx * dx + dy * dy + dz * dz) / two_s2);
