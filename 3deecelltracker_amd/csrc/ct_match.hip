@@ -660,6 +660,11 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
     const double s2 = sc ? sc[S_SIGMA2] : s2v, gamma = sc ? sc[S_GAMMA] : gammav;
     const double two_s2 = 2.0 * s2;
     const double norm = pow(2.0 * M_PI * s2, 1.5);
+    // the three per-element divisions of the formula (d2 / 2 sigma2, .. / norm, num / den) have row-invariant divisors; an fp64
+    // divide is ~15 instructions (two of them quarter-rate), a third of this loop, so they are multiplications by reciprocals
+    // computed once per row (<= 1 ulp per factor, far inside the accumulation-order differences to the numpy formulation):
+    // 134 -> 127 us per batched EM iteration
+    const double inv_two_s2 = 1.0 / two_s2, coef = (1.0 - gamma) / norm;
     const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
     const double* pr = prior + (size_t)t * n;
     double* po = P + (size_t)t * n;
@@ -676,32 +681,34 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
             v[q] = 0.0;
             if (r < n) {
                 const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
-                const double k = exp(-(dx * dx + dy * dy + dz * dz) / two_s2);
-                const double num = legacy ? pr[r] * k : (1.0 - gamma) * pr[r] * k / norm;
+                const double k = exp(-(dx * dx + dy * dy + dz * dz) * inv_two_s2);
+                const double num = legacy ? pr[r] * k : coef * pr[r] * k;
                 v[q] = num;
                 acc += num;
             }
         }
         acc = wave_sum_d(acc);
         const double den = legacy ? acc + gamma * norm / ((1.0 - gamma) * vol) : acc + gamma / vol;
+        const double inv_den = 1.0 / den;
 #pragma unroll
         for (int q = 0; q < PO_REG; ++q) {
             if (64 * q >= n) break;
             const int r = lane + 64 * q;
-            if (r < n) po[r] = v[q] / den;
+            if (r < n) po[r] = v[q] * inv_den;
         }
         return;
     }
     for (int r = lane; r < n; r += 64) {
         const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
-        const double k = exp(-(dx * dx + dy * dy + dz * dz) / two_s2);
-        const double num = legacy ? pr[r] * k : (1.0 - gamma) * pr[r] * k / norm;
+        const double k = exp(-(dx * dx + dy * dy + dz * dz) * inv_two_s2);
+        const double num = legacy ? pr[r] * k : coef * pr[r] * k;
         po[r] = num;
         acc += num;
     }
     acc = wave_sum_d(acc);
     const double den = legacy ? acc + gamma * norm / ((1.0 - gamma) * vol) : acc + gamma / vol;
-    for (int r = lane; r < n; r += 64) po[r] = po[r] / den;
+    const double inv_den = 1.0 / den;
+    for (int r = lane; r < n; r += 64) po[r] = po[r] * inv_den;
 }
 
 // column statistics, stage 1: block (x: 64 columns, y: row segment) -> part[seg][4][n] = colsum, Y^T P
