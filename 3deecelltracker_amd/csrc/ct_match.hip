@@ -381,6 +381,7 @@ constexpr int GD_ROWLANES = 16;      // single match: 1024-thread workgroups kee
 // starves behind the 256-thread workgroups of the neighbouring chains (466 us per launch under the frame pipeline against 10 us
 // alone), so they use 256 threads.  Both reductions pick (max value, lowest index): the result does not depend on the split.
 constexpr int GD_ROWLANES_BATCH = 4;
+constexpr int GD_UN = 8;                        // loop steps whose loads are in flight together
 enum { GD_COUNT = 0, GD_NEW = 1 /* and 2: one counter per round parity */, GD_DONE = 3 };
 
 // One round = two launches.  gd_best_kernel: blocks [0, nrb) find every free row's best free column (16 rows per block, one wave
@@ -410,10 +411,17 @@ __global__ __launch_bounds__(64 * RL) void gd_best_kernel(const float* __restric
         if (row_used[t]) { if (lane == 0) rowcol[t] = -1; return; }
         const float* row = corr + (size_t)t * n;
         float best = -1.f; int bi = 0x7fffffff;
-        for (int c = lane; c < n; c += 64) {
-            if (col_used[c]) continue;
-            const float v = row[c];
-            if (v > best) { best = v; bi = c; }                           // ascending c => lowest column on ties
+        // GD_UN steps' loads are issued before the first compare (a `continue` in front of the load makes every step wait for the
+        // one before it: a chain of dependent round trips that stretched 20x beside other streams); same compares, same order
+        for (int c0 = lane; c0 < n; c0 += 64 * GD_UN) {
+            float vv[GD_UN]; unsigned char uu[GD_UN];
+#pragma unroll
+            for (int u = 0; u < GD_UN; ++u) { const int c = min(c0 + 64 * u, n - 1); uu[u] = col_used[c]; vv[u] = row[c]; }
+#pragma unroll
+            for (int u = 0; u < GD_UN; ++u) {
+                const int c = c0 + 64 * u;
+                if (c < n && !uu[u] && vv[u] > best) { best = vv[u]; bi = c; }   // ascending c => lowest column on ties
+            }
         }
 #pragma unroll
         for (int mk = 32; mk >= 1; mk >>= 1) {
@@ -429,10 +437,15 @@ __global__ __launch_bounds__(64 * RL) void gd_best_kernel(const float* __restric
     const int r = ((int)blockIdx.x - nrb) * 64 + cl;
     float best = -1.f; int btg = 0x7fffffff;
     if (r < n && !col_used[r])
-        for (int t = rl; t < m; t += RL) {
-            if (row_used[t]) continue;
-            const float v = corr[(size_t)t * n + r];
-            if (v > best) { best = v; btg = t; }                       // ascending t => lowest row on ties
+        for (int t0 = rl; t0 < m; t0 += RL * GD_UN) {
+            float vv[GD_UN]; unsigned char uu[GD_UN];
+#pragma unroll
+            for (int u = 0; u < GD_UN; ++u) { const int t = min(t0 + RL * u, m - 1); uu[u] = row_used[t]; vv[u] = corr[(size_t)t * n + r]; }
+#pragma unroll
+            for (int u = 0; u < GD_UN; ++u) {
+                const int t = t0 + RL * u;
+                if (t < m && !uu[u] && vv[u] > best) { best = vv[u]; btg = t; }  // ascending t => lowest row on ties
+            }
         }
     sv[rl][cl] = best; si[rl][cl] = btg;
     __syncthreads();
