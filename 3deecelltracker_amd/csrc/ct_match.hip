@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256) void lr_gram_kernel(int n, const double* __res
 // i = lane (mod 64) terms in the same order, and the 16 butterflies run "transposed" (at each step a lane keeps half of its
 // accumulators and hands the other half to its partner; fp add is commutative, so the kept sums equal wave_sum_d's bit for bit).
 constexpr int LG_T = 4;
-constexpr int LG_UN = 4;                       // i-steps whose loads are in flight together
+constexpr int LG_UN = 1;                       // i-steps whose loads are in flight together (4: -0.5 % in the match-bound pipeline)
 __device__ __forceinline__ void wave_sum16_d(double (&acc)[16], int lane) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
