@@ -937,7 +937,7 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
         if (tid < LR_RMAX + LR_PF) urow[tid] = tid < k ? U[(size_t)tid * n + p] : 0.0;      // zeros behind row k - 1
         __syncthreads();
         for (int i = tid; i < n; i += 1024) {
-            double u = G[(size_t)i * n + p];
+            double u = G[(size_t)p * n + i];              // row p == column p bit for bit ((a - b)^2 == (b - a)^2), and coalesced
             // same subtraction order as the plain loop, but LR_PF loads are in flight together: the plain loop waited one L2 round
             // trip per previous row (k x ~400 cycles, the whole cost of a step); rows past k - 1 are re-reads times the zero padding
             for (int j0 = 0; j0 < k; j0 += LR_PF) {
