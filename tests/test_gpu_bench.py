@@ -45,6 +45,18 @@ def test_single_gpu_modes_share_one_schema():
     assert ens["unit"] == "predictions/s" and ens["value"] > 0 and ens["scaling"] == "strong"
 
 
+def test_lcn_beside_the_match_chains_and_priority_pipeline_run():
+    """--lcn-stream match (LCN of frame t+1 on FramePipeline.prep_stream while the U-Net of frame t runs) and the pipeline without a
+    CU partition do the same work as the default line."""
+    base = [sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-realistic-pass"]
+    ref = _run(base)
+    for extra in (["--lcn-stream", "match"], ["--priority-streams"], ["--priority-streams", "--lcn-stream", "seg"]):
+        line = _run(base + extra)
+        assert KEYS <= set(line) and line["steps"] == 8
+        assert line["config"]["prgls_iterations"] == ref["config"]["prgls_iterations"]
+        assert 0.4 < line["value"] / ref["value"] < 1.6, (extra, ref["value"], line["value"])
+
+
 def _two_ranks(backend, extra):
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

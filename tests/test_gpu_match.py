@@ -683,3 +683,21 @@ def test_tiled_gram_and_row_group_kernels_are_bit_identical_to_the_simple_kernel
         assert r.returncode == 0, r.stderr[-2000:]
         hashes[(gram, rg)] = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1]
     assert len(set(hashes.values())) == 1, hashes
+
+
+@pytest.mark.parametrize("arrangement", [["prio", "unet"], ["unet", "segplain"], ["unet"], ["prio", "unet", "front"]])
+def test_match_is_unaffected_by_a_unet_sharing_its_cus(arrangement):
+    """Concurrent batched matches must return what a stand-alone match returns - bit for bit - also when the U-Net's conv kernels
+    are resident on the same CUs (priority-stream pipeline, or an unmasked U-Net stream beside the CU-masked match streams).
+    They did not while ct_match was built with packed-fp32 instructions (csrc/Makefile): FFN scores came back wrong in every
+    fourth target row and the PR-GLS iteration count of the benchmark's match varied from run to run (364 / 438 / 461).
+    The U-Net's own output must not depend on the neighbours either."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(repo / "scripts" / "probe" / "race_probe.py"), "2"] + arrangement, capture_output=True, text=True,
+                       timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mismatching results: 0 of" in r.stdout, r.stdout[-1500:]
+    assert "== alone: True" in r.stdout, r.stdout[-1500:]
