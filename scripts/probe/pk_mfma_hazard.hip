@@ -1,5 +1,9 @@
-// Minimal reproducer attempt for the co-residency hazard recorded in DESIGN.md section 5: waves that execute packed-fp32 VALU
-// instructions (victim) beside waves that execute v_mfma_f32_16x16x32_f16 (aggressor) on the same SIMDs, two streams.
+// Reproducer ATTEMPTS for the co-residency hazard recorded in DESIGN.md section 5 (FFN pair grid wrong in lanes 48-63 beside the
+// split conv kernels).  Two streams, victim and aggressor resident on the same CUs:
+//   1. a packed-fp32 recurrence beside loops of v_mfma_f32_16x16x32_f16 / v_mfma_f32_16x16x4_f32;
+//   2. a kernel with ffn_pair_kernel's structure (LDS tiles, broadcast reads, 2 x 2 pairs -> v_pk_*_f32) beside an MFMA loop fed from
+//      LDS through v_cvt_pkrtz, like the split conv kernels' main loop.
+// Neither reproduces it (0 differing values; a control without the aggressor is included) - the trigger is narrower than these.
 //   hipcc --offload-arch=gfx950 -O3 scripts/probe/pk_mfma_hazard.hip -o scripts/probe/pk_mfma_hazard && scripts/probe/pk_mfma_hazard
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,10 +44,63 @@ __global__ __launch_bounds__(256) void victim(float* out, int iters) {
     out[(blockIdx.x * 256 + threadIdx.x) * 2 + 1] = x[1] + y[1];
 }
 
+// victim 2: the structure of ffn_pair_kernel (LDS tiles, broadcast reads, 2 x 2 pairs per thread -> packed fp32 after SLP)
+__global__ __launch_bounds__(256) void victim2(const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ corr, int n) {
+    constexpr int KC = 64, HID = 512;
+    __shared__ float Us[32][KC + 1];
+    __shared__ float Vs[32][KC + 1];
+    __shared__ float inv_s[KC], mean_s[KC], beta_s[KC], w3_s[KC];
+    const int tid = threadIdx.x, tr = tid & 15, tt = tid >> 4;
+    const int r0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    float acc[2][2] = {};
+    for (int k0 = 0; k0 < HID; k0 += KC) {
+        for (int e = tid; e < 32 * KC; e += 256) {
+            const int row = e / KC, kk = e - row * KC;
+            Us[row][kk] = U[(size_t)(r0 + row) * HID + k0 + kk];
+            Vs[row][kk] = V[(size_t)(t0 + row) * HID + k0 + kk];
+        }
+        if (tid < KC) { inv_s[tid] = 1.0f + 0.001f * tid; mean_s[tid] = 0.01f * tid; beta_s[tid] = 0.02f; w3_s[tid] = 0.05f - 0.001f * tid; }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < KC; ++kk) {
+            const float u0 = Us[tr][kk], u1 = Us[tr + 16][kk];
+            const float v0 = Vs[tt][kk], v1 = Vs[tt + 16][kk];
+            const float inv = inv_s[kk], mu = mean_s[kk], be = beta_s[kk], ww = w3_s[kk];
+            float y;
+            y = ((u0 + v0) - mu) * inv + be; y = y >= 0.f ? y : y * 0.3f; acc[0][0] = fmaf(y, ww, acc[0][0]);
+            y = ((u1 + v0) - mu) * inv + be; y = y >= 0.f ? y : y * 0.3f; acc[0][1] = fmaf(y, ww, acc[0][1]);
+            y = ((u0 + v1) - mu) * inv + be; y = y >= 0.f ? y : y * 0.3f; acc[1][0] = fmaf(y, ww, acc[1][0]);
+            y = ((u1 + v1) - mu) * inv + be; y = y >= 0.f ? y : y * 0.3f; acc[1][1] = fmaf(y, ww, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) corr[(size_t)(t0 + tt + 16 * i) * n + r0 + tr + 16 * j] = acc[i][j];
+}
+// aggressor 2: MFMA 16x16x32 fed from LDS with fp16 conversions, like the split conv kernels' main loop
+__global__ __launch_bounds__(256) void aggressor2(const float* __restrict__ in, float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2][8192];
+    float4v acc = {0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+        for (int e = threadIdx.x; e < 4096; e += 256) {
+            const float x = in[(blockIdx.x * 4096 + e + it) & 0xfffff], y2 = in[(blockIdx.x * 4096 + e + it + 7) & 0xfffff];
+            auto pk = __builtin_amdgcn_cvt_pkrtz(x, y2);
+            *(decltype(pk)*)&tile[it & 1][2 * e] = pk;
+        }
+        __syncthreads();
+        for (int q = 0; q < 16; ++q) {
+            const half8 a = *(const half8*)&tile[it & 1][((threadIdx.x * 8) + q * 512) & 8184];
+            const half8 b = *(const half8*)&tile[it & 1][((threadIdx.x * 8) + q * 512 + 2048) & 8184];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
 int main() {
     const int VB = 2048, AB = 512;        // 2 aggressor workgroups per CU: the victim must fit beside them
     float *vo, *ao;
-    hipMalloc(&vo, VB * 256 * 2 * sizeof(float)); hipMalloc(&ao, AB * 256 * sizeof(float));
+    hipMalloc(&vo, VB * 256 * 2 * sizeof(float)); hipMalloc(&ao, 4096 * 256 * sizeof(float));
     hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
     std::vector<float> ref(VB * 256 * 2), got(VB * 256 * 2);
     hipLaunchKernelGGL(victim, dim3(VB), dim3(256), 0, s1, vo, 4000); hipStreamSynchronize(s1);
@@ -60,6 +117,31 @@ int main() {
         }
         printf("aggressor %s: %d differing values (of %zu x 5); by lane quarter: %d %d %d %d\n", mode == 0 ? "mfma 16x16x32 f16" : "mfma 16x16x4 f32",
                bad, got.size(), badlanes[0], badlanes[1], badlanes[2], badlanes[3]);
+    }
+    {   // the pair-kernel-shaped victim beside the LDS-fed MFMA aggressor
+        const int n = 608;
+        float *U, *V, *C, *in; hipMalloc(&U, n * 512 * 4); hipMalloc(&V, n * 512 * 4); hipMalloc(&C, n * n * 4); hipMalloc(&in, (1 << 20) * 4);
+        std::vector<float> h(n * 512), hin(1 << 20);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = 0.001f * (float)((i * 2654435761u) % 2001) - 1.0f;
+        for (size_t i = 0; i < hin.size(); ++i) hin[i] = 0.001f * (float)((i * 40503u) % 1999) - 1.0f;
+        hipMemcpy(U, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = 0.001f * (float)((i * 2246822519u) % 1777) - 0.9f;
+        hipMemcpy(V, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(in, hin.data(), hin.size() * 4, hipMemcpyHostToDevice);
+        std::vector<float> r2(n * n), g2(n * n);
+        hipLaunchKernelGGL(victim2, dim3(n / 32, n / 32), dim3(256), 0, s1, U, V, C, n); hipDeviceSynchronize();
+        hipMemcpy(r2.data(), C, r2.size() * 4, hipMemcpyDeviceToHost);
+        for (int with = 0; with < 2; ++with) {
+        int bad = 0, q[4] = {0, 0, 0, 0};
+        for (int rep = 0; rep < 20; ++rep) {
+            if (with) hipLaunchKernelGGL(aggressor2, dim3(1024), dim3(256), 0, s2, in, ao, 300);
+            for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(victim2, dim3(n / 32, n / 32), dim3(256), 0, s1, U, V, C, n);
+            hipDeviceSynchronize();
+            hipMemcpy(g2.data(), C, g2.size() * 4, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < g2.size(); ++i) if (memcmp(&g2[i], &r2[i], 4)) { ++bad; ++q[(i / n) % 4]; }
+        }
+        printf("pair-kernel-shaped victim %s: %d differing values of %zu x 20; target rows mod 4: %d %d %d %d\n",
+               with ? "beside LDS-fed mfma 16x16x32" : "alone (control)", bad, g2.size(), q[0], q[1], q[2], q[3]);
+        }
     }
     return 0;
 }
