@@ -305,3 +305,16 @@ def test_volume_path_ignores_uncomputed_workspace(name, shape, shrink):
     for poison in (float("nan"), float("inf"), -3.0e38):
         ws.view(torch.float32).fill_(poison)
         assert torch.equal(model.predict_volume_device(vol, shrink=shrink), ref_out), f"{name} {shape} {shrink}: poison {poison} leaked"
+
+
+@pytest.mark.gpu
+def test_volume_path_writes_nothing_outside_its_buffers():
+    """Workspace, input and output between 64-MB guard bands (scripts/probe/guard_probe.py): no byte of a band may change."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(repo / "scripts" / "probe" / "guard_probe.py"), "unet3_a"], capture_output=True, text=True,
+                       timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "guard bytes overwritten: 0" in r.stdout, r.stdout[-1000:]
