@@ -394,15 +394,20 @@ def main():
                     help="frames mode: where the LCN of a frame runs (match: beside the match chains, one frame ahead of the U-Net; "
                          "auto: there when the pipeline has no CU partition, i.e. when the match side has slack)")
     ap.add_argument("--disjoint-match-cus", action="store_true", help="give every match chain its own CU slice (measured: worse)")
-    ap.add_argument("--match-workers", type=int, default=3, help="match chains in flight concurrently")
+    ap.add_argument("--match-workers", type=int, default=None, help="match chains in flight concurrently (default: 2; 3 with --partition)")
     ap.add_argument("--realistic-match-cus", type=int, default=32, help="match partition of the informative pass with the discriminating FFN")
-    ap.add_argument("--priority-streams", action="store_true", help="headline pass without a CU partition: U-Net on a normal-priority full-chip stream, match chains on high-priority streams (loses with the 364-iteration matches of the random-init FFN: 63 vs 89 volumes/s)")
+    ap.add_argument("--partition", action="store_true",
+                    help="CU-partitioned pipeline (U-Net on n_cu - match_cus CUs, match chains on --match-cus) instead of the default: U-Net on a "
+                         "normal-priority full-chip stream, match chains on high-priority streams (132 vs 124 volumes/s)")
+    ap.add_argument("--priority-streams", action="store_true", help="(the default now; kept for old command lines)")
     ap.add_argument("--realistic-partition", action="store_true", help="discriminating-FFN pass on a CU partition (--realistic-match-cus) instead of priority streams (116 vs 121 volumes/s)")
     ap.add_argument("--match-batch", type=int, default=16, help="frames whose matches share one chain of launches (ct_prgls_two_ref_batched); capped at steps // 4 so that a short run still overlaps its matches with the U-Net")
     ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
     ap.add_argument("--cpu-patches", type=int, default=20, help="U-Net patches timed by the CPU baseline sample")
     args = ap.parse_args()
     args.match_batch = max(1, min(args.match_batch, max(1, args.steps // 4)))
+    if args.match_workers is None:
+        args.match_workers = 3 if args.partition else 2
 
     import torch
     import torch.distributed as dist
@@ -448,7 +453,7 @@ def main():
     # dependent chain of tiny matching kernels only advances between conv launches: measured step = sum, not max), and one
     # PR-GLS chain is latency-bound.  FramePipeline splits the CUs with masked streams and lets `--match-workers` host threads
     # each drive the match of a different frame (frames are independent units).
-    ctx.pipe = par.FramePipeline(device=ctx.local, match_cus=args.match_cus, workers=args.match_workers, disjoint=args.disjoint_match_cus, priority=args.priority_streams)
+    ctx.pipe = par.FramePipeline(device=ctx.local, match_cus=args.match_cus, workers=args.match_workers, disjoint=args.disjoint_match_cus, priority=not args.partition)
     ctx.iters_log = []
     ctx.active = {"ffn": ctx.ffn}
     ctx.on_timed_start = None
@@ -537,7 +542,8 @@ def main():
             "data": "synthetic",
             "config": dict({"workload": workload, "mode": args.mode, "patches_per_volume": n_patches, "cells": args.cells,
                             "prgls_iterations": int(np.median(iters_main)) if iters_main else None,
-                            "cu_partition": {"unet": ctx.pipe.n_cu - ctx.pipe.match_cus, "match": ctx.pipe.match_cus},
+                            "cu_partition": ({"unet": ctx.pipe.n_cu - ctx.pipe.match_cus, "match": ctx.pipe.match_cus} if ctx.pipe.match_cus else
+                                             {"unet": ctx.pipe.n_cu, "match": "no partition: match chains on high-priority streams"}),
                             "match_chains_in_flight": args.match_workers, "frames_per_match_chain": args.match_batch,
                             "parallelism": parallelism}, **extra),
             "roofline": roofline,

@@ -46,11 +46,12 @@ def test_single_gpu_modes_share_one_schema():
 
 
 def test_lcn_beside_the_match_chains_and_priority_pipeline_run():
-    """--lcn-stream match (LCN of frame t+1 on FramePipeline.prep_stream while the U-Net of frame t runs) and the pipeline without a
-    CU partition do the same work as the default line."""
+    """The CU-partitioned pipeline (--partition) and the other placement of the LCN (--lcn-stream) do the same work as the default line
+    (priority streams, LCN of frame t+1 on FramePipeline.prep_stream while the U-Net of frame t runs): same PR-GLS iteration count -
+    the check that exposed the co-residency hazard of DESIGN.md section 5."""
     base = [sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-realistic-pass"]
     ref = _run(base)
-    for extra in (["--lcn-stream", "match"], ["--priority-streams"], ["--priority-streams", "--lcn-stream", "seg"]):
+    for extra in (["--lcn-stream", "seg"], ["--partition"], ["--partition", "--lcn-stream", "match"]):
         line = _run(base + extra)
         assert KEYS <= set(line) and line["steps"] == 8
         assert line["config"]["prgls_iterations"] == ref["config"]["prgls_iterations"]
