@@ -236,7 +236,7 @@ class FramePipeline:
     `n_cu - match_cus` CUs, and `workers` host threads each drive the match chain of a *different* frame on their
     own stream inside the remaining `match_cus` CUs (ctypes releases the GIL while a chain runs).  Frames are
     independent units, so results are identical to processing them one after another.
-    `priority=True` replaces the partition by stream priorities (light matches only, see below).
+    `priority=True` replaces the partition by stream priorities (the faster arrangement, see below; bench.py's default).
     """
 
     def __init__(self, device: int = 0, match_cus: int = 32, workers: int = 3, disjoint: bool = False, priority: bool = False):
@@ -261,8 +261,10 @@ class FramePipeline:
             return torch.cuda.ExternalStream(h.value, device=f"cuda:{device}")
         if priority:
             # no CU partition: the U-Net on a normal-priority full-chip stream, the match chains on high-priority streams.  Every
-            # tiny kernel of a chain then waits for a workgroup slot to drain (~10 us), which a 10-iteration match can afford
-            # (121 vs 116 volumes/s in bench.py's discriminating-FFN pass) and a 364-iteration one cannot (63 vs 89).
+            # tiny kernel of a chain then waits for a workgroup slot to drain (~10 us), and the U-Net keeps all 256 CUs: 134 vs 126
+            # volumes/s for the benchmark's 364-iteration matches, 170 vs 116 for 10-iteration ones.  (Round 2 first measured 63 for
+            # the former: the FFN scores were wrong whenever conv and match waves shared a SIMD - DESIGN.md section 5 - and the
+            # matches ran 440-460 iterations on garbage priors.)
             self.seg_stream = torch.cuda.Stream(device=f"cuda:{device}", priority=0)
             self._match_streams = [torch.cuda.Stream(device=f"cuda:{device}", priority=-1) for _ in range(self.workers)]
             self.match_cus = 0

@@ -494,7 +494,7 @@ def main():
                 "cu_partition": ({"unet": ctx.pipe.n_cu - ctx.pipe.match_cus, "match": ctx.pipe.match_cus} if ctx.pipe.match_cus else
                                  {"unet": ctx.pipe.n_cu, "match": "no partition: match chains on high-priority streams"}),
                 "ffn": "tests/golden/ffn_synthetic_trained.npz (synthetic-pair training, 84 % of the true pairs found at 600 cells)",
-                "note": "same inputs as the headline run; the FFN weights differ, and with them the way the two halves share the chip (a 10-iteration match is light enough to ride on high-priority streams beside a full-chip U-Net)"}
+                "note": "same inputs and the same pipeline as the headline run; only the FFN weights differ (10 instead of 364 PR-GLS iterations per match)"}
             ctx.pipe.close(); ctx.pipe = headline_pipe
             ctx.active["ffn"] = ctx.ffn
         if world == 1 and args.mode == "frames":
