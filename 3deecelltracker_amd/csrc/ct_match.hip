@@ -846,12 +846,13 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
                                                          double* __restrict__ predl, double* __restrict__ norm_part,
                                                          const double* __restrict__ sc, const double* __restrict__ dvec,
                                                          const double* __restrict__ sqd, const double* __restrict__ rhs,
-                                                         double* __restrict__ res_part, Bt bt = Bt{0, nullptr}) {
+                                                         double* __restrict__ res_part, Bt bt = Bt{0, nullptr}, int first_only = 0) {
     BT_SHIFT(const double*, C); BT_SHIFT(const double*, G); BT_SHIFT(double*, predn); BT_SHIFT(const double*, Gln);
     BT_SHIFT(double*, predl); BT_SHIFT(double*, norm_part); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
     BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs);
     if (res_part) BT_SHIFT(double*, res_part);
     if (bt.dims) { n = bt.dims[4 * blockIdx.z + 1]; l = bt.dims[4 * blockIdx.z + 2]; }
+    if (first_only) l = 0;
     if (sc[S_DONE] != 0.0) return;
     const bool add = sc[S_IT] >= 1.0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1150,12 +1151,13 @@ __global__ __launch_bounds__(256) void apply_dual_rg_kernel(const double* __rest
                                                             double* __restrict__ predl, double* __restrict__ norm_part,
                                                             const double* __restrict__ sc, const double* __restrict__ dvec,
                                                             const double* __restrict__ sqd, const double* __restrict__ rhs,
-                                                            double* __restrict__ res_part, Bt bt) {
+                                                            double* __restrict__ res_part, Bt bt, int first_only = 0) {
     BT_SHIFT(const double*, C); BT_SHIFT(const double*, G); BT_SHIFT(double*, predn); BT_SHIFT(const double*, Gln);
     BT_SHIFT(double*, predl); BT_SHIFT(double*, norm_part); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
     BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs);
     if (res_part) BT_SHIFT(double*, res_part);
     if (bt.dims) { n = bt.dims[4 * blockIdx.z + 1]; l = bt.dims[4 * blockIdx.z + 2]; }
+    if (first_only) l = 0;
     if (sc[S_DONE] != 0.0) return;
     const bool add = sc[S_IT] >= 1.0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1204,6 +1206,31 @@ __global__ __launch_bounds__(256) void apply_dual_rg_kernel(const double* __rest
         res_part[n + j] = fmax(fabs(bx), fmax(fabs(by), fabs(bz)));
     }
 }
+
+// The tracked set only rides along (trackerlite.py:335-341: predicted_l += C . G_nl with a FIXED G_nl, from the second iteration on),
+// nothing in the EM reads it.  By linearity its final position is tracked + (sum of those C) . G_nl: the batched chain sums the
+// coefficients (lr_coeff_kernel) and streams the l x n matrix ONCE here instead of once per iteration (a sixth of an iteration's
+// bytes).  Same terms, added in another order: the tracked coordinates differ from the per-iteration form by ~2e-11 in normalised
+// units - the cancellation error eps |C| |G| that either form carries (|C| ~ 1e5) -
+// (CT_DEFER_TRACKED=0 keeps the per-iteration form; the EM state, iteration counts and posteriors are untouched either way).
+__global__ __launch_bounds__(256) void apply_tracked_kernel(const double* __restrict__ Csum, const double* __restrict__ Gln, int n,
+                                                            double* __restrict__ predl, int l, const unsigned char* __restrict__ skip, Bt bt) {
+    if (skip && skip[blockIdx.z]) return;
+    BT_SHIFT(const double*, Csum); BT_SHIFT(const double*, Gln); BT_SHIFT(double*, predl);
+    if (bt.dims) { n = bt.dims[4 * blockIdx.z + 1]; l = bt.dims[4 * blockIdx.z + 2]; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= l) return;
+    const double* row = Gln + (size_t)j * n;
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double g = row[i];
+        ax = fma(Csum[i], g, ax); ay = fma(Csum[n + i], g, ay); az = fma(Csum[2 * n + i], g, az);
+    }
+    ax = wave_sum_d(ax); ay = wave_sum_d(ay); az = wave_sum_d(az);
+    if (lane == 0) { predl[3 * j] += ax; predl[3 * j + 1] += ay; predl[3 * j + 2] += az; }
+}
+static bool defer_tracked() { static const bool v = !(getenv("CT_DEFER_TRACKED") && getenv("CT_DEFER_TRACKED")[0] == '0'); return v; }
 
 constexpr int LS_B = 8;
 // In-LDS solve of the SPD system S q = y for 3 right-hand sides stored as rows r..r+2 of S (augmented Cholesky,
@@ -1720,9 +1747,10 @@ __global__ __launch_bounds__(256) void dense_small_solve_kernel(const double* __
 __global__ __launch_bounds__(256) void lr_coeff_kernel(const double* __restrict__ U, int n, const int* __restrict__ rank_p,
                                                        const double* __restrict__ q, const double* __restrict__ sqd,
                                                        const double* __restrict__ rhs, const double* __restrict__ sc,
-                                                       double* __restrict__ C, Bt bt = Bt{0, nullptr}) {
+                                                       double* __restrict__ C, Bt bt = Bt{0, nullptr}, double* __restrict__ Csum = nullptr) {
     BT_SHIFT(const double*, U); BT_SHIFT(const int*, rank_p); BT_SHIFT(const double*, q); BT_SHIFT(const double*, sqd);
     BT_SHIFT(const double*, rhs); BT_SHIFT(const double*, sc); BT_SHIFT(double*, C);
+    if (Csum) BT_SHIFT(double*, Csum);
     if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
     if (sc[S_DONE] != 0.0) return;
     __shared__ double ps[4][64][3];
@@ -1745,9 +1773,11 @@ __global__ __launch_bounds__(256) void lr_coeff_kernel(const double* __restrict_
         ax = (ps[0][lane][0] + ps[1][lane][0]) + (ps[2][lane][0] + ps[3][lane][0]);
         ay = (ps[0][lane][1] + ps[1][lane][1]) + (ps[2][lane][1] + ps[3][lane][1]);
         az = (ps[0][lane][2] + ps[1][lane][2]) + (ps[2][lane][2] + ps[3][lane][2]);
-        C[i] = s * (rhs[3 * i] - s * ax) / c;
-        C[n + i] = s * (rhs[3 * i + 1] - s * ay) / c;
-        C[2 * n + i] = s * (rhs[3 * i + 2] - s * az) / c;
+        const double c0 = s * (rhs[3 * i] - s * ax) / c, c1 = s * (rhs[3 * i + 1] - s * ay) / c, c2 = s * (rhs[3 * i + 2] - s * az) / c;
+        C[i] = c0; C[n + i] = c1; C[2 * n + i] = c2;
+        // deferred field application for the tracked set (apply_tracked_kernel): the coefficients of every iteration whose movement
+        // counts (from the second on, trackerlite.py:339-341) are summed; this kernel returns early once the problem has converged
+        if (Csum && sc[S_IT] >= 1.0) { Csum[i] += c0; Csum[n + i] += c1; Csum[2 * n + i] += c2; }
     }
 }
 
@@ -2083,9 +2113,9 @@ int lowrank_prepare(const PrglsWs& w, int n, hipStream_t st, int* rank_coarse, i
 __global__ __launch_bounds__(256) void prgls_init_batch_kernel(const double* __restrict__ ref, const double* __restrict__ tracked,
                                                                double two_b2, double* __restrict__ G, double* __restrict__ Gln,
                                                                double* __restrict__ predn, double* __restrict__ predl,
-                                                               double* __restrict__ sc, Bt bt) {
+                                                               double* __restrict__ sc, double* __restrict__ csum, Bt bt) {
     BT_SHIFT(const double*, ref); BT_SHIFT(const double*, tracked); BT_SHIFT(double*, G); BT_SHIFT(double*, Gln);
-    BT_SHIFT(double*, predn); BT_SHIFT(double*, predl); BT_SHIFT(double*, sc);
+    BT_SHIFT(double*, predn); BT_SHIFT(double*, predl); BT_SHIFT(double*, sc); BT_SHIFT(double*, csum);
     const int n = bt.dims[4 * blockIdx.z + 1], l = bt.dims[4 * blockIdx.z + 2];
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid < (size_t)n * n) {
@@ -2100,7 +2130,7 @@ __global__ __launch_bounds__(256) void prgls_init_batch_kernel(const double* __r
         const double d2 = dx * dx + dy * dy + dz * dz;
         Gln[gid] = exp(-d2 / two_b2);
     }
-    if (gid < 3 * (size_t)n) predn[gid] = ref[gid];
+    if (gid < 3 * (size_t)n) { predn[gid] = ref[gid]; csum[gid] = 0.0; }
     if (gid < 3 * (size_t)l) predl[gid] = tracked[gid];
     if (gid < S_NUM) sc[gid] = gid == S_GAMMA ? 0.05 : 0.0;
 }
@@ -2294,7 +2324,7 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
         const size_t tot = (size_t)nn * (nn > ll ? nn : ll);
         const size_t cover = tot > 3 * (size_t)(nn > ll ? nn : ll) ? tot : 3 * (size_t)(nn > ll ? nn : ll);
         hipLaunchKernelGGL(prgls_init_batch_kernel, dim3((unsigned)((cover + 255) / 256), 1, zB), dim3(256), 0, st, in_ref, in_trk,
-                           2.0 * beta * beta, w.G, w.Gln, w.predn, w.predl, w.sc, bt);
+                           2.0 * beta * beta, w.G, w.Gln, w.predn, w.predl, w.sc, w.M, bt);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_ref, nn, in_tgt, mm, (const double*)nullptr,
@@ -2324,6 +2354,8 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
     }
     const int total = max_iteration - 1;
     const bool rgm = B >= RG_MIN_BATCH && row_groups();
+    const bool defer = ll > 0 && defer_tracked();         // tracked set moved once, after the loop (apply_tracked_kernel); Csum lives in w.M
+    const int lla = defer ? 0 : ll;
     std::vector<double> hsc((size_t)B * S_NUM, 0.0);
     for (int enq = 0; enq < total && live > 0;) {
         const int chunk = prgls_chunk(enq, total);
@@ -2348,14 +2380,15 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
             const size_t lds = (size_t)(rank + 3) * (rank | 1) * sizeof(double);
             hipLaunchKernelGGL(lr_solve_kernel, dim3(1, 1, zB), dim3(256), lds, st, w.Spart, w.ypart, nn, w.rank, lambda, w.dvec, w.sc, w.q, bt);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL(lr_coeff_kernel, dim3((nn + 63) / 64, 1, zB), dim3(256), 0, st, w.U, nn, w.rank, w.q, w.sqd, w.rhs, w.sc, w.C, bt);
+            hipLaunchKernelGGL(lr_coeff_kernel, dim3((nn + 63) / 64, 1, zB), dim3(256), 0, st, w.U, nn, w.rank, w.q, w.sqd, w.rhs, w.sc, w.C, bt,
+                               defer ? w.M : (double*)nullptr);
             LAUNCH_CHECK();
             if (rgm)
-                hipLaunchKernelGGL(apply_dual_rg_kernel, dim3(((nn + RG - 1) / RG + (ll + RG - 1) / RG + 3) / 4, 1, zB), dim3(256), 0, st, w.C, w.G, nn,
-                                   w.predn, w.Gln, ll, w.predl, w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart, bt);
+                hipLaunchKernelGGL(apply_dual_rg_kernel, dim3(((nn + RG - 1) / RG + (lla + RG - 1) / RG + 3) / 4, 1, zB), dim3(256), 0, st, w.C, w.G, nn,
+                                   w.predn, w.Gln, ll, w.predl, w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart, bt, defer ? 1 : 0);
             else
-                hipLaunchKernelGGL(apply_dual_kernel, dim3((nn + ll + 3) / 4, 1, zB), dim3(256), 0, st, w.C, w.G, nn, w.predn, w.Gln, ll, w.predl,
-                                   w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart, bt);
+                hipLaunchKernelGGL(apply_dual_kernel, dim3((nn + lla + 3) / 4, 1, zB), dim3(256), 0, st, w.C, w.G, nn, w.predn, w.Gln, ll, w.predl,
+                                   w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart, bt, defer ? 1 : 0);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, w.predn, nn, in_tgt, mm, w.P, w.rowpart, w.sc, bt);
             LAUNCH_CHECK();
@@ -2380,6 +2413,10 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
             if (iters) iters[b] = (int)h[S_IT];
             if (h[S_DONE] != 0.0) finished[b] = 1; else ++live;
         }
+    }
+    if (defer) {
+        hipLaunchKernelGGL(apply_tracked_kernel, dim3((ll + 3) / 4, 1, zB), dim3(256), 0, st, w.M, w.Gln, nn, w.predl, ll, (const unsigned char*)nullptr, bt);
+        LAUNCH_CHECK();
     }
     for (int b = 0; b < B; ++b) {
         if (fallback[b]) {

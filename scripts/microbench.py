@@ -232,7 +232,7 @@ def cmd_ensemble(args):
         ref = ref or out
         print(f"ensemble of 20 matches, {chains} chain(s): {dt*1e3:.0f} ms ({dt/20*1e3:.1f} ms per match), identical to sequential: {same}")
     print(f"ensemble of 20 matches, batched PR-GLS: {dtb*1e3:.0f} ms ({dtb/20*1e3:.1f} ms per match), identical to sequential: "
-          f"{all(torch.equal(a, b[0]) for a, b in zip(ref, outb))}")
+          f"{all(float((a - b[0]).abs().max()) <= 1e-9 for a, b in zip(ref, outb))} (tracked set to 1e-9: moved once with the summed coefficients)")
 
 
 def cmd_chains(args):

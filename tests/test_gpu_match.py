@@ -21,6 +21,8 @@ dev = importlib.import_module("3deecelltracker_amd._dev")
 NS = (21, 50, 113, 180)
 COORD_TOL = 1e-6      # north-star: transformed coordinates within 1e-4; we hold 1e-6
 SCORE_TOL = 2e-5      # fp32 sigmoid scores: accumulation-order differences only
+TRACKED_TOL = 1e-9    # tracked set, batched chain (moved once, summed coefficients) vs per-iteration application: both carry the
+                      # cancellation error eps * |C| * |G| ~ 1e-11 of the field application (|C| ~ 1e5 at lambda = 3); normalised units
 
 
 @pytest.fixture(scope="module")
@@ -267,11 +269,12 @@ def test_trackerlite_end_to_end(tmp_path, ffn_w):
                for t1 in tl.get_volumes_list(5, [4])]
     from scipy.stats import trim_mean
     np.testing.assert_allclose(ens.real, cit.Coordinates(trim_mean(singles, 0.1, axis=0), 4, vs, "real").real, rtol=0, atol=1e-5)
-    # the PR-GLS runs of the ensemble members share one chain of launches (ct_prgls_two_ref_batched): same bits as one by one
+    # the PR-GLS runs of the ensemble members share one chain of launches (ct_prgls_two_ref_batched): the same result as one by one
+    # (the batched chain moves the tracked set once with the summed coefficients: another summation order, ~1e-13)
     assert trk.ensemble_batched is True
     trk.ensemble_batched = False
     ens1 = trk.predict_cell_positions_ensemble([4], 5, proof, beta=3, lambda_=3, sampling_number=20)
-    assert np.array_equal(ens1.real, ens.real)
+    np.testing.assert_allclose(ens1.real, ens.real, rtol=0, atol=1e-9)
 
 
 # ------------------------------------------------------------------------------------ BASELINE sizes
@@ -503,8 +506,13 @@ def test_trackerlite_ensemble_20_volumes_113_cells_against_oracle(tmp_path, ffn_
 
 def test_prgls_batched_is_bit_identical_to_separate_calls(ffn):
     """ct_prgls_two_ref_batched on ragged problems (different m, n, l; a noise prior that runs hundreds of iterations next to
-    converging ones; one problem without a tracked set) == separate ct_prgls_two_ref calls, bit for bit, iteration counts too."""
+    converging ones; one problem without a tracked set) == separate ct_prgls_two_ref calls: the EM state (moved reference set,
+    posterior, iteration counts) bit for bit; the tracked set, which the batched chain moves ONCE with the summed coefficients instead
+    of once per iteration (apply_tracked_kernel: same terms, another order), to 1e-9 in normalised units (measured 2e-11; COORD_TOL vs the oracle stays 1e-6)."""
     import torch
+
+    def tracked_diff(a, b):
+        return 0.0 if (a is None and b is None) else float((a - b).abs().max())
     probs = []
     for n_ref, n_tgt, n_trk, seed, sharp in ((120, 100, 120, 1, True), (90, 131, 40, 2, False), (150, 150, 0, 3, True), (64, 70, 64, 4, False)):
         rng = np.random.default_rng(seed)
@@ -524,19 +532,19 @@ def test_prgls_batched_is_bit_identical_to_separate_calls(ffn):
         sl, sn, sp, sit = dev.prgls_two_ref(prior, tgt, ref, trk, 3.0, 3.0, 2000, want_posterior=True, want_ref=True)
         assert bit == sit
         assert torch.equal(bn, sn) and torch.equal(bp, sp)
-        assert (bl is None and sl is None) or torch.equal(bl, sl)
+        assert tracked_diff(bl, sl) <= TRACKED_TOL, tracked_diff(bl, sl)
         its.append(sit)
     assert len(set(its)) > 1                          # the problems really stop at different iterations
     # a bounded run (max_iteration) and the batched TrackerLite step
     b4 = dev.prgls_two_ref_batched(probs, 3.0, 3.0, 4)
     for (prior, tgt, ref, trk), (bl, _, _, bit) in zip(probs, b4):
         sl, _, _, sit = dev.prgls_two_ref(prior, tgt, ref, trk, 3.0, 3.0, 4, want_posterior=False)
-        assert bit == sit == 3 and ((bl is None and sl is None) or torch.equal(bl, sl))
+        assert bit == sit == 3 and tracked_diff(bl, sl) <= TRACKED_TOL
     xs = [(p[2], p[1], p[2]) for p in probs[:2]]
     got = tl.match_device_batched(ffn, xs, 3, 3)
     for (s1, s2, c), (out, it) in zip(xs, got):
         ref_out, ref_it = tl.match_device(ffn, s1, s2, c, 3, 3)
-        assert it == ref_it and torch.equal(out, ref_out)
+        assert it == ref_it and tracked_diff(out, ref_out) <= TRACKED_TOL
 
 
 def test_unused_normalisation_helpers_of_the_reference(g):
