@@ -657,14 +657,44 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
 }
 
 // E-step: one wave per target row (trackerlite.py:375-382 / track.py:81-88)
+// Is the prior "one value per row, except at most one column"?  (simple_match: 0.1/(n-1) everywhere, 0.9 at the matched column,
+// trackerlite.py:242-259.)  One wave per row: lo = the value at least two of the first three columns share; the row is structured
+// if at most one entry differs from lo BITWISE.  Table (doubles, sp_m = the batch's largest m): lo[sp_m], hi[sp_m], then idx as
+// int32.  A problem with any other row sets dense[problem] and keeps streaming its matrix: the values posterior_kernel uses are
+// the matrix's own either way (bit-identical; CT_PRIOR_SCAN=0 always streams).
+__global__ __launch_bounds__(256) void prior_scan_kernel(const double* __restrict__ prior, int m, int n, double* __restrict__ sp, int sp_m,
+                                                         int* __restrict__ dense, Bt bt) {
+    BT_SHIFT(const double*, prior); BT_SHIFT(double*, sp);
+    if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= m) return;
+    const double* row = prior + (size_t)t * n;
+    const long long b0 = __double_as_longlong(row[0]), b1 = __double_as_longlong(row[min(1, n - 1)]), b2 = __double_as_longlong(row[min(2, n - 1)]);
+    const long long lo = (b0 == b1 || b0 == b2) ? b0 : b1;
+    int cnt = 0, last = -1;
+    for (int r = lane; r < n; r += 64)
+        if (__double_as_longlong(row[r]) != lo) { ++cnt; last = r; }
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) { cnt += __shfl_xor(cnt, mk); last = max(last, __shfl_xor(last, mk)); }
+    if (lane != 0) return;
+    if (cnt > 1) { atomicExch(&dense[blockIdx.z], 1); return; }
+    sp[t] = __longlong_as_double(lo);
+    sp[sp_m + t] = cnt == 1 ? row[last] : __longlong_as_double(lo);
+    ((int*)(sp + 2 * (size_t)sp_m))[t] = cnt == 1 ? last : -1;
+}
+static bool prior_scan() { static const bool v = !(getenv("CT_PRIOR_SCAN") && getenv("CT_PRIOR_SCAN")[0] == '0'); return v; }
+
 constexpr int PO_REG = 16;                      // posterior_kernel: rows of up to 64 * PO_REG columns are held in registers
 __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict__ prior, const double* __restrict__ pred,
                                                         int n, const double* __restrict__ tgt, int m,
                                                         const double* __restrict__ sc, int legacy, double vol,
                                                         double* __restrict__ P, double s2v = 0.0, double gammav = 0.0,
-                                                        Bt bt = Bt{0, nullptr}) {
+                                                        Bt bt = Bt{0, nullptr}, const double* __restrict__ sp = nullptr,
+                                                        const int* __restrict__ sp_dense = nullptr, int sp_m = 0) {
     BT_SHIFT(const double*, prior); BT_SHIFT(const double*, pred); BT_SHIFT(const double*, tgt); BT_SHIFT(double*, P);
     if (sc) BT_SHIFT(const double*, sc);
+    if (sp) BT_SHIFT(const double*, sp);
     if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
     if (sc && sc[S_DONE] != 0.0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -682,6 +712,11 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
     const double* pr = prior + (size_t)t * n;
     double* po = P + (size_t)t * n;
     double acc = 0.0;
+    // a prior built by simple_match is one value per row plus at most one matched column (prior_scan_kernel): its m x n matrix
+    // need not be streamed from HBM in every EM iteration
+    const bool structured = sp && sp_dense[blockIdx.z] == 0;
+    double sp_lo = 0.0, sp_hi = 0.0; int sp_idx = -1;
+    if (structured) { sp_lo = sp[t]; sp_hi = sp[sp_m + t]; sp_idx = ((const int*)(sp + 2 * (size_t)sp_m))[t]; }
     if (n <= 64 * PO_REG) {
         // the row's numerators stay in registers until the row sum is known: P is written once (the two-pass form below writes
         // every row twice and reads it back, which made this kernel the largest HBM consumer of an EM iteration).  Same values,
@@ -695,7 +730,9 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
             if (r < n) {
                 const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
                 const double k = exp(-(dx * dx + dy * dy + dz * dz) * inv_two_s2);
-                const double num = legacy ? pr[r] * k : coef * pr[r] * k;
+                double prv;
+                if (structured) prv = (r == sp_idx) ? sp_hi : sp_lo; else prv = pr[r];
+                const double num = legacy ? prv * k : coef * prv * k;
                 v[q] = num;
                 acc += num;
             }
@@ -714,7 +751,9 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
     for (int r = lane; r < n; r += 64) {
         const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
         const double k = exp(-(dx * dx + dy * dy + dz * dz) * inv_two_s2);
-        const double num = legacy ? pr[r] * k : coef * pr[r] * k;
+        double prv;
+        if (structured) prv = (r == sp_idx) ? sp_hi : sp_lo; else prv = pr[r];
+        const double num = legacy ? prv * k : coef * prv * k;
         po[r] = num;
         acc += num;
     }
@@ -2356,12 +2395,22 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
     const bool rgm = B >= RG_MIN_BATCH && row_groups();
     const bool defer = ll > 0 && defer_tracked();         // tracked set moved once, after the loop (apply_tracked_kernel); Csum lives in w.M
     const int lla = defer ? 0 : ll;
+    // structured priors (prior_scan_kernel): the table follows the coefficient sums in the dense path's matrix, idle in this loop;
+    // d_grank has been read back
+    const bool sp_on = prior_scan() && 3 * (size_t)nn + 3 * (size_t)mm + 8 <= (size_t)nn * nn;
+    double* sp_tab = w.M + 3 * (size_t)nn;
+    int* d_dense = d_grank;
+    if (sp_on) {
+        HIPCHK(hipMemsetAsync(d_dense, 0, (size_t)B * sizeof(int), st));
+        hipLaunchKernelGGL(prior_scan_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_prior, mm, nn, sp_tab, mm, d_dense, bt);
+        LAUNCH_CHECK();
+    }
     std::vector<double> hsc((size_t)B * S_NUM, 0.0);
     for (int enq = 0; enq < total && live > 0;) {
         const int chunk = prgls_chunk(enq, total);
         for (int k = 0; k < chunk; ++k) {
             hipLaunchKernelGGL(posterior_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_prior, w.predn, nn, in_tgt, mm, w.sc, 0, 1.0,
-                               w.P, 0.0, 0.0, bt);
+                               w.P, 0.0, 0.0, bt, sp_on ? (const double*)sp_tab : (const double*)nullptr, (const int*)d_dense, mm);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(colstats_kernel, dim3((nn + 63) / 64, CS_SEG, zB), dim3(256), 0, st, w.P, in_tgt, mm, nn, w.part, w.sc, bt);
             LAUNCH_CHECK();

@@ -665,6 +665,22 @@ for n, seed in ((50, 0), (113, 1), (301, 2), (600, 3), (599, 4)):
             h.update(t.cpu().numpy().tobytes())
     h.update(str(out[-1]).encode())
 res = dev.prgls_two_ref_batched(probs, 3.0, 3.0, 60)          # ragged batch of 5: the row-group kernels
+# priors as simple_match builds them (one value per row + at most one matched column; some rows unmatched), one problem of the batch
+# with two odd entries in a row, which must send IT back to the dense read, and a large problem on the two-pass path (n > 1024)
+sprobs = []
+for n, seed in ((64, 5), (301, 6), (600, 7), (599, 8), (1100, 9)):
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(n, 3)) * 0.3
+    m = n - (seed % 3)
+    perm = rng.permutation(n)
+    b = (a[perm] * 1.05 + rng.normal(size=(n, 3)) * 0.01)[:m]
+    pr = np.full((m, n), np.float32(0.1 / (n - 1)), dtype=np.float64)
+    rows = np.flatnonzero(rng.uniform(size=m) < 0.8)
+    pr[rows, perm[rows]] = np.float32(0.9)
+    if seed == 8:
+        pr[3, 5] = 0.25; pr[3, 9] = 0.125
+    sprobs.append((torch.from_numpy(pr).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(a).cuda(), torch.from_numpy(a[: n - 7] + 0.001).cuda()))
+res += dev.prgls_two_ref_batched(sprobs, 3.0, 3.0, 40)
 torch.cuda.synchronize()
 for r in res:
     for t in r[:3]:
@@ -675,8 +691,8 @@ print("HASH", h.hexdigest())
 """
 
 
-def test_tiled_gram_and_row_group_kernels_are_bit_identical_to_the_simple_kernels():
-    """lr_gram_tiled_kernel (4 x 4 entries per wave, transposed butterflies) and the row-group variant of apply_dual (4 rows per
+def test_tiled_gram_row_group_and_structured_prior_paths_are_bit_identical_to_the_simple_kernels():
+    """The structured-prior read of posterior_kernel (prior_scan_kernel; CT_PRIOR_SCAN), lr_gram_tiled_kernel (4 x 4 entries per wave, transposed butterflies) and the row-group variant of apply_dual (4 rows per
     wave) must reproduce the entry-per-wave / wave-per-row kernels' sums bit for bit: whole PR-GLS runs
     (single, and a ragged batch with m != n != l, sizes and ranks that are not multiples of 4) hash equal under every switch."""
     import os
@@ -685,11 +701,11 @@ def test_tiled_gram_and_row_group_kernels_are_bit_identical_to_the_simple_kernel
     from pathlib import Path
     repo = Path(__file__).resolve().parent.parent
     hashes = {}
-    for gram, rg in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
-        r = subprocess.run([sys.executable, "-c", GRAM_CHILD, str(repo)], env=dict(os.environ, CT_GRAM_TILED=gram, CT_ROW_GROUPS=rg),
-                           capture_output=True, text=True, timeout=600)
+    for gram, rg, scan in (("0", "0", "0"), ("1", "0", "0"), ("0", "1", "0"), ("1", "1", "0"), ("1", "1", "1"), ("0", "0", "1")):
+        r = subprocess.run([sys.executable, "-c", GRAM_CHILD, str(repo)],
+                           env=dict(os.environ, CT_GRAM_TILED=gram, CT_ROW_GROUPS=rg, CT_PRIOR_SCAN=scan), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        hashes[(gram, rg)] = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1]
+        hashes[(gram, rg, scan)] = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][-1]
     assert len(set(hashes.values())) == 1, hashes
 
 
