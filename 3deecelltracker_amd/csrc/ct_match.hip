@@ -596,7 +596,9 @@ __global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restr
 __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ rowpart, int m, int n, int mode,
                                                       double* __restrict__ sc, const double* __restrict__ normpart = nullptr,
                                                       const double* __restrict__ respart = nullptr, int* __restrict__ rank_p = nullptr,
-                                                      Bt bt = Bt{0, nullptr}) {
+                                                      Bt bt = Bt{0, nullptr}, const double* __restrict__ tr_tgt = nullptr,
+                                                      const double* __restrict__ tr_arow = nullptr, const double* __restrict__ tr_pred = nullptr,
+                                                      const double* __restrict__ tr_d = nullptr, const double* __restrict__ tr_b = nullptr) {
     __shared__ double red[4];
     __shared__ double red2[4];
     __shared__ double red3[4], red4[4];
@@ -620,7 +622,23 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
         if ((threadIdx.x & 63) == 0) red2[threadIdx.x >> 6] = nacc;
     }
     double acc = 0.0;
-    for (int t = threadIdx.x; t < m; t += 256) acc += rowpart[t];
+    if (tr_arow) {
+        // sum_tr P_tr |x_r - y_t|^2 = sum_t a_t |y_t|^2 - 2 sum_r x_r . b_r + sum_r d_r |x_r|^2   (a = row sums of P, d = column sums,
+        // b = P^T Y: all by-products of the E-step; x = the reference set AFTER this iteration's movement).  O(m + n) instead of one
+        // more pass over the m x n posterior; the cancellation (terms ~ sumP, result ~ 3 sigma2 sumP) costs ~1e-12 relative in sigma2
+        // where the direct sum has ~1e-15 - far inside what the low-rank M-step already tolerates.
+        BT_SHIFT(const double*, tr_tgt); BT_SHIFT(const double*, tr_arow); BT_SHIFT(const double*, tr_pred); BT_SHIFT(const double*, tr_d);
+        BT_SHIFT(const double*, tr_b);
+        for (int t = threadIdx.x; t < m; t += 256) {
+            const double yx = tr_tgt[3 * t], yy = tr_tgt[3 * t + 1], yz = tr_tgt[3 * t + 2];
+            acc += tr_arow[t] * (yx * yx + yy * yy + yz * yz);
+        }
+        for (int r = threadIdx.x; r < n; r += 256) {
+            const double xx = tr_pred[3 * r], xy = tr_pred[3 * r + 1], xz = tr_pred[3 * r + 2];
+            acc += tr_d[r] * (xx * xx + xy * xy + xz * xz) - 2.0 * (xx * tr_b[3 * r] + xy * tr_b[3 * r + 1] + xz * tr_b[3 * r + 2]);
+        }
+    } else
+        for (int t = threadIdx.x; t < m; t += 256) acc += rowpart[t];
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -683,6 +701,8 @@ __global__ __launch_bounds__(256) void prior_scan_kernel(const double* __restric
     sp[sp_m + t] = cnt == 1 ? row[last] : __longlong_as_double(lo);
     ((int*)(sp + 2 * (size_t)sp_m))[t] = cnt == 1 ? last : -1;
 }
+// CT_SIGMA_TRACE=0: sigma2 from one more pass over the posterior (dist2_rowsum_kernel) instead of the trace identity
+static bool sigma_trace() { static const bool v = !(getenv("CT_SIGMA_TRACE") && getenv("CT_SIGMA_TRACE")[0] == '0'); return v; }
 static bool prior_scan() { static const bool v = !(getenv("CT_PRIOR_SCAN") && getenv("CT_PRIOR_SCAN")[0] == '0'); return v; }
 
 constexpr int PO_REG = 16;                      // posterior_kernel: rows of up to 64 * PO_REG columns are held in registers
@@ -691,10 +711,12 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
                                                         const double* __restrict__ sc, int legacy, double vol,
                                                         double* __restrict__ P, double s2v = 0.0, double gammav = 0.0,
                                                         Bt bt = Bt{0, nullptr}, const double* __restrict__ sp = nullptr,
-                                                        const int* __restrict__ sp_dense = nullptr, int sp_m = 0) {
+                                                        const int* __restrict__ sp_dense = nullptr, int sp_m = 0,
+                                                        double* __restrict__ arow = nullptr) {
     BT_SHIFT(const double*, prior); BT_SHIFT(const double*, pred); BT_SHIFT(const double*, tgt); BT_SHIFT(double*, P);
     if (sc) BT_SHIFT(const double*, sc);
     if (sp) BT_SHIFT(const double*, sp);
+    if (arow) BT_SHIFT(double*, arow);
     if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
     if (sc && sc[S_DONE] != 0.0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -740,12 +762,14 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
         acc = wave_sum_d(acc);
         const double den = legacy ? acc + gamma * norm / ((1.0 - gamma) * vol) : acc + gamma / vol;
         const double inv_den = 1.0 / den;
+        double asum = 0.0;
 #pragma unroll
         for (int q = 0; q < PO_REG; ++q) {
             if (64 * q >= n) break;
             const int r = lane + 64 * q;
-            if (r < n) po[r] = v[q] * inv_den;
+            if (r < n) { const double p = v[q] * inv_den; po[r] = p; asum += p; }
         }
+        if (arow) { asum = wave_sum_d(asum); if (lane == 0) arow[t] = asum; }
         return;
     }
     for (int r = lane; r < n; r += 64) {
@@ -760,7 +784,9 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
     acc = wave_sum_d(acc);
     const double den = legacy ? acc + gamma * norm / ((1.0 - gamma) * vol) : acc + gamma / vol;
     const double inv_den = 1.0 / den;
-    for (int r = lane; r < n; r += 64) po[r] = po[r] * inv_den;
+    double asum = 0.0;
+    for (int r = lane; r < n; r += 64) { const double p = po[r] * inv_den; po[r] = p; asum += p; }
+    if (arow) { asum = wave_sum_d(asum); if (lane == 0) arow[t] = asum; }
 }
 
 // column statistics, stage 1: block (x: 64 columns, y: row segment) -> part[seg][4][n] = colsum, Y^T P
@@ -1000,9 +1026,11 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
 // 4 waves; writes d_i, sqrt d_i and the scaled right-hand side b~_i = (Y^T P[:, i] - x_i d_i) / sqrt d_i.
 __global__ __launch_bounds__(256) void colstats_finish_par_kernel(const double* __restrict__ part, int n, const double* __restrict__ xref,
                                                                   const double* __restrict__ sc, double* __restrict__ dvec,
-                                                                  double* __restrict__ sqd, double* __restrict__ rhs, Bt bt = Bt{0, nullptr}) {
+                                                                  double* __restrict__ sqd, double* __restrict__ rhs, Bt bt = Bt{0, nullptr},
+                                                                  double* __restrict__ braw = nullptr) {
     BT_SHIFT(const double*, part); BT_SHIFT(const double*, xref); BT_SHIFT(const double*, sc); BT_SHIFT(double*, dvec);
     BT_SHIFT(double*, sqd); BT_SHIFT(double*, rhs);
+    if (braw) BT_SHIFT(double*, braw);
     if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
     if (sc[S_DONE] != 0.0) return;
     __shared__ double red[4][64][4];
@@ -1026,6 +1054,7 @@ __global__ __launch_bounds__(256) void colstats_finish_par_kernel(const double* 
         dvec[i] = s; sqd[i] = q;
         rhs[3 * i] = (sx - xref[3 * i] * s) * iq; rhs[3 * i + 1] = (sy - xref[3 * i + 1] * s) * iq;
         rhs[3 * i + 2] = (sz - xref[3 * i + 2] * s) * iq;
+        if (braw) { braw[3 * i] = sx; braw[3 * i + 1] = sy; braw[3 * i + 2] = sz; }      // P^T Y for the sigma2 trace identity (scalars_kernel)
     }
 }
 
@@ -2060,6 +2089,7 @@ namespace {
 struct PrglsWs {
     double *G, *Gln, *M, *P, *part, *dvec, *sqd, *rhs, *C, *predn, *predl, *rowpart, *rowpart0, *normpart, *sc;
     double *U, *Spart, *ypart, *q, *resid, *respart; int* rank;
+    double *trb, *tra;                          // P^T Y [n][3] and the row sums of P [m]: sigma2 by the trace identity (scalars_kernel)
 };
 size_t prgls_layout(int m, int n, int l, unsigned char* base, PrglsWs* w) {
     size_t off = 0;
@@ -2072,6 +2102,7 @@ size_t prgls_layout(int m, int n, int l, unsigned char* base, PrglsWs* w) {
     t.U = take((size_t)LR_RMAX * n); t.ypart = take((size_t)LR_RMAX * 3);
     t.Spart = take((size_t)LR_RMAX * LR_RMAX > 3 * (size_t)n ? (size_t)LR_RMAX * LR_RMAX : 3 * (size_t)n);   // also the dense path's [3][n] right-hand sides
     t.q = take(LR_RMAX * 3); t.resid = take(n); t.respart = take(2 * (size_t)n); t.rank = (int*)take(8);
+    t.trb = take(3 * (size_t)n); t.tra = take(m);
     if (w) *w = t;
     return off;
 }
@@ -2097,13 +2128,15 @@ int cholesky_solve(const PrglsWs& w, int n, hipStream_t st) {
 // one E-step + M-step solve; leaves C in w.C and sumP in the scalar block.
 // rank > 0: low-rank Woodbury M-step (4 launches); rank <= 0: dense blocked Cholesky.
 int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int n, const double* xref, double lambda,
-            int legacy, double vol, int rank, hipStream_t st) {
-    hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4), dim3(256), 0, st, prior, w.predn, n, tgt, m, w.sc, legacy, vol, w.P, 0.0, 0.0);
+            int legacy, double vol, int rank, hipStream_t st, bool trace = false) {
+    hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4), dim3(256), 0, st, prior, w.predn, n, tgt, m, w.sc, legacy, vol, w.P, 0.0, 0.0,
+                       Bt{0, nullptr}, (const double*)nullptr, (const int*)nullptr, 0, trace ? w.tra : (double*)nullptr);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(colstats_kernel, dim3((n + 63) / 64, CS_SEG), dim3(256), 0, st, w.P, tgt, m, n, w.part, w.sc);
     LAUNCH_CHECK();
     if (rank > 0) {
-        hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((n + 63) / 64), dim3(256), 0, st, w.part, n, xref, w.sc, w.dvec, w.sqd, w.rhs);
+        hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((n + 63) / 64), dim3(256), 0, st, w.part, n, xref, w.sc, w.dvec, w.sqd, w.rhs,
+                           Bt{0, nullptr}, trace ? w.trb : (double*)nullptr);
         LAUNCH_CHECK();
         const int nent = rank * (rank + 1) / 2 + 3 * rank;
         const int ntile = (rank + LG_T - 1) / LG_T, nwave = ntile * (ntile + 1) / 2 + ntile;
@@ -2258,14 +2291,22 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
             HIPCHK(hipMemcpyAsync(ck_sc, w.sc, S_NUM * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
         for (int k = 0; k < chunk; ++k) {
-            if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, rank, st))) return rc;
+            // low-rank iterations take sigma2 from the trace identity (as the batched chain does: the two stay bit-identical);
+            // the dense continuation keeps the direct sum
+            const bool trace = rank > 0 && sigma_trace();
+            if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, rank, st, trace))) return rc;
             hipLaunchKernelGGL(apply_dual_kernel, dim3((n + l + 3) / 4), dim3(256), 0, st, w.C, w.G, n, w.predn, w.Gln, l, w.predl,
                                w.normpart, w.sc, w.dvec, w.sqd, w.rhs, rank > 0 ? w.respart : (double*)nullptr);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, tgt, m, w.P, w.rowpart, w.sc);
-            LAUNCH_CHECK();
-            hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 1, w.sc, w.normpart,
-                               rank > 0 ? w.respart : (const double*)nullptr, rank > 0 ? w.rank : (int*)nullptr);
+            if (trace) {
+                hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 1, w.sc, w.normpart, w.respart, w.rank, Bt{0, nullptr},
+                                   tgt, (const double*)w.tra, (const double*)w.predn, (const double*)w.dvec, (const double*)w.trb);
+            } else {
+                hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((m + 3) / 4), dim3(256), 0, st, w.predn, n, tgt, m, w.P, w.rowpart, w.sc);
+                LAUNCH_CHECK();
+                hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, w.rowpart, m, n, 1, w.sc, w.normpart,
+                                   rank > 0 ? w.respart : (const double*)nullptr, rank > 0 ? w.rank : (int*)nullptr);
+            }
             LAUNCH_CHECK();
         }
         HIPCHK(hipMemcpyAsync(hsc, w.sc, sizeof(hsc), hipMemcpyDeviceToHost, st));
@@ -2399,6 +2440,8 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
     // d_grank has been read back
     const bool sp_on = prior_scan() && 3 * (size_t)nn + 3 * (size_t)mm + 8 <= (size_t)nn * nn;
     double* sp_tab = w.M + 3 * (size_t)nn;
+    const bool trace = sigma_trace();                     // sigma2 by the trace identity (scalars_kernel)
+    double* tr_b = w.trb; double* tr_a = w.tra;
     int* d_dense = d_grank;
     if (sp_on) {
         HIPCHK(hipMemsetAsync(d_dense, 0, (size_t)B * sizeof(int), st));
@@ -2410,12 +2453,13 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
         const int chunk = prgls_chunk(enq, total);
         for (int k = 0; k < chunk; ++k) {
             hipLaunchKernelGGL(posterior_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_prior, w.predn, nn, in_tgt, mm, w.sc, 0, 1.0,
-                               w.P, 0.0, 0.0, bt, sp_on ? (const double*)sp_tab : (const double*)nullptr, (const int*)d_dense, mm);
+                               w.P, 0.0, 0.0, bt, sp_on ? (const double*)sp_tab : (const double*)nullptr, (const int*)d_dense, mm,
+                               trace ? tr_a : (double*)nullptr);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(colstats_kernel, dim3((nn + 63) / 64, CS_SEG, zB), dim3(256), 0, st, w.P, in_tgt, mm, nn, w.part, w.sc, bt);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((nn + 63) / 64, 1, zB), dim3(256), 0, st, w.part, nn, w.predn, w.sc, w.dvec,
-                               w.sqd, w.rhs, bt);
+                               w.sqd, w.rhs, bt, trace ? tr_b : (double*)nullptr);
             LAUNCH_CHECK();
             const int nent = rank * (rank + 1) / 2 + 3 * rank;
             const int ntile = (rank + LG_T - 1) / LG_T, nwave = ntile * (ntile + 1) / 2 + ntile;
@@ -2439,9 +2483,15 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
                 hipLaunchKernelGGL(apply_dual_kernel, dim3((nn + lla + 3) / 4, 1, zB), dim3(256), 0, st, w.C, w.G, nn, w.predn, w.Gln, ll, w.predl,
                                    w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart, bt, defer ? 1 : 0);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, w.predn, nn, in_tgt, mm, w.P, w.rowpart, w.sc, bt);
-            LAUNCH_CHECK();
-            hipLaunchKernelGGL(scalars_kernel, dim3(1, 1, zB), dim3(256), 0, st, w.rowpart, mm, nn, 1, w.sc, w.normpart, w.respart, w.rank, bt);
+            if (!trace) {
+                hipLaunchKernelGGL(dist2_rowsum_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, w.predn, nn, in_tgt, mm, w.P, w.rowpart, w.sc, bt);
+                LAUNCH_CHECK();
+            }
+            if (trace)
+                hipLaunchKernelGGL(scalars_kernel, dim3(1, 1, zB), dim3(256), 0, st, w.rowpart, mm, nn, 1, w.sc, w.normpart, w.respart, w.rank, bt,
+                                   (const double*)in_tgt, (const double*)tr_a, (const double*)w.predn, (const double*)w.dvec, (const double*)tr_b);
+            else
+                hipLaunchKernelGGL(scalars_kernel, dim3(1, 1, zB), dim3(256), 0, st, w.rowpart, mm, nn, 1, w.sc, w.normpart, w.respart, w.rank, bt);
             LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(prgls_gather_kernel, dim3((B * S_NUM + 63) / 64), dim3(64), 0, st, w.sc, (const int*)nullptr, stride, B, d_gsc, (int*)nullptr);
