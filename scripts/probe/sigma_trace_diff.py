@@ -1,0 +1,29 @@
+"""How far do PR-GLS results move when sigma2 comes from the trace identity instead of the direct sum?  (child: prints a .npy path)"""
+import importlib, os, subprocess, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import torch
+    sys.path.insert(0, REPO)
+    mod = lambda n: importlib.import_module("3deecelltracker_amd." + n)
+    synth, ffn_mod, tl, _dev = mod("synth"), mod("ffn"), mod("trackerlite"), mod("_dev")
+    out = {}
+    for name, ffn in (("noise", ffn_mod.FFN().set_weights_dict(synth.make_ffn_weights(0))),
+                      ("trained", ffn_mod.FFN().set_weights_dict(synth.load_ffn_npz(os.path.join(REPO, "tests", "golden", "ffn_synthetic_trained.npz"))))):
+        for n in (113, 600):
+            x, y = synth.make_point_pair(n, seed=100 + n)
+            xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True); yn = (y - mean) / scale
+            a, b = _dev.points_dev(xn), _dev.points_dev(yn)
+            o, it = tl.match_device(ffn, a, b, a, 3, 3)
+            out[f"{name}_{n}"] = o.cpu().numpy(); out[f"{name}_{n}_it"] = np.array(it)
+    np.savez(sys.argv[2], **out)
+    sys.exit(0)
+res = []
+for flag in ("0", "1"):
+    path = f"/tmp/sigma_trace_{flag}.npz"
+    subprocess.run([sys.executable, __file__, "child", path], env=dict(os.environ, CT_SIGMA_TRACE=flag), check=True)
+    res.append(np.load(path))
+for k in sorted(res[0].files):
+    if k.endswith("_it"):
+        continue
+    print(f"{k}: iterations {int(res[0][k + '_it'])} / {int(res[1][k + '_it'])}, max |tracked(direct) - tracked(trace)| = {np.abs(res[0][k] - res[1][k]).max():.3e} (normalised units)")
