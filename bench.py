@@ -394,20 +394,25 @@ def main():
                     help="frames mode: where the LCN of a frame runs (match: beside the match chains, one frame ahead of the U-Net; "
                          "auto: there when the pipeline has no CU partition, i.e. when the match side has slack)")
     ap.add_argument("--disjoint-match-cus", action="store_true", help="give every match chain its own CU slice (measured: worse)")
-    ap.add_argument("--match-workers", type=int, default=None, help="match chains in flight concurrently (default: 2; 3 with --partition)")
+    ap.add_argument("--match-workers", type=int, default=None, help="match chains in flight concurrently (default: 1; 3 with --partition)")
     ap.add_argument("--realistic-match-cus", type=int, default=32, help="match partition of the informative pass with the discriminating FFN")
     ap.add_argument("--partition", action="store_true",
                     help="CU-partitioned pipeline (U-Net on n_cu - match_cus CUs, match chains on --match-cus) instead of the default: U-Net on a "
                          "normal-priority full-chip stream, match chains on high-priority streams (132 vs 124 volumes/s)")
     ap.add_argument("--priority-streams", action="store_true", help="(the default now; kept for old command lines)")
     ap.add_argument("--realistic-partition", action="store_true", help="discriminating-FFN pass on a CU partition (--realistic-match-cus) instead of priority streams (116 vs 121 volumes/s)")
-    ap.add_argument("--match-batch", type=int, default=16, help="frames whose matches share one chain of launches (ct_prgls_two_ref_batched); capped at steps // 4 so that a short run still overlaps its matches with the U-Net")
+    ap.add_argument("--match-batch", type=int, default=None, help="frames whose matches share one chain of launches (ct_prgls_two_ref_batched); capped at ceil(steps / chains) so that a short run does not end on queued match batches")
     ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
     ap.add_argument("--cpu-patches", type=int, default=20, help="U-Net patches timed by the CPU baseline sample")
     args = ap.parse_args()
-    args.match_batch = max(1, min(args.match_batch, max(1, args.steps // 4)))
     if args.match_workers is None:
-        args.match_workers = 3 if args.partition else 2
+        args.match_workers = 3 if args.partition else 1
+    if args.match_batch is None:
+        args.match_batch = 16 if args.partition else 32           # one chain of 32 frames: 143 volumes/s at K = 128 and at K = 20 (141.8 with 2 x 16)
+    # a short run (the driver's --steps 20) must not end on a queue of match batches: no more batches than chains in flight, so that
+    # every match starts while the U-Net frames are still running (the host enqueues far ahead of the GPU; the matches of this
+    # benchmark take given point sets, they do not wait for their frame's segmentation - SURVEY 8e's independent units)
+    args.match_batch = max(1, min(args.match_batch, -(-args.steps // args.match_workers)))
 
     import torch
     import torch.distributed as dist
