@@ -1,10 +1,11 @@
-// Reproducer ATTEMPTS for the co-residency hazard recorded in DESIGN.md section 5 (FFN pair grid wrong in lanes 48-63 beside the
-// split conv kernels).  Two streams, victim and aggressor resident on the same CUs:
-//   1. a packed-fp32 recurrence beside loops of v_mfma_f32_16x16x32_f16 / v_mfma_f32_16x16x4_f32;
-//   2. a kernel with ffn_pair_kernel's structure (LDS tiles, broadcast reads, 2 x 2 pairs -> v_pk_*_f32) beside an MFMA loop fed from
-//      LDS through v_cvt_pkrtz, like the split conv kernels' main loop.
-// Neither reproduces it (0 differing values; a control without the aggressor is included) - the trigger is narrower than these.
-//   hipcc --offload-arch=gfx950 -O3 scripts/probe/pk_mfma_hazard.hip -o scripts/probe/pk_mfma_hazard && scripts/probe/pk_mfma_hazard
+// Reproducer for the co-residency hazard recorded in DESIGN.md section 5 (packed-fp32 results wrong in lanes 48-63 beside the split
+// conv kernels).
+//   In-process attempts (two streams; none reproduces it): a packed-fp32 recurrence beside loops of v_mfma_f32_16x16x32_f16 /
+//   v_mfma_f32_16x16x4_f32; a kernel with ffn_pair_kernel's structure (victim2) beside an MFMA loop fed from LDS through v_cvt_pkrtz.
+//   Cross-process (scripts/probe/pk_hazard_xproc.sh; reproduces it): "victimonly N" / "victim1only N" / "victim3only N" run one victim
+//   N times against its first result while another process keeps the real U-Net busy.  victim2 (LDS-fed packed fp32 with op_sel):
+//   every launch wrong in target rows = 3 (mod 4); victim (packed fp32, no LDS) and victim3 (the LDS traffic, no arithmetic): exact.
+//   hipcc --offload-arch=gfx950 -O3 scripts/probe/pk_mfma_hazard.hip -o scripts/probe/pk_mfma_hazard
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -97,7 +98,101 @@ __global__ __launch_bounds__(256) void aggressor2(const float* __restrict__ in, 
     out[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
 }
 
-int main() {
+// "victimonly N": only the pair-kernel-shaped victim, N launches compared with the first - to be run while ANOTHER PROCESS keeps the
+// real U-Net busy on the same GPU (scripts/probe/pk_hazard_xproc.sh)
+static int victim_only(int reps) {
+    const int n = 608;
+    float *U, *V, *C; hipMalloc(&U, n * 512 * 4); hipMalloc(&V, n * 512 * 4); hipMalloc(&C, n * n * 4);
+    std::vector<float> h(n * 512);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = 0.001f * (float)((i * 2654435761u) % 2001) - 1.0f;
+    hipMemcpy(U, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = 0.001f * (float)((i * 2246822519u) % 1777) - 0.9f;
+    hipMemcpy(V, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    std::vector<float> r2(n * n), g2(n * n);
+    hipLaunchKernelGGL(victim2, dim3(n / 32, n / 32), dim3(256), 0, 0, U, V, C, n); hipDeviceSynchronize();
+    hipMemcpy(r2.data(), C, r2.size() * 4, hipMemcpyDeviceToHost);
+    long bad = 0, q[4] = {0, 0, 0, 0}; int badreps = 0;
+    for (int rep = 0; rep < reps; ++rep) {
+        hipLaunchKernelGGL(victim2, dim3(n / 32, n / 32), dim3(256), 0, 0, U, V, C, n); hipDeviceSynchronize();
+        hipMemcpy(g2.data(), C, g2.size() * 4, hipMemcpyDeviceToHost);
+        long b0 = bad;
+        for (size_t i = 0; i < g2.size(); ++i) if (memcmp(&g2[i], &r2[i], 4)) { ++bad; ++q[(i / n) % 4]; }
+        badreps += bad != b0;
+    }
+    printf("victim only, %d launches: %ld differing values in %d launches; target rows mod 4: %ld %ld %ld %ld\n", reps, bad, badreps, q[0], q[1], q[2], q[3]);
+    return 0;
+}
+
+// victim 3: no arithmetic at all - the pair kernel's LDS tile traffic only: stage V rows into Vs[32][65], every thread reads its two
+// broadcast rows back (the ds_read pattern of the pair kernel) and XORs the bits
+__global__ __launch_bounds__(256) void victim3(const float* __restrict__ V, unsigned* __restrict__ out, int n) {
+    constexpr int KC = 64, HID = 512;
+    __shared__ float Us[32][KC + 1];
+    __shared__ float Vs[32][KC + 1];
+    const int tid = threadIdx.x, tr = tid & 15, tt = tid >> 4;
+    const int r0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    unsigned x0 = 0, x1 = 0;
+    for (int k0 = 0; k0 < HID; k0 += KC) {
+        for (int e = tid; e < 32 * KC; e += 256) {
+            const int row = e / KC, kk = e - row * KC;
+            Us[row][kk] = V[(size_t)(r0 + row) * HID + k0 + kk];
+            Vs[row][kk] = V[(size_t)(t0 + row) * HID + k0 + kk];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < KC; ++kk) {
+            x0 ^= __float_as_uint(Us[tr][kk]) * 3u + __float_as_uint(Us[tr + 16][kk]);
+            x1 ^= __float_as_uint(Vs[tt][kk]) * 5u + __float_as_uint(Vs[tt + 16][kk]);
+        }
+        __syncthreads();
+    }
+    out[((size_t)(t0 + tt) * n + r0 + tr) * 2] = x0; out[((size_t)(t0 + tt) * n + r0 + tr) * 2 + 1] = x1;
+}
+static int victim3_only(int reps) {
+    const int n = 608;
+    float* V; unsigned* C; hipMalloc(&V, n * 512 * 4); hipMalloc(&C, (size_t)n * n * 8); hipMemset(C, 0, (size_t)n * n * 8);
+    std::vector<float> h(n * 512);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = 0.001f * (float)((i * 2246822519u) % 1777) - 0.9f;
+    hipMemcpy(V, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    std::vector<unsigned> r2((size_t)n * n * 2), g2((size_t)n * n * 2);
+    hipLaunchKernelGGL(victim3, dim3(n / 32, n / 32), dim3(256), 0, 0, V, C, n); hipDeviceSynchronize();
+    hipMemcpy(r2.data(), C, r2.size() * 4, hipMemcpyDeviceToHost);
+    long badU = 0, badV = 0, q[4] = {0, 0, 0, 0}; int badreps = 0;
+    for (int rep = 0; rep < reps; ++rep) {
+        hipLaunchKernelGGL(victim3, dim3(n / 32, n / 32), dim3(256), 0, 0, V, C, n); hipDeviceSynchronize();
+        hipMemcpy(g2.data(), C, g2.size() * 4, hipMemcpyDeviceToHost);
+        long b0 = badU + badV;
+        for (size_t i = 0; i < g2.size(); ++i) if (g2[i] != r2[i]) { if (i & 1) { ++badV; ++q[((i / 2) / n) % 4]; } else ++badU; }
+        badreps += (badU + badV) != b0;
+    }
+    printf("LDS tile traffic only, %d launches: %ld differing Us-words, %ld differing Vs-words in %d launches; Vs by target row mod 4: %ld %ld %ld %ld\n",
+           reps, badU, badV, badreps, q[0], q[1], q[2], q[3]);
+    return 0;
+}
+
+// the same for the LDS-free packed-fp32 recurrence (victim 1)
+static int victim1_only(int reps) {
+    const int VB = 2048;
+    float* vo; hipMalloc(&vo, VB * 256 * 2 * sizeof(float));
+    std::vector<float> ref(VB * 256 * 2), got(VB * 256 * 2);
+    hipLaunchKernelGGL(victim, dim3(VB), dim3(256), 0, 0, vo, 4000); hipDeviceSynchronize();
+    hipMemcpy(ref.data(), vo, ref.size() * 4, hipMemcpyDeviceToHost);
+    long bad = 0, q[4] = {0, 0, 0, 0}; int badreps = 0;
+    for (int rep = 0; rep < reps; ++rep) {
+        hipLaunchKernelGGL(victim, dim3(VB), dim3(256), 0, 0, vo, 4000); hipDeviceSynchronize();
+        hipMemcpy(got.data(), vo, got.size() * 4, hipMemcpyDeviceToHost);
+        long b0 = bad;
+        for (size_t i = 0; i < got.size(); ++i) if (memcmp(&got[i], &ref[i], 4)) { ++bad; ++q[((i / 2) & 63) / 16]; }
+        badreps += bad != b0;
+    }
+    printf("LDS-free packed-fp32 recurrence, %d launches: %ld differing values in %d launches; lane quarters: %ld %ld %ld %ld\n", reps, bad, badreps, q[0], q[1], q[2], q[3]);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 2 && !strcmp(argv[1], "victimonly")) return victim_only(atoi(argv[2]));
+    if (argc > 2 && !strcmp(argv[1], "victim1only")) return victim1_only(atoi(argv[2]));
+    if (argc > 2 && !strcmp(argv[1], "victim3only")) return victim3_only(atoi(argv[2]));
     const int VB = 2048, AB = 512;        // 2 aggressor workgroups per CU: the victim must fit beside them
     float *vo, *ao;
     hipMalloc(&vo, VB * 256 * 2 * sizeof(float)); hipMalloc(&ao, 4096 * 256 * sizeof(float));
