@@ -9,7 +9,8 @@ all pairs -> greedy prior -> PR-GLS), inputs resident in HBM.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 --mode frames   (default, the contract line) frames are independent units: every rank processes its own frame per step (weak
-                scaling), followed by the all-gather of the tracked centroid sets (RCCL);
+                scaling), followed by the all-gather of the tracked centroid sets (RCCL).  Intra-GPU: the U-Net on a normal-priority
+                full-chip stream, the match chain(s) on high-priority streams (--partition: CU-masked streams instead);
 --mode patches  BASELINE config 3: ONE frame per step, its 75 patches sharded over the N ranks, input broadcast from rank 0,
                 one all_gather_into_tensor of the per-rank centre-crop slabs, match on rank 0 (strong scaling);
 --mode ensemble BASELINE config 4: one ensemble prediction per step = 20 source volumes x 113-cell legacy FFN + PR-GLS
@@ -378,6 +379,19 @@ def cpu_baseline(ctx, args, n_patches):
                       f"PR-GLS iterations); volume time extrapolated as LCN + {n_patches} x patch + match"}
 
 
+def match_schedule(steps: int, partition: bool, workers: int | None, batch: int | None):
+    """(match chains in flight, frames per chain).  Defaults: one chain of 32 frames on the priority-stream pipeline (143 volumes/s
+    at K = 128 and at K = 20; 2 x 16: 142), three chains of 16 on the CU partition.  A short run (the driver's --steps 20) must not
+    end on a queue of match batches: never more batches than chains in flight, so that every match starts while the U-Net frames
+    are still running (the host enqueues far ahead of the GPU; the matches of this benchmark take given point sets, they do not
+    wait for their frame's segmentation - SURVEY 8e's independent units)."""
+    if workers is None:
+        workers = 3 if partition else 1
+    if batch is None:
+        batch = 16 if partition else 32
+    return workers, max(1, min(batch, -(-steps // workers)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,14 +419,7 @@ def main():
     ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
     ap.add_argument("--cpu-patches", type=int, default=20, help="U-Net patches timed by the CPU baseline sample")
     args = ap.parse_args()
-    if args.match_workers is None:
-        args.match_workers = 3 if args.partition else 1
-    if args.match_batch is None:
-        args.match_batch = 16 if args.partition else 32           # one chain of 32 frames: 143 volumes/s at K = 128 and at K = 20 (141.8 with 2 x 16)
-    # a short run (the driver's --steps 20) must not end on a queue of match batches: no more batches than chains in flight, so that
-    # every match starts while the U-Net frames are still running (the host enqueues far ahead of the GPU; the matches of this
-    # benchmark take given point sets, they do not wait for their frame's segmentation - SURVEY 8e's independent units)
-    args.match_batch = max(1, min(args.match_batch, -(-args.steps // args.match_workers)))
+    args.match_workers, args.match_batch = match_schedule(args.steps, args.partition, args.match_workers, args.match_batch)
 
     import torch
     import torch.distributed as dist

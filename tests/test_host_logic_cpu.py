@@ -109,3 +109,21 @@ def test_trained_ffn_fixture_loads_and_discriminates(golden_dir):
     corr = mr.initial_matching(lambda q: mr.ffn_forward(w, q), x, y, 20)
     diag = np.diag(corr); off = corr[~np.eye(80, dtype=bool)]
     assert np.median(diag) > 0.9 and np.median(off) < 0.01
+
+
+def test_bench_match_schedule_never_queues_more_batches_than_chains():
+    """bench.match_schedule: defaults per pipeline, and a short run (the driver's --steps 20) gets ceil(K / chains) frames per
+    chain so that no batch waits behind another one at the end of the timed region."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    assert bench.match_schedule(128, False, None, None) == (1, 32)
+    assert bench.match_schedule(20, False, None, None) == (1, 20)
+    assert bench.match_schedule(128, True, None, None) == (3, 16)
+    assert bench.match_schedule(20, True, None, None) == (3, 7)
+    assert bench.match_schedule(5, False, 2, 16) == (2, 3)
+    for k in (1, 3, 20, 128):
+        for w in (1, 2, 3):
+            _, b = bench.match_schedule(k, False, w, 16)
+            assert b >= 1 and -(-k // b) <= max(w, -(-k // 16))
