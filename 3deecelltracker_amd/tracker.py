@@ -524,9 +524,9 @@ class Tracker:
         else:
             raise ValueError("no image source and no injected segmentation for the target volume")
         r_coor_predicted, anim = self._predict_pos_once(source_volume=1, draw=False)
-        cells_bd = self._get_cells_onBoundary(r_coor_predicted, self.ensemble) if self.x_siz is not None else ()
         cells_on_boundary_local = self.cells_on_boundary.copy()
-        cells_on_boundary_local[cells_bd] = 1
+        if self.x_siz is not None:        # `a[()] = 1` would flag EVERY cell: without a volume size there is no boundary test
+            cells_on_boundary_local[self._get_cells_onBoundary(r_coor_predicted, self.ensemble)] = 1
         i_disp_from_vol1_updated = None
         if self._regions_dev is not None and self.segresult.image_cell_bg_d is not None:
             _, i_disp_from_vol1_updated = self._accurate_correction(cells_on_boundary_local, r_coor_predicted)

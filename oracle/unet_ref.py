@@ -144,6 +144,43 @@ def unet_forward_torch(patch: np.ndarray, weights: dict, arch, dtype=np.float32,
         return torch.sigmoid(F.conv3d(x, k, t(weights["head"]["bias"])))[0, 0].numpy()
 
 
+def unet3_prediction_torch(vol_xyz: np.ndarray, weights: dict, arch, shrink=(24, 24, 2), dtype=np.float64, batch: int = 4):
+    """Whole sliding-window prediction (unet3d.py:203-255) with EVERY patch evaluated by unet_forward_torch's network, `batch` patches
+    per conv call -> stitched (x, y, z) float32 map.  What the full-size GPU parity tests compare all 75 / 18 / 88 patches against."""
+    import torch
+    import torch.nn.functional as F
+    td = torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
+    t = lambda a: torch.tensor(np.asarray(a), dtype=td)
+    plan = tile_plan(vol_xyz.shape, arch.input_shape, arch.input_shape, shrink)
+    patches = gather_patches(np.asarray(vol_xyz), plan)
+    convs = weights["convs"]
+    packed = [(t(l["kernel"]).permute(4, 3, 0, 1, 2).contiguous(), t(l["bias"]),
+               (t(l["gamma"]) / torch.sqrt(t(l["var"]) + BN_EPS)).view(1, -1, 1, 1, 1), t(l["mean"]).view(1, -1, 1, 1, 1),
+               t(l["beta"]).view(1, -1, 1, 1, 1)) for l in convs]
+    head_k = t(weights["head"]["kernel"]).permute(4, 3, 0, 1, 2); head_b = t(weights["head"]["bias"])
+
+    def block(x, i):
+        k, b, inv, mean, beta = packed[i]
+        y = F.conv3d(x, k, b, padding=1)
+        y = F.leaky_relu(y, LEAKY_ALPHA) if arch.act == 0 else F.relu(y)
+        return (y - mean) * inv + beta
+    pred = np.empty(patches.shape, dtype=np.float32)
+    with torch.no_grad():
+        for s in range(0, len(patches), batch):
+            x = t(patches[s:s + batch])[:, None]
+            i = 0; skips = []
+            for _ in arch.down:
+                x = block(x, i); x = block(x, i + 1); i += 2
+                skips.append(x)
+                x = F.max_pool3d(x, arch.pool)
+            for _ in arch.up:
+                x = block(x, i); x = block(x, i + 1); i += 2
+                x = torch.cat([F.interpolate(x, scale_factor=tuple(float(p) for p in arch.pool), mode="nearest"), skips.pop()], 1)
+            x = block(x, i); x = block(x, i + 1)
+            pred[s:s + batch] = torch.sigmoid(F.conv3d(x, head_k, head_b))[:, 0].numpy()
+    return scatter_centres(pred, plan, vol_xyz.shape), pred, plan
+
+
 # --------------------------------------------------------------------------- tiler
 def padded_size(img_size: int, centre: int):
     """unet3d.py:259-279: number of sub-regions and the padded extent along one axis."""

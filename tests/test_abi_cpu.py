@@ -79,3 +79,23 @@ def test_product_raises_without_library_or_gpu(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.CtamdError):
         _lib.lib()
+
+
+def test_no_packed_fp32_outside_the_conv_kernels(L):
+    """Build gate: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on LDS-fed operands returned wrong values beside the
+    split conv kernels' waves.  Every device object except ct_unet must be free of them -- checked on the disassembly of what was
+    built, so a compiler bump or a float2 edit cannot reintroduce them silently -- and only the C ABI leaves the library."""
+    import subprocess
+    import sys
+    sys.path.insert(0, str(REPO / "scripts"))
+    try:
+        import check_packed_fp32 as gate
+    finally:
+        sys.path.pop(0)
+    objs = sorted((REPO / "3deecelltracker_amd" / "csrc").glob("*.o"))
+    assert {o.stem for o in objs} >= {"ct_unet", "ct_match", "ct_preprocess", "ct_segment", "ct_correct"}
+    assert gate.check(objs) == {}
+    assert sum(gate.packed_fp32_by_kernel(REPO / "3deecelltracker_amd" / "csrc" / "ct_unet.o").values()) > 0   # the detector sees them
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = [l.split()[-1] for l in nm.splitlines() if l.strip()]
+    assert exported and all(n.startswith("ct_") for n in exported), [n for n in exported if not n.startswith("ct_")][:5]

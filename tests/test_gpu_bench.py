@@ -85,3 +85,19 @@ def test_two_ranks_nccl():
                     "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode,
                     "--no-realistic-pass"], timeout=1500)
         assert out["scaling"] == "strong" and out["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arrangement", ["prio", "plain"])
+def test_lcn_regions_correction_are_unaffected_by_a_unet_sharing_their_cus(arrangement):
+    """The other small kernels of the frame (LCN with both border modes, regions -> centres, accurate correction) on a high-priority /
+    plain second stream while the U-Net's split conv kernels run: bit-identical to their stand-alone results, and the U-Net's output
+    to its own (scripts/probe/coresident_probe.py; the match side has its own test in test_gpu_match.py)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(repo / "scripts" / "probe" / "coresident_probe.py"), arrangement, "8"], capture_output=True,
+                       text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mismatching results: 0 of" in r.stdout, r.stdout[-1500:]

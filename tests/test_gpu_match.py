@@ -9,6 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import match_ref as mr
+from _parity import check_pairs, pair_set
 
 synth = importlib.import_module("3deecelltracker_amd.synth")
 ffn_mod = importlib.import_module("3deecelltracker_amd.ffn")
@@ -132,22 +133,19 @@ def test_simple_match_crafted_cases(g, meta):
         assert np.array_equal(prior, g[f"smc_prior_{i}"])
 
 
-def test_end_to_end_indices_with_gap_guard(g, ffn):
-    """pairs from GPU scores == pairs from reference scores whenever every greedy decision of the
-    reference has a margin above the fp32 score tolerance (reported otherwise)."""
-    for n in NS:
-        corr_gpu = ffn_mod.initial_matching_ffn(ffn, g[f"ref_pts_{n}"], g[f"tgt_pts_{n}"], 20)
-        _, pairs_gpu = tl.simple_match(corr_gpu)
-        _, pairs_ref_on_gpu_scores = mr.simple_match(corr_gpu)
-        assert np.array_equal(pairs_gpu, pairs_ref_on_gpu_scores)
-        # decision margin of the reference run
-        work = g[f"corr_{n}"].copy(); margin = np.inf
-        for r, t in g[f"sm_pairs_{n}"]:
-            top2 = np.partition(work.ravel(), -2)[-2:]
-            margin = min(margin, float(top2[1] - top2[0]), float(top2[1] - 0.1))
-            work[t, :] = 0; work[:, r] = 0
-        if margin > 2 * SCORE_TOL:
-            assert np.array_equal(pairs_gpu, g[f"sm_pairs_{n}"]), (n, margin)
+@pytest.mark.parametrize("n", NS)
+def test_end_to_end_indices_against_reference(g, ffn, n):
+    """Correspondence indices from the device's own FFN scores against the pairs the REFERENCE produced (golden: its simple_match on
+    the scores recorded with it).  Identical -> pass; different with a robust decision margin -> failure; different at a near-tie below
+    the fp32 score tolerance -> explicit xfail with the margin (tests/_parity.py)."""
+    corr_gpu = ffn_mod.initial_matching_ffn(ffn, g[f"ref_pts_{n}"], g[f"tgt_pts_{n}"], 20)
+    np.testing.assert_allclose(corr_gpu, g[f"corr_{n}"], rtol=0, atol=SCORE_TOL)
+    _, pairs_gpu = tl.simple_match(corr_gpu)
+    _, pairs_ref_on_gpu_scores = mr.simple_match(corr_gpu)
+    assert np.array_equal(pairs_gpu, pairs_ref_on_gpu_scores)         # the device matcher == the reference algorithm, same scores
+    why = check_pairs(pairs_gpu, g[f"corr_{n}"], g[f"sm_pairs_{n}"], SCORE_TOL, f"n={n}")
+    if why:
+        pytest.xfail(why)
 
 
 # ------------------------------------------------------------------------------------ PR-GLS pieces
@@ -201,6 +199,7 @@ def test_tracker_predict_pos_once_vs_reference(g, ffn, n):
     np.testing.assert_allclose(pred, g[f"trk_pred_{n}"], rtol=0, atol=1e-4)
     anim, (bd, vol, i_disp, pred2) = trk.match(7, "min_size")          # reference signature: match(target_volume, method)
     assert vol == 7 and np.array_equal(pred, pred2) and i_disp is None and anim is None
+    assert not bd.any()                                                # no siz_xyz -> no boundary test, nobody flagged
     with pytest.raises(ValueError, match="no image source"):
         trk.match(8)                                                   # the injected segmentation is consumed by one match
     trk.miss_frame = [9]
@@ -293,6 +292,9 @@ def test_match_600_cells_against_oracle(ffn, ffn_w):
     ref, post_o, iters = mr.prgls_with_two_ref(prior_o, yn, xn, xn, beta=3, lambda_=3, return_iters=True)
     np.testing.assert_allclose(got, ref, rtol=0, atol=COORD_TOL)
     np.testing.assert_allclose(post, post_o, rtol=0, atol=COORD_TOL)
+    why = check_pairs(pairs, want, mr.simple_match(want)[1], SCORE_TOL, "N=600, random-init FFN")   # indices from the ORACLE's scores
+    if why:
+        pytest.xfail(why)
 
 
 @pytest.mark.parametrize("n", (150, 400))
@@ -344,20 +346,14 @@ def test_end_to_end_with_a_discriminating_ffn(golden_dir, n):
     assert np.array_equal(pairs, pairs_o) and np.array_equal(prior, prior_o)
     truth = {int(t): int(perm[t]) for t in np.arange(n)[keep]}
     assert sum(1 for r, t in pairs if truth.get(int(t)) == int(r)) >= 0.7 * keep.sum()
-    # correspondence indices from the oracle's own scores: identical whenever every greedy decision has a margin
-    _, pairs_ref = mr.simple_match(want)
-    work = want.copy(); margin = np.inf
-    for r, t in pairs_ref:
-        top2 = np.partition(work.ravel(), -2)[-2:]
-        margin = min(margin, float(top2[1] - top2[0]), float(top2[1] - 0.1))
-        work[t, :] = 0; work[:, r] = 0
-    if margin > 2 * SCORE_TOL:
-        assert np.array_equal(pairs, pairs_ref), (n, margin)
+    why = check_pairs(pairs, want, mr.simple_match(want)[1], SCORE_TOL, f"n={n}, trained FFN")     # indices from the ORACLE's scores
     ref, post_o, iters = mr.prgls_with_two_ref(prior_o, yn, xn, xn, beta=3, lambda_=3, return_iters=True)
     assert 4 <= iters <= 15
     got, post = tl.prgls_with_two_ref(prior, yn, xn, xn, beta=3, lambda_=3)
     np.testing.assert_allclose(got, ref, rtol=0, atol=COORD_TOL)
     np.testing.assert_allclose(post, post_o, rtol=0, atol=COORD_TOL)
+    if why:
+        pytest.xfail(why)
 
 
 def test_match_2000_cells_properties(ffn):
@@ -467,6 +463,55 @@ def test_match_2000_cells_against_oracle(ffn, ffn_w):
     ref, post_o = mr.prgls_with_two_ref(prior_o, yn, xn, tracked, beta=3, lambda_=3, max_iteration=3)
     np.testing.assert_allclose(got, ref, rtol=0, atol=COORD_TOL)
     np.testing.assert_allclose(post, post_o, rtol=0, atol=COORD_TOL)
+    why = check_pairs(pairs, want, mr.simple_match(want)[1], SCORE_TOL, "N=2000, random-init FFN")  # indices from the ORACLE's scores
+    if why:
+        pytest.xfail(why)
+
+
+def _converging_case(n, seed, n_tracked=None):
+    """Point pair + a score table like a trained FFN's (true pairs 0.7-0.99, everything else <= 0.05): PR-GLS converges in ~9 steps."""
+    rng = np.random.default_rng(seed)
+    xn = mr.normalize_points(rng.uniform(0, 1, (n, 3)) * np.array([512.0, 1024.0, 84.0]))
+    a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.2
+    yn = xn @ a + (rng.uniform(0, 1, xn.shape) - 0.5) * 0.004
+    rep = rng.choice(n, int(0.15 * n), replace=False)
+    yn[rep] = rng.uniform(-0.5, 0.5, (len(rep), 3))
+    perm = rng.permutation(n); yn = yn[perm]
+    corr = rng.uniform(0, 0.05, (n, n)).astype(np.float32)
+    keep = ~np.isin(perm, rep)
+    corr[np.arange(n)[keep], perm[keep]] = rng.uniform(0.7, 0.99, keep.sum()).astype(np.float32)
+    tracked = xn if n_tracked is None else xn[:n_tracked] + rng.normal(0, 0.002, (n_tracked, 3))
+    return xn, yn, corr, tracked, perm, keep
+
+
+def test_prgls_2000_cells_to_convergence_against_oracle():
+    """config 5 size, the whole EM run (not 3 iterations): N = 2000 with a converging prior; coordinates, posterior and the iteration
+    count against the reference formulation (numpy: ~1 s per iteration), pairs bit-exact on the same scores."""
+    xn, yn, corr, tracked, perm, keep = _converging_case(2000, seed=2026, n_tracked=700)
+    prior, pairs = tl.simple_match(corr)
+    prior_o, pairs_o = mr.simple_match(corr)
+    assert np.array_equal(pairs, pairs_o) and np.array_equal(prior, prior_o) and len(pairs) >= keep.sum()
+    ref, post_o, iters = mr.prgls_with_two_ref(prior_o, yn, xn, tracked, beta=3, lambda_=3, return_iters=True)
+    assert 4 <= iters <= 15, iters
+    t = dev.torch()
+    out_l, out_n, post, iters_dev = dev.prgls_two_ref(dev.to_dev(prior.astype(np.float64), t.float64), dev.points_dev(yn), dev.points_dev(xn),
+                                                      dev.points_dev(tracked), 3, 3, 2000, want_ref=True)
+    assert int(iters_dev) == iters
+    np.testing.assert_allclose(out_l.cpu().numpy(), ref, rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post.cpu().numpy(), post_o, rtol=0, atol=COORD_TOL)
+    moved = out_n.cpu().numpy()
+    assert float(np.abs(moved[perm[keep]] - yn[keep]).max()) < 0.02       # the true pairs end up on top of each other
+
+
+def test_prgls_legacy_dialect_600_cells_against_oracle():
+    """The legacy dialect (track.py:11-56: beta 1000 -> lambda 1e-5, 10 iterations, dense M-step) at the headline cell count."""
+    xn, yn, corr, _, perm, keep = _converging_case(600, seed=77)
+    X, Y = xn * 300.0 + 250.0, yn * 300.0 + 250.0                          # voxel-like units, like the legacy callers'
+    for beta, lam, mi in ((300, 0.1, 20), (1000 * 0.8 ** 2, 1e-5, 10)):
+        P, TX, C = track.pr_gls_quick(X.copy(), Y, corr, BETA=beta, max_iteration=mi, LAMBDA=lam)
+        P_o, TX_o, C_o = mr.pr_gls_quick(X.copy(), Y, corr, BETA=beta, max_iteration=mi, LAMBDA=lam)
+        np.testing.assert_allclose(P, P_o, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(TX, TX_o, rtol=0, atol=1e-4)                # voxel units: the north-star's 1e-4
 
 
 def test_trackerlite_ensemble_20_volumes_113_cells_against_oracle(tmp_path, ffn_w):
@@ -487,21 +532,30 @@ def test_trackerlite_ensemble_20_volumes_113_cells_against_oracle(tmp_path, ffn_
     ens = trk.predict_cell_positions_ensemble([], t2, proof, beta=3, lambda_=3, sampling_number=20)
     f = lambda q: mr.ffn_forward(ffn_w, q)
     seg2 = cit.Coordinates(coords[t2], 4, vs, "raw").real
-    preds, same_pairs = [], 0
+    preds, reasons = [], []
     for t1 in vols:
         conf = cit.Coordinates(confirmed[t1], 4, vs, "real").real            # through the float32 raw storage like the reference
         seg1 = cit.Coordinates(coords[t1], 4, vs, "raw").real
         conf_n, (mean, scale) = mr.normalize_points(conf, return_para=True)
         s1, s2 = (seg1 - mean) / scale, (seg2 - mean) / scale
         corr = mr.initial_matching(f, s1, s2, 20)
-        prior, pairs = mr.simple_match(corr)
-        moved, _ = mr.prgls_with_two_ref(prior, s2, s1, conf_n, beta=3, lambda_=3)
+        _, pairs = mr.simple_match(corr)
+        # this member on the device: scores within tolerance, the device matcher == the reference algorithm on the same scores
+        corr_dev = ffn_mod.initial_matching_ffn(trk.ffn_model, s1, s2, 20)
+        np.testing.assert_allclose(corr_dev, corr, rtol=0, atol=SCORE_TOL)
+        prior_dev, pairs_dev = tl.simple_match(corr_dev)
+        prior_chk, pairs_chk = mr.simple_match(corr_dev)
+        assert np.array_equal(pairs_dev, pairs_chk) and np.array_equal(prior_dev, prior_chk)
+        why = check_pairs(pairs_dev, corr, pairs, SCORE_TOL, f"ensemble member t1={t1}")     # raises on a robust-margin difference
+        if why:
+            reasons.append(why)
+        # the numeric chain (PR-GLS -> de-normalise -> Coordinates -> trimmed mean) from the member's own index set: EVERY cell
+        moved, _ = mr.prgls_with_two_ref(prior_chk, s2, s1, conf_n, beta=3, lambda_=3)
         preds.append(cit.Coordinates(moved * scale + mean, 4, vs, "real").real)
     want = cit.Coordinates(mr.trim_mean(np.stack(preds), 0.1), 4, vs, "real").real
-    # correspondences come from arg-maxes of fp32 scores: a flipped near-tie in one of the 20 matches moves single cells; the
-    # trimmed mean absorbs at most 2 outliers per coordinate, so compare robustly and require near-total agreement
-    close = np.abs(ens.real - want).max(axis=1) <= 1e-3
-    assert close.mean() >= 0.97, f"only {close.mean():.3f} of the cells agree with the oracle ensemble"
+    np.testing.assert_allclose(ens.real, want, rtol=0, atol=2e-4)            # real units (|coordinates| ~ 1e2, float32 raw storage)
+    if reasons:
+        pytest.xfail(f"{len(reasons)} of {len(vols)} members part ways with the oracle at a near-tie: " + " | ".join(reasons))
 
 
 def test_prgls_batched_is_bit_identical_to_separate_calls(ffn):

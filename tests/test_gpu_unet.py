@@ -114,24 +114,38 @@ def test_keras_predict_surface():
         unet3d.unet3_a().predict(np.zeros((1, 160, 160, 16, 1), np.float32))   # no weights loaded
 
 
-def test_config1_256x256x24_against_oracle_patches():
-    """BASELINE config 1 size (256x256x24 -> 18 patches): full device pipeline; the oracle (3.7 s / patch on CPU) checks
-    the centre crops of two patches (a corner one with reflect padding on three sides and an interior one)."""
+def _full_volume_against_oracle(model, w, arch, vol_xyz, shrink=(24, 24, 2), fp64_patches=(0,)):
+    """EVERY patch of a volume: the device's stitched map against the torch-CPU evaluation of the oracle network on all patches
+    (fp32 oneDNN convolutions, ~0.1-0.2 s per patch; the numpy oracle needs 3.7 s), after the torch evaluation itself has been held to
+    the numpy oracle and to its own fp64 run on `fp64_patches`.  Returns the per-patch maximum error over the kept crops."""
     import torch
+    got = model.predict_volume_device(torch.from_numpy(np.ascontiguousarray(vol_xyz)).cuda(), shrink=shrink).cpu().numpy()
+    want, pred, plan = ur.unet3_prediction_torch(vol_xyz, w, arch, shrink=shrink, dtype=np.float32)
+    patches = ur.gather_patches(vol_xyz, plan)
+    for p in fp64_patches:
+        ref64 = ur.unet_forward_torch(patches[p], w, arch, dtype=np.float64)
+        assert float(np.abs(pred[p] - ref64).max()) <= 2e-6, f"torch fp32 oracle vs torch fp64, patch {p}"
+        ref_np = ur.unet_forward(patches[p], w, arch)
+        assert float(np.abs(ref_np - ref64).max()) <= 2e-6, f"numpy oracle vs torch fp64, patch {p}"
+    gx, gy, gz = plan["grid"]; cx, cy, cz = plan["centre"]
+    errs = np.zeros(gx * gy * gz)
+    for p in range(len(errs)):
+        i, j, k = p // (gy * gz), (p // gz) % gy, p % gz
+        sl = (slice(i * cx, (i + 1) * cx), slice(j * cy, (j + 1) * cy), slice(k * cz, (k + 1) * cz))
+        d = np.abs(got[sl] - want[sl])
+        errs[p] = float(d.max()) if d.size else 0.0
+    return errs, plan
+
+
+def test_config1_256x256x24_all_patches_against_oracle():
+    """BASELINE config 1 size (256x256x24 -> 18 patches): all 18 patches against the oracle network."""
     arch = arch_mod.UNET3_A
     w = synth.make_unet_weights("unet3_a", seed=2)
     model = unet3d.unet3_a().set_weights_dict(w)
-    img = np.random.default_rng(7).normal(size=(1, 256, 256, 24, 1)).astype(np.float32)
-    got = unet3d.unet3_prediction(img, model)[0, :, :, :, 0]
-    plan = ur.tile_plan((256, 256, 24), arch.input_shape, arch.input_shape, (24, 24, 2))
-    assert plan["grid"] == (3, 3, 2)
-    patches = ur.gather_patches(img[0, :, :, :, 0], plan)
-    for p in (0, 9):
-        i, j, k = p // 6, (p // 2) % 3, p % 2
-        want = ur.unet_forward(patches[p], w, arch)[24:136, 24:136, 2:14]
-        sl = got[i * 112:(i + 1) * 112, j * 112:(j + 1) * 112, k * 12:(k + 1) * 12]
-        want = want[:sl.shape[0], :sl.shape[1], :sl.shape[2]]
-        assert float(np.abs(sl - want).max()) <= 1e-4, p
+    vol = np.random.default_rng(7).normal(size=(256, 256, 24)).astype(np.float32)
+    errs, plan = _full_volume_against_oracle(model, w, arch, vol, fp64_patches=(0, 9))
+    assert plan["grid"] == (3, 3, 2) and len(errs) == 18
+    assert errs.max() <= 1e-4, f"worst patch {int(errs.argmax())}: {errs.max()}"
 
 
 def test_config2_512x512x32_size_independent_properties():
@@ -152,16 +166,16 @@ def test_config2_512x512x32_size_independent_properties():
     assert float(whole.min()) > 0.0 and float(whole.max()) < 1.0 and bool(torch.isfinite(whole).all())
 
 
-def test_worm4_shape_88_patches():
-    """168x401x128 (worm4): 88 patches, z needs 11 patch layers; tiler identity through a fake identity model is covered on
-    the CPU; here the real network runs and the stitched volume is finite everywhere."""
-    import torch
-    model = unet3d.unet3_a().set_weights_dict(synth.make_unet_weights("unet3_a", seed=0))
-    vol = torch.randn(168, 401, 128, device="cuda")
-    centre, grid = unet3d.tile_plan(vol.shape, (160, 160, 16), (24, 24, 2))
-    assert grid[0] * grid[1] * grid[2] == 88
-    out = model.predict_volume_device(vol)
-    assert out.shape == vol.shape and bool(torch.isfinite(out).all()) and float(out.min()) > 0 and float(out.max()) < 1
+def test_worm4_shape_88_patches_against_oracle():
+    """168x401x128 (worm4, BASELINE config 4's stack): 88 patches, 11 patch layers in z, ragged far faces in x and y: all 88 patches
+    against the oracle network."""
+    arch = arch_mod.UNET3_A
+    w = synth.make_unet_weights("unet3_a", seed=0)
+    model = unet3d.unet3_a().set_weights_dict(w)
+    vol = np.random.default_rng(3).normal(size=(168, 401, 128)).astype(np.float32)
+    errs, plan = _full_volume_against_oracle(model, w, arch, vol, fp64_patches=(87,))
+    assert len(errs) == 88 and plan["grid"][2] == 11
+    assert errs.max() <= 1e-4, f"worst patch {int(errs.argmax())}: {errs.max()}"
 
 
 def test_tiler_512_golden_with_the_fake_model_on_device(golden_dir):
@@ -198,24 +212,22 @@ def test_tiler_512_golden_with_the_fake_model_on_device(golden_dir):
     assert torch.equal(back, out)
 
 
-def test_config2_512x512x32_against_oracle_patches():
-    """BASELINE metric size (512x512x32 -> 75 patches): the device volume against the oracle on the centre crops of a corner
-    patch (reflect padding on three sides), an interior patch and the far-corner patch (crop clipped by the volume)."""
+def test_config2_512x512x32_all_75_patches_against_oracle():
+    """BASELINE metric size (512x512x32 -> 75 patches, the benchmark's synthetic stack after LCN): ALL 75 patches of the device volume --
+    the 48 full-crop ones and the 27 on the far faces that take the second dependency walk of the crop-aware decoder -- against the
+    oracle network."""
     arch = arch_mod.UNET3_A
     w = synth.make_unet_weights("unet3_a", seed=0)
     model = unet3d.unet3_a().set_weights_dict(w)
     stack, _ = synth.make_stack((512, 512, 32), 600, seed=0)
-    img = synth.normalize_stack(stack)
-    got = unet3d.unet3_prediction(img, model)[0, :, :, :, 0]
-    plan = ur.tile_plan((512, 512, 32), arch.input_shape, arch.input_shape, (24, 24, 2))
-    assert plan["grid"] == (5, 5, 3)
-    patches = ur.gather_patches(img[0, :, :, :, 0], plan)
-    for p in (0, 2 * 15 + 2 * 3 + 1, 74):
-        i, j, k = p // 15, (p // 3) % 5, p % 3
-        want = ur.unet_forward(patches[p], w, arch)[24:136, 24:136, 2:14]
-        sl = got[i * 112:(i + 1) * 112, j * 112:(j + 1) * 112, k * 12:(k + 1) * 12]
-        want = want[:sl.shape[0], :sl.shape[1], :sl.shape[2]]
-        assert sl.size > 0 and float(np.abs(sl - want).max()) <= 1e-4, p
+    vol = np.ascontiguousarray(synth.normalize_stack(stack)[0, :, :, :, 0])
+    errs, plan = _full_volume_against_oracle(model, w, arch, vol, fp64_patches=(0, 74))
+    assert plan["grid"] == (5, 5, 3) and len(errs) == 75
+    assert errs.max() <= 1e-4, f"worst patch {int(errs.argmax())}: {errs.max()}"
+    # the Keras-facing entry point returns the same map
+    got = unet3d.unet3_prediction(vol[None, :, :, :, None], model)[0, :, :, :, 0]
+    import torch
+    assert np.array_equal(got, model.predict_volume_device(torch.from_numpy(vol).cuda()).cpu().numpy())
 
 
 def test_split_fp16_scaling_over_the_dynamic_range():

@@ -127,3 +127,19 @@ def test_bench_match_schedule_never_queues_more_batches_than_chains():
         for w in (1, 2, 3):
             _, b = bench.match_schedule(k, False, w, 16)
             assert b >= 1 and -(-k // b) <= max(w, -(-k // 16))
+
+
+def test_legacy_match_without_volume_size_flags_no_boundary_cells(monkeypatch):
+    """Tracker.for_matching() has no siz_xyz: match() must leave the boundary flags alone (`a[()] = 1` flagged every cell)."""
+    tracker_mod = importlib.import_module("3deecelltracker_amd.tracker")
+    trk = tracker_mod.Tracker.for_matching(None)
+    pts = np.random.default_rng(0).uniform(0, 50, size=(7, 3))
+    trk.set_volume1(pts)
+    trk._injected = True                                    # what inject_segmentation() records (it uploads to the device)
+    monkeypatch.setattr(trk, "_predict_pos_once", lambda source_volume, draw: (pts + 0.25, None))
+    anim, (bd, vol, i_disp, pred) = trk.match(3)
+    assert anim is None and vol == 3 and i_disp is None
+    assert bd.shape == (7,) and not bd.any()
+    trk.cells_on_boundary[2] = 1                            # flags of earlier volumes are kept
+    trk._injected = True
+    assert trk.match(4)[1][0].tolist() == [0, 0, 1, 0, 0, 0, 0]

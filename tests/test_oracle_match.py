@@ -167,3 +167,31 @@ def test_trim_mean_matches_scipy():
     np.testing.assert_allclose(mr.trim_mean(a, 0.1), trim_mean(a, 0.1, axis=0), rtol=0, atol=1e-14)
     a = a[:7]
     np.testing.assert_allclose(mr.trim_mean(a, 0.1), trim_mean(a, 0.1, axis=0), rtol=0, atol=1e-14)
+
+
+def test_greedy_stability_certificate():
+    """tests/_parity.py: a margin > 2 x tol computed from one score table guarantees the same correspondence SET for any table within
+    tol of it (property check by perturbation), and the checker's three outcomes."""
+    from _parity import check_pairs, stability_margin
+    rng = np.random.default_rng(0)
+    decisive = 0
+    for trial in range(300):
+        m, n = rng.integers(3, 14, 2)
+        s = rng.uniform(0, 1, (m, n)).astype(np.float32)
+        _, p = mr.simple_match(s)
+        mg = stability_margin(s, p)
+        if mg <= 1e-6:
+            continue
+        decisive += 1
+        _, p2 = mr.simple_match(s + (rng.uniform(-1, 1, (m, n)) * mg * 0.49).astype(np.float32))
+        assert check_pairs(p2, s, p, tol=mg * 0.49, tag="perturbed") is None
+    assert decisive > 100
+    s = np.array([[0.9, 0.2], [0.3, 0.8]], np.float32)                      # robust: margin 0.6 (the 0.3 entry against its better blocker 0.9)
+    _, p = mr.simple_match(s)
+    assert abs(stability_margin(s, p) - 0.6) < 1e-6
+    with pytest.raises(AssertionError):
+        check_pairs(np.array([[1, 0], [0, 1]]), s, p, tol=1e-5, tag="wrong pairs, robust margin")
+    tie = np.array([[0.9, 0.9 - 1e-6], [0.3, 0.8]], np.float32)              # near-tie in row 0
+    _, p = mr.simple_match(tie)
+    why = check_pairs(np.array([[1, 0], [0, 1]]), tie, p, tol=1e-5, tag="near-tie")
+    assert why is not None and "margin" in why
