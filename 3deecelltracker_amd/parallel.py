@@ -68,6 +68,20 @@ def chain_map(fn: Callable, items: Sequence, chains: int = 3):
     streams = [torch.cuda.Stream(device=device) for _ in range(n)]
     free = list(range(n)); lock = threading.Lock()
     ready = torch.cuda.Event(); ready.record()               # inputs produced on the caller's stream
+    caller = torch.cuda.current_stream(device)
+
+    def hand_over(out):
+        """Results were allocated on a pooled side stream and are consumed on the caller's: tell the caching allocator, or a later
+        chain on the same side stream may get the block while the caller's consumer (torch.stack, a collective) is still pending."""
+        if isinstance(out, torch.Tensor):
+            if out.is_cuda:
+                out.record_stream(caller)
+        elif isinstance(out, (list, tuple)):
+            for o in out:
+                hand_over(o)
+        elif isinstance(out, dict):
+            for o in out.values():
+                hand_over(o)
 
     def run(it):
         with lock:
@@ -79,6 +93,7 @@ def chain_map(fn: Callable, items: Sequence, chains: int = 3):
             with torch.cuda.stream(st):
                 out = fn(it)
             st.synchronize()
+            hand_over(out)
             return out
         finally:
             with lock:

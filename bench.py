@@ -120,14 +120,22 @@ def make_frames_mode(ctx, args):
     import torch
     import torch.distributed as dist
     pre = mod("preprocess")
-    gather_buf = [torch.empty((args.cells, 3), dtype=torch.float64, device=ctx.dev) for _ in range(ctx.world)] if ctx.world > 1 else None
     comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
+    gather_bufs = {}                                         # frames per batch -> [world][frames][cells][3] receive buffer
 
     def gather(tracked):
+        """"gather of centroid sets": the tracked sets of one match batch (up to 32 frames x 14 KB per rank) leave as ONE
+        all_gather_into_tensor on the communication stream (one collective per batch instead of one list all_gather per frame)."""
         if ctx.world > 1:
-            with torch.cuda.stream(comm):                    # "gather of centroid sets" (14 KB / rank and frame) on its own stream
-                for tr in tracked:
-                    dist.all_gather(gather_buf, tr)
+            cur = torch.cuda.current_stream(ctx.dev)
+            with torch.cuda.stream(comm):
+                comm.wait_stream(cur)
+                send = torch.stack(list(tracked))            # [frames][cells][3] fp64, this rank's frames
+                buf = gather_bufs.get(len(tracked))
+                if buf is None:
+                    buf = gather_bufs[len(tracked)] = torch.empty((ctx.world, *send.shape), dtype=send.dtype, device=ctx.dev)
+                dist.all_gather_into_tensor(buf.view(-1, *send.shape[1:]), send)   # dim-0 concatenation: the form gloo (CPU dry runs) accepts too
+                ctx.gathered_sets += ctx.world * len(tracked)
 
     frame_done, finish_matches = _match_batcher(ctx, args, gather)
 
@@ -331,7 +339,11 @@ def roofline_from_timing(ctx, args, n_patches, steps):
             pass
     first = layers[0]
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
-                "frac": round(achieved / peak_tf, 4), "traffic": traffic, "kernel": dom_name,
+                "frac": round(achieved / peak_tf, 4),
+                # the reference operator's flops (2 * 27 * Cin * Cout per computed voxel; one product per fp32 product) over the same
+                # duration against the peak of the pipe the kernel runs on: `frac` is pipe utilisation, this is useful work
+                "algorithmic_frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / peak_tf, 4) if dom["ms"] > 0 else None,
+                "traffic": traffic, "kernel": dom_name,
                 "math": ("f16x3 split (2 fp16 components per operand, 3 MFMA products per fp32 product, per-patch power-of-two scaling, fp32 accumulate)" if dom.get("f16") else
                          "bf16x6 split (6 bf16 MFMA products per fp32 product, fp32 accumulate)") if dom["bf"] else "f32-input MFMA",
                 "fp32_equivalent_tflops": round(dom_fp32_equiv, 2),
@@ -467,6 +479,7 @@ def main():
     # each drive the match of a different frame (frames are independent units).
     ctx.pipe = par.FramePipeline(device=ctx.local, match_cus=args.match_cus, workers=args.match_workers, disjoint=args.disjoint_match_cus, priority=not args.partition)
     ctx.iters_log = []
+    ctx.gathered_sets = 0
     ctx.active = {"ffn": ctx.ffn}
     ctx.on_timed_start = None
     makers = {"frames": make_frames_mode, "patches": make_patches_mode, "ensemble": make_ensemble_mode}
@@ -557,6 +570,12 @@ def main():
                             "cu_partition": ({"unet": ctx.pipe.n_cu - ctx.pipe.match_cus, "match": ctx.pipe.match_cus} if ctx.pipe.match_cus else
                                              {"unet": ctx.pipe.n_cu, "match": "no partition: match chains on high-priority streams"}),
                             "match_chains_in_flight": args.match_workers, "frames_per_match_chain": args.match_batch,
+                            "headline_excludes": ["regions->centres (ct_segment_centroids)", "accurate correction"] if args.mode != "ensemble" else [],
+                            "headline_note": "matches take given ~600-point sets (independent units, SURVEY 8e); the dependent per-frame chain "
+                                             "incl. regions->centres and correction is config.chained",
+                            "rccl_ranks": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                            "tracked_sets_gathered": ctx.gathered_sets} if world > 1 else
+                                           {"world_size": 1, "backend": None, "tracked_sets_gathered": 0}),
                             "parallelism": parallelism}, **extra),
             "roofline": roofline,
             "cpu_baseline": cpu,
