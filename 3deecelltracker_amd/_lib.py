@@ -85,6 +85,9 @@ SIGNATURES = {
     "ct_trim_mean": (_i, [_vp, _i, _i, _d, _vp, _vp]),
     "ct_segment_workspace_bytes": (_sz, [_ip, _i]),
     "ct_segment_centroids": (_i, [_vp, _ip, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ct_watershed_workspace_bytes": (_sz, [_ip, _i]),
+    "ct_watershed_read_stage": (_i, [_vp, _ip, _i, _i, _vp, _vp]),
+    "ct_watershed_segment": (_i, [_vp, _ip, _d, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -789,8 +789,8 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
     if (arow) { asum = wave_sum_d(asum); if (lane == 0) arow[t] = asum; }
 }
 
+constexpr int CS_SEG = 32;       // row segments of the column statistics
 // column statistics, stage 1: block (x: 64 columns, y: row segment) -> part[seg][4][n] = colsum, Y^T P
-constexpr int CS_SEG = 32;
 __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict__ P, const double* __restrict__ tgt, int m, int n,
                                                        double* __restrict__ part, const double* __restrict__ sc = nullptr,
                                                        Bt bt = Bt{0, nullptr}) {
@@ -816,6 +816,112 @@ __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict_
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q * n + r] = (red[0][cl][q] + red[1][cl][q]) + (red[2][cl][q] + red[3][cl][q]);
     }
+}
+
+// Fused E-step (low-rank EM loop, TrackerLite dialect, n <= 64 * NQ <= 1024): posterior_kernel + colstats_kernel in ONE pass that never
+// writes the m x n posterior (unless the caller asked for it).  A wave takes whole target rows t = g, g + 4 CS_SEG, ... (g = its
+// global wave index): numerators in registers -> row sum (the same butterfly as posterior_kernel, the same values bit for bit) ->
+// normalise -> add p and p * y_t to the lane's per-column accumulators.  The four waves of a block then add their accumulators through
+// LDS in a fixed order and the block writes part[seg][colsum | Y^T P][n] -- the layout colstats_finish_par_kernel already reduces.
+// Against posterior + colstats this removes one write and one read of the posterior per iteration (2 x 2.9 MB per 600-cell problem)
+// and one launch; the column sums are added in another order than colstats_kernel's (rows strided over waves instead of contiguous
+// segments), in the single and the batched path alike.  CT_ESTEP_FUSED=0 restores the two-kernel form.
+template <int NQ>
+__global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restrict__ prior, const double* __restrict__ pred, int n,
+                                                         const double* __restrict__ tgt, int m, const double* __restrict__ sc, double vol,
+                                                         double* __restrict__ P /* or null */, double* __restrict__ part, Bt bt,
+                                                         const double* __restrict__ sp, const int* __restrict__ sp_dense, int sp_m,
+                                                         double* __restrict__ arow) {
+    BT_SHIFT(const double*, prior); BT_SHIFT(const double*, pred); BT_SHIFT(const double*, tgt); BT_SHIFT(const double*, sc);
+    BT_SHIFT(double*, part);
+    if (P) BT_SHIFT(double*, P);
+    if (sp) BT_SHIFT(const double*, sp);
+    if (arow) BT_SHIFT(double*, arow);
+    if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
+    if (sc[S_DONE] != 0.0) return;
+    __shared__ __attribute__((aligned(16))) double red[NQ * 64 * 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double s2 = sc[S_SIGMA2], gamma = sc[S_GAMMA];
+    const double two_s2 = 2.0 * s2;
+    const double norm = pow(2.0 * M_PI * s2, 1.5);
+    const double inv_two_s2 = 1.0 / two_s2, coef = (1.0 - gamma) / norm;      // (as in posterior_kernel)
+    const bool structured = sp && sp_dense[blockIdx.z] == 0;
+    double cs[NQ], cx[NQ], cy[NQ], cz[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) cs[q] = cx[q] = cy[q] = cz[q] = 0.0;
+    for (int t = blockIdx.x * 4 + wave; t < m; t += 4 * CS_SEG) {
+        const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
+        const double* pr = prior + (size_t)t * n;
+        double sp_lo = 0.0, sp_hi = 0.0; int sp_idx = -1;
+        if (structured) { sp_lo = sp[t]; sp_hi = sp[sp_m + t]; sp_idx = ((const int*)(sp + 2 * (size_t)sp_m))[t]; }
+        double v[NQ];
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int r = lane + 64 * q;
+            v[q] = 0.0;
+            if (r < n) {
+                const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
+                const double k = exp(-(dx * dx + dy * dy + dz * dz) * inv_two_s2);
+                double prv;
+                if (structured) prv = (r == sp_idx) ? sp_hi : sp_lo; else prv = pr[r];
+                const double num = coef * prv * k;
+                v[q] = num;
+                acc += num;
+            }
+        }
+        acc = wave_sum_d(acc);
+        const double inv_den = 1.0 / (acc + gamma / vol);
+        double asum = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int r = lane + 64 * q;
+            if (r < n) {
+                const double p = v[q] * inv_den;
+                if (P) P[(size_t)t * n + r] = p;
+                asum += p;
+                cs[q] += p; cx[q] = fma(yx, p, cx[q]); cy[q] = fma(yy, p, cy[q]); cz[q] = fma(yz, p, cz[q]);
+            }
+        }
+        if (arow) { asum = wave_sum_d(asum); if (lane == 0) arow[t] = asum; }
+    }
+    // ((wave 3 + wave 2) + wave 1) + wave 0, through one LDS copy of the accumulators
+#pragma unroll
+    for (int w = 3; w >= 1; --w) {
+        if (wave == w) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                double* d = red + (q * 64 + lane) * 4;
+                if (w == 3) { d[0] = cs[q]; d[1] = cx[q]; d[2] = cy[q]; d[3] = cz[q]; }
+                else { d[0] += cs[q]; d[1] += cx[q]; d[2] += cy[q]; d[3] += cz[q]; }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        double* o = part + (size_t)blockIdx.x * 4 * n;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int r = lane + 64 * q;
+            if (r < n) {
+                const double* d = red + (q * 64 + lane) * 4;
+                o[r] = d[0] + cs[q]; o[n + r] = d[1] + cx[q]; o[2 * n + r] = d[2] + cy[q]; o[3 * n + r] = d[3] + cz[q];
+            }
+        }
+    }
+}
+static bool estep_fused() { static const bool v = !(getenv("CT_ESTEP_FUSED") && getenv("CT_ESTEP_FUSED")[0] == '0'); return v; }
+// launches estep_cols_kernel<NQ> with the smallest NQ that covers n columns; false if n is too wide for the register-resident rows
+static bool launch_estep_cols(int n_max, unsigned zB, hipStream_t st, const double* prior, const double* pred, int n, const double* tgt, int m,
+                              const double* sc, double* P, double* part, Bt bt, const double* sp, const int* sp_dense, int sp_m, double* arow) {
+    const int need = (n_max + 63) / 64;
+    if (need > PO_REG || !estep_fused()) return false;
+#define CT_ESTEP(NQv) hipLaunchKernelGGL(estep_cols_kernel<NQv>, dim3(CS_SEG, 1, zB), dim3(256), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, part, bt, \
+                                         sp, sp_dense, sp_m, arow)
+    if (need <= 1) CT_ESTEP(1); else if (need <= 2) CT_ESTEP(2); else if (need <= 4) CT_ESTEP(4); else if (need <= 6) CT_ESTEP(6);
+    else if (need <= 8) CT_ESTEP(8); else if (need <= 10) CT_ESTEP(10); else if (need <= 12) CT_ESTEP(12); else CT_ESTEP(16);
+#undef CT_ESTEP
+    return true;
 }
 
 // stage 2: d[r] = colsum, rhs (scaled) and sumP.  xref = points whose X^T D term is subtracted
@@ -2128,11 +2234,17 @@ int cholesky_solve(const PrglsWs& w, int n, hipStream_t st) {
 // one E-step + M-step solve; leaves C in w.C and sumP in the scalar block.
 // rank > 0: low-rank Woodbury M-step (4 launches); rank <= 0: dense blocked Cholesky.
 int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int n, const double* xref, double lambda,
-            int legacy, double vol, int rank, hipStream_t st, bool trace = false) {
-    hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4), dim3(256), 0, st, prior, w.predn, n, tgt, m, w.sc, legacy, vol, w.P, 0.0, 0.0,
-                       Bt{0, nullptr}, (const double*)nullptr, (const int*)nullptr, 0, trace ? w.tra : (double*)nullptr);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(colstats_kernel, dim3((n + 63) / 64, CS_SEG), dim3(256), 0, st, w.P, tgt, m, n, w.part, w.sc);
+            int legacy, double vol, int rank, hipStream_t st, bool trace = false, bool want_P = true) {
+    // low-rank iterations of the TrackerLite dialect: fused E-step (the posterior is written only if somebody reads it: the caller, or
+    // the direct sigma2 sum when the trace identity is switched off)
+    if (!(rank > 0 && !legacy && vol == 1.0 &&
+          launch_estep_cols(n, 1, st, prior, w.predn, n, tgt, m, w.sc, (want_P || !trace) ? w.P : (double*)nullptr, w.part, Bt{0, nullptr},
+                            (const double*)nullptr, (const int*)nullptr, 0, trace ? w.tra : (double*)nullptr))) {
+        hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4), dim3(256), 0, st, prior, w.predn, n, tgt, m, w.sc, legacy, vol, w.P, 0.0, 0.0,
+                           Bt{0, nullptr}, (const double*)nullptr, (const int*)nullptr, 0, trace ? w.tra : (double*)nullptr);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(colstats_kernel, dim3((n + 63) / 64, CS_SEG), dim3(256), 0, st, w.P, tgt, m, n, w.part, w.sc);
+    }
     LAUNCH_CHECK();
     if (rank > 0) {
         hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((n + 63) / 64), dim3(256), 0, st, w.part, n, xref, w.sc, w.dvec, w.sqd, w.rhs,
@@ -2294,7 +2406,7 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
             // low-rank iterations take sigma2 from the trace identity (as the batched chain does: the two stay bit-identical);
             // the dense continuation keeps the direct sum
             const bool trace = rank > 0 && sigma_trace();
-            if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, rank, st, trace))) return rc;
+            if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, rank, st, trace, posterior != nullptr))) return rc;
             hipLaunchKernelGGL(apply_dual_kernel, dim3((n + l + 3) / 4), dim3(256), 0, st, w.C, w.G, n, w.predn, w.Gln, l, w.predl,
                                w.normpart, w.sc, w.dvec, w.sqd, w.rhs, rank > 0 ? w.respart : (double*)nullptr);
             LAUNCH_CHECK();
@@ -2449,14 +2561,19 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
         LAUNCH_CHECK();
     }
     std::vector<double> hsc((size_t)B * S_NUM, 0.0);
+    bool any_posterior = false;
+    for (int b = 0; b < B && posterior; ++b) any_posterior = any_posterior || posterior[b] != nullptr;
     for (int enq = 0; enq < total && live > 0;) {
         const int chunk = prgls_chunk(enq, total);
         for (int k = 0; k < chunk; ++k) {
-            hipLaunchKernelGGL(posterior_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_prior, w.predn, nn, in_tgt, mm, w.sc, 0, 1.0,
-                               w.P, 0.0, 0.0, bt, sp_on ? (const double*)sp_tab : (const double*)nullptr, (const int*)d_dense, mm,
-                               trace ? tr_a : (double*)nullptr);
-            LAUNCH_CHECK();
-            hipLaunchKernelGGL(colstats_kernel, dim3((nn + 63) / 64, CS_SEG, zB), dim3(256), 0, st, w.P, in_tgt, mm, nn, w.part, w.sc, bt);
+            if (!launch_estep_cols(nn, zB, st, in_prior, w.predn, nn, in_tgt, mm, w.sc, (any_posterior || !trace) ? w.P : (double*)nullptr, w.part, bt,
+                                   sp_on ? (const double*)sp_tab : (const double*)nullptr, (const int*)d_dense, mm, trace ? tr_a : (double*)nullptr)) {
+                hipLaunchKernelGGL(posterior_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_prior, w.predn, nn, in_tgt, mm, w.sc, 0, 1.0,
+                                   w.P, 0.0, 0.0, bt, sp_on ? (const double*)sp_tab : (const double*)nullptr, (const int*)d_dense, mm,
+                                   trace ? tr_a : (double*)nullptr);
+                LAUNCH_CHECK();
+                hipLaunchKernelGGL(colstats_kernel, dim3((nn + 63) / 64, CS_SEG, zB), dim3(256), 0, st, w.P, in_tgt, mm, nn, w.part, w.sc, bt);
+            }
             LAUNCH_CHECK();
             hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((nn + 63) / 64, 1, zB), dim3(256), 0, st, w.part, nn, w.predn, w.sc, w.dvec,
                                w.sqd, w.rhs, bt, trace ? tr_b : (double*)nullptr);

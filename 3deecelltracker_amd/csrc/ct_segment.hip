@@ -3,8 +3,8 @@
 // What it stands in for (reference CellTracker/tracker.py):
 //   :636-648  _segment: regions = watershed(prob); centres = scipy.ndimage.center_of_mass(regions > 0, regions, 1..n)
 //   :671-684  _watershed -> watershed.py:16-108 (skimage distance transform + marker watershed, 2D then 3D)
-// skimage is not installed in this image, so the marker watershed has no runnable reference here and is NOT restated.
-// This file is the variant SURVEY 8f#2 names: threshold (prob > t) + 3D connected components + remove regions smaller
+// Two region steps live here.  (1) ct_watershed_segment: the reference's marker watershed itself (second half of this file).
+// (2) ct_segment_centroids, the variant SURVEY 8f#2 names: threshold (prob > t) + 3D connected components + remove regions smaller
 // than min_size (skimage remove_small_objects semantics: size < min_size is dropped) + sequential relabel + the
 // reference's own centre-of-mass call.  Touching cells are therefore not split; everything downstream of the label image
 // (ordering of labels, centre of mass, the raw-voxel coordinate convention) is the reference's.
@@ -257,6 +257,462 @@ SegLayout seg_layout(long long V, int cap) {
     return L;
 }
 
+
+// ================================================================================================
+// Marker watershed (the reference's own region step): CellTracker/watershed.py:16-53 (watershed_2d), :55-108 (watershed_3d) as called
+// by Tracker._watershed (tracker.py:671-684), followed by relabel_sequential and the reference's centre-of-mass call.
+//   per z slice:  bn = prob > 0.5 -> EDT -> Gaussian(2) -> peak_local_max(min_distance 7) -> label -> watershed(-smooth, markers, bn)
+//                 -> find_boundaries(connectivity 2, outer) removed from bn
+//   volume:       EDT(sampling 1, 1, z_xy_ratio) -> Gaussian(2, 2, 0.3) -> peak_local_max(min_distance 3, no border exclusion) -> label
+//                 -> watershed -> bincount -> min_size / cell_num -> remove_small_objects -> relabel_sequential -> centres
+// Every step reproduces the CPU functions' arithmetic, not just their meaning (oracle/watershed_ref.py):
+//   * EDT: exact integer squared distances in the plane (x sweep, then a bounded outward search along y); the anisotropic z term and
+//     the square root in fp64 in scipy's operand order ((dx^2 + dy^2) + (sz dz)^2);
+//   * Gaussian: scipy's correlate1d for symmetric kernels -- centre tap first, then (in[l - j] + in[l + j]) * w[j] from the farthest
+//     pair inwards, zero 'constant' borders, axis 0 then 1 (then 2), no fused multiply-add (the TU is built with -ffp-contract=off);
+//     the weights are computed by the host exactly as scipy does and passed in;
+//   * peaks: value == separable maximum over the (2 d + 1)^ndim window, none for a constant image, value > the image's minimum, border
+//     exclusion, and among EQUAL peaks closer than d the one with the smaller raveled index (skimage's ensure_spacing can only ever drop
+//     ties: inside the window two surviving maxima are equal); labels in raster order;
+//   * watershed: skimage's priority flood is inherently sequential (a heap of (value, age), labels given at push time).  Connected
+//     components of the mask never interact, and inside a component the order of pops only depends on the component's own entries, so
+//     every component is flooded by ONE thread with its own binary heap (value, age, raveled index): hundreds of components run side
+//     by side, the result is the sequential algorithm's, bit for bit.
+// All volume arrays are [x][y][z] like the probability map; threads run over z fastest so that every 1-D pass along x or y is a
+// coalesced sweep.
+// ================================================================================================
+constexpr int WS_INF = 1 << 14;                       // "no background on this line" (volumes are < 2^14 voxels per axis)
+constexpr int WS_PEAK_CAP2D = 2048, WS_PEAK_CAP3D = 8192;
+
+struct WsHeapEntry { double value; int age; int idx; };
+
+__device__ __forceinline__ void ws_xyz(long long i, const SegGeom& g, int& x, int& y, int& z) {
+    z = (int)(i % g.Z); y = (int)((i / g.Z) % g.Y); x = (int)(i / ((long long)g.Z * g.Y));
+}
+
+__global__ void ws_threshold_kernel(const float* __restrict__ prob, long long V, unsigned char* __restrict__ bn) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < V) bn[i] = prob[i] > 0.5f ? 1 : 0;
+}
+
+// distance (voxels) to the nearest background voxel along x, WS_INF if the line has none; one thread per (y, z) line
+__global__ void ws_edt_x_kernel(SegGeom g, const unsigned char* __restrict__ bn, int32_t* __restrict__ gx) {
+    const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long YZ = (long long)g.Y * g.Z;
+    if (l >= YZ) return;
+    int d = WS_INF;
+    for (int x = 0; x < g.X; ++x) {
+        const long long i = (long long)x * YZ + l;
+        d = bn[i] ? (d >= WS_INF ? WS_INF : d + 1) : 0;
+        gx[i] = d;
+    }
+    d = WS_INF;
+    for (int x = g.X - 1; x >= 0; --x) {
+        const long long i = (long long)x * YZ + l;
+        d = bn[i] ? (d >= WS_INF ? WS_INF : d + 1) : 0;
+        if (d < gx[i]) gx[i] = d;
+    }
+}
+
+// exact squared distance in the (x, y) plane: min_j gx(x, j)^2 + (y - j)^2, searched outwards from j = y until (y - j)^2 >= best
+// (INT_MAX if the slice has no background).  MODE2D: dist = sqrt(d2) is written directly (fp64).
+template <bool MODE2D>
+__global__ void ws_edt_y_kernel(SegGeom g, const int32_t* __restrict__ gx, int32_t* __restrict__ d2, double* __restrict__ dist) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.V) return;
+    int x, y, z; ws_xyz(i, g, x, y, z);
+    const int g0 = gx[i];
+    long long best = g0 >= WS_INF ? 0x7fffffffLL : (long long)g0 * g0;
+    if (g0 != 0) {
+        for (int k = 1; k < g.Y && (long long)k * k < best; ++k) {
+            if (y - k >= 0) { const int v = gx[i - (long long)k * g.Z]; if (v < WS_INF) { const long long c = (long long)v * v + (long long)k * k; if (c < best) best = c; } }
+            if (y + k < g.Y) { const int v = gx[i + (long long)k * g.Z]; if (v < WS_INF) { const long long c = (long long)v * v + (long long)k * k; if (c < best) best = c; } }
+        }
+    }
+    if (MODE2D) dist[i] = best >= 0x7fffffffLL ? 0.0 : sqrt((double)best);
+    else d2[i] = (int32_t)best;
+}
+
+// anisotropic third axis: dist = sqrt(min_k ((dx^2 + dy^2)(k) + (sz (z - k))^2)) in scipy's operand order
+__global__ void ws_edt_z_kernel(SegGeom g, const int32_t* __restrict__ d2, double sz, double* __restrict__ dist) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.V) return;
+    const int z = (int)(i % g.Z);
+    const long long base = i - z;
+    if (d2[i] == 0) { dist[i] = 0.0; return; }
+    double best = INFINITY;
+    for (int k = 0; k < g.Z; ++k) {
+        const int v = d2[base + k];
+        if (v == 0x7fffffff) continue;
+        const double dz = (double)(k - z) * sz;
+        const double c = (double)v + dz * dz;
+        if (c < best) best = c;
+    }
+    dist[i] = isfinite(best) ? sqrt(best) : 0.0;
+}
+
+// scipy.ndimage correlate1d, symmetric kernel w[0..2r], 'constant' (0) borders, along the axis with element stride `stride`
+__global__ void ws_gauss_kernel(SegGeom g, int axis, const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ w, int r) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.V) return;
+    int x, y, z; ws_xyz(i, g, x, y, z);
+    const int pos = axis == 0 ? x : (axis == 1 ? y : z), len = axis == 0 ? g.X : (axis == 1 ? g.Y : g.Z);
+    const long long stride = axis == 0 ? (long long)g.Y * g.Z : (axis == 1 ? g.Z : 1);
+    double acc = in[i] * w[r];
+    for (int j = r; j >= 1; --j) {
+        const double a = pos - j >= 0 ? in[i - j * stride] : 0.0;
+        const double b = pos + j < len ? in[i + j * stride] : 0.0;
+        acc += (a + b) * w[r - j];
+    }
+    out[i] = acc;
+}
+
+// maximum over [pos - r, pos + r] along one axis, 'constant' 0 outside the image
+__global__ void ws_maxfilt_kernel(SegGeom g, int axis, const double* __restrict__ in, double* __restrict__ out, int r) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.V) return;
+    int x, y, z; ws_xyz(i, g, x, y, z);
+    const int pos = axis == 0 ? x : (axis == 1 ? y : z), len = axis == 0 ? g.X : (axis == 1 ? g.Y : g.Z);
+    const long long stride = axis == 0 ? (long long)g.Y * g.Z : (axis == 1 ? g.Z : 1);
+    double m = in[i];
+    if ((pos - r < 0 || pos + r >= len) && m < 0.0) m = 0.0;
+    for (int j = 1; j <= r; ++j) {
+        if (pos - j >= 0) m = fmax(m, in[i - j * stride]);
+        if (pos + j < len) m = fmax(m, in[i + j * stride]);
+    }
+    out[i] = m;
+}
+
+// Peak candidates + the per-group statistics peak_local_max needs (group = z slice in 2-D mode, the whole volume in 3-D mode):
+// eq_count = #(value == window maximum), vmin = the image minimum (values are >= 0: the bit patterns order like the values).
+// A candidate is a positive local maximum outside the excluded border; "value > minimum" and "not a constant image" are applied
+// by ws_peak_select_kernel once the statistics are complete.  Persistent blocks: per-group partials live in LDS, one global atomic
+// per block and group.
+__global__ __launch_bounds__(256) void ws_peak_kernel(SegGeom g, int mode2d, int border, const double* __restrict__ v, const double* __restrict__ vmax,
+                                                      unsigned int* __restrict__ eq_count, unsigned long long* __restrict__ vmin,
+                                                      unsigned int* __restrict__ cand_count, int cap, unsigned long long* __restrict__ cand_val,
+                                                      int32_t* __restrict__ cand_idx, int* __restrict__ overflow) {
+    __shared__ unsigned int s_eq[128];
+    __shared__ unsigned long long s_min[128];
+    const int ngroups = mode2d ? g.Z : 1;
+    for (int t = threadIdx.x; t < 128; t += 256) { s_eq[t] = 0; s_min[t] = ~0ull; }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < g.V; i += (long long)gridDim.x * 256) {
+        int x, y, z; ws_xyz(i, g, x, y, z);
+        const int grp = mode2d ? z : 0;
+        const double a = v[i];
+        const bool eq = a == vmax[i];
+        if (eq) atomicAdd(&s_eq[grp & 127], 1u);
+        atomicMin(&s_min[grp & 127], (unsigned long long)__double_as_longlong(a));
+        const bool inside = x >= border && x < g.X - border && y >= border && y < g.Y - border && (mode2d || (z >= border && z < g.Z - border));
+        if (eq && a > 0.0 && inside) {
+            const unsigned int pos = atomicAdd(&cand_count[grp], 1u);
+            if ((int)pos < cap) { cand_val[(size_t)grp * cap + pos] = (unsigned long long)__double_as_longlong(a); cand_idx[(size_t)grp * cap + pos] = (int32_t)i; }
+            else *overflow = 1;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ngroups && t < 128; t += 256) {
+        if (s_eq[t]) atomicAdd(&eq_count[t], s_eq[t]);
+        if (s_min[t] != ~0ull) atomicMin(&vmin[t], s_min[t]);
+    }
+}
+
+// One workgroup per group: final peak test, ensure_spacing among exact ties, raster-order marker labels.
+// Out: labels[idx] = marker number (1-based, raster order within the group), marker list (idx ascending) and count per group.
+__global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mode2d, int min_distance, const unsigned int* __restrict__ eq_count,
+                                                              const unsigned long long* __restrict__ vmin, const unsigned int* __restrict__ cand_count,
+                                                              int cap, const unsigned long long* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
+                                                              int32_t* __restrict__ labels, int32_t* __restrict__ marker_idx, int32_t* __restrict__ marker_count) {
+    extern __shared__ unsigned long long ws_sm[];
+    const int grp = blockIdx.x;
+    const long long gsize = mode2d ? (long long)g.X * g.Y : g.V;
+    int n = (int)min(cand_count[grp], (unsigned int)cap);
+    if (eq_count[grp] == (unsigned long long)gsize) n = 0;                       // constant image: no peaks
+    int np2 = 1; while (np2 < n) np2 <<= 1;
+    unsigned long long* key = ws_sm;                                             // [np2] ~value bits (descending value = ascending key)
+    int* idx = (int*)(ws_sm + np2);                                              // [np2]
+    int* keep = idx + np2;                                                       // [np2]
+    const unsigned long long mn = vmin[grp];
+    for (int t = threadIdx.x; t < np2; t += 1024) {
+        unsigned long long k = ~0ull; int id = 0x7fffffff;
+        if (t < n) {
+            const unsigned long long vb = cand_val[(size_t)grp * cap + t];
+            if (vb > mn) { k = ~vb; id = cand_idx[(size_t)grp * cap + t]; }      // value > image minimum
+        }
+        key[t] = k; idx[t] = id;
+    }
+    __syncthreads();
+    // bitonic sort by (key, idx)
+    for (int k2 = 2; k2 <= np2; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < np2; t += 1024) {
+                const int p = t ^ j;
+                if (p > t) {
+                    const bool up = (t & k2) == 0;
+                    const unsigned long long ka = key[t], kb = key[p]; const int ia = idx[t], ib = idx[p];
+                    const bool gt = ka > kb || (ka == kb && ia > ib);
+                    if (gt == up) { key[t] = kb; key[p] = ka; idx[t] = ib; idx[p] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    // ensure_spacing: only equal values can be closer than min_distance; the first element of every run of equal keys walks its run
+    for (int t = threadIdx.x; t < np2; t += 1024) keep[t] = (key[t] != ~0ull || idx[t] != 0x7fffffff) ? 1 : 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < np2; t += 1024) {
+        if (!keep[t]) continue;
+        if (t > 0 && key[t - 1] == key[t]) continue;                             // not a run start
+        int e = t + 1;
+        while (e < np2 && key[e] == key[t] && idx[e] != 0x7fffffff) ++e;
+        if (e - t < 2) continue;
+        for (int a = t + 1; a < e; ++a) {
+            int xa, ya, za; ws_xyz(idx[a], g, xa, ya, za);
+            for (int b = t; b < a; ++b) {
+                if (!keep[b]) continue;
+                int xb, yb, zb; ws_xyz(idx[b], g, xb, yb, zb);
+                const int d = max(max(abs(xa - xb), abs(ya - yb)), abs(za - zb));
+                if (d <= min_distance) { keep[a] = 0; break; }
+            }
+        }
+    }
+    __syncthreads();
+    // kept peaks in raster order: sort by idx (dropped entries to the end)
+    for (int t = threadIdx.x; t < np2; t += 1024) { key[t] = keep[t] ? (unsigned long long)(unsigned int)idx[t] : ~0ull; }
+    __syncthreads();
+    for (int k2 = 2; k2 <= np2; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < np2; t += 1024) {
+                const int p = t ^ j;
+                if (p > t) {
+                    const bool up = (t & k2) == 0;
+                    const unsigned long long ka = key[t], kb = key[p];
+                    if ((ka > kb) == up) { key[t] = kb; key[p] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    __shared__ int nkept;
+    if (threadIdx.x == 0) nkept = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < np2; t += 1024)
+        if (key[t] != ~0ull) {
+            const int id = (int)key[t];
+            labels[id] = t + 1;
+            marker_idx[(size_t)grp * cap + t] = id;
+            atomicAdd(&nkept, 1);
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) marker_count[grp] = nkept;
+}
+
+// connectivity-1 components of the mask (2-D mode: inside every z slice) with the union-find of the connected-components path
+template <bool MODE2D>
+__global__ void ws_cc_init_merge_kernel(SegGeom g, const unsigned char* __restrict__ bn, int32_t* __restrict__ parent, int phase) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.V) return;
+    if (phase == 0) { parent[i] = bn[i] ? (int32_t)i : -1; return; }
+    if (!bn[i]) return;
+    int x, y, z; ws_xyz(i, g, x, y, z);
+    if (x + 1 < g.X && bn[i + (long long)g.Y * g.Z]) unite(parent, (int)i, (int)(i + (long long)g.Y * g.Z));
+    if (y + 1 < g.Y && bn[i + g.Z]) unite(parent, (int)i, (int)(i + g.Z));
+    if (!MODE2D && z + 1 < g.Z && bn[i + 1]) unite(parent, (int)i, (int)(i + 1));
+}
+
+// heap space for every component (a bump allocation of `size` entries per root), marker counters cleared
+__global__ void ws_heap_alloc_kernel(long long V, const int32_t* __restrict__ parent, const int32_t* __restrict__ size,
+                                     int32_t* __restrict__ heap_off, int32_t* __restrict__ heap_cnt, unsigned int* __restrict__ bump) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    if (parent[i] == (int32_t)i) { heap_off[i] = (int32_t)atomicAdd(bump, (unsigned int)size[i]); heap_cnt[i] = 0; }
+}
+
+// every marker joins its component's heap (value = -smooth, age 0); components with markers are listed for the flood
+__global__ void ws_marker_append_kernel(int ngroups, int cap, const int32_t* __restrict__ marker_idx, const int32_t* __restrict__ marker_count,
+                                        const double* __restrict__ smooth, const int32_t* __restrict__ parent, const int32_t* __restrict__ heap_off,
+                                        int32_t* __restrict__ heap_cnt, WsHeapEntry* __restrict__ heap, int32_t* __restrict__ roots,
+                                        unsigned int* __restrict__ nroots) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int grp = t / cap, k = t - grp * cap;
+    if (grp >= ngroups || k >= marker_count[grp]) return;
+    const int id = marker_idx[(size_t)grp * cap + k];
+    const int root = parent[id];
+    if (root < 0) return;                                                        // (a marker outside the mask cannot happen: smooth > 0 there only by blur; guarded)
+    const int pos = atomicAdd(&heap_cnt[root], 1);
+    heap[heap_off[root] + pos] = WsHeapEntry{-smooth[id], 0, id};
+    if (pos == 0) roots[atomicAdd(nroots, 1u)] = root;
+}
+
+__device__ __forceinline__ bool ws_less(const WsHeapEntry& a, const WsHeapEntry& b) {
+    return a.value < b.value || (a.value == b.value && (a.age < b.age || (a.age == b.age && a.idx < b.idx)));
+}
+
+// skimage's priority flood of ONE mask component per thread (see the header of this section)
+template <bool MODE2D>
+__global__ void ws_flood_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth, const int32_t* __restrict__ roots,
+                                const unsigned int* __restrict__ nroots, const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
+                                WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ labels) {
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *nroots) return;
+    const int root = roots[t];
+    WsHeapEntry* h = heap_all + heap_off[root];
+    int n = heap_cnt[root];
+    auto sift_down = [&](int k) {
+        const WsHeapEntry e = h[k];
+        while (true) {
+            int c = 2 * k + 1;
+            if (c >= n) break;
+            if (c + 1 < n && ws_less(h[c + 1], h[c])) ++c;
+            if (!ws_less(h[c], e)) break;
+            h[k] = h[c]; k = c;
+        }
+        h[k] = e;
+    };
+    for (int k = n / 2 - 1; k >= 0; --k) sift_down(k);
+    const long long sx = (long long)g.Y * g.Z, sy = g.Z;
+    int age = 0;
+    while (n > 0) {
+        const WsHeapEntry top = h[0];
+        --n;
+        if (n > 0) { h[0] = h[n]; sift_down(0); }
+        const int i = top.idx;
+        int x, y, z; ws_xyz(i, g, x, y, z);
+        const int lab = labels[i];
+        // neighbours in ascending raveled-offset order: x-1, y-1, (z-1, z+1,) y+1, x+1
+        const long long nb[6] = {x > 0 ? i - sx : -1, y > 0 ? i - sy : -1, (!MODE2D && z > 0) ? (long long)i - 1 : -1,
+                                 (!MODE2D && z + 1 < g.Z) ? (long long)i + 1 : -1, y + 1 < g.Y ? i + sy : -1, x + 1 < g.X ? i + sx : -1};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const long long j = nb[q];
+            if (j < 0 || !bn[j] || labels[j] != 0) continue;
+            ++age;
+            labels[j] = lab;
+            // push
+            int k = n++;
+            const WsHeapEntry e{-smooth[j], age, (int)j};
+            while (k > 0) {
+                const int p = (k - 1) >> 1;
+                if (!ws_less(e, h[p])) break;
+                h[k] = h[p]; k = p;
+            }
+            h[k] = e;
+        }
+    }
+}
+
+// find_boundaries(labels, connectivity 2, mode 'outer') inside every z slice, removed from the mask (watershed.py:45-51)
+__global__ void ws_boundary2d_kernel(SegGeom g, const unsigned char* __restrict__ bn, const int32_t* __restrict__ labels, unsigned char* __restrict__ bn_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.V) return;
+    int x, y, z; ws_xyz(i, g, x, y, z);
+    const int own = labels[i];
+    int mx = own, mn = own, mn_obj = own ? own : 0x7fffffff;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int xx = x + dx, yy = y + dy;
+            if (xx < 0 || xx >= g.X || yy < 0 || yy >= g.Y) continue;
+            const int l = labels[((long long)xx * g.Y + yy) * g.Z + z];
+            mx = max(mx, l); mn = min(mn, l);
+            if (l) mn_obj = min(mn_obj, l);
+        }
+    const bool boundary = (mx != mn) && (own == 0 || mx != mn_obj);
+    bn_out[i] = (bn[i] && !boundary) ? 1 : 0;
+}
+
+// bincount of the watershed labels (bins 1..K; bin 0 = V - the rest), wave-aggregated
+__global__ void ws_bincount_kernel(long long V, const int32_t* __restrict__ labels, int K, unsigned int* __restrict__ counts) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int lab = 0;
+    if (i < V) lab = labels[i];
+    const bool active = lab > 0 && lab <= K;
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int ll = __shfl(lab, leader);
+        const unsigned long long same = __ballot(active && lab == ll) & todo;
+        if (lane == leader) atomicAdd(&counts[ll], (unsigned int)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+// watershed.py:88-96: cell_num from min_size or min_size from cell_num (both over ALL bins, the background's included, like
+// np.bincount), labels smaller than min_size dropped, the rest renumbered in order (relabel_sequential).  One workgroup.
+__global__ __launch_bounds__(1024) void ws_finish_kernel(long long V, const int32_t* __restrict__ marker_count, int method, int min_size, int cell_num,
+                                                         unsigned int* __restrict__ counts, int32_t* __restrict__ newlabel, int32_t* __restrict__ n_out) {
+    __shared__ int s_val[2];
+    __shared__ int s_scan[1024];
+    __shared__ int s_carry;
+    const int K = marker_count[0];
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int l = 1; l <= K; ++l) tot += counts[l];
+        counts[0] = (unsigned int)((unsigned long long)V - tot);
+        s_val[0] = 0; s_val[1] = min_size;
+    }
+    __syncthreads();
+    if (method == 0) {
+        int c = 0;
+        for (int l = threadIdx.x; l <= K; l += 1024) c += counts[l] >= (unsigned int)min_size ? 1 : 0;
+        atomicAdd(&s_val[0], c);
+        __syncthreads();
+        if (threadIdx.x == 0) { s_val[0] -= 1; s_val[1] = min_size; }
+    } else {
+        // the (cell_num + 1)-th largest count = np.sort(counts)[-cell_num - 1]
+        for (int l = threadIdx.x; l <= K; l += 1024) {
+            const unsigned int c = counts[l];
+            int rank = 0;
+            for (int q = 0; q <= K; ++q) { const unsigned int cq = counts[q]; rank += (cq > c || (cq == c && q < l)) ? 1 : 0; }
+            if (rank == cell_num) s_val[1] = (int)c;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_val[0] = cell_num;
+    }
+    __syncthreads();
+    const unsigned int ms = (unsigned int)s_val[1];
+    if (threadIdx.x == 0) { s_carry = 0; newlabel[0] = 0; }
+    __syncthreads();
+    for (int base = 1; base <= K; base += 1024) {
+        const int l = base + threadIdx.x;
+        const int keep = (l <= K && counts[l] >= ms) ? 1 : 0;
+        s_scan[threadIdx.x] = keep;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int add = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_scan[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int incl = s_scan[threadIdx.x], c = s_carry;
+        if (l <= K) newlabel[l] = keep ? c + incl : 0;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { n_out[0] = s_carry; n_out[1] = s_val[1]; n_out[2] = s_val[0]; }
+}
+
+struct WsLayout { size_t bn, bn2, gx, d2, dist, tmp, smooth, vmax, labels, parent, size, heap_off, heap_cnt, heap, roots, cand_val, cand_idx, marker_idx,
+                  stats, sums, weights, total; int ngroups2d; };
+WsLayout ws_layout(long long V, int Z, int cap) {
+    WsLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t r = o; o = align_up(o + bytes, 256); return r; };
+    L.bn = take((size_t)V); L.bn2 = take((size_t)V);
+    L.gx = take((size_t)V * 4); L.d2 = take((size_t)V * 4);
+    L.dist = take((size_t)V * 8); L.tmp = take((size_t)V * 8); L.smooth = take((size_t)V * 8); L.vmax = take((size_t)V * 8);
+    L.labels = take((size_t)V * 4); L.parent = take((size_t)V * 4); L.size = take((size_t)V * 4);
+    L.heap_off = take((size_t)V * 4); L.heap_cnt = take((size_t)V * 4);
+    L.heap = take((size_t)V * sizeof(WsHeapEntry)); L.roots = take((size_t)V * 4);
+    const size_t ncand = (size_t)Z * WS_PEAK_CAP2D > (size_t)WS_PEAK_CAP3D ? (size_t)Z * WS_PEAK_CAP2D : (size_t)WS_PEAK_CAP3D;
+    L.cand_val = take(ncand * 8); L.cand_idx = take(ncand * 4); L.marker_idx = take(ncand * 4);
+    L.stats = take(4096 + (size_t)(WS_PEAK_CAP3D + 1) * 8);       // eq_count[128] | vmin[128] | cand_count[128] | marker_count[128] | bump, nroots, overflow | counts / newlabel
+    L.sums = take((size_t)cap * 4 * 8);
+    L.weights = take(64 * 8);
+    L.total = o; L.ngroups2d = Z;
+    return L;
+}
+
 }  // namespace
 
 extern "C" {
@@ -306,6 +762,173 @@ int ct_segment_centroids(const float* prob, const int dims_xyz[3], float thresho
     LAUNCH_CHECK();
     cc_centroid_kernel<<<(cap + 255) / 256, 256, 0, st>>>(n_labels, cap, sums, centres, sizes);
     LAUNCH_CHECK();
+    return CT_OK;
+}
+
+size_t ct_watershed_workspace_bytes(const int dims_xyz[3], int cap) {
+    if (!dims_xyz || cap <= 0) return 0;
+    const long long V = (long long)dims_xyz[0] * dims_xyz[1] * dims_xyz[2];
+    if (V <= 0 || V > 0x7fffffffLL || dims_xyz[2] > 128 || dims_xyz[0] >= WS_INF || dims_xyz[1] >= WS_INF) return 0;
+    return ws_layout(V, dims_xyz[2], cap).total;
+}
+
+int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_ratio, int method, int min_size, int cell_num,
+                         int min_distance_2d, int min_distance_3d, const double* gauss_xy, int radius_xy, const double* gauss_z, int radius_z,
+                         int cap, int32_t* labels_out, double* centres, int32_t* sizes, int32_t* n_out,
+                         void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    if (!prob || !dims_xyz || !centres || !n_out || !workspace || !gauss_xy || !gauss_z) return CT_EINVAL;
+    if (dims_xyz[0] <= 0 || dims_xyz[1] <= 0 || dims_xyz[2] <= 0 || cap <= 0 || min_size < 0 || cell_num < 0) return CT_EINVAL;
+    const int method_in = method;
+    method &= 0xff;
+    if (method != 0 && method != 1) return CT_EINVAL;
+    if (radius_xy < 0 || radius_z < 0 || 2 * radius_xy + 1 > 48 || 2 * radius_z + 1 > 15 || min_distance_2d < 1 || min_distance_3d < 1) return CT_EINVAL;
+    const long long V = (long long)dims_xyz[0] * dims_xyz[1] * dims_xyz[2];
+    if (V > 0x7fffffffLL || dims_xyz[2] > 128 || dims_xyz[0] >= WS_INF || dims_xyz[1] >= WS_INF) return CT_ESHAPE;
+    const int Z = dims_xyz[2];
+    const WsLayout L = ws_layout(V, Z, cap);
+    if (workspace_bytes < L.total) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    unsigned char* bn = (unsigned char*)(ws + L.bn); unsigned char* bn2 = (unsigned char*)(ws + L.bn2);
+    int32_t* gx = (int32_t*)(ws + L.gx); int32_t* d2 = (int32_t*)(ws + L.d2);
+    double* dist = (double*)(ws + L.dist); double* tmp = (double*)(ws + L.tmp); double* smooth = (double*)(ws + L.smooth); double* vmax = (double*)(ws + L.vmax);
+    int32_t* labels = (int32_t*)(ws + L.labels); int32_t* parent = (int32_t*)(ws + L.parent); int32_t* size = (int32_t*)(ws + L.size);
+    int32_t* heap_off = (int32_t*)(ws + L.heap_off); int32_t* heap_cnt = (int32_t*)(ws + L.heap_cnt);
+    WsHeapEntry* heap = (WsHeapEntry*)(ws + L.heap); int32_t* roots = (int32_t*)(ws + L.roots);
+    unsigned long long* cand_val = (unsigned long long*)(ws + L.cand_val); int32_t* cand_idx = (int32_t*)(ws + L.cand_idx);
+    int32_t* marker_idx = (int32_t*)(ws + L.marker_idx);
+    unsigned int* eq_count = (unsigned int*)(ws + L.stats);                       // [128]
+    unsigned long long* vmin = (unsigned long long*)(ws + L.stats + 512);         // [128]
+    unsigned int* cand_count = (unsigned int*)(ws + L.stats + 1536);              // [128]
+    int32_t* marker_count = (int32_t*)(ws + L.stats + 2048);                      // [128]
+    unsigned int* bump = (unsigned int*)(ws + L.stats + 2560);                    // bump | nroots | overflow
+    unsigned int* nroots = bump + 1; int* overflow = (int*)(bump + 2);
+    unsigned int* counts = (unsigned int*)(ws + L.stats + 4096);                  // [WS_PEAK_CAP3D + 1]
+    int32_t* newlabel = (int32_t*)(counts + WS_PEAK_CAP3D + 1);
+    unsigned long long* sums = (unsigned long long*)(ws + L.sums);
+    double* w_xy = (double*)(ws + L.weights); double* w_z = w_xy + 48;
+    const SegGeom g{dims_xyz[0], dims_xyz[1], dims_xyz[2], V};
+    const unsigned nb = (unsigned)((V + 255) / 256);
+    const long long YZ = (long long)g.Y * g.Z;
+    static bool lds_set = false;
+    if (!lds_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_PEAK_CAP3D * 16));
+        lds_set = true;
+    }
+    HIPCHK(hipMemcpyAsync(w_xy, gauss_xy, (size_t)(2 * radius_xy + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(w_z, gauss_z, (size_t)(2 * radius_z + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+
+    // one pass of: peaks of `smooth` -> markers -> components of `mask` -> flood into `labels`
+    auto stage = [&](bool mode2d, const unsigned char* mask, int min_distance, int border) -> int {
+        const int ngroups = mode2d ? Z : 1, pcap = mode2d ? WS_PEAK_CAP2D : WS_PEAK_CAP3D;
+        // separable window maximum: smooth -> tmp -> (dist ->) vmax
+        ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, 0, smooth, tmp, min_distance);
+        LAUNCH_CHECK();
+        if (mode2d) { ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, 1, tmp, vmax, min_distance); LAUNCH_CHECK(); }
+        else {
+            ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, 1, tmp, dist, min_distance); LAUNCH_CHECK();
+            ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, 2, dist, vmax, min_distance); LAUNCH_CHECK();
+        }
+        HIPCHK(hipMemsetAsync(ws + L.stats, 0, 4096, st));
+        HIPCHK(hipMemsetAsync(vmin, 0xff, 128 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(labels, 0, (size_t)V * 4, st));
+        ws_peak_kernel<<<1024, 256, 0, st>>>(g, mode2d ? 1 : 0, border, smooth, vmax, eq_count, vmin, cand_count, pcap, cand_val, cand_idx, overflow);
+        LAUNCH_CHECK();
+        ws_peak_select_kernel<<<ngroups, 1024, (size_t)pcap * 16, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val, cand_idx,
+                                                                    labels, marker_idx, marker_count);
+        LAUNCH_CHECK();
+        if (mode2d) {
+            ws_cc_init_merge_kernel<true><<<nb, 256, 0, st>>>(g, mask, parent, 0); LAUNCH_CHECK();
+            ws_cc_init_merge_kernel<true><<<nb, 256, 0, st>>>(g, mask, parent, 1); LAUNCH_CHECK();
+        } else {
+            ws_cc_init_merge_kernel<false><<<nb, 256, 0, st>>>(g, mask, parent, 0); LAUNCH_CHECK();
+            ws_cc_init_merge_kernel<false><<<nb, 256, 0, st>>>(g, mask, parent, 1); LAUNCH_CHECK();
+        }
+        HIPCHK(hipMemsetAsync(size, 0, (size_t)V * 4, st));
+        cc_flatten_kernel<<<nb, 256, 0, st>>>(V, parent, size);
+        LAUNCH_CHECK();
+        ws_heap_alloc_kernel<<<nb, 256, 0, st>>>(V, parent, size, heap_off, heap_cnt, bump);
+        LAUNCH_CHECK();
+        ws_marker_append_kernel<<<(unsigned)((ngroups * pcap + 255) / 256), 256, 0, st>>>(ngroups, pcap, marker_idx, marker_count, smooth, parent, heap_off,
+                                                                                       heap_cnt, heap, roots, nroots);
+        LAUNCH_CHECK();
+        unsigned int h_nroots = 0; int h_over = 0;
+        HIPCHK(hipMemcpyAsync(&h_nroots, nroots, sizeof(h_nroots), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&h_over, overflow, sizeof(h_over), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h_over) return CT_ESHAPE;                                            // more peak candidates than the per-slice / per-volume table holds
+        if (h_nroots) {
+            if (mode2d) ws_flood_kernel<true><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
+            else ws_flood_kernel<false><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
+            LAUNCH_CHECK();
+        }
+        return CT_OK;
+    };
+
+    // ---- watershed_2d (watershed.py:16-53), all z slices at once
+    ws_threshold_kernel<<<nb, 256, 0, st>>>(prob, V, bn);
+    LAUNCH_CHECK();
+    ws_edt_x_kernel<<<(unsigned)((YZ + 255) / 256), 256, 0, st>>>(g, bn, gx);
+    LAUNCH_CHECK();
+    ws_edt_y_kernel<true><<<nb, 256, 0, st>>>(g, gx, d2, dist);
+    LAUNCH_CHECK();
+    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 0, dist, tmp, w_xy, radius_xy);
+    LAUNCH_CHECK();
+    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 1, tmp, smooth, w_xy, radius_xy);
+    LAUNCH_CHECK();
+    int rc = stage(true, bn, min_distance_2d, min_distance_2d);
+    if (rc) return rc;
+    ws_boundary2d_kernel<<<nb, 256, 0, st>>>(g, bn, labels, bn2);
+    LAUNCH_CHECK();
+    if (method_in & 0x100) { HIPCHK(hipMemsetAsync(n_out, 0, 3 * sizeof(int32_t), st)); return CT_OK; }     // (tests: stop after watershed_2d, see ct_watershed_read_stage)
+
+    // ---- watershed_3d (watershed.py:55-108)
+    ws_edt_x_kernel<<<(unsigned)((YZ + 255) / 256), 256, 0, st>>>(g, bn2, gx);
+    LAUNCH_CHECK();
+    ws_edt_y_kernel<false><<<nb, 256, 0, st>>>(g, gx, d2, dist);
+    LAUNCH_CHECK();
+    ws_edt_z_kernel<<<nb, 256, 0, st>>>(g, d2, z_xy_ratio, dist);
+    LAUNCH_CHECK();
+    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 0, dist, tmp, w_xy, radius_xy);
+    LAUNCH_CHECK();
+    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 1, tmp, dist, w_xy, radius_xy);
+    LAUNCH_CHECK();
+    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 2, dist, smooth, w_z, radius_z);
+    LAUNCH_CHECK();
+    rc = stage(false, bn2, min_distance_3d, 0);
+    if (rc) return rc;
+
+    // ---- sizes, min_size / cell_num, small objects dropped, sequential labels, centres (watershed.py:88-96, tracker.py:680, :646-647)
+    HIPCHK(hipMemsetAsync(counts, 0, (size_t)(WS_PEAK_CAP3D + 1) * 8, st));
+    HIPCHK(hipMemsetAsync(sums, 0, (size_t)cap * 4 * 8, st));
+    ws_bincount_kernel<<<nb, 256, 0, st>>>(V, labels, WS_PEAK_CAP3D, counts);
+    LAUNCH_CHECK();
+    ws_finish_kernel<<<1, 1024, 0, st>>>(V, marker_count, method, min_size, cell_num, counts, newlabel, n_out);
+    LAUNCH_CHECK();
+    cc_label_kernel<<<nb, 256, 0, st>>>(g, labels, newlabel, labels_out, cap, sums);
+    LAUNCH_CHECK();
+    cc_centroid_kernel<<<(cap + 255) / 256, 256, 0, st>>>(n_out, cap, sums, centres, sizes);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+int ct_watershed_read_stage(const void* workspace, const int dims_xyz[3], int cap, int which, void* dst, ct_stream_t stream) {
+    if (!workspace || !dims_xyz || !dst || cap <= 0) return CT_EINVAL;
+    const long long V = (long long)dims_xyz[0] * dims_xyz[1] * dims_xyz[2];
+    if (V <= 0 || V > 0x7fffffffLL || dims_xyz[2] > 128) return CT_ESHAPE;
+    const WsLayout L = ws_layout(V, dims_xyz[2], cap);
+    const char* ws = (const char*)workspace;
+    size_t off, bytes;
+    switch (which) {
+        case 0: off = L.bn; bytes = (size_t)V; break;              // uint8  thresholded map
+        case 1: off = L.bn2; bytes = (size_t)V; break;             // uint8  map without the 2-D watershed boundaries
+        case 2: off = L.dist; bytes = (size_t)V * 8; break;        // fp64   EDT (2-D stage; scratch afterwards)
+        case 3: off = L.smooth; bytes = (size_t)V * 8; break;      // fp64   smoothed EDT of the last stage run
+        case 4: off = L.labels; bytes = (size_t)V * 4; break;      // int32  watershed labels of the last stage run (before relabelling)
+        case 5: off = L.vmax; bytes = (size_t)V * 8; break;        // fp64   window maximum of the last stage run
+        default: return CT_EINVAL;
+    }
+    HIPCHK(hipMemcpyAsync(dst, ws + off, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return CT_OK;
 }
 

@@ -36,6 +36,15 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// CT_ABL: feature ablation of the split conv kernels for the co-residency hazard bisect (scripts/probe/hazard_bisect.sh; results are
+// WRONG with any bit set -- the variants only serve as aggressors beside the packed-fp32 victim):
+//   1 no MFMAs   2 MFMA operands not read from LDS (zeros)   4 no staging stores to LDS   8 no global tile loads
+//   16 no epilogue stores / maxima   32 no SGPR pinning asm   64 no weight loads
+//   128 return at the kernel's first statement (resources only)   256 return after the argument fetch / tile decode, before any LDS use
+//   512 no per-wave column tables (no barrier-free LDS write -> read)   1024 the per-patch maxima are not fetched (no threadIdx.y)
+#ifndef CT_ABL
+#define CT_ABL 0
+#endif
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 static constexpr float kLeakyAlpha = 0.3f;   // keras LeakyReLU() default
@@ -822,6 +831,7 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, const char* base, 
 #pragma unroll
     for (int i = 0; i < S::NIT; ++i) {
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr ((CT_ABL) & 8) { v[i] = f32x4{(float)t[i], 1.f, 2.f, (float)zb}; continue; }
         if ((t[i] | zb) >= 0) v[i] = *reinterpret_cast<const f32x4*>(base + (uint32_t)(t[i] + zb));
     }
     if (with_zhalo) {
@@ -832,7 +842,7 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, const char* base, 
             if (idx < S::NHS) {
                 const int gzh = (idx & 2) ? z0 + G::ZB : z0 - 1;
                 const int t = tab[idx >> 2];
-                if (t >= 0 && gzh >= 0 && gzh < a.Z)
+                if (t >= 0 && gzh >= 0 && gzh < a.Z && !((CT_ABL) & 8))
                     vh[i] = *reinterpret_cast<const f32x4*>(base + (uint32_t)(t + ((gzh >> suz) * 8 + (idx & 1) * 4) * 4));
             }
         }
@@ -913,8 +923,10 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                dst[nt][c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(wp + ((size_t)(kb * nt_total + nt) * NC + c) * 64) + lane16);
+            for (int c = 0; c < NC; ++c) {
+                if constexpr ((CT_ABL) & 64) dst[nt][c] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                else dst[nt][c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(wp + ((size_t)(kb * nt_total + nt) * NC + c) * 64) + lane16);
+            }
     };
 #pragma unroll
     for (int k = 0; k < PFD; ++k) wload(k, wbuf[k]);
@@ -936,8 +948,10 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
                 const int mt = cg + q;
                 const int cpos = bf_col_pos(C8, KFOLD, Z8, mt, G::HYv, G::HZv);
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    av[q][c] = *reinterpret_cast<const u32x4*>(ab + cpos * 16 + c * G::PLANE);
+                for (int c = 0; c < NC; ++c) {
+                    if constexpr ((CT_ABL) & 2) av[q][c] = u32x4{lane16, lane16, lane16, lane16};
+                    else av[q][c] = *reinterpret_cast<const u32x4*>(ab + cpos * 16 + c * G::PLANE);
+                }
             }
             // all fragment reads of the column group go out before its first MFMA (left alone, the scheduler issues them just in
             // time to save registers and every pair of MFMAs then eats a full LDS round trip)
@@ -950,6 +964,9 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr ((CT_ABL) & 1) {           // keep the operands alive, one VALU op instead of the MFMA
+                            acc[cg + q][nt][0] += __uint_as_float(wv[nt][WI[pr]][0] ^ av[q][AI[pr]][1]);
+                        } else
                         if constexpr (F16)
                             acc[cg + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wv[nt][WI[pr]]),
                                                                                      __builtin_bit_cast(f16x8, av[q][AI[pr]]), acc[cg + q][nt], 0, 0, 0);
@@ -975,7 +992,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
     // All kernel arguments are fetched in one go: left alone, the compiler loads each where it is first used, and the ~20 dependent
     // scalar-load round trips (200-300 cycles apiece with every workgroup hitting the same lines) were a third of a thin layer's
     // workgroup lifetime, all of it in front of the first global load.
+    if constexpr ((CT_ABL) & 128) return;
     ConvArgs a = a_in;
+    if constexpr (!((CT_ABL) & 32))
     asm volatile("" : "+s"(a.CA), "+s"(a.CB), "+s"(a.AX), "+s"(a.AY), "+s"(a.AZ), "+s"(a.ux), "+s"(a.uy), "+s"(a.uz),
                       "+s"(a.nchunks), "+s"(a.tilesX), "+s"(a.tilesY), "+s"(a.zblocks), "+s"(a.ngroups), "+s"(a.tx0), "+s"(a.ty0),
                       "+s"(a.nxcd), "+s"(a.xper), "+s"(a.xrem), "+s"(a.mdiv[0]), "+s"(a.mdiv[1]), "+s"(a.mdiv[2]), "+s"(a.mdiv[3]), "+s"(a.mdiv[4])
@@ -1014,6 +1033,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
         if ((xe && x0 >= a.cx1e) || (ye && y0 >= a.cy1e)) return;          // (uniform, before any barrier) nothing kept depends on this tile
         nx1 = xe ? a.nx1e : nx1; ny1 = ye ? a.ny1e : ny1;
     }
+    if constexpr ((CT_ABL) & 256) { if (a.out && x0 == 0x7fffffff) a.out[0] = (float)(y0 + z0 + p + ntb); return; }
     const int g = lane >> 4;
     const int zl = Z8 ? (lane & 7) : (lane & 15);
     const int csel = Z8 ? ((lane >> 3) & 1) : 0;              // Z8: which of the MFMA column's two y-adjacent columns
@@ -1042,7 +1062,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
     // (vector loads on purpose -- threadIdx.y is 0, but the compiler cannot know: a scalar load's return is only waitable as
     //  "everything", and that wait would land in front of the first LDS read, i.e. in front of the tile's global loads)
     uint32_t amax_bits = 0, amax_bits_a = 0;
-    if constexpr (F16) {
+    if constexpr (F16 && !((CT_ABL) & 1024)) {
         amax_bits = a.amaxB[p * AMAX_STRIDE + threadIdx.y];
         amax_bits_a = a.amaxA[p * AMAX_STRIDE + threadIdx.y];     // (the host passes amaxB again when there is no second source)
     }
@@ -1055,7 +1075,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
         if (k < 3) epi_reg = a.epi[k * ECP + ntb * 16 + j];
         else if (k == 3 && a.head) epi_reg = a.head[ntb * 16 + j];
     }
-    const float head_bias = a.head ? a.head[ECP + threadIdx.y] : 0.f;
+    const float head_bias = a.head ? a.head[ECP + (((CT_ABL) & 1024) ? 0 : threadIdx.y)] : 0.f;
     constexpr int NC = SplitMath<F16>::NC;
     const uint4* wbase = reinterpret_cast<const uint4*>(a.wpack);
     const uint32_t lane16 = (uint32_t)lane * 16u;
@@ -1066,8 +1086,10 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
     const int nA = FOLD ? (a.CA >> 3) : 0;                    // folded chunks
     const int nFromA = a.CA >> 3;                             // chunks read from srcA (the decoder's low-res tensor)
     const int cls = C8 ? wy : (wx * 2 + wy);
+    if constexpr (!((CT_ABL) & 512)) {
     if (nFromA > 0) stage_table<Z8>(a, true, x0, y0, lane, coltab[wave][0]);
     if (nFromA < a.nchunks) stage_table<Z8>(a, false, x0, y0, lane, coltab[wave][1]);
+    }
     float in_scale = 1.f, out_mul = 1.f;
     auto stage = [&](int chunk) {
         f32x4 v[S::NIT], vh[S::NHIT];
@@ -1084,7 +1106,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
                 in_scale = pow2f(-k); out_mul = pow2f(k) * a.wscale_inv;
             }
         }
-        stage_store<Z8, F16>(v, vh, tid, zhalo, lds, in_scale);
+        if constexpr (!((CT_ABL) & 4)) stage_store<Z8, F16>(v, vh, tid, zhalo, lds, in_scale);
+        else if (v[0][0] == 12345.678f) lds[tid] = 1;        // (keeps the loads alive)
         __syncthreads();
         if (chunk == 0) CT_TR(3);
     };
@@ -1108,6 +1131,15 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const
     }
 
     CT_TR(4);
+    if constexpr ((CT_ABL) & 16) {
+        float sink = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < NCOL; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sink += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+        if (sink == 12345.678f && a.out) a.out[0] = sink;
+        return;
+    }
     // ---- epilogue: (un-scale) -> bias -> activation -> BatchNorm affine; stores / fused pool / fused head as in the fp32 kernels
     const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
     const int z = z0 + zl;

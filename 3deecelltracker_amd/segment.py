@@ -4,10 +4,17 @@ Reference: ``Tracker._segment`` (CellTracker/tracker.py:636-648) = U-Net prob ma
 marker watershed in watershed.py:16-108) -> ``scipy.ndimage.center_of_mass(regions > 0, regions, 1..n)`` ->
 ``_transform_layer_to_real``.
 
-The skimage watershed has no runnable reference in this image and is not rebuilt; the region step here is
-threshold + 3D connected components (touching cells are not split).  Label numbering (raster order, small regions
-removed, renumbered 1..n) and the centre-of-mass call follow the reference, so the centres feed ``Tracker.match`` /
-``TrackerLite`` exactly like ``seg/coords%06d.npy`` does (raw voxel coordinates, float64).
+Two region steps, both on the device:
+
+* ``watershed_centroids[_device]`` -- the reference's own marker watershed (watershed_2d per z slice, then watershed_3d, min_size /
+  cell_num, relabel_sequential; ct_watershed_segment).  scikit-image is not installable here, so its four functions are restated
+  from their published algorithms (oracle/watershed_ref.py: parity unpinned until tests/golden/watershed_skimage.npz is recorded);
+  scipy's EDT / Gaussian arithmetic is reproduced operand for operand.  This is what ``Tracker._segment`` uses.
+* ``segment_centroids[_device]`` -- threshold + 3D connected components (touching cells are not split): the cheap variant SURVEY 8f#2
+  names, kept as ``method="cc"`` and used by the per-frame ``FrameChain``.
+
+Label numbering (raster order, small regions removed, renumbered 1..n) and the centre-of-mass call follow the reference, so the centres
+feed ``Tracker.match`` / ``TrackerLite`` exactly like ``seg/coords%06d.npy`` does (raw voxel coordinates, float64).
 """
 from __future__ import annotations
 
@@ -63,3 +70,90 @@ def segment_centroids(prob, threshold: float = 0.5, connectivity: int = 1, min_s
     if centres.shape[0] == 0:
         raise ValueError("No cell was detected! Try to reduce the min_size / noise_level.")
     return labels.cpu().numpy(), centres.cpu().numpy(), sizes.cpu().numpy()
+
+
+def gaussian_weights(sigma: float, truncate: float = 4.0):
+    """The correlation weights scipy.ndimage.gaussian_filter1d builds for `sigma` (order 0): -> (float64 [2 r + 1], r)."""
+    sd = float(sigma)
+    radius = int(truncate * sd + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[::-1], dtype=np.float64), radius
+
+
+_METHODS = {"min_size": 0, "cell_num": 1}
+
+
+def watershed_centroids_device(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0, cap: int = 4096,
+                               want_labels: bool = True, min_distance_2d: int = 7, min_distance_3d: int = 3):
+    """Tracker._watershed (reference tracker.py:671-684 = watershed.py:16-108) + relabel_sequential + center_of_mass on the device.
+    prob: contiguous float32 cuda tensor [x, y, z] -> (labels int32 cuda | None, centres fp64 cuda [n, 3], sizes int32 cuda [n],
+    min_size in force, cell_num in force)."""
+    import ctypes as C
+    t = _dev.torch(); L = _lib.lib()
+    if prob.dim() != 3 or not prob.is_cuda or not prob.is_contiguous() or prob.dtype != t.float32:
+        raise ValueError("expected a contiguous float32 cuda tensor (x, y, z)")
+    if method not in _METHODS:
+        raise ValueError("The method parameter should be either min_size or cell_num")        # watershed.py:93
+    if min_size < 0 or cell_num < 0 or cap <= 0:
+        raise ValueError("min_size / cell_num must be >= 0 and cap positive")
+    dims = _lib.ivec(prob.shape)
+    w_xy, r_xy = gaussian_weights(2.0)
+    w_z, r_z = gaussian_weights(0.3)
+    labels = _dev.empty(tuple(prob.shape), t.int32, prob.device) if want_labels else None
+    n_dev = _dev.empty((3,), t.int32, prob.device)
+    while True:
+        centres = _dev.empty((cap, 3), t.float64, prob.device)
+        sizes = _dev.empty((cap,), t.int32, prob.device)
+        nbytes = L.ct_watershed_workspace_bytes(dims, int(cap))
+        if nbytes == 0:
+            raise ValueError(f"volume {tuple(prob.shape)} is outside the watershed kernels' limits (z <= 128, int32 voxel indices)")
+        ws = _dev.workspace(nbytes, prob.device)
+        _lib.check(L.ct_watershed_segment(prob.data_ptr(), dims, float(z_xy_ratio), _METHODS[method], int(min_size), int(cell_num),
+                                          int(min_distance_2d), int(min_distance_3d), w_xy.ctypes.data_as(C.c_void_p), r_xy,
+                                          w_z.ctypes.data_as(C.c_void_p), r_z, int(cap), labels.data_ptr() if want_labels else None,
+                                          centres.data_ptr(), sizes.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _dev.stream(prob.device)), "ct_watershed_segment")
+        n, ms, cn = (int(v) for v in n_dev.cpu().tolist())
+        if n <= cap:
+            return labels, centres[:n], sizes[:n], ms, cn
+        cap = max(2 * cap, n)
+
+
+def watershed_centroids(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0):
+    """numpy (x, y, z) or (1, x, y, z, 1) prob map -> (segmentation_auto int32, centres float64 [n, 3], min_size, cell_num)."""
+    t = _dev.torch()
+    a = np.asarray(prob)
+    if a.ndim == 5:
+        a = a[0, :, :, :, 0]
+    if a.ndim != 3:
+        raise ValueError(f"expected a 3-D probability map (x, y, z), got shape {a.shape}")
+    d = t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    labels, centres, _, ms, cn = watershed_centroids_device(d, z_xy_ratio, method, min_size, cell_num)
+    return labels.cpu().numpy(), centres.cpu().numpy(), ms, cn
+
+
+def watershed_stages_device(prob, z_xy_ratio: float, stage: str = "2d", min_size: int = 0, cap: int = 4096):
+    """Intermediates of the device watershed for the tests (ct_watershed_read_stage): stage "2d" = after watershed_2d (per-slice EDT,
+    smoothed EDT, window maximum, per-slice watershed labels, the two masks), "3d" = after the whole call (the 3-D stage's smoothed EDT,
+    window maximum and watershed labels before relabelling; the EDT array is scratch by then).  -> dict of numpy arrays."""
+    import ctypes as C
+    t = _dev.torch(); L = _lib.lib()
+    dims = _lib.ivec(prob.shape)
+    w_xy, r_xy = gaussian_weights(2.0)
+    w_z, r_z = gaussian_weights(0.3)
+    centres = _dev.empty((cap, 3), t.float64, prob.device); sizes = _dev.empty((cap,), t.int32, prob.device)
+    n_dev = _dev.empty((3,), t.int32, prob.device)
+    ws = _dev.workspace(L.ct_watershed_workspace_bytes(dims, int(cap)), prob.device)
+    _lib.check(L.ct_watershed_segment(prob.data_ptr(), dims, float(z_xy_ratio), 0x100 if stage == "2d" else 0, int(min_size), 0, 7, 3,
+                                      w_xy.ctypes.data_as(C.c_void_p), r_xy, w_z.ctypes.data_as(C.c_void_p), r_z, int(cap), None,
+                                      centres.data_ptr(), sizes.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _dev.stream(prob.device)), "ct_watershed_segment")
+    out = {}
+    for name, which, dt in (("mask", 0, t.uint8), ("mask_wo_boundaries", 1, t.uint8), ("edt", 2, t.float64), ("smooth", 3, t.float64),
+                            ("labels", 4, t.int32), ("window_max", 5, t.float64)):
+        buf = _dev.empty(tuple(prob.shape), dt, prob.device)
+        _lib.check(L.ct_watershed_read_stage(ws.data_ptr(), dims, int(cap), which, buf.data_ptr(), _dev.stream(prob.device)), "ct_watershed_read_stage")
+        out[name] = buf.cpu().numpy()
+    return out

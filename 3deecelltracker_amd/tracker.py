@@ -5,8 +5,9 @@ Per-frame chain, all on the device and on one stream (reference tracker.py):
     match / track_one_vol          :1138-1175, :1473-1536
       _segment                     :605-650    raw stack -> image_gcn, LCN -> U-Net (or unet_cache/t%06i.npy) -> regions -> centres
         _predict_cellregions / _save_unet_regions :652-669   (ct_normalize_image, ct_unet_predict_volume; float16 cache file)
-        _watershed                 :671-684    *replaced* by threshold + connected components (ct_segment_centroids): the skimage
-                                               marker watershed has no runnable reference here (parity unpinned)
+        _watershed                 :671-684    ct_watershed_segment: watershed_2d + watershed_3d + relabel_sequential on the device
+                                               (skimage's functions restated, parity unpinned: oracle/watershed_ref.py);
+                                               region_method = "cc" selects threshold + connected components instead
       _predict_pos_once            :1193-1222  REP_NUM_PRGLS x (FFN -> legacy PR-GLS with beta * 0.8^i), fields re-applied
       _get_cells_onBoundary        :1291-1308
       _accurate_correction         :1177-1191  ct_accurate_correction_legacy (_correction_once_interp :1310-1348,
@@ -169,7 +170,8 @@ class Tracker:
 
     ensemble_chains = 8      # source-volume predictions of one ensemble step in flight on this GPU (parallel.chain_map)
     ensemble_batched = True  # ... or, when the point sets are small enough, all of them as one batched chain of launches
-    connectivity = 1         # region step: 6-connected components (scipy.ndimage.label default)
+    region_method = "watershed"   # region step of _segment: the reference's marker watershed; "cc": threshold + connected components
+    connectivity = 1         # region_method "cc": 6-connected components (scipy.ndimage.label default)
 
     def __init__(self, volume_num, siz_xyz: tuple, z_xy_ratio, z_scaling, noise_level, min_size, beta_tk, lambda_tk, maxiter_tk,
                  folder_path, image_name, unet_model_file, ffn_model_file, cell_num=0, ensemble=False, adjacent=False,
@@ -357,12 +359,28 @@ class Tracker:
         return self._predict_cellregions_device(raw_d, vol, read_cache=False).cpu().numpy()[None, :, :, :, None]
 
     def _regions_device(self, prob_d, method):
-        """Stand-in for _watershed (:671-684): threshold 0.5 + connected components + small-object removal + sequential
-        relabel, then center_of_mass(regions > 0, regions, 1..n) (:646-647), all in ct_segment_centroids."""
-        from .segment import segment_centroids_device
+        """_watershed (:671-684) + center_of_mass(regions > 0, regions, 1..n) (:646-647) on the device -> (labels, centres).
+        region_method "watershed" (default): ct_watershed_segment = watershed_2d / watershed_3d with the reference's parameters
+        (min_distance 7 / 3, sampling [1, 1, z_xy_ratio], method "min_size" | "cell_num"), relabel_sequential; self.min_size and
+        self.cell_num are updated like :681-683.  region_method "cc": threshold 0.5 + connected components (touching cells stay one
+        region)."""
+        from .segment import segment_centroids_device, watershed_centroids_device
         t = _dev.torch()
         if float(prob_d.max()) <= 0.5:
             raise ValueError("No cell was detected by 3D U-Net! Try to reduce the noise_level.")
+        if self.region_method == "watershed":
+            if method not in ("min_size", "cell_num"):
+                raise ValueError("The method parameter should be either min_size or cell_num")
+            labels_d, centres_d, _, min_size, cell_num = watershed_centroids_device(prob_d, float(self.z_xy_ratio), method,
+                                                                                    int(self.min_size or 0), int(self.cell_num or 0))
+            if centres_d.shape[0] == 0:
+                raise ValueError("No cell was detected by watershed! Try to reduce the min_size.")
+            self.min_size = min_size
+            if method == "min_size":
+                self.cell_num = cell_num
+            return labels_d, centres_d
+        if self.region_method != "cc":
+            raise ValueError(f"unknown region_method {self.region_method!r}: use 'watershed' or 'cc'")
         min_size = int(self.min_size or 0)
         labels_d, centres_d, sizes_d = segment_centroids_device(prob_d, 0.5, self.connectivity, min_size if method == "min_size" else 0)
         if method == "cell_num" and self.cell_num and centres_d.shape[0] > self.cell_num:

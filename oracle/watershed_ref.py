@@ -1,0 +1,197 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the marker-watershed region step of the legacy Tracker.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Reference: CellTracker/watershed.py:16-53 (watershed_2d), :55-108 (watershed_3d), called from tracker.py:671-684 (Tracker._watershed):
+per z slice  EDT -> Gaussian(2) -> peak_local_max(min_distance=7) -> label -> watershed(-dist, markers, mask) -> find_boundaries(outer);
+the boundaries are removed from the thresholded map, then in 3D  EDT(sampling 1, 1, z_xy_ratio) -> Gaussian(2, 2, 0.3) ->
+peak_local_max(min_distance=3, exclude_border=0) -> label -> watershed -> min_size / cell_num -> remove_small_objects ->
+relabel_sequential.
+
+PARITY STATUS: **parity unpinned**.  scipy IS installed here, so distance_transform_edt, gaussian_filter, maximum_filter, label and
+center_of_mass are the very functions the reference runs.  scikit-image is neither under /root/reference nor installed (it arrives
+through stardist in the reference's environment; `peak_local_max(indices=False)` dates it to 0.16-0.19), so its four functions are
+RESTATED here from their published algorithms:
+  * peak_local_max  -- skimage/feature/peak.py (0.19): image == maximum_filter(image, footprint (2 d + 1)^ndim, mode='constant'),
+    no peaks for a trivial (constant) image, & image > threshold with threshold = image.min() (no absolute / relative threshold given),
+    border of width min_distance excluded unless exclude_border is 0/False, then the peaks in descending intensity with every peak
+    closer than min_distance (Chebyshev) to an already kept one dropped (ensure_spacing).  Inside the maximum filter's footprint two
+    surviving peaks can only be closer than that if they are EQUAL, so the last step only acts on exact ties; its order among ties
+    (an unstable argsort upstream) is fixed here as "smaller raveled index first".
+  * watershed       -- skimage/segmentation/_watershed_cy.pyx: a priority queue of (value, age), seeded with all marker pixels (age 0),
+    pop the smallest, give every unlabelled in-mask neighbour (connectivity 1, in ascending raveled-offset order) the popped pixel's
+    label at PUSH time and push it with value = image[neighbour] and the next age.  Ties among the age-0 markers (the upstream heap
+    leaves them to its sift order) are fixed here as "smaller raveled index first".
+  * find_boundaries(mode='outer') -- skimage/segmentation/boundaries.py: grey dilation != grey erosion over the connectivity-c
+    structure, kept where the pixel is background or the full-connectivity neighbourhood holds two different OBJECT labels.
+  * remove_small_objects on a label image (sizes by bincount of the labels as they are) and relabel_sequential.
+tests/golden/make_watershed_golden.py is the one-run kit that records skimage's own outputs on any machine that has it; while
+tests/golden/watershed_skimage.npz is absent, tests/test_watershed_pin.py is skipped and this header stays "unpinned".
+"""
+from __future__ import annotations
+
+import heapq
+
+import numpy as np
+import scipy.ndimage as ndi
+
+
+# ------------------------------------------------------------------------------------------------ restated skimage functions
+def peak_local_max_mask(image: np.ndarray, min_distance: int, exclude_border=True) -> np.ndarray:
+    """skimage.feature.peak_local_max(image, min_distance=..., exclude_border=..., indices=False) -> bool mask."""
+    image = np.asarray(image, dtype=np.float64)
+    size = 2 * int(min_distance) + 1
+    image_max = ndi.maximum_filter(image, footprint=np.ones((size,) * image.ndim, dtype=bool), mode="constant")
+    out = image == image_max
+    if np.all(out):                                   # "no peak for a trivial image"
+        out[:] = False
+    out &= image > image.min()
+    if exclude_border is True:
+        border = int(min_distance)
+    else:
+        border = int(exclude_border)                  # 0 / False: nothing excluded
+    if border > 0:
+        for ax in range(image.ndim):
+            sl = [slice(None)] * image.ndim
+            sl[ax] = slice(None, border); out[tuple(sl)] = False
+            sl[ax] = slice(-border, None); out[tuple(sl)] = False
+    # ensure_spacing: descending intensity (ties: raveled index ascending), drop what is within min_distance of a kept peak
+    idx = np.flatnonzero(out)
+    if idx.size > 1:
+        vals = image.ravel()[idx]
+        order = np.lexsort((idx, -vals))
+        coords = np.stack(np.unravel_index(idx[order], image.shape), axis=1)
+        kept = []
+        keep_mask = np.zeros(len(coords), dtype=bool)
+        for i, c in enumerate(coords):
+            if kept and np.any(np.max(np.abs(np.asarray(kept) - c), axis=1) <= min_distance):
+                continue
+            kept.append(c); keep_mask[i] = True
+        out[:] = False
+        out.ravel()[idx[order][keep_mask]] = True
+    return out
+
+
+def label_full(mask: np.ndarray) -> np.ndarray:
+    """skimage.morphology.label(mask) (connectivity = ndim): raster-order numbering, like scipy's."""
+    lab, _ = ndi.label(mask, structure=np.ones((3,) * mask.ndim, dtype=bool))
+    return lab.astype(np.int32)
+
+
+def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """skimage.segmentation.watershed(image, markers, mask=mask) (connectivity 1, no compactness, no watershed line)."""
+    image = np.asarray(image, dtype=np.float64)
+    shape = image.shape
+    out = np.where(mask, markers, 0).astype(np.int32).ravel().copy()      # markers outside the mask are dropped (skimage: markers[~mask] = 0)
+    img = image.ravel()
+    msk = np.asarray(mask, dtype=bool).ravel()
+    strides = [int(np.prod(shape[a + 1:])) for a in range(len(shape))]
+    offs = sorted([(-s, a, -1) for a, s in enumerate(strides)] + [(s, a, 1) for a, s in enumerate(strides)])   # ascending raveled offset
+    heap = [(img[i], 0, int(i)) for i in np.flatnonzero(out)]
+    heapq.heapify(heap)
+    age = 0
+    coords_of = lambda i: np.unravel_index(i, shape)
+    while heap:
+        _, _, i = heapq.heappop(heap)
+        ci = coords_of(i)
+        for off, ax, sgn in offs:
+            c = ci[ax] + sgn
+            if c < 0 or c >= shape[ax]:
+                continue
+            j = i + off
+            if not msk[j] or out[j]:
+                continue
+            age += 1
+            out[j] = out[i]
+            heapq.heappush(heap, (img[j], age, int(j)))
+    return out.reshape(shape)
+
+
+def find_boundaries_outer(labels: np.ndarray, connectivity: int) -> np.ndarray:
+    """skimage.segmentation.find_boundaries(labels, connectivity=c, mode='outer', background=0)."""
+    lab = np.asarray(labels)
+    nd = lab.ndim
+    fp = ndi.generate_binary_structure(nd, connectivity)
+    boundaries = ndi.grey_dilation(lab, footprint=fp) != ndi.grey_erosion(lab, footprint=fp)      # (scipy's default border: reflect)
+    bg = lab == 0
+    full = ndi.generate_binary_structure(nd, nd)
+    inv = lab.copy()
+    inv[bg] = np.iinfo(lab.dtype).max
+    adjacent = (ndi.grey_dilation(lab, footprint=full) != ndi.grey_erosion(inv, footprint=full)) & ~bg
+    return boundaries & (bg | adjacent)
+
+
+def remove_small_objects(labels: np.ndarray, min_size: int) -> np.ndarray:
+    sizes = np.bincount(labels.ravel())
+    small = sizes < min_size
+    out = labels.copy()
+    out[small[labels]] = 0
+    return out
+
+
+def relabel_sequential(labels: np.ndarray) -> np.ndarray:
+    present = np.unique(labels)
+    present = present[present > 0]
+    lut = np.zeros(int(labels.max()) + 1, dtype=np.int32)
+    lut[present] = np.arange(1, present.size + 1, dtype=np.int32)
+    return lut[labels]
+
+
+# ------------------------------------------------------------------------------------------------ the reference's functions
+def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, collect=None):
+    """watershed.py:16-53 -> (bn_output, boundary)."""
+    image_pred = np.asarray(image_pred)
+    boundary = np.zeros(image_pred.shape, dtype=bool)
+    for z in range(z_range):
+        bn = image_pred[:, :, z] > 0.5
+        dist = ndi.distance_transform_edt(bn, sampling=[1, 1])
+        dist_smooth = ndi.gaussian_filter(dist, 2, mode="constant")
+        local_maxi = peak_local_max_mask(dist_smooth, min_distance=min_distance)
+        markers = label_full(local_maxi)
+        labels_ws = watershed(-dist_smooth, markers, bn)
+        boundary[:, :, z] = find_boundaries_outer(labels_ws, connectivity=2)
+        if collect is not None:
+            collect.append({"dist": dist, "dist_smooth": dist_smooth, "peaks": local_maxi, "labels": labels_ws})
+    bn_output = image_pred > 0.5
+    bn_output[boundary] = False
+    return bn_output, boundary
+
+
+def watershed_3d(image_watershed2d: np.ndarray, samplingrate, method: str, min_size: int, cell_num: int, min_distance: int, collect=None):
+    """watershed.py:55-108 -> (labels_wo_bd, labels_clear, min_size, cell_num)."""
+    dist = ndi.distance_transform_edt(image_watershed2d, sampling=samplingrate)
+    dist_smooth = ndi.gaussian_filter(dist, (2, 2, 0.3), mode="constant")
+    local_maxi = peak_local_max_mask(dist_smooth, min_distance=min_distance, exclude_border=0)
+    markers = label_full(local_maxi)
+    labels_ws = watershed(-dist_smooth, markers, image_watershed2d)
+    counts = np.sort(np.bincount(labels_ws.ravel()))
+    if method == "min_size":
+        cell_num = int(np.sum(counts >= min_size) - 1)
+    elif method == "cell_num":
+        min_size = int(counts[-cell_num - 1])
+    else:
+        raise ValueError("The method parameter should be either min_size or cell_num")
+    labels_clear = remove_small_objects(labels_ws, min_size)
+    labels_bd = find_boundaries_outer(labels_clear, connectivity=3)
+    labels_wo_bd = labels_clear.copy()
+    labels_wo_bd[labels_bd] = 0
+    labels_wo_bd = remove_small_objects(labels_wo_bd, min_size)
+    if collect is not None:
+        collect.append({"dist": dist, "dist_smooth": dist_smooth, "peaks": local_maxi, "labels": labels_ws})
+    return labels_wo_bd, labels_clear, min_size, cell_num
+
+
+def tracker_watershed(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0):
+    """Tracker._watershed (tracker.py:671-684) -> (segmentation_auto int32, min_size, cell_num)."""
+    img = np.asarray(image_cell_bg_xyz)
+    wo_border, _ = watershed_2d(img, z_range=img.shape[2], min_distance=7)
+    _, wi_border, min_size, cell_num = watershed_3d(wo_border, [1, 1, z_xy_ratio], method, min_size, cell_num, min_distance=3)
+    return relabel_sequential(wi_border), min_size, cell_num
+
+
+def segment_centroids(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0):
+    """-> (labels int32, centres float64 [n, 3] via the reference's center_of_mass call (tracker.py:646-647), min_size, cell_num)."""
+    labels, min_size, cell_num = tracker_watershed(image_cell_bg_xyz, z_xy_ratio, method, min_size, cell_num)
+    n = int(labels.max())
+    centres = np.asarray(ndi.center_of_mass(labels > 0, labels, range(1, n + 1)), dtype=np.float64).reshape(n, 3) if n else np.zeros((0, 3))
+    return labels, centres, min_size, cell_num

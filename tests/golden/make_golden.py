@@ -389,10 +389,72 @@ def gen_legacy_tracker():
     np.savez_compressed(HERE / "legacy_tracker.npz", **out)
 
 
+def _reference_watershed_on_restated_skimage():
+    """The reference's watershed.py / Tracker._watershed with the four scikit-image primitives (absent here) bound to their restatements
+    in oracle/watershed_ref.py; scipy's distance_transform_edt / gaussian_filter are the real ones.  -> (ref_watershed module, restore())"""
+    from oracle import watershed_ref as wr
+    ref_ws = importlib.import_module("CellTracker.watershed")
+    saved = {(m, k): getattr(m, k) for m, k in ((ref_ws, "peak_local_max"), (ref_ws, "morphology"), (ref_ws, "watershed"), (ref_ws, "find_boundaries"),
+                                                (ref_ws, "remove_small_objects"), (ref_tracker, "relabel_sequential"))}
+    ref_ws.peak_local_max = lambda image, min_distance=1, exclude_border=True, indices=True: wr.peak_local_max_mask(image, min_distance, exclude_border)
+    ref_ws.morphology = types.SimpleNamespace(label=wr.label_full)
+    ref_ws.watershed = lambda image, markers, mask=None: wr.watershed(image, markers, mask)
+    ref_ws.find_boundaries = lambda lab, connectivity=1, mode="thick", background=0: wr.find_boundaries_outer(lab, connectivity)
+    ref_ws.remove_small_objects = lambda ar, min_size=64, connectivity=1: wr.remove_small_objects(ar, min_size)
+    ref_tracker.relabel_sequential = lambda a: (wr.relabel_sequential(a), None, None)
+
+    def restore():
+        for (m, k), v in saved.items():
+            setattr(m, k, v)
+    return ref_ws, restore
+
+
+def gen_watershed():
+    """The reference's OWN watershed_2d / watershed_3d (watershed.py:16-108) and Tracker._watershed (tracker.py:671-684) run on synthetic
+    probability maps, with scikit-image's four primitives replaced by their restatements (see _reference_watershed_on_restated_skimage):
+    pins the composite logic -- slice loop, boundary removal, sampling, min_size / cell_num bookkeeping, relabelling -- of the oracle
+    (oracle/watershed_ref.py) and, through it, of the device path.  The primitives themselves stay parity-unpinned."""
+    import warnings
+    ref_ws, restore = _reference_watershed_on_restated_skimage()
+    out = {}
+    cases = []
+    rng = np.random.default_rng(5)
+    for ci, (shape, n, zr, ms) in enumerate((((96, 96, 12), 0, 3.0, 40), ((90, 70, 14), 25, 4.0, 15), ((64, 80, 9), 14, 2.5, 10))):
+        g = np.stack(np.meshgrid(*(np.arange(s) for s in shape), indexing="ij"), -1).astype(float)
+        prob = np.zeros(shape, np.float32)
+        if n == 0:       # two touching cells, one isolated, one speck (tests/test_watershed.py::touching_case)
+            cr = [((30, 30, 6), 9), ((45, 30, 6), 9), ((70, 70, 5), 8), ((20, 75, 3), 2.2)]
+        else:
+            cr = [(rng.uniform([8, 8, 2], [shape[0] - 8, shape[1] - 8, shape[2] - 2]), rng.uniform(4, 8)) for _ in range(n)]
+        for c, r in cr:
+            prob[(((g - np.asarray(c, float)) / np.array([r, r, r / 3.0])) ** 2).sum(-1) <= 1.0] = 0.9 if n == 0 else 0.8
+        if n:
+            prob += rng.uniform(0, 0.2, shape).astype(np.float32) * (prob > 0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wo, bd = ref_ws.watershed_2d(prob, z_range=shape[2], min_distance=7)
+            wo_bd, clear, ms_out, cn_out = ref_ws.watershed_3d(wo, samplingrate=[1, 1, zr], method="min_size", min_size=ms, cell_num=0, min_distance=3)
+            wo_bd2, clear2, ms2, cn2 = ref_ws.watershed_3d(wo, samplingrate=[1, 1, zr], method="cell_num", min_size=0, cell_num=max(cn_out - 2, 1), min_distance=3)
+            trk = object.__new__(ref_tracker.Tracker)
+            trk.z_siz, trk.z_xy_ratio, trk.min_size, trk.cell_num, trk.shrink = shape[2], zr, ms, 0, (24, 24, 2)
+            seg_auto = ref_tracker.Tracker._watershed(trk, prob[None, :, :, :, None], "min_size")
+        out[f"ws_prob_{ci}"] = prob.astype(np.float16)          # 0 / 0.8..1.0 values: exact in float16? no -> stored as float32 below
+        out[f"ws_prob_{ci}"] = prob
+        out[f"ws_para_{ci}"] = np.array([zr, ms, ms_out, cn_out, ms2, cn2, trk.min_size, trk.cell_num], dtype=np.float64)
+        out[f"ws_wo2d_{ci}"] = np.packbits(wo); out[f"ws_bd2d_{ci}"] = np.packbits(bd)
+        out[f"ws_wo_bd_{ci}"] = wo_bd.astype(np.int16); out[f"ws_clear_{ci}"] = clear.astype(np.int16)
+        out[f"ws_clear_cellnum_{ci}"] = clear2.astype(np.int16)
+        out[f"ws_seg_auto_{ci}"] = np.asarray(seg_auto).astype(np.int16)
+        cases.append((ci, shape, int(cn_out), int(np.asarray(seg_auto).max())))
+        print("watershed case", ci, shape, "cells (min_size)", cn_out, "cell_num method -> min_size", ms2, "segmentation_auto max", int(np.asarray(seg_auto).max()))
+    restore()
+    np.savez_compressed(HERE / "watershed.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name, fn in (("tiler", gen_tiler), ("match", gen_match), ("preprocess", gen_preprocess), ("correction", gen_correction),
-                     ("legacy_tracker", gen_legacy_tracker)):
+                     ("legacy_tracker", gen_legacy_tracker), ("watershed", gen_watershed)):
         if not only or name in only:
             fn()
     leftovers = [p for p in Path("/root/reference").rglob("__pycache__")]

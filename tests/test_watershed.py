@@ -1,0 +1,171 @@
+"""Marker-watershed region step (reference watershed.py:16-108 through Tracker._watershed): oracle properties on the CPU, device vs oracle
+on the GPU.  The oracle restates four scikit-image functions (parity unpinned, oracle/watershed_ref.py); scipy's functions are the
+reference's own."""
+import importlib
+
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+from oracle import watershed_ref as wr
+
+synth = importlib.import_module("3deecelltracker_amd.synth")
+seg = importlib.import_module("3deecelltracker_amd.segment")
+
+
+def blobs(shape, centres, radii, z_flat=3.0, level=0.9):
+    g = np.stack(np.meshgrid(*(np.arange(s) for s in shape), indexing="ij"), -1).astype(float)
+    prob = np.zeros(shape, np.float32)
+    for c, r in zip(centres, radii):
+        prob[(((g - np.asarray(c, float)) / np.array([r, r, r / z_flat])) ** 2).sum(-1) <= 1.0] = level
+    return prob
+
+
+def touching_case():
+    """two overlapping blobs (one connected component), one isolated blob, one blob below min_size"""
+    return blobs((96, 96, 12), [(30, 30, 6), (45, 30, 6), (70, 70, 5), (20, 75, 3)], [9, 9, 8, 2.2])
+
+
+def random_case(shape, n, seed):
+    rng = np.random.default_rng(seed)
+    lo = np.array([8, 8, 2]); hi = np.array([shape[0] - 8, shape[1] - 8, shape[2] - 2])
+    c = rng.uniform(lo, hi, (n, 3))
+    prob = blobs(shape, c, rng.uniform(4, 8, n), level=0.8)
+    prob += rng.uniform(0, 0.2, shape).astype(np.float32) * (prob > 0)       # ragged plateau
+    prob[rng.uniform(size=shape) > 0.995] = 0.7                               # isolated specks (dropped by min_size)
+    return prob
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the oracle itself
+def test_gaussian_weights_are_scipys():
+    from scipy.ndimage import _filters
+    for sigma in (2.0, 0.3, 1.0):
+        w, r = seg.gaussian_weights(sigma)
+        assert np.array_equal(w, _filters._gaussian_kernel1d(sigma, 0, r)[::-1])
+
+
+def test_oracle_splits_touching_cells_and_keeps_reference_conventions():
+    prob = touching_case()
+    labels, centres, min_size, cell_num = wr.segment_centroids(prob, 3.0, "min_size", 40)
+    assert ndi.label(prob > 0.5)[1] == 3                       # connected components see the touching pair as ONE region
+    assert labels.max() == 3 and cell_num == 3                 # the watershed splits it; the speck is below min_size
+    assert sorted(np.round(centres[:, 0]).astype(int).tolist()) == [30, 45, 70]
+    assert np.array_equal(np.unique(labels), np.arange(4))     # relabel_sequential: 1..n without gaps
+    # the "cell_num" method derives min_size from the requested count (watershed.py:92)
+    l2, c2, ms2, cn2 = wr.segment_centroids(prob, 3.0, "cell_num", 0, 3)
+    assert cn2 == 3 and np.array_equal(l2, labels) and ms2 == np.sort(np.bincount(labels.ravel()))[0]
+    with pytest.raises(ValueError):
+        wr.watershed_3d(prob > 0.5, [1, 1, 3.0], "nearest", 1, 1, 3)
+
+
+def test_oracle_pieces():
+    # peak_local_max: plateau ties keep the smaller raveled index only; border exclusion; constant image has no peaks
+    img = np.zeros((30, 30)); img[10, 10] = img[10, 12] = 2.0; img[20, 20] = 1.0; img[2, 2] = 5.0
+    pk = wr.peak_local_max_mask(img, 7)
+    assert sorted(zip(*np.nonzero(pk))) == [(10, 10), (20, 20)]
+    assert wr.peak_local_max_mask(img, 7, exclude_border=0)[2, 2]
+    assert not wr.peak_local_max_mask(np.ones((9, 9)), 2).any()
+    # watershed: a 1-D ridge between two basins goes to the basin whose flood reaches it first (lower value first, then age)
+    im = np.array([[0., 1., 2., 3., 2., 1., 0.]]); mk = np.zeros((1, 7), np.int32); mk[0, 0] = 1; mk[0, 6] = 2
+    assert wr.watershed(im, mk, np.ones((1, 7), bool)).tolist() == [[1, 1, 1, 1, 2, 2, 2]]
+    # find_boundaries(outer): pixels where two different labels meet (both sides), nothing on an object's edge to the background
+    lab = np.zeros((6, 6), np.int32); lab[1:5, 1:3] = 1; lab[1:5, 3:5] = 2
+    bd = wr.find_boundaries_outer(lab, 2)
+    assert bd[2, 2] and bd[2, 3] and not bd[2, 1] and not bd[2, 4] and bd[0, 2]
+
+
+@pytest.fixture(scope="module")
+def gw(golden_dir):
+    return np.load(golden_dir / "watershed.npz")
+
+
+@pytest.mark.parametrize("ci", (0, 1, 2))
+def test_oracle_composite_equals_the_references_own_watershed_py(gw, ci):
+    """tests/golden/watershed.npz holds what the REFERENCE's watershed_2d / watershed_3d / Tracker._watershed return when scikit-image's
+    four primitives are bound to the restatements (make_golden.py gen_watershed): the oracle's composite -- slice loop, boundary removal,
+    sampling, min_size / cell_num bookkeeping, relabelling -- must reproduce them exactly."""
+    prob = gw[f"ws_prob_{ci}"]
+    zr, ms, ms_out, cn_out, ms2, cn2, trk_ms, trk_cn = gw[f"ws_para_{ci}"]
+    wo, bd = wr.watershed_2d(prob, prob.shape[2], 7)
+    assert np.array_equal(np.packbits(wo), gw[f"ws_wo2d_{ci}"]) and np.array_equal(np.packbits(bd), gw[f"ws_bd2d_{ci}"])
+    wo_bd, clear, m1, c1 = wr.watershed_3d(wo, [1, 1, zr], "min_size", int(ms), 0, 3)
+    assert (m1, c1) == (int(ms_out), int(cn_out))
+    assert np.array_equal(wo_bd, gw[f"ws_wo_bd_{ci}"]) and np.array_equal(clear, gw[f"ws_clear_{ci}"])
+    _, clear2, m2, c2 = wr.watershed_3d(wo, [1, 1, zr], "cell_num", 0, max(int(cn_out) - 2, 1), 3)
+    assert (m2, c2) == (int(ms2), int(cn2)) and np.array_equal(clear2, gw[f"ws_clear_cellnum_{ci}"])
+    seg, m3, c3 = wr.tracker_watershed(prob, zr, "min_size", int(ms), 0)
+    assert (m3, c3) == (int(trk_ms), int(trk_cn)) and np.array_equal(seg, gw[f"ws_seg_auto_{ci}"])
+
+
+# ------------------------------------------------------------------------------------------------ GPU: device vs oracle
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", (0, 1, 2))
+def test_device_watershed_equals_the_reference_golden(gw, ci):
+    """segmentation_auto, min_size and cell_num of Tracker._watershed as recorded from the reference's code (restated primitives)."""
+    prob = gw[f"ws_prob_{ci}"]
+    zr, ms, _, _, _, _, trk_ms, trk_cn = gw[f"ws_para_{ci}"]
+    labels, centres, got_ms, got_cn = seg.watershed_centroids(prob, float(zr), "min_size", int(ms), 0)
+    assert (got_ms, got_cn) == (int(trk_ms), int(trk_cn))
+    assert np.array_equal(labels, gw[f"ws_seg_auto_{ci}"])
+    n = int(labels.max())
+    assert np.array_equal(centres, np.asarray(ndi.center_of_mass(labels > 0, labels, range(1, n + 1))))     # tracker.py:646-647
+
+
+@pytest.mark.gpu
+def test_device_edt_and_gaussian_are_scipys(gw):
+    """The two scipy steps are the reference's own functions and run here: the device's per-slice EDT and its Gaussian-smoothed EDT equal
+    distance_transform_edt / gaussian_filter(., 2, mode='constant') bit for bit; the 3-D stage's smoothed anisotropic EDT likewise."""
+    import torch
+    prob = random_case((120, 100, 16), 40, 1)
+    d = torch.from_numpy(prob).cuda()
+    st = seg.watershed_stages_device(d, 4.0, "2d")
+    for z in range(prob.shape[2]):
+        dist = ndi.distance_transform_edt(prob[:, :, z] > 0.5, sampling=[1, 1])
+        assert np.array_equal(st["edt"][:, :, z], dist), z
+        assert np.array_equal(st["smooth"][:, :, z], ndi.gaussian_filter(dist, 2, mode="constant")), z
+        assert np.array_equal(st["window_max"][:, :, z], ndi.maximum_filter(st["smooth"][:, :, z], footprint=np.ones((15, 15), bool), mode="constant"))
+    wo = st["mask_wo_boundaries"].astype(bool)
+    assert np.array_equal(wo, wr.watershed_2d(prob, prob.shape[2], 7)[0])
+    st3 = seg.watershed_stages_device(d, 4.0, "3d")
+    dist3 = ndi.distance_transform_edt(wo, sampling=[1, 1, 4.0])
+    assert np.array_equal(st3["smooth"], ndi.gaussian_filter(dist3, (2, 2, 0.3), mode="constant"))
+
+def _device(prob, z_ratio, method, min_size, cell_num):
+    labels, centres, ms, cn = seg.watershed_centroids(prob, z_ratio, method, min_size, cell_num)
+    return labels, centres, ms, cn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["touching", "random_small", "ragged", "empty_slices"])
+def test_device_watershed_equals_the_oracle(case):
+    if case == "touching":
+        prob, zr, ms = touching_case(), 3.0, 40
+    elif case == "random_small":
+        prob, zr, ms = random_case((120, 100, 16), 40, 1), 4.0, 20
+    elif case == "ragged":
+        prob, zr, ms = random_case((97, 131, 21), 60, 2), 2.5, 15
+    else:
+        prob = random_case((80, 80, 20), 12, 3); prob[:, :, :6] = 0; prob[:, :, 15:] = 0; zr, ms = 5.0, 10
+    want_l, want_c, want_ms, want_cn = wr.segment_centroids(prob, zr, "min_size", ms)
+    got_l, got_c, got_ms, got_cn = _device(prob, zr, "min_size", ms, 0)
+    assert want_l.max() >= (3 if case == "touching" else 8)
+    assert (got_ms, got_cn) == (want_ms, want_cn)
+    assert np.array_equal(got_l, want_l), f"{int((got_l != want_l).sum())} voxels differ"
+    assert np.array_equal(got_c, want_c)                       # integer coordinate sums / counts: bit-exact
+    # the other method on the same map
+    want2 = wr.segment_centroids(prob, zr, "cell_num", 0, max(want_cn - 2, 1))
+    got2 = _device(prob, zr, "cell_num", 0, max(want_cn - 2, 1))
+    assert (got2[2], got2[3]) == (want2[2], want2[3]) and np.array_equal(got2[0], want2[0])
+
+
+@pytest.mark.gpu
+def test_device_watershed_headline_size():
+    """512x512x32 / ~600 cells (the benchmark's stack): labels, sizes and centres equal the oracle's."""
+    stack, _ = synth.make_stack((512, 512, 32), 600, seed=0)
+    prob = np.clip((stack.astype(np.float32) - 100.0) / 600.0, 0, 1)
+    want_l, want_c, want_ms, want_cn = wr.segment_centroids(prob, 4.0, "min_size", 20)
+    got_l, got_c, got_ms, got_cn = _device(prob, 4.0, "min_size", 20, 0)
+    assert want_cn > 500 and (got_ms, got_cn) == (want_ms, want_cn)
+    assert np.array_equal(got_l, want_l), f"{int((got_l != want_l).sum())} voxels differ"
+    assert np.array_equal(got_c, want_c)
+    assert want_cn > ndi.label(prob > 0.5)[1]                   # more cells than connected components: touching cells were split
