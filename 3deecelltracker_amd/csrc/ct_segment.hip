@@ -531,13 +531,13 @@ __global__ void ws_heap_alloc_kernel(long long V, const int32_t* __restrict__ pa
 __global__ void ws_marker_append_kernel(int ngroups, int cap, const int32_t* __restrict__ marker_idx, const int32_t* __restrict__ marker_count,
                                         const double* __restrict__ smooth, const int32_t* __restrict__ parent, const int32_t* __restrict__ heap_off,
                                         int32_t* __restrict__ heap_cnt, WsHeapEntry* __restrict__ heap, int32_t* __restrict__ roots,
-                                        unsigned int* __restrict__ nroots) {
+                                        unsigned int* __restrict__ nroots, int32_t* __restrict__ labels) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = t / cap, k = t - grp * cap;
     if (grp >= ngroups || k >= marker_count[grp]) return;
     const int id = marker_idx[(size_t)grp * cap + k];
     const int root = parent[id];
-    if (root < 0) return;                                                        // (a marker outside the mask cannot happen: smooth > 0 there only by blur; guarded)
+    if (root < 0) { labels[id] = 0; return; }                                    // a peak of the blurred EDT on a background pixel: skimage's watershed drops markers outside the mask (their numbers stay used)
     const int pos = atomicAdd(&heap_cnt[root], 1);
     heap[heap_off[root] + pos] = WsHeapEntry{-smooth[id], 0, id};
     if (pos == 0) roots[atomicAdd(nroots, 1u)] = root;
@@ -850,7 +850,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         ws_heap_alloc_kernel<<<nb, 256, 0, st>>>(V, parent, size, heap_off, heap_cnt, bump);
         LAUNCH_CHECK();
         ws_marker_append_kernel<<<(unsigned)((ngroups * pcap + 255) / 256), 256, 0, st>>>(ngroups, pcap, marker_idx, marker_count, smooth, parent, heap_off,
-                                                                                       heap_cnt, heap, roots, nroots);
+                                                                                       heap_cnt, heap, roots, nroots, labels);
         LAUNCH_CHECK();
         unsigned int h_nroots = 0; int h_over = 0;
         HIPCHK(hipMemcpyAsync(&h_nroots, nroots, sizeof(h_nroots), hipMemcpyDeviceToHost, st));

@@ -142,10 +142,14 @@ def get_cells_on_boundary(st: LegacyState, r_coords: np.ndarray, ensemble) -> np
     return np.where(bad)[0]
 
 
-def segment_from_prob(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, min_size: int, connectivity: int = 1):
-    """-> (l_center_coordinates (n, 3), segmentation_auto int32, r_coordinates_segment): the tail of _segment (:640-648) with
-    connected components as the region step."""
-    labels, centres, _ = sr.segment_centroids(image_cell_bg_xyz, 0.5, connectivity, min_size)
+def segment_from_prob(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, min_size: int, connectivity: int = 1, region_method: str = "watershed"):
+    """-> (l_center_coordinates (n, 3), segmentation_auto int32, r_coordinates_segment): the tail of _segment (:640-648).  Region step:
+    the reference's marker watershed (oracle/watershed_ref.py, method "min_size") or, region_method "cc", connected components."""
+    if region_method == "watershed":
+        from oracle import watershed_ref as wr
+        labels, centres, _, _ = wr.segment_centroids(np.asarray(image_cell_bg_xyz, dtype=np.float32), z_xy_ratio, "min_size", min_size)
+    else:
+        labels, centres, _ = sr.segment_centroids(image_cell_bg_xyz, 0.5, connectivity, min_size)
     r = np.array(centres).copy()
     r[:, 2] = r[:, 2] * z_xy_ratio
     return centres, labels, r

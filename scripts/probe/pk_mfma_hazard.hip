@@ -189,7 +189,58 @@ static int victim1_only(int reps) {
     return 0;
 }
 
+
+// "aggr <class> <seconds>": ONLY an aggressor, for the cross-process arrangement (scripts/probe/hazard_mfma_class.sh): waves that issue
+// nothing but one class of MFMA instruction (register operands, no LDS, no memory traffic in the loop).
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+template <int CLS>
+__global__ __launch_bounds__(256) void aggr_class(float* out, int iters) {
+    half8 a, b; half4 a4, b4; bf16x8v ab, bb;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (threadIdx.x + i)); b[i] = (_Float16)(0.002f * (threadIdx.x % 7 + i));
+                                  ab[i] = (__bf16)(0.001f * (threadIdx.x + i)); bb[i] = (__bf16)(0.002f * (threadIdx.x % 7 + i)); }
+    for (int i = 0; i < 4; ++i) { a4[i] = a[i]; b4[i] = b[i]; }
+    float4v acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}; float16v big = {}; int4v iacc = {0, 0, 0, 0};
+    const long ai = 0x0102030405060708L + threadIdx.x, bi = 0x0101010101010101L * (threadIdx.x & 3);
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (CLS == 0) { acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, acc2, 0, 0, 0); }
+        if constexpr (CLS == 1) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(0.001f * threadIdx.x, 0.002f, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(0.002f, 0.001f * threadIdx.x, acc2, 0, 0, 0); }
+        if constexpr (CLS == 2) { acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_16x16x16f16(b4, a4, acc2, 0, 0, 0); }
+        if constexpr (CLS == 3) { big = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, big, 0, 0, 0); }
+        if constexpr (CLS == 4) { acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, ab, acc2, 0, 0, 0); }
+        if constexpr (CLS == 5) { big = __builtin_amdgcn_mfma_f32_32x32x8f16(a4, b4, big, 0, 0, 0); }
+        if constexpr (CLS == 6) { iacc = __builtin_amdgcn_mfma_i32_16x16x32_i8(ai, bi, iacc, 0, 0, 0); }
+        if constexpr (CLS == 7) { acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ai, bi, acc, 0, 0, 0); }
+        if constexpr (CLS == 8) {             // no MFMA at all: a dependent fp32 FMA chain (control)
+            acc[0] = fmaf(acc[0], 0.999f, 1e-3f); acc[1] = fmaf(acc[1], 1.001f, -1e-3f); }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc[0] + acc[1] + acc2[2] + acc2[3] + big[0] + big[7] + (float)iacc[0];
+}
+static int aggr_only(int cls, double secs) {
+    float* ao; hipMalloc(&ao, 4096 * 256 * sizeof(float));
+    printf("running\n"); fflush(stdout);
+    const char* names[] = {"v_mfma_f32_16x16x32_f16", "v_mfma_f32_16x16x4_f32", "v_mfma_f32_16x16x16_f16", "v_mfma_f32_32x32x16_f16", "v_mfma_f32_16x16x32_bf16",
+                           "v_mfma_f32_32x32x8_f16", "v_mfma_i32_16x16x32_i8", "v_mfma_f32_16x16x32_fp8_fp8", "no MFMA (fp32 FMA chain)"};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    long launches = 0; float ms = 0;
+    while (ms < secs * 1000.0) {
+        for (int k = 0; k < 4; ++k) {
+#define CT_AG(c) hipLaunchKernelGGL(aggr_class<c>, dim3(1024), dim3(256), 0, 0, ao, 20000)
+            switch (cls) { case 0: CT_AG(0); break; case 1: CT_AG(1); break; case 2: CT_AG(2); break; case 3: CT_AG(3); break; case 4: CT_AG(4); break;
+                           case 5: CT_AG(5); break; case 6: CT_AG(6); break; case 7: CT_AG(7); break; default: CT_AG(8); }
+#undef CT_AG
+        }
+        hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); launches += 4;
+    }
+    printf("aggressor %s: %ld launches of 1024 x 256 threads in %.1f s\n", names[cls < 9 ? cls : 8], launches, ms / 1000.0);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 3 && !strcmp(argv[1], "aggr")) return aggr_only(atoi(argv[2]), atof(argv[3]));
     if (argc > 2 && !strcmp(argv[1], "victimonly")) return victim_only(atoi(argv[2]));
     if (argc > 2 && !strcmp(argv[1], "victim1only")) return victim1_only(atoi(argv[2]));
     if (argc > 2 && !strcmp(argv[1], "victim3only")) return victim3_only(atoi(argv[2]));

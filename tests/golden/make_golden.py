@@ -314,8 +314,7 @@ def gen_legacy_tracker():
     _correction_once_interp, _accurate_correction and match (:1138-1175).
 
     What cannot run here and is replaced, nothing else: tifffile's imread inside read_image_ts (the stack is handed over in
-    memory), the skimage watershed inside _segment (`_watershed` -> threshold + connected components, the region step the
-    build implements, oracle/segment_ref.py), the matplotlib animation of _predict_pos_once(draw=True) (draw forced off) and
+    memory), scikit-image's four primitives under the reference's own `_watershed` (restated, oracle/watershed_ref.py), the matplotlib animation of _predict_pos_once(draw=True) (draw forced off) and
     interpolate_seg (skimage; its results -- seg_cells_interpolated_corrected, Z_RANGE_INTERP, r_coordinates_tracked_t0 --
     are set from a synthetic label image with the same scipy.ndimage.center_of_mass call, :1070-1075).  The probability map
     comes from unet_cache/t%06i.npy (float16), i.e. the reference's cache-hit path (:656-660): no Keras call is involved."""
@@ -330,6 +329,7 @@ def gen_legacy_tracker():
     for ci, (seed, siz, zs, ratio, ncell, ens, margin) in enumerate(((0, (120, 136, 14), 5, 4.0, 40, False, 6.5), (1, (96, 110, 12), 3, 2.5, 30, 5, 10.0))):
         case = ct_synth.make_legacy_frame_case(seed, siz, zs, ratio, ncell, margin=margin, edge_cells=2 if margin < 10 else 0)
         tmp = tempfile.mkdtemp()
+        _, restore_ws = _reference_watershed_on_restated_skimage()
         with contextlib.redirect_stdout(io.StringIO()):
             trk = ref_tracker.Tracker(volume_num=8, siz_xyz=siz, z_xy_ratio=ratio, z_scaling=zs, noise_level=100, min_size=20,
                                       beta_tk=300, lambda_tk=0.1, maxiter_tk=20, folder_path=tmp, image_name="img_t%04i_z%04i.tif",
@@ -351,12 +351,9 @@ def gen_legacy_tracker():
             np.save(trk.paths.unet_cache + "t%06i.npy" % 7, case["prob_f16"][None, :, :, :, None])
             ref_tracker.read_image_ts = lambda vol, path, name, z_range, print_=False: case["raw"]
 
-            def cc_watershed(image_cell_bg, method, _t=trk):
-                labels, _, _ = sr.segment_centroids(np.asarray(image_cell_bg[0, :, :, :, 0], dtype=np.float32), 0.5, 1, _t.min_size)
-                if method == "min_size":
-                    _t.cell_num = int(labels.max())
-                return labels
-            trk._watershed = cc_watershed
+            # _watershed (:671-684) is the reference's own code; scikit-image's primitives underneath are the restated ones
+            # (_reference_watershed_on_restated_skimage): the regions of these well-separated synthetic cells are the same as the
+            # connected components the goldens were first recorded with
             orig = trk._predict_pos_once
             trk._predict_pos_once = lambda source_volume, draw=False: orig(source_volume, draw=False)
             anim, (bd_local, vol, i_disp, r_pred) = trk.match(7, "min_size")
@@ -371,6 +368,7 @@ def gen_legacy_tracker():
             iw[3] = iw[2] + (np.asarray(trk.region_xyz_min[2]) - np.asarray(trk.region_xyz_min[3]))
             lab_w, msk_w = trk._transform_cells_quick(iw)
             r1w, i1w, corr1w = trk._correction_once_interp(iw, bd_local)
+        restore_ws()
         out[f"lt_case_{ci}"] = np.array([seed, *siz, zs, ncell, int(ens)]); out[f"lt_ratio_{ci}"] = np.float64(ratio)
         out[f"lt_margin_{ci}"] = np.float64(margin)
         out[f"lt_tracked_t0_{ci}"] = trk.r_coordinates_tracked_t0; out[f"lt_seg_t0_{ci}"] = trk.r_coordinates_segment_t0
