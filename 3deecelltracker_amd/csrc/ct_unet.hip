@@ -1597,6 +1597,237 @@ __global__ __launch_bounds__(256, OCC) void conv_first_f16_kernel(const float* _
     if (amax_out) amax_publish(vmax, amax_out + lp * AMAX_STRIDE, tid, amax_red);
 }
 
+// ------------------------------------------------------------------------------------------------
+// First conv fused INTO the second (volume path of unet3_a, split-fp16 family): L0 (1 -> 8) is evaluated on the 6 x 10 x 16 halo tile of
+// an L1 (8 -> 16) workgroup straight from the reflect-padded volume and handed to L1's MFMA phase through LDS -- the 8-channel tensor
+// between them (0.98 GB per 512 x 512 x 32 volume, written once and read once) never exists.  L0 is cheap enough to recompute on the halo
+// (1.9 x its outputs, 150 of the tile's 820 MFMAs); L1 keeps its tile, weights, pool and epilogue.  Cin(L1) = 8 is a single chunk, so
+// one power-of-two scale per TILE (the maximum of the L0 values the tile holds) serves the fp16 split -- as conv_first_f16_kernel does for
+// its 1-channel input.  Values differ from the two-kernel path only through those scale exponents (both are exact splits of fp32 data).
+// Preconditions (run_network): one z block (Z = 16), Cout(L1) = 16, plain (not folded, not 8 x 8 x 8) tiles, whole-patch region.
+// ------------------------------------------------------------------------------------------------
+struct FirstArgs { const float* vol; TileGeom q; int p_begin; const u32x4* wf16; float wscale_inv; const float* epi; };
+
+__global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs a_in, const FirstArgs f) {
+    using G = BfGeom<false>;
+    constexpr int HYg = G::HYv, HZg = G::HZv;                                 // L1 halo tile: 6 x 10 columns x 18 z
+    constexpr int IX = G::HXv + 2, IY = G::HYv + 2, IZ = G::ZB + 2;           // L0's input tile: 8 x 12 x 18
+    constexpr int NPAIR = (G::HXv / 2) * G::HYv;                              // 30 x-pairs of L0 outputs
+    __shared__ __attribute__((aligned(16))) char lds[2 * G::PLANE];
+    // L0's packed input tile lives in the first 6.9 KB of L1's planes: nobody writes the planes before every wave has finished its L0
+    // MFMAs (the barrier of the output-maximum reduction), and 35 KB instead of 42 keep FOUR workgroups on a CU like the plain L1 kernel
+    uint32_t* const itile = reinterpret_cast<uint32_t*>(lds);
+    static_assert(IX * IY * IZ * 4 <= G::PLANE, "input tile must fit into the first plane");
+    __shared__ int mapx[IX], mapy[IY], mapz[IZ];
+    __shared__ float amax_red[4], tmax_red[4], omax_red[4];
+    __shared__ __attribute__((aligned(16))) float epi_s[3 * 16];
+    __shared__ __attribute__((aligned(16))) float epi0_s[3 * 8];
+    const ConvArgs& a = a_in;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t b = blockIdx.x;
+    auto divmod = [](uint32_t& n, uint32_t d, uint32_t m) { uint32_t q = __umulhi(n, m), r = n - q * d; if (r >= d) { ++q; r -= d; }
+                                                             n = q; return (int)r; };
+    {
+        const uint32_t xcd = (uint32_t)divmod(b, (uint32_t)a.nxcd, a.mdiv[4]);
+        b += xcd * a.xper + (xcd < a.xrem ? xcd : a.xrem);
+    }
+    const int ty = divmod(b, (uint32_t)a.tilesY, a.mdiv[2]);
+    const int tx = divmod(b, (uint32_t)a.tilesX, a.mdiv[3]);
+    const int p = (int)b;
+    const int x0 = tx * G::TXv, y0 = ty * G::TYv;
+    const int g = lane >> 4, zl = lane & 15;
+    const TileGeom& q = f.q;
+    {
+        const int pg = f.p_begin + p;
+        const int pk = pg % q.gz, pj = (pg / q.gz) % q.gy, pi = pg / (q.gz * q.gy);
+        if (tid < IX) { const int l = x0 - 2 + tid; mapx[tid] = (l >= 0 && l < q.nx) ? reflect_idx(pi * q.cx + l - q.bx, q.vx) : -1; }
+        else if (tid >= 64 && tid < 64 + IY) { const int t = tid - 64, l = y0 - 2 + t; mapy[t] = (l >= 0 && l < q.ny) ? reflect_idx(pj * q.cy + l - q.by, q.vy) : -1; }
+        else if (tid >= 128 && tid < 128 + IZ) { const int t = tid - 128, l = t - 1; mapz[t] = (l >= 0 && l < q.nz) ? reflect_idx(pk * q.cz + l - q.bz, q.vz) : -1; }
+        else if (tid >= 192 && tid < 192 + 48) { const int t = tid - 192; epi_s[t] = a.epi[(t >> 4) * (a.nt_total * 16) + (t & 15)]; }
+        if (tid >= 32 && tid < 32 + 24) epi0_s[tid - 32] = f.epi[tid - 32];
+    }
+    __syncthreads();
+    // ---- gather of the 1-channel input tile (thread t < 2 * IX * IY: half a z column), its maximum, packed (hi, lo) fp16 pairs
+    constexpr int HALF = IZ / 2;
+    static_assert(IZ % 2 == 0 && 2 * IX * IY <= 256, "gather mapping");
+    float vals[HALF]; float tmax = 0.f;
+    const int gcol = tid >> 1, gz0 = (tid & 1) * HALF;
+    const bool gact = tid < 2 * IX * IY;
+    {
+        const int hx = gcol / IY, hy = gcol - hx * IY;
+        const int sx = gact ? mapx[hx] : -1, sy = gact ? mapy[hy] : -1;
+        const float* rowp = f.vol + ((size_t)(sx < 0 ? 0 : sx) * q.vy + (sy < 0 ? 0 : sy)) * q.vz;
+        const bool rowok = sx >= 0 && sy >= 0;
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            const int sz = mapz[gz0 + i];
+            const float v = (rowok && sz >= 0) ? rowp[sz] : 0.f;
+            vals[i] = v; tmax = fmaxf(tmax, fabsf(v));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+    if (lane == 0) tmax_red[wave] = tmax;
+    __syncthreads();
+    float out_mul0;
+    {
+        const int kexp = amax_exponent(__float_as_uint(fmaxf(fmaxf(tmax_red[0], tmax_red[1]), fmaxf(tmax_red[2], tmax_red[3]))));
+        const float in_scale0 = pow2f(-kexp);
+        out_mul0 = pow2f(kexp) * f.wscale_inv;
+        if (gact) {
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) {
+                const float x = vals[i] * in_scale0;
+                const float hi = __uint_as_float(__float_as_uint(x) & 0xffffe000u);
+                itile[gcol * IZ + gz0 + i] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(hi, x - hi));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- L0 on the halo: pair column c = wave + 4 m (x pair c / 10, y c % 10), rows (x-select, cout) as in conv_first_f16_kernel
+    f32x4 acc0[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc0[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int cbase[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int c = min(wave + 4 * m, NPAIR - 1);
+        const int pxi = c / G::HYv, hy = c - pxi * G::HYv;
+        cbase[m] = ((2 * pxi) * IY + hy) * IZ + zl;
+    }
+    {
+        u32x4 wcur = f.wf16[lane];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const u32x4 wj = wcur;
+            if (j + 1 < 5) wcur = f.wf16[(j + 1) * 64 + lane];
+            const int k0 = 8 * j + 2 * g, k1 = k0 + 1;
+            const int o0 = k0 < 36 ? ((k0 / 9) * IY + (k0 / 3) % 3) * IZ + k0 % 3 : 0;
+            const int o1 = k1 < 36 ? ((k1 / 9) * IY + (k1 / 3) % 3) * IZ + k1 % 3 : 0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (wave + 4 * m < NPAIR) {                     // (wave-uniform)
+                    const uint32_t a0 = itile[cbase[m] + o0], a1 = itile[cbase[m] + o1];
+                    const u32x4 av = u32x4{a0, a0 & 0xffffu, a1, a1 & 0xffffu};
+                    acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wj), __builtin_bit_cast(f16x8, av), acc0[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
+    float omax = 0.f;
+    {
+        const int cb = 4 * (g & 1);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(epi0_s + cb);
+        const f32x4 scale = *reinterpret_cast<const f32x4*>(epi0_s + 8 + cb);
+        const f32x4 shift = *reinterpret_cast<const f32x4*>(epi0_s + 16 + cb);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int c = wave + 4 * m;
+            const int pxi = c / G::HYv, hy = c - pxi * G::HYv;
+            const int px = x0 - 1 + 2 * pxi + (g >> 1), py = y0 - 1 + hy;
+            const bool inside = c < NPAIR && px >= 0 && px < a.X && py >= 0 && py < a.Y;       // outside the patch: L1's zero padding
+            f32x4 r = acc0[m] * out_mul0 + bias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = r[e];
+                r[e] = inside ? fmaxf(t, t * alpha) * scale[e] + shift[e] : 0.f;
+                omax = fmaxf(omax, fabsf(r[e]));
+            }
+            acc0[m] = r;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+    if (lane == 0) omax_red[wave] = omax;
+    __syncthreads();
+    float out_mul;
+    {
+        const int k1e = amax_exponent(__float_as_uint(fmaxf(fmaxf(omax_red[0], omax_red[1]), fmaxf(omax_red[2], omax_red[3]))));
+        const float in_scale = pow2f(-k1e);
+        out_mul = pow2f(k1e) * a.wscale_inv;
+        if (tid < 4 * G::HXv * G::HYv) {          // the z-halo rows of L1's tile are its 'same' padding (one z block): zeros in both planes
+            const int col = tid >> 2, row = (tid & 2) ? HZg - 1 : 0, plane = tid & 1;
+            *reinterpret_cast<uint4*>(lds + plane * G::PLANE + (col * HZg + row) * 16) = uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int c = wave + 4 * m;
+            if (c < NPAIR) {
+                const int pxi = c / G::HYv, hy = c - pxi * G::HYv;
+                const int hx = 2 * pxi + (g >> 1);
+                char* d = lds + (((hx * HYg + hy) * HZg + 1 + zl) * 2 + (g & 1)) * 8;
+                stage_put<false, true>(acc0[m], d, in_scale);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- L1: the ordinary single-chunk MFMA phase and epilogue of conv3_split_kernel<true, 1, false, false, false>
+    constexpr int NT = 1;
+    const int wx = 2 * (wave >> 1), wy = 4 * (wave & 1);
+    const int lanepos = (wx * HYg + wy) * HZg + zl;
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        int tapoff[KB_STD];
+        bf_tap_offsets<KB_STD, false, false, false>(lanepos, g, tapoff);
+        bf_chunk_mma<true, NT, 8, KB_STD, false, false, false, false>(acc, lds, tapoff, reinterpret_cast<const uint4*>(a.wpack), (uint32_t)lane * 16u, a.nt_total);
+    }
+    const int z = zl;
+    float vmax = 0.f;
+    {
+        const int cbl = 4 * g;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(epi_s + cbl);
+        const f32x4 scale = *reinterpret_cast<const f32x4*>(epi_s + 16 + cbl);
+        const f32x4 shift = *reinterpret_cast<const f32x4*>(epi_s + 32 + cbl);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            f32x4 r = acc[mt][0] * out_mul + bias;
+            float cmax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = r[e];
+                r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e];
+                cmax = fmaxf(cmax, fabsf(r[e]));
+            }
+            const int x = x0 + wx + (mt >> 2), y = y0 + wy + (mt & 3);
+            if (x >= a.nx0 && x < a.nx1 && y >= a.ny0 && y < a.ny1) vmax = fmaxf(vmax, cmax);
+            acc[mt][0] = r;
+        }
+    }
+    if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red);
+    const int OQ = a.cout >> 3;
+    const int cb = 4 * g;
+    if (a.out) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int x = x0 + wx + (mt >> 2), y = y0 + wy + (mt & 3);
+            if (x < a.X && y < a.Y && z < a.Z && cb < a.cout)
+                *reinterpret_cast<f32x4*>(a.out + ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7)) = acc[mt][0];
+        }
+    }
+    if (a.pool) {      // MaxPooling3D (2, 2, pz): the wave's 2 x 4 columns are two 2 x 2 blocks
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int x = x0 + wx, y = y0 + wy + 2 * blk;
+            const bool ok = (x + 1 < a.X) && (y + 1 < a.Y) && (z < a.Z);
+            f32x4 m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = fmaxf(fmaxf(acc[2 * blk][0][e], acc[2 * blk + 1][0][e]), fmaxf(acc[4 + 2 * blk][0][e], acc[5 + 2 * blk][0][e]));
+                if (a.pz == 2) t = fmaxf(t, __shfl_xor(t, 1));
+                m[e] = t;
+            }
+            const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
+            if (ok && zok && cb < a.cout) {
+                const int pzc = a.pz == 2 ? (z >> 1) : z;
+                *reinterpret_cast<f32x4*>(a.pool + ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7)) = m;
+            }
+        }
+    }
+}
+
 // blocked [X][Y][C/8][Z][8] (patch 0) -> Keras NDHWC [X][Y][Z][C]   (parity tests only)
 __global__ __launch_bounds__(256) void unblock_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       int X, int Y, int Z, int C) {
@@ -1671,6 +1902,7 @@ struct ct_unet {
     size_t first_f16_off;            // packed (hi, hi, lo, 0) fp16 weights of conv_first_f16_kernel
     float first_wscale_inv;          // 1 / their power-of-two scale
     bool first_f16;                  // the split-fp16 first conv is in use
+    bool fused01 = false;            // the last run evaluated the first conv inside the second one's workgroups (conv_l0l1_fused_kernel)
     size_t arena_floats;
     // optional per-launch HIP-event timing (bench.py roofline): pairs recorded on the launch stream
     bool timing;
@@ -2365,9 +2597,21 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             }
         }
     }
+    // L0 fused into L1 (conv_l0l1_fused_kernel): volume path of the split-fp16 family when L1 is a plain single-row-tile layer with one z block
+    static const bool fuse01_on = !(getenv("CT_FUSE_L0L1") && atoi(getenv("CT_FUSE_L0L1")) == 0);
+    bool fuse01 = false;
+    if (fuse01_on && vsrc && !layer_dump && h->first_f16 && h->convs.size() > 1) {
+        const ConvPlan& c0 = h->convs[0]; const ConvPlan& c1 = h->convs[1];
+        const int* d1 = h->dims[c1.level];
+        fuse01 = c0.cout == 8 && c1.cin == 8 && c1.bf && c1.f16 && !c1.c8 && !c1.fold && !c1.head && c1.nt_total == 1 && c1.NT == 1 && c1.srcA < 0 &&
+                 c1.level == c0.level && d1[2] == 16 && d1[0] % TX == 0 && d1[1] % TY == 0 &&
+                 c1.region[0] == 0 && c1.region[2] == 0 && c1.region[1] == d1[0] && c1.region[3] == d1[1];
+    }
+    h->fused01 = fuse01;
     for (size_t i = 0; i < h->convs.size(); ++i) {
         ConvPlan& c = h->convs[i];
         const int* d = h->dims[c.level];
+        if (i == 0 && fuse01) continue;                        // evaluated inside layer 1's workgroups
         TimedScope timed(h, (int)i, st);
         if (i == 0) {
             const size_t nvox = (size_t)P * d[0] * d[1] * d[2];
@@ -2454,6 +2698,19 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             }
             c.nt_used = NTsel;
             int rc;
+            if (i == 1 && fuse01) {
+                ConvArgs af = a;
+                const uint32_t nblk = (uint32_t)P * af.tilesX * af.tilesY;
+                af.ngroups = 1;
+                if (af.nxcd < 1) af.nxcd = 1;
+                af.xper = nblk / (uint32_t)af.nxcd; af.xrem = nblk - af.xper * (uint32_t)af.nxcd;
+                const int dd[5] = {1, 1, af.tilesY, af.tilesX, af.nxcd};
+                for (int k = 0; k < 5; ++k) af.mdiv[k] = dd[k] <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)dd[k]);
+                FirstArgs fa{vsrc->vol, vsrc->q, vsrc->p_begin, reinterpret_cast<const u32x4*>(h->d_weights + h->first_f16_off), h->first_wscale_inv,
+                             h->d_weights + h->convs[0].epi_off};
+                hipLaunchKernelGGL(conv_l0l1_fused_kernel, dim3(nblk), dim3(256), 0, st, af, fa);
+                rc = (int)hipGetLastError();
+            } else
             if (c.bf) {
                 rc = c.f16 ? launch_conv_split<true>(a, P, NTsel, c.c8, c.fold, z8, st)
                            : launch_conv_split<false>(a, P, NTsel, c.c8, c.fold, z8, st);

@@ -267,6 +267,7 @@ def roofline_from_timing(ctx, args, n_patches, steps):
     ctx._lib.check(L.ct_unet_get_timing(model._handle, ms, cnt, nl), "ct_unet_get_timing")
     by_kernel = {}
     layers = []
+    carry = None
     for i in range(nl):
         cin, cout, nt = C.c_int(), C.c_int(), C.c_int(); d = (C.c_int * 3)()
         L.ct_unet_layer_info(model._handle, i, C.byref(cin), C.byref(cout), d, C.byref(nt))
@@ -275,6 +276,17 @@ def roofline_from_timing(ctx, args, n_patches, steps):
         part = (reg[1] - reg[0]) * (reg[3] - reg[2]) / float(d[0] * d[1]) if d[0] * d[1] else 1.0
         flops = 2.0 * d[0] * d[1] * d[2] * 27 * cin.value * cout.value * n_patches * part       # per launch (one volume), computed part
         abytes = 4.0 * d[0] * d[1] * d[2] * (cin.value + cout.value) * n_patches * part
+        if cnt[i] == 0 and i + 1 < nl and cnt[i + 1] > 0:
+            # this conv ran inside the next layer's workgroups (conv_l0l1_fused_kernel): its flops join that launch, the tensor
+            # between the two never reaches HBM
+            carry = {"flops": flops, "cin": cin.value}
+            layers.append({"layer": i, "cin": cin.value, "cout": cout.value, "dims": [d[0], d[1], d[2]], "computed_fraction": round(part, 4),
+                           "kernel": "(fused into layer %d)" % (i + 1), "ms": 0.0, "fused_into_next": True})
+            continue
+        fused_prev = carry is not None
+        if fused_prev:
+            flops += carry["flops"]
+            abytes = 4.0 * d[0] * d[1] * d[2] * (carry["cin"] + cout.value) * n_patches * part
         code = nt.value
         bf = abs(code) >= 1000
         f16 = abs(code) >= 2000
@@ -282,7 +294,10 @@ def roofline_from_timing(ctx, args, n_patches, steps):
             off = 2000 if f16 else 1000
             code = code - off if code > 0 else code + off
         nprod = 3.0 if f16 else 6.0                       # matrix-pipe products executed per fp32 product
-        if code == 0:
+        if fused_prev:
+            name = "conv_l0l1_fused_kernel"
+            carry = None
+        elif code == 0:
             name = "conv_first_kernel"                 # resolved below (depends on the arithmetic family of the other layers)
         elif bf:
             z8 = "true" if (code > 0 and d[2] <= 8 and os.environ.get("CT_CONV_Z8", "1") != "0") else "false"   # 8 x 8 x 8 tiles
@@ -314,8 +329,9 @@ def roofline_from_timing(ctx, args, n_patches, steps):
     # the fused first conv follows the family of the rest: fp16 matrix pipe with f16x3, f32-input MFMAs otherwise
     first_name = "conv_first_f16_kernel<5>" if any(k.get("f16") for k in by_kernel.values()) and os.environ.get("CT_FIRST_F16", "1") != "0" \
         else "conv_first_mfma_kernel"
-    by_kernel[first_name] = by_kernel.pop("conv_first_kernel")
-    layers[0]["kernel"] = first_name
+    if "conv_first_kernel" in by_kernel:
+        by_kernel[first_name] = by_kernel.pop("conv_first_kernel")
+        layers[0]["kernel"] = first_name
     dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
     dom = by_kernel[dom_name]
     # flops the kernel really executes (== the reference op's 2*27*Cin*Cout per voxel unless the kernel folds upsampled taps).
@@ -337,7 +353,7 @@ def roofline_from_timing(ctx, args, n_patches, steps):
                 break
         except Exception:
             pass
-    first = layers[0]
+    first = layers[0] if not layers[0].get("fused_into_next") else layers[1]
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4),
                 # the reference operator's flops (2 * 27 * Cin * Cout per computed voxel; one product per fp32 product) over the same
@@ -358,7 +374,8 @@ def roofline_from_timing(ctx, args, n_patches, steps):
                 "conv_stack_hbm_frac": round(n_patches * arch.algorithmic_bytes_per_patch() / (conv_ms_total * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if conv_ms_total else None,
                 "hbm_bound_kernel": {"kernel": first["kernel"], "layer": 0, "achieved_GBps": first["gbps"], "peak_GBps": HBM_PEAK_TBS * 1e3,
                                      "frac": first["hbm_frac"], "avg_launch_ms": first["ms"],
-                                     "note": "the Cin = 1 first conv is the only HBM-bound instantiation (AI 12 flop/B); SURVEY 8d's fused bytes"}}
+                                     "note": "the first conv (Cin = 1, AI 12 flop/B) is the HBM-bound instantiation; when it runs inside the second conv's "
+                                             "workgroups (conv_l0l1_fused_kernel) this entry is the fused pair: it reads the 1-channel patch and writes 16 channels"}}
     return roofline, layers
 
 

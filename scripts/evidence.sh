@@ -2,7 +2,7 @@
 # the U-Net alone, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate PMC passes), SQ counters, the match chain, the bench line.
 #   usage: bash scripts/evidence.sh r02
 set -u
-R=${1:-r02}
+R=${1:-r03}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
@@ -20,6 +20,6 @@ bash scripts/prof.sh match600_$R $GRAFT_REPO_ROOT/scripts/microbench.py match 60
 bash scripts/prof.sh batched_$R $GRAFT_REPO_ROOT/scripts/microbench.py batched 600 16 | head -3
 cd $GRAFT_REPO_ROOT
 python scripts/hbm_traffic.py gpurun_out/prof/unet_${R}_FETCH_SIZE.csv gpurun_out/prof/unet_${R}_WRITE_SIZE.csv gpurun_out/prof/${R}_unet_hbm_traffic.json "python scripts/microbench.py unet" | head -30
-for s in unet "unet --layers" lcn segment correction "match 600" "goodprior 600" legacy ensemble frame pcie; do timeout 300 python scripts/microbench.py $s 2>&1 | grep -v amdgpu.ids | tail -16; done > gpurun_out/microbench_$R.txt 2>&1
+for s in unet "unet --layers" lcn segment watershed correction "match 600" "goodprior 600" legacy ensemble frame pcie; do timeout 300 python scripts/microbench.py $s 2>&1 | grep -v amdgpu.ids | tail -16; done > gpurun_out/microbench_$R.txt 2>&1
 tail -60 gpurun_out/microbench_$R.txt
 timeout 900 python bench.py > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err; tail -c 400 gpurun_out/bench_$R.err; head -c 1500 gpurun_out/bench_$R.json

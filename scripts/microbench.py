@@ -5,6 +5,7 @@
     python scripts/microbench.py families              A/B of the conv kernel families (CT_CONV_MATH x CT_CONV_FOLD)
     python scripts/microbench.py lcn                   ct_normalize_image on a 512x512x32 uint16 frame
     python scripts/microbench.py segment               ct_segment_centroids
+    python scripts/microbench.py watershed             ct_watershed_segment vs connected components
     python scripts/microbench.py correction            ct_accurate_correction (600 cells)
     python scripts/microbench.py match [n gain shift]  FFN + greedy + PR-GLS, per-iteration time
     python scripts/microbench.py batched [n [B]]       B matches as one batched PR-GLS chain vs separate calls
@@ -106,6 +107,19 @@ def cmd_segment(args):
         for conn in (1, 3):
             dt, out = timeit(lambda: seg.segment_centroids_device(prob, 0.5, conn, 30), reps=20, warm=3)
             print(f"{shape} conn={conn}: {dt*1e3:.3f} ms/frame, {len(out[2])} regions, {prob.numel()*32/dt/1e9:.0f} GB/s (8 sweeps x 4 B/voxel)")
+
+
+def cmd_watershed(args):
+    """ct_watershed_segment (the reference's marker watershed) beside the connected-components variant, 512x512x32 / ~600 cells."""
+    synth, seg = mod("synth"), mod("segment")
+    stack, _ = synth.make_stack((512, 512, 32), 600, seed=0)
+    prob = torch.from_numpy(np.clip((stack.astype(np.float32) - 100.0) / 600.0, 0, 1)).cuda()
+    dt, out = timeit(lambda: seg.watershed_centroids_device(prob, 4.0, "min_size", 20), reps=10, warm=2)
+    print(f"watershed 512x512x32: {dt*1e3:.2f} ms/frame, {len(out[1])} cells (min_size {out[3]})")
+    dt, out = timeit(lambda: seg.watershed_centroids_device(prob, 4.0, "min_size", 20, want_labels=False), reps=10, warm=2)
+    print(f"watershed 512x512x32, centres only: {dt*1e3:.2f} ms/frame")
+    dt, out = timeit(lambda: seg.segment_centroids_device(prob, 0.5, 1, 20), reps=20, warm=3)
+    print(f"connected components 512x512x32: {dt*1e3:.3f} ms/frame, {len(out[1])} regions")
 
 
 def cmd_correction(args):
