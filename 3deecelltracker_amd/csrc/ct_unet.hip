@@ -711,6 +711,15 @@ __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t
 // load-and-compare first makes every wave wait for a memory round trip right before it retires: +0.2 ms on the first conv).
 constexpr int AMAX_STRIDE = 32;        // uint32 words between the slots of consecutive patches
 
+// wave maximum of non-negative floats by DPP (six 2-cycle VALU ops instead of six ds_bpermute round trips); the result is valid in lane 63
+__device__ __forceinline__ float wave_max_nonneg_l63(float m) {
+    int v = __builtin_bit_cast(int, m);
+#define CT_DPPMAX2(ctrl, rmask) { const int t = __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false); v = v > t ? v : t; }
+    CT_DPPMAX2(0xB1, 0xf) CT_DPPMAX2(0x4E, 0xf) CT_DPPMAX2(0x141, 0xf) CT_DPPMAX2(0x140, 0xf) CT_DPPMAX2(0x142, 0xa) CT_DPPMAX2(0x143, 0xc)
+#undef CT_DPPMAX2
+    return __builtin_bit_cast(float, v);
+}
+
 // block-wide max of non-negative floats (256 threads = 4 waves) -> one atomicMax on the tensor's per-patch slot
 __device__ __forceinline__ void amax_publish(float m, uint32_t* slot, int tid, float* red /* [4] LDS */) {
     // wave maximum by DPP (six 2-cycle VALU ops; __shfl_xor is a chain of six LDS-crossbar round trips): non-negative floats
@@ -900,6 +909,9 @@ __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)
 }
 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
+#ifndef CT_LB2
+#define CT_LB2 3           // workgroups per CU the NT = 2 instantiations are compiled for (4: 128 VGPRs -- measured slower)
+#endif
 #ifndef CT_WPF1
 #define CT_WPF1 2          // K-blocks of weight fragments in flight ahead of the MFMAs, NT = 1 / 2 / 4
 #endif
@@ -979,7 +991,7 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 }
 
 template <bool F16, int NT, bool C8, bool FOLD, bool Z8>
-__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void conv3_split_kernel(const ConvArgs a_in) {
+__global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void conv3_split_kernel(const ConvArgs a_in) {
     static_assert(!C8 || NT == 1, "the Cout = 8 kernel has one row tile");
     static_assert(!(C8 && Z8), "Cout = 8 layers sit at the full-resolution level");
     using G = BfGeom<Z8>;
@@ -1637,6 +1649,11 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     const int x0 = tx * G::TXv, y0 = ty * G::TYv;
     const int g = lane >> 4, zl = lane & 15;
     const TileGeom& q = f.q;
+    u32x4* const wlds = reinterpret_cast<u32x4*>(lds + G::PLANE);
+    static_assert(320 * 16 <= G::PLANE, "L0 weights fit into the second plane");
+    const u32x4 w_pre0 = f.wf16[tid];
+    u32x4 w_pre1 = u32x4{0u, 0u, 0u, 0u};
+    if (tid < 64) w_pre1 = f.wf16[256 + tid];
     {
         const int pg = f.p_begin + p;
         const int pk = pg % q.gz, pj = (pg / q.gz) % q.gy, pi = pg / (q.gz * q.gy);
@@ -1665,9 +1682,12 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
             vals[i] = v; tmax = fmaxf(tmax, fabsf(v));
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
-    if (lane == 0) tmax_red[wave] = tmax;
+    tmax = wave_max_nonneg_l63(tmax);
+    if (lane == 63) tmax_red[wave] = tmax;
+    // L0's packed weights (5 K-blocks x 64 lanes x 16 B) were requested at kernel entry; parked in the second plane (free until L0 is done)
+    // they are LDS reads in the K loop instead of five dependent L2 round trips per wave
+    wlds[tid] = w_pre0;
+    if (tid < 64) wlds[256 + tid] = w_pre1;
     __syncthreads();
     float out_mul0;
     {
@@ -1696,11 +1716,9 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
         cbase[m] = ((2 * pxi) * IY + hy) * IZ + zl;
     }
     {
-        u32x4 wcur = f.wf16[lane];
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const u32x4 wj = wcur;
-            if (j + 1 < 5) wcur = f.wf16[(j + 1) * 64 + lane];
+            const u32x4 wj = wlds[j * 64 + lane];
             const int k0 = 8 * j + 2 * g, k1 = k0 + 1;
             const int o0 = k0 < 36 ? ((k0 / 9) * IY + (k0 / 3) % 3) * IZ + k0 % 3 : 0;
             const int o1 = k1 < 36 ? ((k1 / 9) * IY + (k1 / 3) % 3) * IZ + k1 % 3 : 0;
@@ -1737,9 +1755,8 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
             acc0[m] = r;
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
-    if (lane == 0) omax_red[wave] = omax;
+    omax = wave_max_nonneg_l63(omax);
+    if (lane == 63) omax_red[wave] = omax;
     __syncthreads();
     float out_mul;
     {
