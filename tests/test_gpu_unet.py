@@ -261,6 +261,41 @@ def test_split_fp16_scaling_over_the_dynamic_range():
         assert float(np.abs(got[p] - want).max()) <= tol, f"patch {p}: probability map (tolerance {tol})"
 
 
+@pytest.mark.parametrize("amp_log2", (12, 20))
+def test_split_fp16_with_batchnorm_statistics_that_amplify_one_channel(amp_log2):
+    """The split's precision is relative to the per-patch TENSOR maximum.  A trained net can hold a channel whose BatchNorm scale dwarfs
+    the others': here one channel of two tensors (the first conv of level 1; the first conv of the last decoder level) is amplified by
+    2^12 / 2^20 through gamma and beta, and the single consumer's weights for it are divided by the same power of two -- the network
+    function is unchanged in exact arithmetic, but every OTHER channel of those tensors now sits 2^12 / 2^20 below the tensor maximum.
+    Values down to 2^-17 of the maximum keep full precision, below that the absolute error is 2^-39 of the maximum: at
+    2^20 that is 2^-19 relative to O(1) activations.  The probability map must stay within 1e-4 of the fp64 oracle of the SAME weights
+    and of the unamplified network, on the patch path and on the (fused, crop-aware) volume path."""
+    import copy
+    import torch
+    arch = arch_mod.UNET3_A
+    w0 = synth.make_unet_weights("unet3_a", seed=9)
+    w = copy.deepcopy(w0)
+    amp = np.float32(2.0 ** amp_log2)
+    for layer, ch in ((2, 5), (12, 3)):                      # tensors with exactly one consumer: conv `layer + 1`
+        w["convs"][layer]["gamma"][ch] *= amp; w["convs"][layer]["beta"][ch] *= amp
+        w["convs"][layer]["mean"] = w["convs"][layer]["mean"].copy()
+        w["convs"][layer + 1]["kernel"][:, :, :, ch, :] /= amp
+    rng = np.random.default_rng(10)
+    patch = rng.normal(size=arch.input_shape).astype(np.float32)
+    want = ur.unet_forward_torch(patch, w, arch, dtype=np.float64)
+    base = ur.unet_forward_torch(patch, w0, arch, dtype=np.float64)
+    assert float(np.abs(want - base).max()) <= 1e-9           # the same function
+    m_amp = unet3d.unet3_a().set_weights_dict(w)
+    m_ref = unet3d.unet3_a().set_weights_dict(w0)
+    got = m_amp.predict_device(torch.from_numpy(patch[None]).cuda())[0].cpu().numpy()
+    ref = m_ref.predict_device(torch.from_numpy(patch[None]).cuda())[0].cpu().numpy()
+    assert np.isfinite(got).all()
+    assert float(np.abs(got - want).max()) <= 1e-4, float(np.abs(got - want).max())
+    assert float(np.abs(got - ref).max()) <= 1e-4
+    vol = torch.from_numpy(rng.normal(size=(200, 180, 20)).astype(np.float32)).cuda()
+    assert float((m_amp.predict_volume_device(vol) - m_ref.predict_volume_device(vol)).abs().max()) <= 1e-4
+
+
 def test_volume_path_computes_only_what_the_centre_crops_need():
     """ct_unet_predict_volume evaluates decoder tiles only where a kept (centre-crop) voxel depends on them; the rest of its
     workspace is never read by a kept voxel.  (1) The stitched map equals -- within the arithmetic's own noise -- the one
