@@ -23,6 +23,7 @@
 //   cc_centroid  centres[l] = sums / count
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ctamd.h"
 
@@ -527,7 +528,8 @@ __global__ void ws_heap_alloc_kernel(long long V, const int32_t* __restrict__ pa
     if (parent[i] == (int32_t)i) { heap_off[i] = (int32_t)atomicAdd(bump, (unsigned int)size[i]); heap_cnt[i] = 0; }
 }
 
-// every marker joins its component's heap (value = -smooth, age 0); components with markers are listed for the flood
+// every marker joins its component's queue (value = -smooth, age 0); components with two or more markers are listed for the flood
+// (a component with ONE marker is filled with its label by ws_fill_single_kernel: nothing competes for its voxels)
 __global__ void ws_marker_append_kernel(int ngroups, int cap, const int32_t* __restrict__ marker_idx, const int32_t* __restrict__ marker_count,
                                         const double* __restrict__ smooth, const int32_t* __restrict__ parent, const int32_t* __restrict__ heap_off,
                                         int32_t* __restrict__ heap_cnt, WsHeapEntry* __restrict__ heap, int32_t* __restrict__ roots,
@@ -540,7 +542,7 @@ __global__ void ws_marker_append_kernel(int ngroups, int cap, const int32_t* __r
     if (root < 0) { labels[id] = 0; return; }                                    // a peak of the blurred EDT on a background pixel: skimage's watershed drops markers outside the mask (their numbers stay used)
     const int pos = atomicAdd(&heap_cnt[root], 1);
     heap[heap_off[root] + pos] = WsHeapEntry{-smooth[id], 0, id};
-    if (pos == 0) roots[atomicAdd(nroots, 1u)] = root;
+    if (pos == 1) roots[atomicAdd(nroots, 1u)] = root;                          // listed for the flood once it has a second marker
 }
 
 __device__ __forceinline__ bool ws_less(const WsHeapEntry& a, const WsHeapEntry& b) {
@@ -597,6 +599,87 @@ __global__ void ws_flood_kernel(SegGeom g, const unsigned char* __restrict__ bn,
             }
             h[k] = e;
         }
+    }
+}
+
+// components with exactly one marker: every voxel gets that marker's label (what the flood would do, without its sequential walk)
+__global__ void ws_fill_single_kernel(long long V, const int32_t* __restrict__ parent, const int32_t* __restrict__ heap_off,
+                                      const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap, int32_t* __restrict__ labels) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const int root = parent[i];
+    if (root < 0 || heap_cnt[root] != 1) return;
+    const int m = heap[heap_off[root]].idx;
+    if (m != (int)i) labels[i] = labels[m];
+}
+
+// skimage's priority flood of ONE mask component per WAVE.  The queue is an unsorted array (LDS when the component fits, its slice of the
+// global queue memory otherwise): pop = wave-wide arg-min over (value, age, raveled index) -- the same total order as the binary heap of
+// ws_flood_kernel, so the same pops in the same sequence --, the popped pixel's 4 / 6 neighbours are fetched by as many lanes at once and
+// pushed with consecutive ages in ascending raveled-offset order (ballot prefix), labels given at push time.  Per pop: one LDS sweep, one
+// butterfly, ONE global round trip (the single-thread version pays a dozen dependent ones).
+constexpr int WS_Q_LDS = 2048;                     // queue entries held in LDS (32 KB + 8 KB of labels per 64-thread block)
+template <bool MODE2D>
+__global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth,
+                                                           const int32_t* __restrict__ roots, const int32_t* __restrict__ size,
+                                                           const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
+                                                           WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ qlab_all, int32_t* __restrict__ labels) {
+    __shared__ WsHeapEntry q_lds[WS_Q_LDS];
+    __shared__ int32_t l_lds[WS_Q_LDS];
+    const int lane = threadIdx.x;
+    const int root = roots[blockIdx.x];
+    const bool in_lds = size[root] <= WS_Q_LDS;
+    WsHeapEntry* const gq = heap_all + heap_off[root];
+    int32_t* const gl = qlab_all + heap_off[root];
+    WsHeapEntry* const q = in_lds ? q_lds : gq;
+    int32_t* const ql = in_lds ? l_lds : gl;
+    int n = heap_cnt[root];
+    for (int e = lane; e < n; e += 64) { const WsHeapEntry t = gq[e]; q[e] = t; ql[e] = labels[t.idx]; }
+    __syncthreads();
+    const long long sx = (long long)g.Y * g.Z, sy = g.Z;
+    int age = 0;
+    while (n > 0) {
+        // ---- arg-min over the queue
+        WsHeapEntry best{INFINITY, 0x7fffffff, 0x7fffffff}; int bpos = -1;
+        for (int e = lane; e < n; e += 64) { const WsHeapEntry t = q[e]; if (ws_less(t, best)) { best = t; bpos = e; } }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            WsHeapEntry o;
+            const long long vb = __double_as_longlong(best.value);
+            const int lo = __shfl_xor((int)(vb & 0xffffffffLL), m), hi = __shfl_xor((int)(vb >> 32), m);
+            o.value = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+            o.age = __shfl_xor(best.age, m); o.idx = __shfl_xor(best.idx, m);
+            const int op = __shfl_xor(bpos, m);
+            if (ws_less(o, best)) { best = o; bpos = op; }
+        }
+        // every lane now holds the winner; remove it (last entry into the hole)
+        const int lab = ql[bpos];
+        --n;
+        if (lane == 0 && bpos != n) { q[bpos] = q[n]; ql[bpos] = ql[n]; }
+        const int i = best.idx;
+        int x, y, z; ws_xyz(i, g, x, y, z);
+        // ---- neighbours in ascending raveled-offset order: x-1, y-1, (z-1, z+1,) y+1, x+1 : one lane each
+        long long j = -1;
+        if (MODE2D) {
+            if (lane == 0) j = x > 0 ? i - sx : -1; else if (lane == 1) j = y > 0 ? i - sy : -1;
+            else if (lane == 2) j = y + 1 < g.Y ? i + sy : -1; else if (lane == 3) j = x + 1 < g.X ? i + sx : -1;
+        } else {
+            if (lane == 0) j = x > 0 ? i - sx : -1; else if (lane == 1) j = y > 0 ? i - sy : -1;
+            else if (lane == 2) j = z > 0 ? (long long)i - 1 : -1; else if (lane == 3) j = z + 1 < g.Z ? (long long)i + 1 : -1;
+            else if (lane == 4) j = y + 1 < g.Y ? i + sy : -1; else if (lane == 5) j = x + 1 < g.X ? i + sx : -1;
+        }
+        bool take = false; double val = 0.0;
+        if (j >= 0) { take = bn[j] && labels[j] == 0; if (take) val = -smooth[j]; }
+        const unsigned long long mask = __ballot(take);
+        if (take) {
+            const int rank = (int)__popcll(mask & ((1ull << lane) - 1ull));
+            labels[j] = lab;
+            q[n + rank] = WsHeapEntry{val, age + rank + 1, (int)j};
+            ql[n + rank] = lab;
+        }
+        const int cnt = (int)__popcll(mask);
+        n += cnt; age += cnt;
+        __syncthreads();                                   // one wave: orders this iteration's queue writes before the next sweep
     }
 }
 
@@ -692,7 +775,7 @@ __global__ __launch_bounds__(1024) void ws_finish_kernel(long long V, const int3
     if (threadIdx.x == 0) { n_out[0] = s_carry; n_out[1] = s_val[1]; n_out[2] = s_val[0]; }
 }
 
-struct WsLayout { size_t bn, bn2, gx, d2, dist, tmp, smooth, vmax, labels, parent, size, heap_off, heap_cnt, heap, roots, cand_val, cand_idx, marker_idx,
+struct WsLayout { size_t bn, bn2, gx, d2, dist, tmp, smooth, vmax, labels, parent, size, heap_off, heap_cnt, heap, qlab, roots, cand_val, cand_idx, marker_idx,
                   stats, sums, weights, total; int ngroups2d; };
 WsLayout ws_layout(long long V, int Z, int cap) {
     WsLayout L{};
@@ -703,7 +786,7 @@ WsLayout ws_layout(long long V, int Z, int cap) {
     L.dist = take((size_t)V * 8); L.tmp = take((size_t)V * 8); L.smooth = take((size_t)V * 8); L.vmax = take((size_t)V * 8);
     L.labels = take((size_t)V * 4); L.parent = take((size_t)V * 4); L.size = take((size_t)V * 4);
     L.heap_off = take((size_t)V * 4); L.heap_cnt = take((size_t)V * 4);
-    L.heap = take((size_t)V * sizeof(WsHeapEntry)); L.roots = take((size_t)V * 4);
+    L.heap = take((size_t)V * sizeof(WsHeapEntry)); L.qlab = take((size_t)V * 4); L.roots = take((size_t)V * 4);
     const size_t ncand = (size_t)Z * WS_PEAK_CAP2D > (size_t)WS_PEAK_CAP3D ? (size_t)Z * WS_PEAK_CAP2D : (size_t)WS_PEAK_CAP3D;
     L.cand_val = take(ncand * 8); L.cand_idx = take(ncand * 4); L.marker_idx = take(ncand * 4);
     L.stats = take(4096 + (size_t)(WS_PEAK_CAP3D + 1) * 8);       // eq_count[128] | vmin[128] | cand_count[128] | marker_count[128] | bump, nroots, overflow | counts / newlabel
@@ -794,7 +877,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     double* dist = (double*)(ws + L.dist); double* tmp = (double*)(ws + L.tmp); double* smooth = (double*)(ws + L.smooth); double* vmax = (double*)(ws + L.vmax);
     int32_t* labels = (int32_t*)(ws + L.labels); int32_t* parent = (int32_t*)(ws + L.parent); int32_t* size = (int32_t*)(ws + L.size);
     int32_t* heap_off = (int32_t*)(ws + L.heap_off); int32_t* heap_cnt = (int32_t*)(ws + L.heap_cnt);
-    WsHeapEntry* heap = (WsHeapEntry*)(ws + L.heap); int32_t* roots = (int32_t*)(ws + L.roots);
+    WsHeapEntry* heap = (WsHeapEntry*)(ws + L.heap); int32_t* roots = (int32_t*)(ws + L.roots); int32_t* qlab = (int32_t*)(ws + L.qlab);
     unsigned long long* cand_val = (unsigned long long*)(ws + L.cand_val); int32_t* cand_idx = (int32_t*)(ws + L.cand_idx);
     int32_t* marker_idx = (int32_t*)(ws + L.marker_idx);
     unsigned int* eq_count = (unsigned int*)(ws + L.stats);                       // [128]
@@ -857,9 +940,17 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         HIPCHK(hipMemcpyAsync(&h_over, overflow, sizeof(h_over), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (h_over) return CT_ESHAPE;                                            // more peak candidates than the per-slice / per-volume table holds
+        ws_fill_single_kernel<<<nb, 256, 0, st>>>(V, parent, heap_off, heap_cnt, heap, labels);
+        LAUNCH_CHECK();
         if (h_nroots) {
-            if (mode2d) ws_flood_kernel<true><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
-            else ws_flood_kernel<false><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
+            static const bool thread_flood = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 0;      // (A/B: one thread per component, binary heap)
+            if (thread_flood) {
+                if (mode2d) ws_flood_kernel<true><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
+                else ws_flood_kernel<false><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
+            } else {
+                if (mode2d) ws_flood_wave_kernel<true><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels);
+                else ws_flood_wave_kernel<false><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels);
+            }
             LAUNCH_CHECK();
         }
         return CT_OK;

@@ -5,7 +5,7 @@ set -u
 R=${1:-r03}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 bash scripts/prof.sh bench_$R $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-realistic-pass | head -4
 bash scripts/prof.sh unet_$R $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -4
