@@ -827,11 +827,12 @@ __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict_
 // and one launch; the column sums are added in another order than colstats_kernel's (rows strided over waves instead of contiguous
 // segments), in the single and the batched path alike.  CT_ESTEP_FUSED=0 restores the two-kernel form.
 template <int NQ>
-__global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restrict__ prior, const double* __restrict__ pred, int n,
+__global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restrict__ prior, const double* __restrict__ pred_in, int n,
                                                          const double* __restrict__ tgt, int m, const double* __restrict__ sc, double vol,
                                                          double* __restrict__ P /* or null */, double* __restrict__ part, Bt bt,
                                                          const double* __restrict__ sp, const int* __restrict__ sp_dense, int sp_m,
                                                          double* __restrict__ arow) {
+    const double* pred = pred_in;
     BT_SHIFT(const double*, prior); BT_SHIFT(const double*, pred); BT_SHIFT(const double*, tgt); BT_SHIFT(const double*, sc);
     BT_SHIFT(double*, part);
     if (P) BT_SHIFT(double*, P);
@@ -852,23 +853,27 @@ __global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restric
     for (int t = blockIdx.x * 4 + wave; t < m; t += 4 * CS_SEG) {
         const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
         const double* pr = prior + (size_t)t * n;
+
         double sp_lo = 0.0, sp_hi = 0.0; int sp_idx = -1;
         if (structured) { sp_lo = sp[t]; sp_hi = sp[sp_m + t]; sp_idx = ((const int*)(sp + 2 * (size_t)sp_m))[t]; }
-        double v[NQ];
+        // numerators: a ROLLED loop that parks them in the wave's slice of LDS (the reduction buffer, idle until the rows are done).
+        // Unrolled with the numerators in registers the compiler interleaves all NQ fp64 exp chains: 246 VGPRs at NQ = 10, two waves per
+        // SIMD, and in the pipelined benchmark those waves wait for half a register file to come free beside the conv waves.
+        double* const vq = red + wave * (NQ * 64) + lane;
         double acc = 0.0;
-#pragma unroll
+#pragma clang loop unroll(disable)
         for (int q = 0; q < NQ; ++q) {
             const int r = lane + 64 * q;
-            v[q] = 0.0;
+            double num = 0.0;
             if (r < n) {
                 const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
                 const double k = exp(-(dx * dx + dy * dy + dz * dz) * inv_two_s2);
                 double prv;
                 if (structured) prv = (r == sp_idx) ? sp_hi : sp_lo; else prv = pr[r];
-                const double num = coef * prv * k;
-                v[q] = num;
+                num = coef * prv * k;
                 acc += num;
             }
+            vq[64 * q] = num;
         }
         acc = wave_sum_d(acc);
         const double inv_den = 1.0 / (acc + gamma / vol);
@@ -877,7 +882,7 @@ __global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restric
         for (int q = 0; q < NQ; ++q) {
             const int r = lane + 64 * q;
             if (r < n) {
-                const double p = v[q] * inv_den;
+                const double p = vq[64 * q] * inv_den;
                 if (P) P[(size_t)t * n + r] = p;
                 asum += p;
                 cs[q] += p; cx[q] = fma(yx, p, cx[q]); cy[q] = fma(yy, p, cy[q]); cz[q] = fma(yz, p, cz[q]);
@@ -885,6 +890,7 @@ __global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restric
         }
         if (arow) { asum = wave_sum_d(asum); if (lane == 0) arow[t] = asum; }
     }
+    __syncthreads();                                       // every wave is done with its numerator slice: the buffer becomes the reduction's
     // ((wave 3 + wave 2) + wave 1) + wave 0, through one LDS copy of the accumulators
 #pragma unroll
     for (int w = 3; w >= 1; --w) {
