@@ -41,6 +41,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   1 no MFMAs   2 MFMA operands not read from LDS (zeros)   4 no staging stores to LDS   8 no global tile loads
 //   16 no epilogue stores / maxima   32 no SGPR pinning asm   64 no weight loads
 //   128 return at the kernel's first statement (resources only)   256 return after the argument fetch / tile decode, before any LDS use
+//   2048 epilogue arithmetic kept, global stores (output, pool) skipped   4096 no per-patch maximum (reduction, barrier, atomic)
 //   512 no per-wave column tables (no barrier-free LDS write -> read)   1024 the per-patch maxima are not fetched (no threadIdx.y)
 #ifndef CT_ABL
 #define CT_ABL 0
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
             const int y = y0 + col_y(mt);
             if constexpr (F16) { if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax); }
             const bool ok = x < a.X && y < a.Y && z < a.Z;
-            if (a.out && ok)
+            if (a.out && ok && !((CT_ABL) & 2048))
                 *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
             if (a.head) {
                 const f32x4 hw = *reinterpret_cast<const f32x4*>(epi_s + 3 * ECH + cb);
@@ -1186,7 +1187,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                     a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + head_bias)));
             }
         }
-        if constexpr (F16) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
+        if constexpr (F16 && !((CT_ABL) & 4096)) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
     } else {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -1211,9 +1212,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                 acc[mt][nt] = r;
             }
         }
-        if constexpr (F16) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
+        if constexpr (F16 && !((CT_ABL) & 4096)) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
         const int OQ = a.cout >> 3;
-        if (a.out) {
+        if (a.out && !((CT_ABL) & 2048)) {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 const int x = x0 + col_x(mt), y = y0 + col_y(mt);
@@ -1256,7 +1257,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                         }
                         const int cb = 16 * (ntb + nt) + 4 * g;
                         const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
-                        if (ok && zok && cb < a.cout) {
+                        if (ok && zok && cb < a.cout && !((CT_ABL) & 2048)) {
                             const int pzc = a.pz == 2 ? (z >> 1) : z;
                             const size_t idx = ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7);
                             *reinterpret_cast<f32x4*>(a.pool + idx) = m;
