@@ -80,6 +80,8 @@ struct ConvArgs {
     uint32_t mdivp[2];      // floor(2^32 / d) for d = pg_yz, pg_z
     int nx0, nx1, ny0, ny1; // outputs some kept voxel depends on: only they enter the tensor's per-patch maximum (the rest of a computed
                             // tile may have been fed from voxels nobody computed)
+    int sx0, sx1, sy0, sy1; // window of the FULL-RESOLUTION output that some consumer reads (volume path: an encoder conv whose output only feeds a
+                            // skip connection is computed in full for its pool, but the decoder reads just the part the centre crops depend on)
     int cout;
     int nt_total;           // cout tiles of 16 in the packed weights (a block computes NT of them)
     int ngroups;            // nt_total / NT  (blocks along the cout dimension; 1 unless Cout > 64)
@@ -1177,7 +1179,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
             const int y = y0 + col_y(mt);
             if constexpr (F16) { if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax); }
             const bool ok = x < a.X && y < a.Y && z < a.Z;
-            if (a.out && ok && !((CT_ABL) & 2048))
+            if (a.out && ok && x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && !((CT_ABL) & 2048))
                 *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
             if (a.head) {
                 const f32x4 hw = *reinterpret_cast<const f32x4*>(epi_s + 3 * ECH + cb);
@@ -1218,7 +1220,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 const int x = x0 + col_x(mt), y = y0 + col_y(mt);
-                if (x < a.X && y < a.Y && z < a.Z) {
+                if (x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && z < a.Z) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const int cb = 16 * (ntb + nt) + 4 * g;
@@ -1821,7 +1823,7 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             const int x = x0 + wx + (mt >> 2), y = y0 + wy + (mt & 3);
-            if (x < a.X && y < a.Y && z < a.Z && cb < a.cout)
+            if (x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && z < a.Z && cb < a.cout)
                 *reinterpret_cast<f32x4*>(a.out + ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7)) = acc[mt][0];
         }
     }
@@ -1888,6 +1890,7 @@ struct ConvPlan {
     int region[4];        // x0, x1, y0, y1 computed by the last run (volume path: the part the centre crops depend on)
     int needed[4];        // the part of it some kept voxel really depends on (region = needed rounded out to whole tiles)
     int region_e[4], needed_e[4];   // the same for patches on the volume's far faces (their kept crop is shorter)
+    int store[4];         // x0, x1, y0, y1 of the full-resolution output that has a reader (stores outside it are skipped)
     size_t wpack_off;     // float4 offset into the device weight arena
     size_t epi_off;       // float offset
 };
@@ -2577,6 +2580,14 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                     join(n, lo, hi);
                 }
             }
+            if (edge == 0) {                                   // what of the full-resolution output is ever read (consumers come later in the list)
+                static const bool store_cut = !(getenv("CT_CONV_STORE_CUT") && atoi(getenv("CT_CONV_STORE_CUT")) == 0);
+                const bool w = cut && store_cut && c.f16 && ii > 0 && c.dst >= 0 && !c.head && need[c.dst].any;
+                for (int ax = 0; ax < 2; ++ax) {
+                    c.store[2 * ax] = w ? (need[c.dst].lo[ax] < 0 ? 0 : need[c.dst].lo[ax]) : 0;
+                    c.store[2 * ax + 1] = w ? (need[c.dst].hi[ax] > d[ax] ? d[ax] : need[c.dst].hi[ax]) : d[ax];
+                }
+            }
             const bool z8 = z8_on && c.bf && !c.c8 && d[2] <= 8;
             const int tile[2] = {z8 ? 8 : TX, TY};
             for (int ax = 0; ax < 2; ++ax) {
@@ -2671,6 +2682,8 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             a.epi = h->d_weights + c.epi_off;
             a.out = (c.head && !layer_dump) ? nullptr : tptr(c.dst);
             a.cout = c.cout; a.nt_total = c.nt_total; a.ngroups = c.nt_total / c.NT;
+            a.sx0 = c.store[0]; a.sx1 = c.store[1]; a.sy0 = c.store[2]; a.sy1 = c.store[3];
+            if (layer_dump || !vsrc) { a.sx0 = 0; a.sx1 = d[0]; a.sy0 = 0; a.sy1 = d[1]; }
             if (c.pool_dst >= 0) {
                 const int* dp = h->dims[c.level + 1];
                 a.pool = tptr(c.pool_dst); a.pz = ad.pool[2]; a.PX = dp[0]; a.PY = dp[1]; a.PZ = dp[2];
