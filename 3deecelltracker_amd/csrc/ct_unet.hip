@@ -80,6 +80,8 @@ struct ConvArgs {
     uint32_t mdivp[2];      // floor(2^32 / d) for d = pg_yz, pg_z
     int nx0, nx1, ny0, ny1; // outputs some kept voxel depends on: only they enter the tensor's per-patch maximum (the rest of a computed
                             // tile may have been fed from voxels nobody computed)
+    float* vol_out;         // head layer of the volume path: probabilities go straight into the stitched volume (centre crop of patch (i, j, k) at
+    int vb[3], vc[3], vv[3];   // (i, j, k) * vc, crop origin vb inside the patch, clipped to the volume extents vv) instead of into per-patch maps
     int sx0, sx1, sy0, sy1; // window of the FULL-RESOLUTION output that some consumer reads (volume path: an encoder conv whose output only feeds a
                             // skip connection is computed in full for its pool, but the decoder reads just the part the centre crops depend on)
     int cout;
@@ -1039,11 +1041,13 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
     const int p = (int)b;
     const int x0 = a.tx0 + tx * G::TXv, y0 = a.ty0 + ty * G::TYv, z0 = zb * G::ZB;
     int nx1 = a.nx1, ny1 = a.ny1;
-    if (a.gx1 >= 0) {                                          // volume path: is this a patch on a far face of the volume?
+    int pgi = 0, pgj = 0, pgk = 0;                             // the patch's place in the volume's patch grid (head layer: direct stitch)
+    if (a.gx1 >= 0 || a.vol_out) {                             // volume path: is this a patch on a far face of the volume?
         uint32_t pg = (uint32_t)(a.p_first + p);
         const int rem = divmod(pg, (uint32_t)a.pg_yz, a.mdivp[0]);         // pg = i
         uint32_t jq = (uint32_t)rem;
-        (void)divmod(jq, (uint32_t)a.pg_z, a.mdivp[1]);                    // jq = j
+        pgk = divmod(jq, (uint32_t)a.pg_z, a.mdivp[1]);                    // jq = j
+        pgi = (int)pg; pgj = (int)jq;
         const bool xe = (int)pg == a.gx1, ye = (int)jq == a.gy1;
         if ((xe && x0 >= a.cx1e) || (ye && y0 >= a.cy1e)) return;          // (uniform, before any barrier) nothing kept depends on this tile
         nx1 = xe ? a.nx1e : nx1; ny1 = ye ? a.ny1e : ny1;
@@ -1158,6 +1162,17 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
     // ---- epilogue: (un-scale) -> bias -> activation -> BatchNorm affine; stores / fused pool / fused head as in the fp32 kernels
     const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
     const int z = z0 + zl;
+    // head output: per-patch probability map, or (volume path) the patch's centre crop straight into the stitched volume -- what
+    // tile_scatter_kernel did in a pass of its own (unet3d.py:246-254)
+    auto stitch = [&](int x, int y, int zz, float v) {
+        if (a.vol_out) {
+            const int lx = x - a.vb[0], ly = y - a.vb[1], lz = zz - a.vb[2];
+            if ((unsigned)lx < (unsigned)a.vc[0] && (unsigned)ly < (unsigned)a.vc[1] && (unsigned)lz < (unsigned)a.vc[2]) {
+                const int ox = pgi * a.vc[0] + lx, oy = pgj * a.vc[1] + ly, oz = pgk * a.vc[2] + lz;
+                if (ox < a.vv[0] && oy < a.vv[1] && oz < a.vv[2]) a.vol_out[((size_t)ox * a.vv[1] + oy) * a.vv[2] + oz] = v;
+            }
+        } else a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + zz] = v;
+    };
     float vmax = 0.f;                                         // |max| of what this wave writes (split-fp16 consumers scale by it)
     if constexpr (C8) {
         // lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx + (g>>1), y = y0 + col_y(mt)
@@ -1186,7 +1201,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                 float part = r[0] * hw[0] + r[1] * hw[1] + r[2] * hw[2] + r[3] * hw[3];
                 part += __shfl_xor(part, 16);                    // the other channel half of the same voxel
                 if ((g & 1) == 0 && ok)
-                    a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + head_bias)));
+                    stitch(x, y, z, 1.f / (1.f + expf(-(part + head_bias))));
             }
         }
         if constexpr (F16 && !((CT_ABL) & 4096)) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
@@ -1283,7 +1298,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                 part += __shfl_xor(part, 32);
                 const int x = x0 + col_x(mt), y = y0 + col_y(mt);
                 if (g == 0 && x < a.X && y < a.Y && z < a.Z)
-                    a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + z] = 1.f / (1.f + expf(-(part + hb)));
+                    stitch(x, y, z, 1.f / (1.f + expf(-(part + hb))));
             }
         }
     }
@@ -2515,7 +2530,7 @@ size_t ct_unet_workspace_bytes(const ct_unet_t* h, int n_patches) {
 struct VolSource { const float* vol; TileGeom q; int p_begin; };
 
 static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* layer_dump, hipStream_t st,
-                       const VolSource* vsrc = nullptr) {
+                       const VolSource* vsrc = nullptr, float* vol_out = nullptr) {
     // ws: tensor t of patch batch lives at ws + tensors[t].off * P  (each tensor is [P][...])
     auto tptr = [&](int t) { return ws + h->tensors[t].off * (size_t)P; };
     // per-patch |max| slots (split-fp16 kernels): after the tensors of this batch, zeroed per run
@@ -2688,7 +2703,15 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 const int* dp = h->dims[c.level + 1];
                 a.pool = tptr(c.pool_dst); a.pz = ad.pool[2]; a.PX = dp[0]; a.PY = dp[1]; a.PZ = dp[2];
             }
-            if (c.head) { a.head = h->d_weights + h->head_off; a.head_out = prob_out; }
+            if (c.head) {
+                a.head = h->d_weights + h->head_off; a.head_out = prob_out;
+                if (vol_out && vsrc && c.bf) {                 // split kernels: the centre crops go straight into the stitched volume
+                    const TileGeom& q = vsrc->q;
+                    a.vol_out = vol_out;
+                    a.vb[0] = q.bx; a.vb[1] = q.by; a.vb[2] = q.bz; a.vc[0] = q.cx; a.vc[1] = q.cy; a.vc[2] = q.cz;
+                    a.vv[0] = q.vx; a.vv[1] = q.vy; a.vv[2] = q.vz;
+                }
+            }
             a.act = ad.act;
             a.nxcd = nxcd;
 #ifdef CT_TRACE
@@ -2710,8 +2733,12 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 a.gx1 = a.gy1 = -1;
                 const bool edges = crop_mode > 0 && vsrc && !layer_dump && c.f16 &&
                                    (c.region_e[1] < c.region[1] || c.region_e[3] < c.region[3] || c.needed_e[1] < c.needed[1] || c.needed_e[3] < c.needed[3]);
-                if (edges) {
+                if (edges || a.vol_out) {
                     a.p_first = vsrc->p_begin; a.pg_yz = vsrc->q.gy * vsrc->q.gz; a.pg_z = vsrc->q.gz;
+                    const int dd[2] = {a.pg_yz, a.pg_z};
+                    for (int k = 0; k < 2; ++k) a.mdivp[k] = dd[k] <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)dd[k]);
+                }
+                if (edges) {
                     a.gx1 = vsrc->q.gx - 1; a.gy1 = vsrc->q.gy - 1;
                     a.cx1e = c.region_e[1]; a.cy1e = c.region_e[3]; a.nx1e = c.needed_e[1]; a.ny1e = c.needed_e[3];
                     const int dd[2] = {a.pg_yz, a.pg_z};
@@ -2883,10 +2910,15 @@ int ct_unet_predict_volume(ct_unet_t* h, const float* vol, const int v[3], const
             if (rc) return rc;
         }
         VolSource vs{vol, q, p_begin + done};
-        rc = run_network(h, ws, nb, prob, nullptr, st, fused_first ? &vs : nullptr);
+        // split-kernel head layers write their centre crops straight into the stitched volume (CT_DIRECT_STITCH=0: per-patch maps + scatter)
+        static const bool direct_on = !(getenv("CT_DIRECT_STITCH") && atoi(getenv("CT_DIRECT_STITCH")) == 0);
+        const bool direct = direct_on && fused_first && h->convs.back().head && h->convs.back().bf;
+        rc = run_network(h, ws, nb, prob, nullptr, st, fused_first ? &vs : nullptr, direct ? out_vol : nullptr);
         if (rc) return rc;
-        rc = ct_tile_scatter_center(prob, v, h->ad.in, shrink, p_begin + done, nb, out_vol, stream);
-        if (rc) return rc;
+        if (!direct) {
+            rc = ct_tile_scatter_center(prob, v, h->ad.in, shrink, p_begin + done, nb, out_vol, stream);
+            if (rc) return rc;
+        }
         (void)vox0;
         done += nb;
     }
