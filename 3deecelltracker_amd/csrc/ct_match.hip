@@ -916,12 +916,107 @@ __global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restric
         }
     }
 }
-static bool estep_fused() { static const bool v = !(getenv("CT_ESTEP_FUSED") && getenv("CT_ESTEP_FUSED")[0] == '0'); return v; }
-// launches estep_cols_kernel<NQ> with the smallest NQ that covers n columns; false if n is too wide for the register-resident rows
+// Fused E-step, narrow-wave form: a BLOCK owns a contiguous segment of target rows and walks them one at a time; wave w of the block owns
+// the columns [64 NQ w, 64 NQ (w + 1)) of every row, so a lane carries only NQ numerators and 4 NQ accumulators (~70-90 VGPRs: such a wave
+// fits beside the conv waves of the pipelined benchmark instead of waiting for half a register file, which is what estep_cols_kernel's
+// 183-246-VGPR waves do).  Row sum = per-wave butterfly sums added in wave order through a double-buffered LDS slot (one barrier per
+// row); every column belongs to exactly one wave, so the block writes its part[seg][4][n] slice without any cross-wave reduction.
+// The posterior's row sums for the sigma2 trace identity are total * 1 / den (the exact sum of the normalised row up to rounding).
+template <int NQ>
+__global__ __launch_bounds__(1024) void estep_rows_kernel(const double* __restrict__ prior, const double* __restrict__ pred, int n,
+                                                          const double* __restrict__ tgt, int m, const double* __restrict__ sc, double vol,
+                                                          double* __restrict__ P /* or null */, double* __restrict__ part, Bt bt,
+                                                          const double* __restrict__ sp, const int* __restrict__ sp_dense, int sp_m,
+                                                          double* __restrict__ arow) {
+    BT_SHIFT(const double*, prior); BT_SHIFT(const double*, pred); BT_SHIFT(const double*, tgt); BT_SHIFT(const double*, sc);
+    BT_SHIFT(double*, part);
+    if (P) BT_SHIFT(double*, P);
+    if (sp) BT_SHIFT(const double*, sp);
+    if (arow) BT_SHIFT(double*, arow);
+    if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
+    if (sc[S_DONE] != 0.0) return;
+    __shared__ double psum[2][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, W = blockDim.x >> 6;
+    const double s2 = sc[S_SIGMA2], gamma = sc[S_GAMMA];
+    const double two_s2 = 2.0 * s2;
+    const double norm = pow(2.0 * M_PI * s2, 1.5);
+    const double inv_two_s2 = 1.0 / two_s2, coef = (1.0 - gamma) / norm;
+    const bool structured = sp && sp_dense[blockIdx.z] == 0;
+    double cs[NQ], cx[NQ], cy[NQ], cz[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) cs[q] = cx[q] = cy[q] = cz[q] = 0.0;
+    const int per = (m + CS_SEG - 1) / CS_SEG;
+    const int t0 = blockIdx.x * per, t1 = min(m, t0 + per);
+    int buf = 0;
+    for (int t = t0; t < t1; ++t, buf ^= 1) {
+        const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
+        const double* pr = prior + (size_t)t * n;
+        double sp_lo = 0.0, sp_hi = 0.0; int sp_idx = -1;
+        if (structured) { sp_lo = sp[t]; sp_hi = sp[sp_m + t]; sp_idx = ((const int*)(sp + 2 * (size_t)sp_m))[t]; }
+        double v[NQ];
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int r = (wave * NQ + q) * 64 + lane;
+            v[q] = 0.0;
+            if (r < n) {
+                const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
+                const double k = exp(-(dx * dx + dy * dy + dz * dz) * inv_two_s2);
+                double prv;
+                if (structured) prv = (r == sp_idx) ? sp_hi : sp_lo; else prv = pr[r];
+                const double num = coef * prv * k;
+                v[q] = num;
+                acc += num;
+            }
+        }
+        acc = wave_sum_d(acc);
+        if (lane == 0) psum[buf][wave] = acc;
+        __syncthreads();
+        double tot = 0.0;
+        for (int w = 0; w < W; ++w) tot += psum[buf][w];
+        const double inv_den = 1.0 / (tot + gamma / vol);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int r = (wave * NQ + q) * 64 + lane;
+            if (r < n) {
+                const double p = v[q] * inv_den;
+                if (P) P[(size_t)t * n + r] = p;
+                cs[q] += p; cx[q] = fma(yx, p, cx[q]); cy[q] = fma(yy, p, cy[q]); cz[q] = fma(yz, p, cz[q]);
+            }
+        }
+        if (arow && threadIdx.x == 0) arow[t] = tot * inv_den;
+    }
+    double* o = part + (size_t)blockIdx.x * 4 * n;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int r = (wave * NQ + q) * 64 + lane;
+        if (r < n) { o[r] = cs[q]; o[n + r] = cx[q]; o[2 * n + r] = cy[q]; o[3 * n + r] = cz[q]; }
+    }
+}
+// CT_ESTEP_FUSED: 0 = posterior + colstats kernels, 1 = estep_cols_kernel (a wave owns whole rows), 2 (default) = estep_rows_kernel
+static int estep_mode() { static const int v = getenv("CT_ESTEP_FUSED") ? atoi(getenv("CT_ESTEP_FUSED")) : 2; return v; }
+// columns per lane: a CONSTANT, so that wave w always owns columns [320 w, 320 (w + 1)) and the row sums of a problem do not depend on the
+// widest problem of its batch (waves beyond a problem's n add +0.0): single and batched runs stay bit-identical.  5 = two waves at n = 600.
+static int estep_nq() { static const int v = getenv("CT_ESTEP_NQ") ? atoi(getenv("CT_ESTEP_NQ")) : 5; return v; }
+// launches the fused E-step; false if it is switched off or n is too wide for it
 static bool launch_estep_cols(int n_max, unsigned zB, hipStream_t st, const double* prior, const double* pred, int n, const double* tgt, int m,
                               const double* sc, double* P, double* part, Bt bt, const double* sp, const int* sp_dense, int sp_m, double* arow) {
     const int need = (n_max + 63) / 64;
-    if (need > PO_REG || !estep_fused()) return false;
+    const int mode = estep_mode();
+    if (mode <= 0) return false;
+    if (mode >= 2) {
+        int nq = estep_nq(); if (nq < 1 || nq > 6) nq = 5;
+        const int W = (need + nq - 1) / nq;
+        if (W <= 16) {
+#define CT_ESTEPR(NQv) hipLaunchKernelGGL(estep_rows_kernel<NQv>, dim3(CS_SEG, 1, zB), dim3(64 * W), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, part, bt, \
+                                          sp, sp_dense, sp_m, arow)
+            switch (nq) { case 1: CT_ESTEPR(1); break; case 2: CT_ESTEPR(2); break; case 3: CT_ESTEPR(3); break; case 4: CT_ESTEPR(4); break;
+                          case 6: CT_ESTEPR(6); break; default: CT_ESTEPR(5); }
+#undef CT_ESTEPR
+            return true;
+        }
+    }
+    if (need > PO_REG) return false;
 #define CT_ESTEP(NQv) hipLaunchKernelGGL(estep_cols_kernel<NQv>, dim3(CS_SEG, 1, zB), dim3(256), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, part, bt, \
                                          sp, sp_dense, sp_m, arow)
     if (need <= 1) CT_ESTEP(1); else if (need <= 2) CT_ESTEP(2); else if (need <= 4) CT_ESTEP(4); else if (need <= 6) CT_ESTEP(6);
