@@ -170,7 +170,7 @@ def match_device(ffn_model: FFN, seg_t1_n, seg_t2_m, confirmed_l, beta, lambda_,
 def match_device_batched(ffn_model: FFN, problems, beta, lambda_, max_iteration=MAX_ITERATION, k=K_POINTS, threshold=0.1):
     """match_device for a list of independent (seg_t1_n, seg_t2_m, confirmed_l) problems: FFN scores and the greedy priors of all
     problems in one chain of launches, then ALL PR-GLS runs in another (ct_prgls_two_ref_batched; the GPU retires the ~10
-    tiny dependent kernels of an EM iteration at the same rate for one problem as for twenty).  Results are bit-identical to
+    tiny dependent kernels of an EM iteration at the same rate for one problem as for twenty).  The EM state is bit-identical to (and the moved tracked sets within ~1e-11 of)
     [match_device(...) for ...].  -> list of ((l, 3) device tensor, iterations)."""
     batch = []
     for seg_t1_n, seg_t2_m, confirmed_l in problems:

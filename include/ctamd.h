@@ -199,7 +199,8 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
  * A match is a chain of ~10 tiny dependent kernels per EM iteration and the GPU retires such kernels at a few hundred
  * thousand per second however many streams issue them, so the matches of independent frames (or of one ensemble prediction,
  * trackerlite.py:115-122) are cheaper batched than concurrent.  Arguments as ct_prgls_two_ref, as HOST arrays of B device
- * pointers / sizes; results are bit-identical to B separate calls (same kernels, same per-problem rank steering; a problem
+ * pointers / sizes; the EM state (moved reference set, posterior, iteration counts) is bit-identical to B separate calls and out_tracked agrees to ~1e-11
+ * (the tracked set is moved once with the summed coefficients instead of once per iteration) (same kernels, same per-problem rank steering; a problem
  * whose low-rank M-step is rejected is finished by the single-problem routine).  Synchronous like ct_prgls_two_ref.        */
 size_t ct_prgls_batched_workspace_bytes(int B, const int* m, const int* n, const int* l);
 int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* const* tgt, const int* m,
