@@ -789,7 +789,11 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
     if (arow) { asum = wave_sum_d(asum); if (lane == 0) arow[t] = asum; }
 }
 
-constexpr int CS_SEG = 32;       // row segments of the column statistics
+#ifndef CT_CS_SEG
+#define CT_CS_SEG 64
+#endif
+constexpr int CS_SEG = CT_CS_SEG;       // row segments of the column statistics / of the fused E-step (32: +0.7 % in the pipelined benchmark, but a single
+                                        // match's EM iteration 93 instead of 80 us: a segment's rows are a dependent chain; 128: 77 us, -1.4 %)
 // column statistics, stage 1: block (x: 64 columns, y: row segment) -> part[seg][4][n] = colsum, Y^T P
 __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict__ P, const double* __restrict__ tgt, int m, int n,
                                                        double* __restrict__ part, const double* __restrict__ sc = nullptr,
