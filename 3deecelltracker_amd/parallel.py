@@ -242,6 +242,46 @@ def gather_centroids(local_coords, cap: int = 4096):
     return [o[:int(o[cap, 0].item())] for o in out]
 
 
+class TrackedSetGather:
+    """The "gather of centroid sets" of the frames mode: the tracked (cells, 3) sets of one match batch leave as ONE
+    all_gather_into_tensor ([frames][cells][3] per rank -> [world][frames][cells][3]) on a communication stream ordered after the
+    producer; the receive buffers are kept per batch size.  `gathered` counts the sets received (world x frames per call): a SCALE
+    record shows that the collective saw every rank.  CPU tensors + gloo in the tests, RCCL on the GPUs."""
+
+    def __init__(self, comm_stream=None):
+        self.comm = comm_stream
+        self.bufs = {}
+        self.gathered = 0
+
+    def __call__(self, tracked):
+        import torch
+        import torch.distributed as dist
+        rank, world = dist_info()
+        tracked = list(tracked)
+        if world == 1 or not tracked:
+            return None
+        cuda = tracked[0].is_cuda
+        ctx = torch.cuda.stream(self.comm) if (cuda and self.comm is not None) else _Null()
+        if cuda and self.comm is not None:
+            self.comm.wait_stream(torch.cuda.current_stream(tracked[0].device))
+        with ctx:
+            send = torch.stack(tracked)                      # [frames][cells][3], this rank's frames
+            key = (len(tracked), tuple(send.shape[1:]), send.dtype)
+            buf = self.bufs.get(key)
+            if buf is None:
+                buf = self.bufs[key] = torch.empty((world, *send.shape), dtype=send.dtype, device=send.device)
+            dist.all_gather_into_tensor(buf.view(-1, *send.shape[1:]), send)   # dim-0 concatenation: the form gloo accepts too
+            if cuda and self.comm is not None:
+                send.record_stream(self.comm)
+        self.gathered += world * len(tracked)
+        return buf
+
+
+class _Null:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
 class FramePipeline:
     """Intra-GPU overlap of the two halves of the path across frames.
 

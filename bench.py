@@ -121,21 +121,12 @@ def make_frames_mode(ctx, args):
     import torch.distributed as dist
     pre = mod("preprocess")
     comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
-    gather_bufs = {}                                         # frames per batch -> [world][frames][cells][3] receive buffer
+    gatherer = mod("parallel").TrackedSetGather(comm)        # one all_gather_into_tensor per match batch (up to 32 frames x 14 KB per rank)
 
     def gather(tracked):
-        """"gather of centroid sets": the tracked sets of one match batch (up to 32 frames x 14 KB per rank) leave as ONE
-        all_gather_into_tensor on the communication stream (one collective per batch instead of one list all_gather per frame)."""
         if ctx.world > 1:
-            cur = torch.cuda.current_stream(ctx.dev)
-            with torch.cuda.stream(comm):
-                comm.wait_stream(cur)
-                send = torch.stack(list(tracked))            # [frames][cells][3] fp64, this rank's frames
-                buf = gather_bufs.get(len(tracked))
-                if buf is None:
-                    buf = gather_bufs[len(tracked)] = torch.empty((ctx.world, *send.shape), dtype=send.dtype, device=ctx.dev)
-                dist.all_gather_into_tensor(buf.view(-1, *send.shape[1:]), send)   # dim-0 concatenation: the form gloo (CPU dry runs) accepts too
-                ctx.gathered_sets += ctx.world * len(tracked)
+            gatherer(tracked)
+            ctx.gathered_sets = gatherer.gathered
 
     frame_done, finish_matches = _match_batcher(ctx, args, gather)
 

@@ -71,6 +71,8 @@ def test_two_ranks_gloo_same_device_runs_all_sharding_passes():
     line = _two_ranks("gloo", ["--same-device"])
     assert KEYS <= set(line) and line["n_gpus"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
     cfg = line["config"]
+    assert cfg["rccl_ranks"]["world_size"] == 2 and cfg["rccl_ranks"]["backend"] == "gloo"
+    assert cfg["rccl_ranks"]["tracked_sets_gathered"] == 2 * (line["steps"] + line["warmup"])   # every frame (warm-up included) from every rank
     assert cfg["patches_sharded"]["per_s"] > 0 and cfg["ensemble_sharded"]["per_s"] > 0
     assert cfg["with_discriminating_ffn"]["prgls_iterations"] <= 30
 

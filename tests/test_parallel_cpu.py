@@ -52,6 +52,16 @@ def _worker(rank, world, port, q):
         assert tuple(f32.shape) == (1, 2) and f32.dtype == torch.float32 and float(f32[0, 0]) == 3.0
         none = par.sharded_map_gather(fn, [], tail_shape=(4, 3), dtype=torch.float64, device="cpu")
         assert tuple(none.shape) == (0, 4, 3)
+        # the frames mode's gather: a batch of tracked sets per rank in ONE all_gather_into_tensor
+        g = par.TrackedSetGather()
+        for frames in (3, 1, 3):
+            mine = [torch.full((5, 3), 10.0 * rank + f, dtype=torch.float64) for f in range(frames)]
+            buf = g(mine)
+            assert tuple(buf.shape) == (2, frames, 5, 3)
+            for r in range(2):
+                for f in range(frames):
+                    assert torch.equal(buf[r, f], torch.full((5, 3), 10.0 * r + f, dtype=torch.float64))
+        assert g.gathered == 2 * (3 + 1 + 3) and len(g.bufs) == 2          # buffers are reused per batch size
         # variable-size centroid sets
         local = torch.arange((rank + 2) * 3, dtype=torch.float64).reshape(-1, 3) + 100 * rank
         sets = par.gather_centroids(local, cap=16)
