@@ -789,11 +789,13 @@ __global__ __launch_bounds__(256) void posterior_kernel(const double* __restrict
     if (arow) { asum = wave_sum_d(asum); if (lane == 0) arow[t] = asum; }
 }
 
-#ifndef CT_CS_SEG
-#define CT_CS_SEG 64
+constexpr int CS_SEG = 32;              // row segments of colstats_kernel (dense / legacy paths and the unfused E-step)
+#ifndef CT_ES_SEG
+#define CT_ES_SEG 64
 #endif
-constexpr int CS_SEG = CT_CS_SEG;       // row segments of the column statistics / of the fused E-step (32: +0.7 % in the pipelined benchmark, but a single
-                                        // match's EM iteration 93 instead of 80 us: a segment's rows are a dependent chain; 128: 77 us, -1.4 %)
+constexpr int ES_SEG = CT_ES_SEG;       // row segments of the fused E-step (32: +0.7 % in the pipelined benchmark, but a single match's EM iteration
+                                        // 93 instead of 80 us: a segment's rows are a dependent chain; 128: 77 us, -1.4 %)
+constexpr int PART_SEG = ES_SEG > CS_SEG ? ES_SEG : CS_SEG;      // slices the partial-sum buffer is sized for
 // column statistics, stage 1: block (x: 64 columns, y: row segment) -> part[seg][4][n] = colsum, Y^T P
 __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict__ P, const double* __restrict__ tgt, int m, int n,
                                                        double* __restrict__ part, const double* __restrict__ sc = nullptr,
@@ -854,7 +856,7 @@ __global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restric
     double cs[NQ], cx[NQ], cy[NQ], cz[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) cs[q] = cx[q] = cy[q] = cz[q] = 0.0;
-    for (int t = blockIdx.x * 4 + wave; t < m; t += 4 * CS_SEG) {
+    for (int t = blockIdx.x * 4 + wave; t < m; t += 4 * (int)gridDim.x) {
         const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
         const double* pr = prior + (size_t)t * n;
 
@@ -949,7 +951,7 @@ __global__ __launch_bounds__(1024) void estep_rows_kernel(const double* __restri
     double cs[NQ], cx[NQ], cy[NQ], cz[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) cs[q] = cx[q] = cy[q] = cz[q] = 0.0;
-    const int per = (m + CS_SEG - 1) / CS_SEG;
+    const int per = (m + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t0 = blockIdx.x * per, t1 = min(m, t0 + per);
     int buf = 0;
     for (int t = t0; t < t1; ++t, buf ^= 1) {
@@ -1012,7 +1014,7 @@ static bool launch_estep_cols(int n_max, unsigned zB, hipStream_t st, const doub
         int nq = estep_nq(); if (nq < 1 || nq > 6) nq = 5;
         const int W = (need + nq - 1) / nq;
         if (W <= 16) {
-#define CT_ESTEPR(NQv) hipLaunchKernelGGL(estep_rows_kernel<NQv>, dim3(CS_SEG, 1, zB), dim3(64 * W), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, part, bt, \
+#define CT_ESTEPR(NQv) hipLaunchKernelGGL(estep_rows_kernel<NQv>, dim3(ES_SEG, 1, zB), dim3(64 * W), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, part, bt, \
                                           sp, sp_dense, sp_m, arow)
             switch (nq) { case 1: CT_ESTEPR(1); break; case 2: CT_ESTEPR(2); break; case 3: CT_ESTEPR(3); break; case 4: CT_ESTEPR(4); break;
                           case 6: CT_ESTEPR(6); break; default: CT_ESTEPR(5); }
@@ -1021,7 +1023,7 @@ static bool launch_estep_cols(int n_max, unsigned zB, hipStream_t st, const doub
         }
     }
     if (need > PO_REG) return false;
-#define CT_ESTEP(NQv) hipLaunchKernelGGL(estep_cols_kernel<NQv>, dim3(CS_SEG, 1, zB), dim3(256), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, part, bt, \
+#define CT_ESTEP(NQv) hipLaunchKernelGGL(estep_cols_kernel<NQv>, dim3(ES_SEG, 1, zB), dim3(256), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, part, bt, \
                                          sp, sp_dense, sp_m, arow)
     if (need <= 1) CT_ESTEP(1); else if (need <= 2) CT_ESTEP(2); else if (need <= 4) CT_ESTEP(4); else if (need <= 6) CT_ESTEP(6);
     else if (need <= 8) CT_ESTEP(8); else if (need <= 10) CT_ESTEP(10); else if (need <= 12) CT_ESTEP(12); else CT_ESTEP(16);
@@ -1238,7 +1240,7 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
 __global__ __launch_bounds__(256) void colstats_finish_par_kernel(const double* __restrict__ part, int n, const double* __restrict__ xref,
                                                                   const double* __restrict__ sc, double* __restrict__ dvec,
                                                                   double* __restrict__ sqd, double* __restrict__ rhs, Bt bt = Bt{0, nullptr},
-                                                                  double* __restrict__ braw = nullptr) {
+                                                                  double* __restrict__ braw = nullptr, int nseg = CS_SEG) {
     BT_SHIFT(const double*, part); BT_SHIFT(const double*, xref); BT_SHIFT(const double*, sc); BT_SHIFT(double*, dvec);
     BT_SHIFT(double*, sqd); BT_SHIFT(double*, rhs);
     if (braw) BT_SHIFT(double*, braw);
@@ -1249,7 +1251,7 @@ __global__ __launch_bounds__(256) void colstats_finish_par_kernel(const double* 
     const int i = blockIdx.x * 64 + cl;
     double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
     if (i < n)
-        for (int seg = wv; seg < CS_SEG; seg += 4) {
+        for (int seg = wv; seg < nseg; seg += 4) {
             const double* o = part + (size_t)seg * 4 * n;
             s += o[i]; sx += o[n + i]; sy += o[2 * n + i]; sz += o[3 * n + i];
         }
@@ -2307,7 +2309,7 @@ size_t prgls_layout(int m, int n, int l, unsigned char* base, PrglsWs* w) {
     auto take = [&](size_t count) { double* p = base ? (double*)(base + off) : nullptr; off += align_up(count * sizeof(double), 256); return p; };
     PrglsWs t{};
     t.G = take((size_t)n * n); t.Gln = take((size_t)n * (l > 0 ? l : 1)); t.M = take((size_t)n * n);
-    t.P = take((size_t)m * n); t.part = take((size_t)CS_SEG * 4 * n); t.dvec = take(n); t.sqd = take(n);
+    t.P = take((size_t)m * n); t.part = take((size_t)PART_SEG * 4 * n); t.dvec = take(n); t.sqd = take(n);
     t.rhs = take(3 * (size_t)n); t.C = take(3 * (size_t)n); t.predn = take(3 * (size_t)n);
     t.predl = take(3 * (size_t)(l > 0 ? l : 1)); t.rowpart = take(m); t.rowpart0 = take(m); t.normpart = take(n); t.sc = take(S_NUM);
     t.U = take((size_t)LR_RMAX * n); t.ypart = take((size_t)LR_RMAX * 3);
@@ -2342,9 +2344,11 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
             int legacy, double vol, int rank, hipStream_t st, bool trace = false, bool want_P = true) {
     // low-rank iterations of the TrackerLite dialect: fused E-step (the posterior is written only if somebody reads it: the caller, or
     // the direct sigma2 sum when the trace identity is switched off)
-    if (!(rank > 0 && !legacy && vol == 1.0 &&
+    int nseg = CS_SEG;
+    if (rank > 0 && !legacy && vol == 1.0 &&
           launch_estep_cols(n, 1, st, prior, w.predn, n, tgt, m, w.sc, (want_P || !trace) ? w.P : (double*)nullptr, w.part, Bt{0, nullptr},
-                            (const double*)nullptr, (const int*)nullptr, 0, trace ? w.tra : (double*)nullptr))) {
+                            (const double*)nullptr, (const int*)nullptr, 0, trace ? w.tra : (double*)nullptr)) nseg = ES_SEG;
+    else {
         hipLaunchKernelGGL(posterior_kernel, dim3((m + 3) / 4), dim3(256), 0, st, prior, w.predn, n, tgt, m, w.sc, legacy, vol, w.P, 0.0, 0.0,
                            Bt{0, nullptr}, (const double*)nullptr, (const int*)nullptr, 0, trace ? w.tra : (double*)nullptr);
         LAUNCH_CHECK();
@@ -2353,7 +2357,7 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
     LAUNCH_CHECK();
     if (rank > 0) {
         hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((n + 63) / 64), dim3(256), 0, st, w.part, n, xref, w.sc, w.dvec, w.sqd, w.rhs,
-                           Bt{0, nullptr}, trace ? w.trb : (double*)nullptr);
+                           Bt{0, nullptr}, trace ? w.trb : (double*)nullptr, nseg);
         LAUNCH_CHECK();
         const int nent = rank * (rank + 1) / 2 + 3 * rank;
         const int ntile = (rank + LG_T - 1) / LG_T, nwave = ntile * (ntile + 1) / 2 + ntile;
@@ -2671,8 +2675,10 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
     for (int enq = 0; enq < total && live > 0;) {
         const int chunk = prgls_chunk(enq, total);
         for (int k = 0; k < chunk; ++k) {
+            int nseg = ES_SEG;
             if (!launch_estep_cols(nn, zB, st, in_prior, w.predn, nn, in_tgt, mm, w.sc, (any_posterior || !trace) ? w.P : (double*)nullptr, w.part, bt,
                                    sp_on ? (const double*)sp_tab : (const double*)nullptr, (const int*)d_dense, mm, trace ? tr_a : (double*)nullptr)) {
+                nseg = CS_SEG;
                 hipLaunchKernelGGL(posterior_kernel, dim3((mm + 3) / 4, 1, zB), dim3(256), 0, st, in_prior, w.predn, nn, in_tgt, mm, w.sc, 0, 1.0,
                                    w.P, 0.0, 0.0, bt, sp_on ? (const double*)sp_tab : (const double*)nullptr, (const int*)d_dense, mm,
                                    trace ? tr_a : (double*)nullptr);
@@ -2681,7 +2687,7 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
             }
             LAUNCH_CHECK();
             hipLaunchKernelGGL(colstats_finish_par_kernel, dim3((nn + 63) / 64, 1, zB), dim3(256), 0, st, w.part, nn, w.predn, w.sc, w.dvec,
-                               w.sqd, w.rhs, bt, trace ? tr_b : (double*)nullptr);
+                               w.sqd, w.rhs, bt, trace ? tr_b : (double*)nullptr, nseg);
             LAUNCH_CHECK();
             const int nent = rank * (rank + 1) / 2 + 3 * rank;
             const int ntile = (rank + LG_T - 1) / LG_T, nwave = ntile * (ntile + 1) / 2 + ntile;
