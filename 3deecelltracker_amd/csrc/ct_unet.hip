@@ -29,6 +29,7 @@
 #include <math.h>
 #include <cmath>
 #include <vector>
+#include <type_traits>
 #include <new>
 
 #include "../../include/ctamd.h"
@@ -82,6 +83,7 @@ struct ConvArgs {
                             // tile may have been fed from voxels nobody computed)
     float* vol_out;         // head layer of the volume path: probabilities go straight into the stitched volume (centre crop of patch (i, j, k) at
     int vb[3], vc[3], vv[3];   // (i, j, k) * vc, crop origin vb inside the patch, clipped to the volume extents vv) instead of into per-patch maps
+    int lowa;               // folded decoder convs: stage the upsampled source at its own resolution (StageGeom LOW; needs ux = uy = 1, uz = 0)
     int sx0, sx1, sy0, sy1; // window of the FULL-RESOLUTION output that some consumer reads (volume path: an encoder conv whose output only feeds a
                             // skip connection is computed in full for its pool, but the decoder reads just the part the centre crops depend on)
     int cout;
@@ -758,7 +760,11 @@ template <bool Z8> struct BfGeom {
 static_assert(BfGeom<false>::HXv == HX && BfGeom<false>::HYv == HY && BfGeom<false>::HZv == HZ, "geometry of the f32 kernels");
 
 // LDS position offset of tap slot t for the four tap sets (0 for the zero-weight padding slots); hy, hz = halo tile strides
-__host__ __device__ constexpr int bf_tap_pos(bool c8, bool folded, int t, int hy, int hz) {
+__host__ __device__ constexpr int bf_tap_pos(bool c8, bool folded, int t, int hy, int hz, bool low = false) {
+    if (folded && low) {                                      // low-resolution tile of the upsampled source: the 2 (x: 3 for a Cout = 8 pair) x 2 distinct voxels are neighbours
+        const int nt = c8 ? 18 : 12;
+        return t < nt ? ((t / 6) * hy + (t / 3) % 2) * hz + t % 3 : 0;
+    }
     if (!folded) {
         const int ntap = c8 ? 36 : 27;
         return t < ntap ? ((t / 9) * hy + (t / 3) % 3) * hz + t % 3 : 0;
@@ -768,7 +774,8 @@ __host__ __device__ constexpr int bf_tap_pos(bool c8, bool folded, int t, int hy
 }
 
 // position offset of the wave's MFMA column mt (relative to the wave / lane base) for the column mappings of the kernel
-__host__ __device__ constexpr int bf_col_pos(bool c8, bool kfold, bool z8, int mt, int hy, int hz) {
+__host__ __device__ constexpr int bf_col_pos(bool c8, bool kfold, bool z8, int mt, int hy, int hz, bool low = false) {
+    if (low) return c8 ? mt * hz : ((mt >> 2) * hy + (mt & 3)) * hz;       // parity class members are neighbours at half resolution
     if (c8) return mt * (kfold ? 2 : 1) * hz;
     if (!z8) return kfold ? (2 * (mt >> 2) * hy + 2 * (mt & 3)) * hz : ((mt >> 2) * hy + (mt & 3)) * hz;
     return kfold ? (2 * (mt >> 1) * hy + 4 * (mt & 1)) * hz : ((mt >> 2) * hy + 2 * (mt & 3)) * hz;
@@ -798,11 +805,15 @@ __device__ __forceinline__ void bf_split4(const f32x4 v, uint2& h, uint2& m, uin
 //     zero padding) built once per workgroup and source tensor;
 //   * the two z-halo planes are separate slots, read only when the layer has more than one z block (otherwise they are the 'same'
 //     padding: written as zeros with the first chunk and never touched again).
-template <bool Z8> struct StageGeom {
+// LOW: the tile of a source that reaches the conv through UpSampling3D(2, 2, 1) is staged at ITS resolution -- (TX / 2 + 2) x (TY / 2 + 2)
+// = 4 x 6 columns instead of the 6 x 10 full-resolution halo columns that repeat every voxel up to four times (2.5 x fewer loads, splits
+// and LDS stores for half of a decoder conv's chunks); the folded taps then read neighbours (bf_tap_pos / bf_col_pos `low`).
+constexpr int LHX = TX / 2 + 2, LHY = TY / 2 + 2;
+template <bool Z8, bool LOW = false> struct StageGeom {
     using G = BfGeom<Z8>;
     static constexpr int ZS = G::ZB * 2;                      // float4 slots of one column's interior: (z, channel half)
     static constexpr int NCG = 256 / ZS;                      // columns per iteration
-    static constexpr int NCOLS = G::HXv * G::HYv;
+    static constexpr int NCOLS = LOW ? LHX * LHY : G::HXv * G::HYv;
     static constexpr int NIT = (NCOLS + NCG - 1) / NCG;
     static constexpr int NHS = NCOLS * 4;                     // z-halo slots: (column, plane, channel half)
     static constexpr int NHIT = (NHS + 255) / 256;
@@ -810,11 +821,19 @@ template <bool Z8> struct StageGeom {
 
 // Every wave builds its own copy of the table (its lanes write it and read it back: LDS keeps one wave's requests in order, so no
 // workgroup barrier stands between the kernel's entry and its first global loads).
-template <bool Z8>
+template <bool Z8, bool LOW = false>
 __device__ __forceinline__ void stage_table(const ConvArgs& a, bool from_a, int x0, int y0, int lane, int* tab) {
     using G = BfGeom<Z8>;
     const int CQ = from_a ? (a.CA >> 3) : (a.CB >> 3), SY = from_a ? a.AY : a.Y, SZ = from_a ? a.AZ : a.Z;
     const int sux = from_a ? a.ux : 0, suy = from_a ? a.uy : 0;
+    if constexpr (LOW) {                                      // columns of the low-resolution source itself (x0, y0 even)
+        for (int c = lane; c < LHX * LHY; c += 64) {
+            const int lx = c / LHY, ly = c - lx * LHY;
+            const int gx = (x0 >> 1) - 1 + lx, gy = (y0 >> 1) - 1 + ly;
+            tab[c] = (gx >= 0 && gx < a.AX && gy >= 0 && gy < a.AY) ? ((gx * SY + gy) * CQ * SZ) * 32 : -1;
+        }
+        return;
+    }
 #pragma unroll
     for (int c = lane; c < StageGeom<Z8>::NCOLS; c += 64) {
         const int hx = c / G::HYv, hy = c - hx * G::HYv;
@@ -829,10 +848,10 @@ __device__ __forceinline__ const char* stage_base(const ConvArgs& a, int c0, int
     return reinterpret_cast<const char*>(a.srcB + ((size_t)p * a.X * a.Y * (a.CB >> 3) + ((c0 - a.CA) >> 3)) * a.Z * 8);
 }
 
-template <bool Z8>
+template <bool Z8, bool LOW = false>
 __device__ __forceinline__ void stage_load(const ConvArgs& a, const char* base, const int* tab, int suz, int z0, int tid, bool with_zhalo,
-                                           f32x4 (&v)[StageGeom<Z8>::NIT], f32x4 (&vh)[StageGeom<Z8>::NHIT]) {
-    using S = StageGeom<Z8>; using G = BfGeom<Z8>;
+                                           f32x4 (&v)[StageGeom<Z8, LOW>::NIT], f32x4 (&vh)[StageGeom<Z8, LOW>::NHIT]) {
+    using S = StageGeom<Z8, LOW>; using G = BfGeom<Z8>;
     const int zs = tid % S::ZS, cgp = tid / S::ZS;
     const int gz = z0 + (zs >> 1);
     const int zb = gz < a.Z ? ((gz >> suz) * 8 + (zs & 1) * 4) * 4 : -1;
@@ -880,10 +899,10 @@ __device__ __forceinline__ void stage_put(const f32x4 v, char* d, float in_scale
     }
 }
 
-template <bool Z8, bool F16>
-__device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8>::NIT], const f32x4 (&vh)[StageGeom<Z8>::NHIT], int tid,
+template <bool Z8, bool F16, bool LOW = false>
+__device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8, LOW>::NIT], const f32x4 (&vh)[StageGeom<Z8, LOW>::NHIT], int tid,
                                             bool with_zhalo, char* lds, float in_scale) {
-    using S = StageGeom<Z8>; using G = BfGeom<Z8>;
+    using S = StageGeom<Z8, LOW>; using G = BfGeom<Z8>;
     const int zs = tid % S::ZS, cgp = tid / S::ZS;
     char* d0 = lds + ((cgp * G::HZv + 1 + (zs >> 1)) * 2 + (zs & 1)) * 8;
 #pragma unroll
@@ -902,13 +921,14 @@ __device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8>::NIT]
 
 // byte offset (inside one component plane) of the lane's B fragment for every K-block of a tap set: lane group g supplies tap slot
 // 4 kb + g.  Built once per kernel -- inside the K loop the four-way select cost a dozen instructions per K-block.
-template <int KB, bool C8, bool FOLDED, bool Z8>
+template <int KB, bool C8, bool FOLDED, bool Z8, bool LOW = false>
 __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)[KB]) {
     using G = BfGeom<Z8>;
+    constexpr int HYt = LOW ? LHY : G::HYv;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-        const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb, G::HYv, G::HZv), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1, G::HYv, G::HZv),
-                  t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2, G::HYv, G::HZv), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3, G::HYv, G::HZv);
+        const int t0 = bf_tap_pos(C8, FOLDED, 4 * kb, HYt, G::HZv, LOW), t1 = bf_tap_pos(C8, FOLDED, 4 * kb + 1, HYt, G::HZv, LOW),
+                  t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2, HYt, G::HZv, LOW), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3, HYt, G::HZv, LOW);
         tapoff[kb] = (lanepos + (g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3)))) * 16;
     }
 }
@@ -926,7 +946,7 @@ __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)
 #ifndef CT_WPF4
 #define CT_WPF4 0
 #endif
-template <bool F16, int NT, int NCOL, int KB, bool C8, bool FOLDED, bool KFOLD, bool Z8>
+template <bool F16, int NT, int NCOL, int KB, bool C8, bool FOLDED, bool KFOLD, bool Z8, bool LOW = false>
 __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char* lds, const int (&tapoff)[KB],
                                              const uint4* wp /* uniform */, uint32_t lane16, int nt_total) {   // (no __restrict__: see the prefetch)
     // A K-block is 12-96 MFMAs (200-1600 cycles); the L2 round trip of its weight fragments is 200+ cycles and nothing else in the
@@ -963,7 +983,7 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int mt = cg + q;
-                const int cpos = bf_col_pos(C8, KFOLD, Z8, mt, G::HYv, G::HZv);
+                const int cpos = bf_col_pos(C8, KFOLD, Z8, mt, LOW ? LHY : G::HYv, G::HZv, LOW);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     if constexpr ((CT_ABL) & 2) av[q][c] = u32x4{lane16, lane16, lane16, lane16};
@@ -1101,20 +1121,22 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
     constexpr int KBS = C8 ? KB_C8 : KB_STD;                  // skip / ordinary chunks
     constexpr int KBF = C8 ? KB_C8F : KB_FOLD;                // folded chunks
     constexpr int NCLS = C8 ? 2 : 4;
-    using S = StageGeom<Z8>;
     const int nA = FOLD ? (a.CA >> 3) : 0;                    // folded chunks
     const int nFromA = a.CA >> 3;                             // chunks read from srcA (the decoder's low-res tensor)
     const int cls = C8 ? wy : (wx * 2 + wy);
+    const bool lowa = FOLD && !Z8 && a.lowa != 0;
     if constexpr (!((CT_ABL) & 512)) {
-    if (nFromA > 0) stage_table<Z8>(a, true, x0, y0, lane, coltab[wave][0]);
+    if (nFromA > 0) { if (lowa) stage_table<Z8, true>(a, true, x0, y0, lane, coltab[wave][0]); else stage_table<Z8>(a, true, x0, y0, lane, coltab[wave][0]); }
     if (nFromA < a.nchunks) stage_table<Z8>(a, false, x0, y0, lane, coltab[wave][1]);
     }
     float in_scale = 1.f, out_mul = 1.f;
-    auto stage = [&](int chunk) {
-        f32x4 v[S::NIT], vh[S::NHIT];
+    auto stage = [&](int chunk, auto low_tag) {
+        constexpr bool LOW = decltype(low_tag)::value;
+        using SL = StageGeom<Z8, LOW>;
+        f32x4 v[SL::NIT], vh[SL::NHIT];
         const bool from_a = chunk < nFromA;
         const bool zhalo = a.zblocks > 1 || chunk == 0;       // one z block: the z halo is zero padding, written once
-        stage_load<Z8>(a, stage_base(a, chunk * 8, p), coltab[wave][from_a ? 0 : 1], from_a ? a.uz : 0, z0, tid, zhalo, v, vh);
+        stage_load<Z8, LOW>(a, stage_base(a, chunk * 8, p), coltab[wave][from_a ? 0 : 1], from_a ? a.uz : 0, z0, tid, zhalo, v, vh);
         if (chunk == 0) CT_TR(1);
         __syncthreads();                                      // every wave is done reading the previous tile
         if (chunk == 0) {
@@ -1125,25 +1147,53 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                 in_scale = pow2f(-k); out_mul = pow2f(k) * a.wscale_inv;
             }
         }
-        if constexpr (!((CT_ABL) & 4)) stage_store<Z8, F16>(v, vh, tid, zhalo, lds, in_scale);
+        if constexpr (!((CT_ABL) & 4)) stage_store<Z8, F16, LOW>(v, vh, tid, zhalo, lds, in_scale);
         else if (v[0][0] == 12345.678f) lds[tid] = 1;        // (keeps the loads alive)
+        if constexpr (LOW) {
+            // one z block: the z-halo rows are the 'same' padding, written as zeros with the first chunk only -- for ALL 6 x 10 columns the
+            // later full-resolution chunks read, not just the 4 x 6 this chunk staged
+            if (chunk == 0 && a.zblocks == 1) {
+                for (int idx = tid; idx < StageGeom<Z8, false>::NHS; idx += 256) {
+                    char* d = lds + (((idx >> 2) * HZg + ((idx & 2) ? HZg - 1 : 0)) * 2 + (idx & 1)) * 8;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) *reinterpret_cast<uint2*>(d + c * G::PLANE) = uint2{0u, 0u};
+                }
+            }
+        }
         __syncthreads();
         if (chunk == 0) CT_TR(3);
     };
+    using NoLow = std::integral_constant<bool, false>;
     if constexpr (FOLD) {
-        int tapoff[KBF];
-        bf_tap_offsets<KBF, C8, true, Z8>(foldpos, g, tapoff);
-        for (int chunk = 0; chunk < nA; ++chunk) {
-            stage(chunk);
-            const uint4* wp = wbase + (((size_t)chunk * NCLS + cls) * KBF * a.nt_total + ntb) * NC * 64;
-            bf_chunk_mma<F16, NT, NCOL, KBF, C8, true, FOLD, Z8>(acc, lds, tapoff, wp, lane16, a.nt_total);
+        bool done = false;
+        if constexpr (!Z8) {
+            if (lowa) {                                       // (uniform) the upsampled chunks from a 4 x 6-column tile of the low-resolution tensor
+                int tapoff[KBF];
+                const int lowpos = C8 ? ((wx >> 1) * LHY + wy) * HZg + zl : (wx * LHY + wy) * HZg + zl;
+                bf_tap_offsets<KBF, C8, true, Z8, true>(lowpos, g, tapoff);
+                for (int chunk = 0; chunk < nA; ++chunk) {
+                    stage(chunk, std::integral_constant<bool, true>{});
+                    const uint4* wp = wbase + (((size_t)chunk * NCLS + cls) * KBF * a.nt_total + ntb) * NC * 64;
+                    bf_chunk_mma<F16, NT, NCOL, KBF, C8, true, FOLD, Z8, true>(acc, lds, tapoff, wp, lane16, a.nt_total);
+                }
+                done = true;
+            }
+        }
+        if (!done) {
+            int tapoff[KBF];
+            bf_tap_offsets<KBF, C8, true, Z8>(foldpos, g, tapoff);
+            for (int chunk = 0; chunk < nA; ++chunk) {
+                stage(chunk, NoLow{});
+                const uint4* wp = wbase + (((size_t)chunk * NCLS + cls) * KBF * a.nt_total + ntb) * NC * 64;
+                bf_chunk_mma<F16, NT, NCOL, KBF, C8, true, FOLD, Z8>(acc, lds, tapoff, wp, lane16, a.nt_total);
+            }
         }
     }
     {
         int tapoff[KBS];
         bf_tap_offsets<KBS, C8, false, Z8>(lanepos, g, tapoff);
         for (int chunk = nA; chunk < a.nchunks; ++chunk) {
-            stage(chunk);
+            stage(chunk, NoLow{});
             const uint4* wp = wbase + (((size_t)nA * NCLS * KBF + (size_t)(chunk - nA) * KBS) * a.nt_total + ntb) * NC * 64;
             bf_chunk_mma<F16, NT, NCOL, KBS, C8, false, FOLD, Z8>(acc, lds, tapoff, wp, lane16, a.nt_total);
         }
@@ -2697,6 +2747,10 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             a.epi = h->d_weights + c.epi_off;
             a.out = (c.head && !layer_dump) ? nullptr : tptr(c.dst);
             a.cout = c.cout; a.nt_total = c.nt_total; a.ngroups = c.nt_total / c.NT;
+            {
+                static const bool lowa_on = !(getenv("CT_CONV_LOWA") && atoi(getenv("CT_CONV_LOWA")) == 0);
+                a.lowa = lowa_on && c.fold && c.srcA >= 0 && a.ux == 1 && a.uy == 1 && a.uz == 0 && (d[0] & 1) == 0 && (d[1] & 1) == 0;
+            }
             a.sx0 = c.store[0]; a.sx1 = c.store[1]; a.sy0 = c.store[2]; a.sy1 = c.store[3];
             if (layer_dump || !vsrc) { a.sx0 = 0; a.sx1 = d[0]; a.sy0 = 0; a.sy1 = d[1]; }
             if (c.pool_dst >= 0) {
