@@ -893,11 +893,8 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     double* w_xy = (double*)(ws + L.weights); double* w_z = w_xy + 48;
     const SegGeom g{dims_xyz[0], dims_xyz[1], dims_xyz[2], V};
     const unsigned nb = (unsigned)((V + 255) / 256);
-    static bool lds_set = false;
-    if (!lds_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_PEAK_CAP3D * 16));
-        lds_set = true;
-    }
+    // (per call: the attribute belongs to the current device's copy of the kernel, and a process may drive several devices)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_PEAK_CAP3D * 16));
     HIPCHK(hipMemcpyAsync(w_xy, gauss_xy, (size_t)(2 * radius_xy + 1) * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(w_z, gauss_z, (size_t)(2 * radius_z + 1) * sizeof(double), hipMemcpyHostToDevice, st));
 
