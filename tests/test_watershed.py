@@ -26,6 +26,18 @@ def touching_case():
     return blobs((96, 96, 12), [(30, 30, 6), (45, 30, 6), (70, 70, 5), (20, 75, 3)], [9, 9, 8, 2.2])
 
 
+def tie_case():
+    """Shapes whose EDT has exact ties: a long bar (a ridge of EQUAL smoothed-EDT maxima: ensure_spacing has to thin it in raveled
+    order), two identical touching squares (two markers of equal value in ONE mask component: the flood's tie rule decides the boundary),
+    a symmetric cross, the same bar again in other slices and a thick slab spanning several z (ties in the 3-D stage too)."""
+    prob = np.zeros((96, 80, 10), np.float32)
+    prob[10:70, 8:17, 1:4] = 0.9                       # bar, 60 x 9, three slices
+    prob[20:33, 30:43, 2] = 0.9; prob[33:46, 30:43, 2] = 0.9      # two 13 x 13 squares sharing an edge
+    prob[60:81, 50:53, 5:8] = 0.9; prob[69:72, 41:62, 5:8] = 0.9  # cross
+    prob[12:40, 56:70, 6:9] = 0.9                      # slab
+    return prob
+
+
 def random_case(shape, n, seed):
     rng = np.random.default_rng(seed)
     lo = np.array([8, 8, 2]); hi = np.array([shape[0] - 8, shape[1] - 8, shape[2] - 2])
@@ -135,8 +147,20 @@ def _device(prob, z_ratio, method, min_size, cell_num):
     return labels, centres, ms, cn
 
 
+def test_oracle_tie_rules_are_exercised():
+    """The crafted tie case really has equal peak candidates (otherwise the device test below proves nothing about them)."""
+    prob = tie_case()
+    bn = prob[:, :, 2] > 0.5
+    sm = ndi.gaussian_filter(ndi.distance_transform_edt(bn), 2, mode="constant")
+    mx = ndi.maximum_filter(sm, footprint=np.ones((15, 15), bool), mode="constant")
+    cand = (sm == mx) & (sm > sm.min())
+    vals = sm[cand]
+    assert cand.sum() > wr.peak_local_max_mask(sm, 7, exclude_border=0).sum() >= 2      # ensure_spacing dropped equal neighbours
+    assert len(np.unique(vals)) < len(vals)                                              # exact ties among the candidates
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["touching", "random_small", "ragged", "empty_slices"])
+@pytest.mark.parametrize("case", ["touching", "random_small", "ragged", "empty_slices", "ties"])
 def test_device_watershed_equals_the_oracle(case):
     if case == "touching":
         prob, zr, ms = touching_case(), 3.0, 40
@@ -144,11 +168,13 @@ def test_device_watershed_equals_the_oracle(case):
         prob, zr, ms = random_case((120, 100, 16), 40, 1), 4.0, 20
     elif case == "ragged":
         prob, zr, ms = random_case((97, 131, 21), 60, 2), 2.5, 15
+    elif case == "ties":
+        prob, zr, ms = tie_case(), 2.0, 5
     else:
         prob = random_case((80, 80, 20), 12, 3); prob[:, :, :6] = 0; prob[:, :, 15:] = 0; zr, ms = 5.0, 10
     want_l, want_c, want_ms, want_cn = wr.segment_centroids(prob, zr, "min_size", ms)
     got_l, got_c, got_ms, got_cn = _device(prob, zr, "min_size", ms, 0)
-    assert want_l.max() >= (3 if case == "touching" else 8)
+    assert want_l.max() >= (3 if case in ("touching", "ties") else 8)
     assert (got_ms, got_cn) == (want_ms, want_cn)
     assert np.array_equal(got_l, want_l), f"{int((got_l != want_l).sum())} voxels differ"
     assert np.array_equal(got_c, want_c)                       # integer coordinate sums / counts: bit-exact
