@@ -21,6 +21,7 @@
 //   D^1/2 G D^1/2 + c I  =: M  (SPD),   x = D^1/2 M^-1 D^-1/2 b,
 // i.e. a blocked Cholesky without pivoting (no D^-1 is formed: b_i / sqrt(d_i) is a weighted mean
 // times sqrt(d_i), and rows with d_i = 0 decouple with x_i = 0 = b_i / c).
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -86,6 +87,42 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
     return v;
+}
+
+// exp(x) for x <= 0 (or NaN): the device library's algorithm restated operation for operation (n = rint(x log2 e); r = x - n ln2 in two
+// pieces; degree-11 Horner polynomial with its coefficients; ldexp; 0 below -1075), so the value is the one `exp` returns, bit for bit.
+// Why it exists: the compiler evaluates the library's Horner steps with the two-address v_fmac_f64, whose addend is the destination -- every
+// step then needs a 64-bit register copy of its coefficient first (11 v_mov_b64 per exponential, a fifth of the E-step's instructions).
+// v_fma_f64 in its three-address form takes the coefficient where it lives.
+// (coefficient in a scalar register pair: one constant-bus operand per instruction is allowed, and the vector registers stay free)
+__device__ __forceinline__ double fma_vvs(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ double fma_svv(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double exp_nonpos(double x) {
+    const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma_svv(-0x1.62e42fefa39efp-1, n, x);
+    r = fma_svv(-0x1.abc9e3b39803fp-56, n, r);
+    double p = 0x1.ade156a5dcb37p-26;
+    p = fma_vvs(r, p, 0x1.28af3fca7ab0cp-22);
+    p = fma_vvs(r, p, 0x1.71dee623fde64p-19);
+    p = fma_vvs(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma_vvs(r, p, 0x1.a01a014761f6ep-13);
+    p = fma_vvs(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma_vvs(r, p, 0x1.1111111122322p-7);
+    p = fma_vvs(r, p, 0x1.55555555502a1p-5);
+    p = fma_vvs(r, p, 0x1.5555555555511p-3);
+    p = fma_vvs(r, p, 0x1.000000000000bp-1);
+    p = __builtin_fma(r, p, 1.0);
+    p = __builtin_fma(r, p, 1.0);
+    const double z = __builtin_ldexp(p, (int)n);
+    return x < -1075.0 ? 0.0 : z;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -923,13 +960,16 @@ __global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restric
     }
 }
 // Fused E-step, narrow-wave form: a BLOCK owns a contiguous segment of target rows and walks them one at a time; wave w of the block owns
-// the columns [64 NQ w, 64 NQ (w + 1)) of every row, so a lane carries only NQ numerators and 4 NQ accumulators (~70-90 VGPRs: such a wave
-// fits beside the conv waves of the pipelined benchmark instead of waiting for half a register file, which is what estep_cols_kernel's
-// 183-246-VGPR waves do).  Row sum = per-wave butterfly sums added in wave order through a double-buffered LDS slot (one barrier per
+// the columns [64 NQ w, 64 NQ (w + 1)) of every row, so a lane carries NQ column coordinates, NQ numerators and 4 NQ accumulators (139 VGPRs
+// at NQ = 5; estep_cols_kernel's waves need 183-246 and wait for half a register file beside the conv waves of the pipelined benchmark).
+// Row sum = per-wave butterfly sums added in wave order through a double-buffered LDS slot (one barrier per
 // row); every column belongs to exactly one wave, so the block writes its part[seg][4][n] slice without any cross-wave reduction.
+// The row loop is straight-line code: NQ independent exponentials (exp_nonpos) interleave, 52 instructions per pair (72 when every
+// pair sat in its own `r < n` branch with the library exp: one match's EM iteration 80 -> 71 us; the pipelined benchmark is unchanged,
+// there the kernel's time is the wait for slots between conv workgroups).  MAXT = 512 up to 8 waves (n <= 2560), 1024 beyond (128 VGPRs).
 // The posterior's row sums for the sigma2 trace identity are total * 1 / den (the exact sum of the normalised row up to rounding).
-template <int NQ>
-__global__ __launch_bounds__(1024) void estep_rows_kernel(const double* __restrict__ prior, const double* __restrict__ pred, int n,
+template <int NQ, int MAXT>
+__global__ __launch_bounds__(MAXT) void estep_rows_kernel(const double* __restrict__ prior, const double* __restrict__ pred, int n,
                                                           const double* __restrict__ tgt, int m, const double* __restrict__ sc, double vol,
                                                           double* __restrict__ P /* or null */, double* __restrict__ part, Bt bt,
                                                           const double* __restrict__ sp, const int* __restrict__ sp_dense, int sp_m,
@@ -949,31 +989,43 @@ __global__ __launch_bounds__(1024) void estep_rows_kernel(const double* __restri
     const double inv_two_s2 = 1.0 / two_s2, coef = (1.0 - gamma) / norm;
     const bool structured = sp && sp_dense[blockIdx.z] == 0;
     double cs[NQ], cx[NQ], cy[NQ], cz[NQ];
+    // this lane's columns do not change from row to row: their coordinates are read once.  A column beyond n gets prior 0, so its
+    // numerator is +0.0 and every sum below is what skipping it gives, without a branch around each exponential (the NQ chains of
+    // dependent fp64 operations interleave, which is what hides their latency when few waves share the SIMD).
+    double px[NQ], py[NQ], pz[NQ];
+    bool ok[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) cs[q] = cx[q] = cy[q] = cz[q] = 0.0;
+    for (int q = 0; q < NQ; ++q) {
+        cs[q] = cx[q] = cy[q] = cz[q] = 0.0;
+        const int r = (wave * NQ + q) * 64 + lane;
+        ok[q] = r < n;
+        const int rc = ok[q] ? r : 0;
+        px[q] = pred[3 * rc]; py[q] = pred[3 * rc + 1]; pz[q] = pred[3 * rc + 2];
+    }
     const int per = (m + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t0 = blockIdx.x * per, t1 = min(m, t0 + per);
+    // (the row loop exists once per prior form, so that no branch sits between the exponentials)
+    auto rows = [&](auto structured_c) {
+    constexpr bool STRUCT = decltype(structured_c)::value;
     int buf = 0;
     for (int t = t0; t < t1; ++t, buf ^= 1) {
         const double yx = tgt[3 * t], yy = tgt[3 * t + 1], yz = tgt[3 * t + 2];
         const double* pr = prior + (size_t)t * n;
         double sp_lo = 0.0, sp_hi = 0.0; int sp_idx = -1;
-        if (structured) { sp_lo = sp[t]; sp_hi = sp[sp_m + t]; sp_idx = ((const int*)(sp + 2 * (size_t)sp_m))[t]; }
+        if (STRUCT) { sp_lo = sp[t]; sp_hi = sp[sp_m + t]; sp_idx = ((const int*)(sp + 2 * (size_t)sp_m))[t]; }
         double v[NQ];
         double acc = 0.0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int r = (wave * NQ + q) * 64 + lane;
-            v[q] = 0.0;
-            if (r < n) {
-                const double dx = pred[3 * r] - yx, dy = pred[3 * r + 1] - yy, dz = pred[3 * r + 2] - yz;
-                const double k = exp(-(dx * dx + dy * dy + dz * dz) * inv_two_s2);
-                double prv;
-                if (structured) prv = (r == sp_idx) ? sp_hi : sp_lo; else prv = pr[r];
-                const double num = coef * prv * k;
-                v[q] = num;
-                acc += num;
-            }
+            const double dx = px[q] - yx, dy = py[q] - yy, dz = pz[q] - yz;
+            const double k = exp_nonpos(-(dx * dx + dy * dy + dz * dz) * inv_two_s2);
+            double prv;
+            if (STRUCT) prv = (r == sp_idx) ? sp_hi : sp_lo; else prv = pr[ok[q] ? r : 0];
+            prv = ok[q] ? prv : 0.0;
+            const double num = coef * prv * k;
+            v[q] = num;
+            acc += num;
         }
         acc = wave_sum_d(acc);
         if (lane == 0) psum[buf][wave] = acc;
@@ -984,14 +1036,14 @@ __global__ __launch_bounds__(1024) void estep_rows_kernel(const double* __restri
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int r = (wave * NQ + q) * 64 + lane;
-            if (r < n) {
-                const double p = v[q] * inv_den;
-                if (P) P[(size_t)t * n + r] = p;
-                cs[q] += p; cx[q] = fma(yx, p, cx[q]); cy[q] = fma(yy, p, cy[q]); cz[q] = fma(yz, p, cz[q]);
-            }
+            const double p = v[q] * inv_den;
+            if (P && ok[q]) P[(size_t)t * n + r] = p;
+            cs[q] += p; cx[q] = fma(yx, p, cx[q]); cy[q] = fma(yy, p, cy[q]); cz[q] = fma(yz, p, cz[q]);
         }
         if (arow && threadIdx.x == 0) arow[t] = tot * inv_den;
     }
+    };
+    if (structured) rows(std::true_type{}); else rows(std::false_type{});
     double* o = part + (size_t)blockIdx.x * 4 * n;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -1014,10 +1066,12 @@ static bool launch_estep_cols(int n_max, unsigned zB, hipStream_t st, const doub
         int nq = estep_nq(); if (nq < 1 || nq > 6) nq = 5;
         const int W = (need + nq - 1) / nq;
         if (W <= 16) {
-#define CT_ESTEPR(NQv) hipLaunchKernelGGL(estep_rows_kernel<NQv>, dim3(ES_SEG, 1, zB), dim3(64 * W), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, part, bt, \
-                                          sp, sp_dense, sp_m, arow)
+#define CT_ESTEPR(NQv) do { if (W <= 8) CT_ESTEPR2(NQv, 512); else CT_ESTEPR2(NQv, 1024); } while (0)
+#define CT_ESTEPR2(NQv, MT) hipLaunchKernelGGL((estep_rows_kernel<NQv, MT>), dim3(ES_SEG, 1, zB), dim3(64 * W), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, \
+                                               part, bt, sp, sp_dense, sp_m, arow)
             switch (nq) { case 1: CT_ESTEPR(1); break; case 2: CT_ESTEPR(2); break; case 3: CT_ESTEPR(3); break; case 4: CT_ESTEPR(4); break;
                           case 6: CT_ESTEPR(6); break; default: CT_ESTEPR(5); }
+#undef CT_ESTEPR2
 #undef CT_ESTEPR
             return true;
         }
