@@ -779,3 +779,15 @@ def test_match_is_unaffected_by_a_unet_sharing_its_cus(arrangement):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "mismatching results: 0 of" in r.stdout, r.stdout[-1500:]
     assert "== alone: True" in r.stdout, r.stdout[-1500:]
+
+
+@pytest.mark.gpu
+def test_exp_nonpos_is_the_library_exp():
+    """The E-step's exponential (csrc/ct_exp.h: three-address FMAs with the library's coefficients) returns the device library's exp
+    bit for bit: 2^28 arguments over [-1100, 0] incl. the rint switch points, denormal results, -0.0, -inf, NaN (scripts/probe/exp_check.hip)."""
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "scripts" / "probe" / "exp_check"
+    assert exe.exists(), "scripts/probe/exp_check missing: __graft_entry__.build() compiles it"
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatches in 268435456 arguments" in r.stdout, r.stdout + r.stderr
