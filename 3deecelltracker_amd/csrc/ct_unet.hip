@@ -44,6 +44,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   128 return at the kernel's first statement (resources only)   256 return after the argument fetch / tile decode, before any LDS use
 //   2048 epilogue arithmetic kept, global stores (output, pool) skipped   4096 no per-patch maximum (reduction, barrier, atomic)
 //   512 no per-wave column tables (no barrier-free LDS write -> read)   1024 the per-patch maxima are not fetched (no threadIdx.y)
+//   (conv_l0l1_fused_kernel honours 8, 2048 and 16384 = no L0 MFMAs: profiles/r03_fuse01_ablation.txt)
 #ifndef CT_ABL
 #define CT_ABL 0
 #endif
@@ -1746,7 +1747,7 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < HALF; ++i) {
             const int sz = mapz[gz0 + i];
-            const float v = (rowok && sz >= 0) ? rowp[sz] : 0.f;
+            const float v = ((CT_ABL) & 8) ? (float)(sz & 7) : ((rowok && sz >= 0) ? rowp[sz] : 0.f);
             vals[i] = v; tmax = fmaxf(tmax, fabsf(v));
         }
     }
@@ -1792,7 +1793,7 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
             const int o1 = k1 < 36 ? ((k1 / 9) * IY + (k1 / 3) % 3) * IZ + k1 % 3 : 0;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                if (wave + 4 * m < NPAIR) {                     // (wave-uniform)
+                if (wave + 4 * m < NPAIR && !((CT_ABL) & 16384)) {                     // (wave-uniform)
                     const uint32_t a0 = itile[cbase[m] + o0], a1 = itile[cbase[m] + o1];
                     const u32x4 av = u32x4{a0, a0 & 0xffffu, a1, a1 & 0xffffu};
                     acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wj), __builtin_bit_cast(f16x8, av), acc0[m], 0, 0, 0);
@@ -1884,7 +1885,7 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red);
     const int OQ = a.cout >> 3;
     const int cb = 4 * g;
-    if (a.out) {
+    if (a.out && !((CT_ABL) & 2048)) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             const int x = x0 + wx + (mt >> 2), y = y0 + wy + (mt & 3);
@@ -1905,7 +1906,7 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
                 m[e] = t;
             }
             const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
-            if (ok && zok && cb < a.cout) {
+            if (ok && zok && cb < a.cout && !((CT_ABL) & 2048)) {
                 const int pzc = a.pz == 2 ? (z >> 1) : z;
                 *reinterpret_cast<f32x4*>(a.pool + ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7)) = m;
             }
