@@ -474,7 +474,7 @@ __global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mod
                 if (!keep[b]) continue;
                 int xb, yb, zb; ws_xyz(idx[b], g, xb, yb, zb);
                 const int d = max(max(abs(xa - xb), abs(ya - yb)), abs(za - zb));
-                if (d <= min_distance) { keep[a] = 0; break; }
+                if (d < min_distance) { keep[a] = 0; break; }           // strict: peaks exactly min_distance apart both stay (skimage ensure_spacing)
             }
         }
     }

@@ -6,7 +6,7 @@ Per-frame chain, all on the device and on one stream (reference tracker.py):
       _segment                     :605-650    raw stack -> image_gcn, LCN -> U-Net (or unet_cache/t%06i.npy) -> regions -> centres
         _predict_cellregions / _save_unet_regions :652-669   (ct_normalize_image, ct_unet_predict_volume; float16 cache file)
         _watershed                 :671-684    ct_watershed_segment: watershed_2d + watershed_3d + relabel_sequential on the device
-                                               (skimage's functions restated, parity unpinned: oracle/watershed_ref.py);
+                                               (pinned against the reference on scikit-image 0.18.3: tests/test_watershed_pin.py);
                                                region_method = "cc" selects threshold + connected components instead
       _predict_pos_once            :1193-1222  REP_NUM_PRGLS x (FFN -> legacy PR-GLS with beta * 0.8^i), fields re-applied
       _get_cells_onBoundary        :1291-1308

@@ -8,25 +8,30 @@ the boundaries are removed from the thresholded map, then in 3D  EDT(sampling 1,
 peak_local_max(min_distance=3, exclude_border=0) -> label -> watershed -> min_size / cell_num -> remove_small_objects ->
 relabel_sequential.
 
-PARITY STATUS: **parity unpinned**.  scipy IS installed here, so distance_transform_edt, gaussian_filter, maximum_filter, label and
-center_of_mass are the very functions the reference runs.  scikit-image is neither under /root/reference nor installed (it arrives
-through stardist in the reference's environment; `peak_local_max(indices=False)` dates it to 0.16-0.19), so its four functions are
-RESTATED here from their published algorithms:
-  * peak_local_max  -- skimage/feature/peak.py (0.19): image == maximum_filter(image, footprint (2 d + 1)^ndim, mode='constant'),
+PARITY STATUS: **pinned** against the reference's own code running on the real scikit-image.  scipy IS installed here, so
+distance_transform_edt, gaussian_filter, maximum_filter, label and center_of_mass are the very functions the reference runs.  scikit-image is
+not importable by the image's main interpreter, so its four functions are RESTATED below -- but the image's second interpreter
+(/opt/conda/bin/python3.9) carries scikit-image 0.18.3 (the generation `peak_local_max(indices=False)` needs): tests/golden/
+make_watershed_golden.py runs CellTracker/watershed.py and Tracker._watershed there, unmodified, and records every stage
+(tests/golden/watershed_skimage.npz); tests/test_watershed_pin.py holds each restatement to scikit-image's output exactly (fed with the
+recorded output of the stage before it), the composite to the reference's segmentation on seven volumes and -- given the recorded run's
+choice among exactly tied peaks, see below -- on the 512 x 512 x 32 benchmark stack (all 8.4 M voxels), the device path on the same.  The restatements:
+  * peak_local_max  -- skimage/feature/peak.py (0.18): image == maximum_filter(image, footprint (2 d + 1)^ndim, mode='constant'),
     no peaks for a trivial (constant) image, & image > threshold with threshold = image.min() (no absolute / relative threshold given),
     border of width min_distance excluded unless exclude_border is 0/False, then the peaks in descending intensity with every peak
-    closer than min_distance (Chebyshev) to an already kept one dropped (ensure_spacing).  Inside the maximum filter's footprint two
-    surviving peaks can only be closer than that if they are EQUAL, so the last step only acts on exact ties; its order among ties
-    (an unstable argsort upstream) is fixed here as "smaller raveled index first".
+    CLOSER THAN min_distance (Chebyshev, strict: two peaks exactly min_distance apart both stay) to an already kept one dropped
+    (ensure_spacing).  Inside the maximum filter's footprint two surviving peaks can only be that close if they are EQUAL, so the last
+    step only acts on exact ties.  THE ONE THING THAT CANNOT BE PINNED: upstream orders tied candidates with np.argsort(-intensities), an
+    unstable sort (numpy >= 1.25 dispatches it to an AVX-512 network sort where the CPU has one), so which of several exactly equal
+    candidates stay is machine-dependent in the reference itself (symmetric shapes produce such ties: adjacent pixels either side of a
+    blob's centre line; the recorded run keeps the later one where this oracle keeps the earlier).  The order is fixed here as "smaller
+    raveled index first" -- one admissible outcome; the pin test compares peaks up to that choice and everything downstream exactly.
   * watershed       -- skimage/segmentation/_watershed_cy.pyx: a priority queue of (value, age), seeded with all marker pixels (age 0),
     pop the smallest, give every unlabelled in-mask neighbour (connectivity 1, in ascending raveled-offset order) the popped pixel's
-    label at PUSH time and push it with value = image[neighbour] and the next age.  Ties among the age-0 markers (the upstream heap
-    leaves them to its sift order) are fixed here as "smaller raveled index first".
+    label at PUSH time and push it with value = image[neighbour] and the next age.  Markers enter in raveled order (ages ascending).
   * find_boundaries(mode='outer') -- skimage/segmentation/boundaries.py: grey dilation != grey erosion over the connectivity-c
     structure, kept where the pixel is background or the full-connectivity neighbourhood holds two different OBJECT labels.
   * remove_small_objects on a label image (sizes by bincount of the labels as they are) and relabel_sequential.
-tests/golden/make_watershed_golden.py is the one-run kit that records skimage's own outputs on any machine that has it; while
-tests/golden/watershed_skimage.npz is absent, tests/test_watershed_pin.py is skipped and this header stays "unpinned".
 """
 from __future__ import annotations
 
@@ -64,7 +69,7 @@ def peak_local_max_mask(image: np.ndarray, min_distance: int, exclude_border=Tru
         kept = []
         keep_mask = np.zeros(len(coords), dtype=bool)
         for i, c in enumerate(coords):
-            if kept and np.any(np.max(np.abs(np.asarray(kept) - c), axis=1) <= min_distance):
+            if kept and np.any(np.max(np.abs(np.asarray(kept) - c), axis=1) < min_distance):     # (strict: peaks exactly min_distance apart both stay)
                 continue
             kept.append(c); keep_mask[i] = True
         out[:] = False
@@ -138,15 +143,16 @@ def relabel_sequential(labels: np.ndarray) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------ the reference's functions
-def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, collect=None):
-    """watershed.py:16-53 -> (bn_output, boundary)."""
+def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, collect=None, peaks=None):
+    """watershed.py:16-53 -> (bn_output, boundary).  peaks (tests only): a recorded peak mask [x, y, z] used instead of peak_local_max's --
+    the choice among exactly tied candidates that one particular upstream run made (see the header)."""
     image_pred = np.asarray(image_pred)
     boundary = np.zeros(image_pred.shape, dtype=bool)
     for z in range(z_range):
         bn = image_pred[:, :, z] > 0.5
         dist = ndi.distance_transform_edt(bn, sampling=[1, 1])
         dist_smooth = ndi.gaussian_filter(dist, 2, mode="constant")
-        local_maxi = peak_local_max_mask(dist_smooth, min_distance=min_distance)
+        local_maxi = peak_local_max_mask(dist_smooth, min_distance=min_distance) if peaks is None else np.asarray(peaks[:, :, z], dtype=bool)
         markers = label_full(local_maxi)
         labels_ws = watershed(-dist_smooth, markers, bn)
         boundary[:, :, z] = find_boundaries_outer(labels_ws, connectivity=2)
@@ -157,11 +163,11 @@ def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, co
     return bn_output, boundary
 
 
-def watershed_3d(image_watershed2d: np.ndarray, samplingrate, method: str, min_size: int, cell_num: int, min_distance: int, collect=None):
-    """watershed.py:55-108 -> (labels_wo_bd, labels_clear, min_size, cell_num)."""
+def watershed_3d(image_watershed2d: np.ndarray, samplingrate, method: str, min_size: int, cell_num: int, min_distance: int, collect=None, peaks=None):
+    """watershed.py:55-108 -> (labels_wo_bd, labels_clear, min_size, cell_num).  peaks: as in watershed_2d."""
     dist = ndi.distance_transform_edt(image_watershed2d, sampling=samplingrate)
     dist_smooth = ndi.gaussian_filter(dist, (2, 2, 0.3), mode="constant")
-    local_maxi = peak_local_max_mask(dist_smooth, min_distance=min_distance, exclude_border=0)
+    local_maxi = peak_local_max_mask(dist_smooth, min_distance=min_distance, exclude_border=0) if peaks is None else np.asarray(peaks, dtype=bool)
     markers = label_full(local_maxi)
     labels_ws = watershed(-dist_smooth, markers, image_watershed2d)
     counts = np.sort(np.bincount(labels_ws.ravel()))
@@ -181,11 +187,12 @@ def watershed_3d(image_watershed2d: np.ndarray, samplingrate, method: str, min_s
     return labels_wo_bd, labels_clear, min_size, cell_num
 
 
-def tracker_watershed(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0):
+def tracker_watershed(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0,
+                      peaks2d=None, peaks3d=None):
     """Tracker._watershed (tracker.py:671-684) -> (segmentation_auto int32, min_size, cell_num)."""
     img = np.asarray(image_cell_bg_xyz)
-    wo_border, _ = watershed_2d(img, z_range=img.shape[2], min_distance=7)
-    _, wi_border, min_size, cell_num = watershed_3d(wo_border, [1, 1, z_xy_ratio], method, min_size, cell_num, min_distance=3)
+    wo_border, _ = watershed_2d(img, z_range=img.shape[2], min_distance=7, peaks=peaks2d)
+    _, wi_border, min_size, cell_num = watershed_3d(wo_border, [1, 1, z_xy_ratio], method, min_size, cell_num, min_distance=3, peaks=peaks3d)
     return relabel_sequential(wi_border), min_size, cell_num
 
 

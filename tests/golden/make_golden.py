@@ -411,7 +411,8 @@ def gen_watershed():
     """The reference's OWN watershed_2d / watershed_3d (watershed.py:16-108) and Tracker._watershed (tracker.py:671-684) run on synthetic
     probability maps, with scikit-image's four primitives replaced by their restatements (see _reference_watershed_on_restated_skimage):
     pins the composite logic -- slice loop, boundary removal, sampling, min_size / cell_num bookkeeping, relabelling -- of the oracle
-    (oracle/watershed_ref.py) and, through it, of the device path.  The primitives themselves stay parity-unpinned."""
+    (oracle/watershed_ref.py) and, through it, of the device path.  The primitives themselves are pinned against scikit-image itself by
+    tests/golden/make_watershed_golden.py (run under the image's second interpreter, which has it)."""
     import warnings
     ref_ws, restore = _reference_watershed_on_restated_skimage()
     out = {}

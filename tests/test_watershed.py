@@ -1,6 +1,6 @@
 """Marker-watershed region step (reference watershed.py:16-108 through Tracker._watershed): oracle properties on the CPU, device vs oracle
-on the GPU.  The oracle restates four scikit-image functions (parity unpinned, oracle/watershed_ref.py); scipy's functions are the
-reference's own."""
+on the GPU.  The oracle restates four scikit-image functions (pinned against scikit-image 0.18.3 itself in tests/test_watershed_pin.py); scipy's
+functions are the reference's own."""
 import importlib
 
 import numpy as np
@@ -13,39 +13,7 @@ synth = importlib.import_module("3deecelltracker_amd.synth")
 seg = importlib.import_module("3deecelltracker_amd.segment")
 
 
-def blobs(shape, centres, radii, z_flat=3.0, level=0.9):
-    g = np.stack(np.meshgrid(*(np.arange(s) for s in shape), indexing="ij"), -1).astype(float)
-    prob = np.zeros(shape, np.float32)
-    for c, r in zip(centres, radii):
-        prob[(((g - np.asarray(c, float)) / np.array([r, r, r / z_flat])) ** 2).sum(-1) <= 1.0] = level
-    return prob
-
-
-def touching_case():
-    """two overlapping blobs (one connected component), one isolated blob, one blob below min_size"""
-    return blobs((96, 96, 12), [(30, 30, 6), (45, 30, 6), (70, 70, 5), (20, 75, 3)], [9, 9, 8, 2.2])
-
-
-def tie_case():
-    """Shapes whose EDT has exact ties: a long bar (a ridge of EQUAL smoothed-EDT maxima: ensure_spacing has to thin it in raveled
-    order), two identical touching squares (two markers of equal value in ONE mask component: the flood's tie rule decides the boundary),
-    a symmetric cross, the same bar again in other slices and a thick slab spanning several z (ties in the 3-D stage too)."""
-    prob = np.zeros((96, 80, 10), np.float32)
-    prob[10:70, 8:17, 1:4] = 0.9                       # bar, 60 x 9, three slices
-    prob[20:33, 30:43, 2] = 0.9; prob[33:46, 30:43, 2] = 0.9      # two 13 x 13 squares sharing an edge
-    prob[60:81, 50:53, 5:8] = 0.9; prob[69:72, 41:62, 5:8] = 0.9  # cross
-    prob[12:40, 56:70, 6:9] = 0.9                      # slab
-    return prob
-
-
-def random_case(shape, n, seed):
-    rng = np.random.default_rng(seed)
-    lo = np.array([8, 8, 2]); hi = np.array([shape[0] - 8, shape[1] - 8, shape[2] - 2])
-    c = rng.uniform(lo, hi, (n, 3))
-    prob = blobs(shape, c, rng.uniform(4, 8, n), level=0.8)
-    prob += rng.uniform(0, 0.2, shape).astype(np.float32) * (prob > 0)       # ragged plateau
-    prob[rng.uniform(size=shape) > 0.995] = 0.7                               # isolated specks (dropped by min_size)
-    return prob
+from _ws_cases import blobs, random_case, tie_case, touching_case  # noqa: E402,F401
 
 
 # ------------------------------------------------------------------------------------------------ CPU: the oracle itself

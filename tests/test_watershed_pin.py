@@ -1,34 +1,150 @@
-"""Holds the restated scikit-image primitives (oracle/watershed_ref.py) to scikit-image's own outputs -- once
-tests/golden/watershed_skimage.npz has been recorded with tests/golden/make_watershed_golden.py on a machine that has scikit-image
-(not installable in the build container).  Skipped while the file is absent: the oracle stays "parity unpinned" for those primitives."""
+"""The marker watershed held to THE REFERENCE'S OWN CODE RUN ON THE REAL scikit-image 0.18.3 (tests/golden/watershed_skimage.npz, recorded
+by tests/golden/make_watershed_golden.py under the image's second interpreter, /opt/conda/bin/python3.9: CellTracker/watershed.py and
+Tracker._watershed unmodified, nothing of scikit-image / scipy stubbed).  CPU: the oracle's restated primitives and its composite equal
+every recorded stage.  GPU: the device path equals the recorded segmentation, sizes bookkeeping and centres on seven volumes -- compared
+with the golden directly, no oracle in between -- and on the 512 x 512 x 32 benchmark stack up to the reference's own machine-dependent
+choice among exactly tied peak candidates (isolated and proven to be the only difference on the CPU)."""
+import importlib
+
 import numpy as np
 import pytest
-import scipy.ndimage as ndi
 
+import _ws_cases as cases
 from oracle import watershed_ref as wr
+
+synth = importlib.import_module("3deecelltracker_amd.synth")
+SMALL_FINAL = cases.TIE_FREE + ("random_a", "random_b", "random_c")
 
 
 @pytest.fixture(scope="module")
 def pin(golden_dir):
-    f = golden_dir / "watershed_skimage.npz"
-    if not f.exists():
-        pytest.skip("tests/golden/watershed_skimage.npz not recorded yet (needs scikit-image; see make_watershed_golden.py)")
-    return np.load(f)
+    return np.load(golden_dir / "watershed_skimage.npz")
 
 
-@pytest.mark.parametrize("ci", (0, 1, 2))
-def test_restated_primitives_equal_skimage(pin, golden_dir, ci):
-    g = np.load(golden_dir / "watershed.npz")
-    prob = g[f"ws_prob_{ci}"]
-    zr, ms = float(g[f"ws_para_{ci}"][0]), int(g[f"ws_para_{ci}"][1])
-    col = []
-    wo, bd = wr.watershed_2d(prob, prob.shape[2], 7, collect=col)
-    peaks2d = np.stack([c["peaks"] for c in col], axis=2); labels2d = np.stack([c["labels"] for c in col], axis=2)
-    assert np.array_equal(np.packbits(peaks2d), pin[f"peaks2d_{ci}"])
-    assert np.array_equal(labels2d, pin[f"labels2d_{ci}"])
-    assert np.array_equal(np.packbits(bd), pin[f"boundary2d_{ci}"])
-    col3 = []
-    _, clear, _, _ = wr.watershed_3d(wo, [1, 1, zr], "min_size", ms, 0, 3, collect=col3)
-    assert np.array_equal(np.packbits(col3[0]["peaks"]), pin[f"peaks3d_{ci}"])
-    assert np.array_equal(col3[0]["labels"], pin[f"labels3d_{ci}"])
-    assert np.array_equal(wr.relabel_sequential(clear), pin[f"seg_auto_{ci}"])
+def _case(pin, name):
+    build, zr, ms = cases.PIN_CASES[name]
+    prob = build(synth.make_stack)
+    assert cases.sha(prob) == str(pin[f"{name}_sha"]), "the regenerated input differs from the one the golden was recorded on"
+    assert (zr, ms) == (float(pin[f"{name}_para"][0]), int(pin[f"{name}_para"][1]))
+    return prob, zr, ms
+
+
+def test_golden_is_the_real_thing(pin):
+    v = [str(s) for s in pin["versions"]]
+    assert v[0].startswith("scikit-image 0.1") and [str(s) for s in pin["names"]] == list(cases.PIN_CASES)
+    assert int(pin["headline_para"][3]) == 566 and int(pin["headline_seg_auto"].max()) == 566
+
+
+def _same_up_to_ties(got, want, values):
+    """two peak masks that may differ only in WHICH of several exactly equal candidates were kept"""
+    return got.sum() == want.sum() and np.array_equal(np.sort(values[got]), np.sort(values[want]))
+
+
+@pytest.mark.parametrize("name", cases.TIE_FREE + ("random_a", "random_b", "random_c", "ties"))
+def test_restated_primitives_equal_skimage_stage_by_stage(pin, name):
+    """Every restated primitive against scikit-image's own output, each fed with the RECORDED output of the stage before it (so that the
+    machine-dependent choice among exactly tied peaks upstream -- see _ws_cases.PIN_CASES -- does not leak into the later stages):
+    peak_local_max up to ties; label + watershed, find_boundaries, the 2-D composite, label + watershed in 3-D exactly."""
+    import scipy.ndimage as ndi
+    prob, zr, ms = _case(pin, name)
+    unpack = lambda key, dt=bool: np.unpackbits(pin[f"{name}_{key}"])[:prob.size].reshape(prob.shape).astype(dt)
+    peaks2d, bd2d, wo2d, peaks3d = unpack("peaks2d"), unpack("bd2d"), unpack("wo2d"), unpack("peaks3d")
+    labels2d = pin[f"{name}_labels2d"]
+    for z in range(prob.shape[2]):
+        bn = prob[:, :, z] > 0.5
+        smooth = ndi.gaussian_filter(ndi.distance_transform_edt(bn, sampling=[1, 1]), 2, mode="constant")
+        assert _same_up_to_ties(wr.peak_local_max_mask(smooth, 7), peaks2d[:, :, z], smooth), f"peak_local_max, slice {z}"
+        lab = wr.watershed(-smooth, wr.label_full(peaks2d[:, :, z]), bn)
+        assert np.array_equal(lab, labels2d[:, :, z]), f"label + watershed, slice {z}"
+        assert np.array_equal(wr.find_boundaries_outer(lab, 2), bd2d[:, :, z]), f"find_boundaries, slice {z}"
+    wo = prob > 0.5
+    wo[bd2d] = False
+    assert np.array_equal(wo, wo2d)
+    smooth3 = ndi.gaussian_filter(ndi.distance_transform_edt(wo2d, sampling=[1, 1, zr]), (2, 2, 0.3), mode="constant")
+    if name != "ties":          # (on a 2-D plateau of equal maxima even the NUMBER of peaks that survive the spacing rule depends on the order)
+        assert _same_up_to_ties(wr.peak_local_max_mask(smooth3, 3, exclude_border=0), peaks3d, smooth3), "peak_local_max (3-D)"
+    lab3 = wr.watershed(-smooth3, wr.label_full(peaks3d), wo2d)
+    assert np.array_equal(lab3, pin[f"{name}_labels3d"]), "label + watershed (3-D)"
+    # min_size bookkeeping, remove_small_objects, relabel_sequential on the recorded 3-D labels
+    counts = np.sort(np.bincount(lab3.ravel()))
+    assert int(np.sum(counts >= ms) - 1) == int(pin[f"{name}_para"][3])
+    assert np.array_equal(wr.relabel_sequential(wr.remove_small_objects(lab3, ms)), pin[f"{name}_seg_auto"])
+
+
+@pytest.mark.parametrize("name", cases.TIE_FREE)
+def test_cell_num_method_equals_the_reference(pin, name):
+    prob, zr, ms = _case(pin, name)
+    wo = np.unpackbits(pin[f"{name}_wo2d"])[:prob.size].reshape(prob.shape).astype(bool)
+    cn_in, ms2, cn2 = (int(v) for v in pin[f"{name}_cellnum"])
+    _, clear_cn, oms2, ocn2 = wr.watershed_3d(wo, [1, 1, zr], "cell_num", 0, cn_in, 3)
+    assert (oms2, ocn2) == (ms2, cn2) and np.array_equal(clear_cn, pin[f"{name}_clear_cellnum"])
+
+
+@pytest.mark.parametrize("name", SMALL_FINAL)
+def test_oracle_composite_equals_the_reference_on_real_skimage(pin, name):
+    prob, zr, ms = _case(pin, name)
+    labels, centres, oms, ocn = wr.segment_centroids(prob, zr, "min_size", ms)
+    assert (oms, ocn) == (int(pin[f"{name}_para"][2]), int(pin[f"{name}_para"][3]))
+    assert np.array_equal(labels, pin[f"{name}_seg_auto"])
+    assert np.array_equal(centres, pin[f"{name}_centres"])
+
+
+def _recorded_peaks(pin, name, shape):
+    n = int(np.prod(shape))
+    return (np.unpackbits(pin[f"{name}_peaks2d"])[:n].reshape(shape).astype(bool), np.unpackbits(pin[f"{name}_peaks3d"])[:n].reshape(shape).astype(bool))
+
+
+def test_benchmark_stack_equals_the_reference_given_its_tie_choices(pin):
+    """512 x 512 x 32 / 566 cells.  45 of the ~4000 per-slice peak candidates come in exactly tied adjacent pairs (blobs symmetric about a
+    pixel edge); the recorded run kept the later pixel of each, the oracle keeps the earlier (machine-dependent upstream, see _ws_cases).
+    (1) With the recorded peaks in place of its own choice the oracle reproduces the reference's segmentation_auto and centres EXACTLY;
+    (2) with its own choice it differs in 96 of 8.4 M voxels (the boundary between one touching pair, one voxel elsewhere), same 566 cells."""
+    import scipy.ndimage as ndi
+    prob, zr, ms = _case(pin, "headline")
+    want = pin["headline_seg_auto"]
+    p2, p3 = _recorded_peaks(pin, "headline", prob.shape)
+    labels, oms, ocn = wr.tracker_watershed(prob, zr, "min_size", ms, 0, peaks2d=p2, peaks3d=p3)
+    assert (oms, ocn) == (int(pin["headline_para"][2]), 566)
+    assert np.array_equal(labels, want)
+    centres = np.asarray(ndi.center_of_mass(labels > 0, labels, range(1, 567)))
+    assert np.array_equal(centres, pin["headline_centres"])
+    own, _, oms2, ocn2 = wr.segment_centroids(prob, zr, "min_size", ms)
+    assert (oms2, ocn2) == (oms, ocn) and 0 < int((own != want).sum()) < 200
+
+
+def test_exact_ties_are_resolved_by_an_unstable_sort_upstream(pin):
+    """The designed tie case (ridges of EQUAL maxima): scikit-image orders tied candidates with np.argsort(-intensities) -- unstable, on this
+    image's CPU an AVX-512 network sort -- so WHICH of the tied peaks stay is machine-dependent upstream.  What does not depend on the order
+    is pinned: per slice the same number of peaks with the same intensities (the spacing rule is `distance < min_distance`, strict)."""
+    import scipy.ndimage as ndi
+    prob, zr, ms = _case(pin, "ties")
+    want = np.unpackbits(pin["ties_peaks2d"])[:prob.size].reshape(prob.shape).astype(bool)
+    differs = 0
+    for z in range(prob.shape[2]):
+        smooth = ndi.gaussian_filter(ndi.distance_transform_edt(prob[:, :, z] > 0.5, sampling=[1, 1]), 2, mode="constant")
+        got = wr.peak_local_max_mask(smooth, 7)
+        assert got.sum() == want[:, :, z].sum()
+        assert np.array_equal(np.sort(smooth[got]), np.sort(smooth[want[:, :, z]]))
+        differs += int((got != want[:, :, z]).any())
+    assert differs > 0, "the recorded order agrees with the oracle's everywhere: the tie case no longer exercises what it documents"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in cases.PIN_CASES if n != "ties"])
+def test_device_watershed_equals_the_reference_on_real_skimage(pin, name):
+    seg = importlib.import_module("3deecelltracker_amd.segment")
+    import torch
+    prob, zr, ms = _case(pin, name)
+    labels, centres, sizes, oms, ocn = seg.watershed_centroids_device(torch.from_numpy(prob).cuda(), zr, "min_size", ms, 0)
+    assert (oms, ocn) == (int(pin[f"{name}_para"][2]), int(pin[f"{name}_para"][3]))
+    got = labels.cpu().numpy()
+    want = pin[f"{name}_seg_auto"]
+    if name == "headline":
+        # the tied-pair choices of the recorded run (previous test): the device makes the oracle's choice, and must then equal the ORACLE
+        # exactly (tests/test_watershed.py::test_device_watershed_headline_size); against the recording the same 96 voxels differ
+        own, _, _, _ = wr.segment_centroids(prob, zr, "min_size", ms)
+        assert np.array_equal(got, own) and 0 < int((got != want).sum()) < 200
+        return
+    assert np.array_equal(got, want), f"{int((got != want).sum())} voxels differ"
+    assert np.array_equal(centres.cpu().numpy(), pin[f"{name}_centres"])
+    assert np.array_equal(sizes.cpu().numpy(), np.bincount(want.ravel())[1:])
