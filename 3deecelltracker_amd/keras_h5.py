@@ -1,9 +1,10 @@
 """Keras `.h5` weight import for the U-Nets (`model.save_weights` / `model.save` files, reference
 tracker.py:579, unet3d.py TrainingUNet3D) and the FFN (reference trackerlite.py:57-63, ffn.py TrainFFN).
 
-Needs h5py, which is NOT part of this image: the module is imported lazily.  tests/test_keras_h5.py writes files in the Keras 2.x
+Needs h5py, which the image's main interpreter lacks: the module is imported lazily.  tests/test_keras_h5.py writes files in the Keras 2.x
 layout (weights-only and full-model, flat for the functional U-Nets, nested Sequential groups for the subclassed FFN) and reads
-them back wherever h5py is importable; no real Keras-written file has been available ("parity unpinned").  `.npz`
+them back wherever h5py is importable -- on this image under /opt/conda/bin/python3.9 (h5py 3.3), in a subprocess; no real Keras-written
+file has been available ("parity unpinned").  `.npz`
 files written by `save_weights` of the mirrors are the native format.
 
 Keras HDF5 layout (Keras 2.x `save_weights_to_hdf5_group`): weights live under the root (weights-only file) or under
