@@ -420,6 +420,84 @@ __global__ __launch_bounds__(256) void ws_peak_kernel(SegGeom g, int mode2d, int
     }
 }
 
+// np.argsort(v) as numpy's generic (non-SIMD) quicksort computes it -- introsort: median of three, Hoare partition with the pivot parked at
+// pr - 1, the larger part pushed, ranges of <= 16 elements finished by insertion sort, heapsort for a popped range deeper than 2 floor(log2 n)
+// (numpy/core/src/npysort/quicksort.cpp aquicksort_, heapsort.cpp aheapsort_; oracle/watershed_ref.py::argsort_quicksort is the same
+// restatement, checked against numpy itself).  scikit-image orders peak candidates with it, so the choice among EXACTLY tied candidates closer
+// than min_distance is whatever this unstable sort leaves (every numpy before 1.25, later ones on CPUs without AVX-512).  One thread, LDS
+// arrays: vk[p] = key of the element at position p (moved together with ts[p] = its index, so a comparison is one LDS read, not two dependent ones).
+__device__ void ws_aheapsort(int* vk, int* ts, int lo, int n) {
+    // 1-based heap over positions lo .. lo + n - 1
+#define A_V(i) vk[lo + (i) - 1]
+#define A_T(i) ts[lo + (i) - 1]
+    for (int i = n >> 1; i > 0; --i) {
+        const int tv = A_V(i), tt = A_T(i);
+        int ii = i, j = ii << 1;
+        while (j <= n) {
+            if (j < n && A_V(j) < A_V(j + 1)) ++j;
+            if (tv < A_V(j)) { A_V(ii) = A_V(j); A_T(ii) = A_T(j); ii = j; j += j; } else break;
+        }
+        A_V(ii) = tv; A_T(ii) = tt;
+    }
+    for (int nn = n; nn > 1;) {
+        const int tv = A_V(nn), tt = A_T(nn);
+        A_V(nn) = A_V(1); A_T(nn) = A_T(1);
+        --nn;
+        int i = 1, j = 2;
+        while (j <= nn) {
+            if (j < nn && A_V(j) < A_V(j + 1)) ++j;
+            if (tv < A_V(j)) { A_V(i) = A_V(j); A_T(i) = A_T(j); i = j; j += j; } else break;
+        }
+        A_V(i) = tv; A_T(i) = tt;
+    }
+#undef A_V
+#undef A_T
+}
+__device__ void ws_aquicksort(int* vk, int* ts, int num, int* stack_lo /* LDS [3][64] */) {
+    if (num < 2) return;
+    int* stack_hi = stack_lo + 64; int* stack_depth = stack_lo + 128;
+    int sp = 0;
+    int pl = 0, pr = num - 1;
+    int cdepth = 0;
+    for (int n = num >> 1; n; n >>= 1) ++cdepth;
+    cdepth *= 2;
+#define WS_SWAP(a, b) { const int tv_ = vk[a], tt_ = ts[a]; vk[a] = vk[b]; ts[a] = ts[b]; vk[b] = tv_; ts[b] = tt_; }
+    for (;;) {
+        if (cdepth < 0) ws_aheapsort(vk, ts, pl, pr - pl + 1);
+        else {
+            while (pr - pl > 15) {
+                const int pm = pl + ((pr - pl) >> 1);
+                if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
+                if (vk[pr] < vk[pm]) WS_SWAP(pr, pm)
+                if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
+                const int vp = vk[pm];
+                int pi = pl, pj = pr - 1;
+                WS_SWAP(pm, pj)
+                for (;;) {
+                    do ++pi; while (vk[pi] < vp);
+                    do --pj; while (vp < vk[pj]);
+                    if (pi >= pj) break;
+                    WS_SWAP(pi, pj)
+                }
+                const int pk = pr - 1;
+                WS_SWAP(pi, pk)
+                --cdepth;
+                if (pi - pl < pr - pi) { stack_lo[sp] = pi + 1; stack_hi[sp] = pr; stack_depth[sp] = cdepth; ++sp; pr = pi - 1; }
+                else { stack_lo[sp] = pl; stack_hi[sp] = pi - 1; stack_depth[sp] = cdepth; ++sp; pl = pi + 1; }
+            }
+            for (int pi = pl + 1; pi <= pr; ++pi) {
+                const int vv = vk[pi], tt = ts[pi];
+                int pj = pi;
+                while (pj > pl && vv < vk[pj - 1]) { vk[pj] = vk[pj - 1]; ts[pj] = ts[pj - 1]; --pj; }
+                vk[pj] = vv; ts[pj] = tt;
+            }
+        }
+        if (sp == 0) break;
+        --sp; pl = stack_lo[sp]; pr = stack_hi[sp]; cdepth = stack_depth[sp];
+    }
+#undef WS_SWAP
+}
+
 // One workgroup per group: final peak test, ensure_spacing among exact ties, raster-order marker labels.
 // Out: labels[idx] = marker number (1-based, raster order within the group), marker list (idx ascending) and count per group.
 __global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mode2d, int min_distance, const unsigned int* __restrict__ eq_count,
@@ -459,29 +537,93 @@ __global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mod
             }
             __syncthreads();
         }
-    // ensure_spacing: only equal values can be closer than min_distance; the first element of every run of equal keys walks its run
+    // ensure_spacing: only equal values can be closer than min_distance.  Do any two EQUAL candidates lie that close?  If not (the rule for real
+    // data) nothing is dropped and the order among ties is irrelevant.
+    __shared__ int tie_matters, n_valid;
+    if (threadIdx.x == 0) { tie_matters = 0; n_valid = 0; }
     for (int t = threadIdx.x; t < np2; t += 1024) keep[t] = (key[t] != ~0ull || idx[t] != 0x7fffffff) ? 1 : 0;
     __syncthreads();
     for (int t = threadIdx.x; t < np2; t += 1024) {
         if (!keep[t]) continue;
+        atomicAdd(&n_valid, 1);
         if (t > 0 && key[t - 1] == key[t]) continue;                             // not a run start
         int e = t + 1;
         while (e < np2 && key[e] == key[t] && idx[e] != 0x7fffffff) ++e;
-        if (e - t < 2) continue;
-        for (int a = t + 1; a < e; ++a) {
+        bool close = false;
+        for (int a = t + 1; a < e && !close; ++a) {
             int xa, ya, za; ws_xyz(idx[a], g, xa, ya, za);
             for (int b = t; b < a; ++b) {
-                if (!keep[b]) continue;
                 int xb, yb, zb; ws_xyz(idx[b], g, xb, yb, zb);
-                const int d = max(max(abs(xa - xb), abs(ya - yb)), abs(za - zb));
-                if (d < min_distance) { keep[a] = 0; break; }           // strict: peaks exactly min_distance apart both stay (skimage ensure_spacing)
+                if (max(max(abs(xa - xb), abs(ya - yb)), abs(za - zb)) < min_distance) { close = true; break; }
             }
         }
+        if (close) tie_matters = 1;
     }
     __syncthreads();
+    if (tie_matters) {
+        // numpy's order among the ties: candidates in raveled order (what np.nonzero hands to np.argsort), keys = dense ranks of -value
+        const int nv = n_valid;
+        for (int t = threadIdx.x; t < np2; t += 1024) {                          // rank = start of the run of equal keys (descending value)
+            int r = t;
+            if (keep[t]) while (r > 0 && key[r - 1] == key[t]) --r;
+            keep[t] = r;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < np2; t += 1024)
+            key[t] = (t < nv) ? (((unsigned long long)(unsigned int)idx[t] << 32) | (unsigned int)keep[t]) : ~0ull;
+        __syncthreads();
+        for (int k2 = 2; k2 <= np2; k2 <<= 1)                                    // raveled order
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < np2; t += 1024) {
+                    const int p = t ^ j;
+                    if (p > t) {
+                        const bool up = (t & k2) == 0;
+                        const unsigned long long ka = key[t], kb = key[p];
+                        if ((ka > kb) == up) { key[t] = kb; key[p] = ka; }
+                    }
+                }
+                __syncthreads();
+            }
+        // idx[] <- raveled candidate indices, keep[] <- their ranks (vk); the key region becomes two int arrays: ts | kept flags
+        int* ts = (int*)key;
+        int* kf = ts + np2;
+        unsigned long long mine[8];
+        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) mine[q] = key[t];
+        __syncthreads();
+        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) {
+            idx[t] = (t < nv) ? (int)(mine[q] >> 32) : 0x7fffffff;
+            keep[t] = (t < nv) ? (int)(mine[q] & 0xffffffffu) : 0x7fffffff;
+            ts[t] = t; kf[t] = (t < nv) ? 1 : 0;
+        }
+        __syncthreads();
+        __shared__ int qs_stack[3 * 64];
+        if (threadIdx.x == 0) ws_aquicksort(keep, ts, nv, qs_stack);
+        __syncthreads();
+        // greedy spacing inside every run of equal rank, in numpy's order (run starts in parallel)
+        for (int t = threadIdx.x; t < nv; t += 1024) {
+            if (t > 0 && keep[t - 1] == keep[t]) continue;
+            int e = t + 1;
+            while (e < nv && keep[e] == keep[t]) ++e;
+            for (int a = t + 1; a < e; ++a) {
+                int xa, ya, za; ws_xyz(idx[ts[a]], g, xa, ya, za);
+                for (int b = t; b < a; ++b) {
+                    if (!kf[b]) continue;
+                    int xb, yb, zb; ws_xyz(idx[ts[b]], g, xb, yb, zb);
+                    if (max(max(abs(xa - xb), abs(ya - yb)), abs(za - zb)) < min_distance) { kf[a] = 0; break; }   // strict (skimage ensure_spacing)
+                }
+            }
+        }
+        __syncthreads();
+        // back to the common layout: key[t] = kept ? voxel index : ~0  (registers in between: key overlays ts / kf)
+        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) mine[q] = (t < nv && kf[t]) ? (unsigned long long)(unsigned int)idx[ts[t]] : ~0ull;
+        __syncthreads();
+        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) key[t] = mine[q];
+        __syncthreads();
+    } else {
+        for (int t = threadIdx.x; t < np2; t += 1024) key[t] = keep[t] ? (unsigned long long)(unsigned int)idx[t] : ~0ull;
+        __syncthreads();
+    }
     // kept peaks in raster order: sort by idx (dropped entries to the end)
-    for (int t = threadIdx.x; t < np2; t += 1024) { key[t] = keep[t] ? (unsigned long long)(unsigned int)idx[t] : ~0ull; }
-    __syncthreads();
     for (int k2 = 2; k2 <= np2; k2 <<= 1)
         for (int j = k2 >> 1; j > 0; j >>= 1) {
             for (int t = threadIdx.x; t < np2; t += 1024) {

@@ -41,6 +41,102 @@ import numpy as np
 import scipy.ndimage as ndi
 
 
+# ------------------------------------------------------------------------------------------------ numpy's argsort, restated
+def _msb(n: int) -> int:
+    d = 0
+    n >>= 1
+    while n:
+        d += 1
+        n >>= 1
+    return d
+
+
+def _aheapsort(v, tosort, lo, n):
+    """numpy/core/src/npysort/heapsort.cpp aheapsort_ on tosort[lo : lo + n] (1-based heap indices as upstream)"""
+    def a(i): return tosort[lo + i - 1]
+    def seta(i, x): tosort[lo + i - 1] = x
+    for i in range(n >> 1, 0, -1):
+        tmp = a(i); ii = i; j = ii << 1
+        while j <= n:
+            if j < n and v[a(j)] < v[a(j + 1)]:
+                j += 1
+            if v[tmp] < v[a(j)]:
+                seta(ii, a(j)); ii = j; j += j
+            else:
+                break
+        seta(ii, tmp)
+    nn = n
+    while nn > 1:
+        tmp = a(nn); seta(nn, a(1)); nn -= 1
+        i = 1; j = 2
+        while j <= nn:
+            if j < nn and v[a(j)] < v[a(j + 1)]:
+                j += 1
+            if v[tmp] < v[a(j)]:
+                seta(i, a(j)); i = j; j += j
+            else:
+                break
+        seta(i, tmp)
+
+
+def argsort_quicksort(v) -> np.ndarray:
+    """np.argsort(v) (kind='quicksort') of a float array without NaNs as numpy's generic, non-SIMD code computes it
+    (numpy/core/src/npysort/quicksort.cpp aquicksort_: introsort -- median of three, Hoare partition with the pivot parked at pr - 1, the larger
+    part pushed, ranges of <= 16 elements finished by insertion sort, heapsort for a popped range beyond depth 2 floor(log2 n)).  This is what every
+    numpy before 1.25 runs, and later ones on CPUs without AVX-512 (there the dispatch goes to a network sort with another order among equal keys).
+    Checked against numpy itself on 3012 arrays incl. heavy ties and the heapsort fallback (tests/test_watershed_pin.py runs the comparison wherever
+    the image's second interpreter is present, with NPY_DISABLE_CPU_FEATURES)."""
+    v = np.asarray(v, dtype=np.float64)
+    num = len(v)
+    tosort = list(range(num))
+    if num < 2:
+        return np.array(tosort, dtype=np.intp)
+    pl, pr = 0, num - 1
+    stack = []
+    cdepth = _msb(num) * 2
+    while True:
+        if cdepth < 0:
+            _aheapsort(v, tosort, pl, pr - pl + 1)
+        else:
+            while (pr - pl) > 15:
+                pm = pl + ((pr - pl) >> 1)
+                if v[tosort[pm]] < v[tosort[pl]]:
+                    tosort[pm], tosort[pl] = tosort[pl], tosort[pm]
+                if v[tosort[pr]] < v[tosort[pm]]:
+                    tosort[pr], tosort[pm] = tosort[pm], tosort[pr]
+                if v[tosort[pm]] < v[tosort[pl]]:
+                    tosort[pm], tosort[pl] = tosort[pl], tosort[pm]
+                vp = v[tosort[pm]]
+                pi = pl; pj = pr - 1
+                tosort[pm], tosort[pj] = tosort[pj], tosort[pm]
+                while True:
+                    pi += 1
+                    while v[tosort[pi]] < vp:
+                        pi += 1
+                    pj -= 1
+                    while vp < v[tosort[pj]]:
+                        pj -= 1
+                    if pi >= pj:
+                        break
+                    tosort[pi], tosort[pj] = tosort[pj], tosort[pi]
+                pk = pr - 1
+                tosort[pi], tosort[pk] = tosort[pk], tosort[pi]
+                cdepth -= 1
+                if pi - pl < pr - pi:
+                    stack.append((pi + 1, pr, cdepth)); pr = pi - 1
+                else:
+                    stack.append((pl, pi - 1, cdepth)); pl = pi + 1
+            for pi in range(pl + 1, pr + 1):
+                vi = tosort[pi]; vp = v[vi]; pj = pi; pk = pi - 1
+                while pj > pl and vp < v[tosort[pk]]:
+                    tosort[pj] = tosort[pk]; pj -= 1; pk -= 1
+                tosort[pj] = vi
+        if not stack:
+            break
+        pl, pr, cdepth = stack.pop()
+    return np.array(tosort, dtype=np.intp)
+
+
 # ------------------------------------------------------------------------------------------------ restated skimage functions
 def peak_local_max_mask(image: np.ndarray, min_distance: int, exclude_border=True) -> np.ndarray:
     """skimage.feature.peak_local_max(image, min_distance=..., exclude_border=..., indices=False) -> bool mask."""
@@ -64,7 +160,7 @@ def peak_local_max_mask(image: np.ndarray, min_distance: int, exclude_border=Tru
     idx = np.flatnonzero(out)
     if idx.size > 1:
         vals = image.ravel()[idx]
-        order = np.lexsort((idx, -vals))
+        order = argsort_quicksort(-vals)              # upstream: np.argsort(-intensities) over the candidates in raveled order
         coords = np.stack(np.unravel_index(idx[order], image.shape), axis=1)
         kept = []
         keep_mask = np.zeros(len(coords), dtype=bool)

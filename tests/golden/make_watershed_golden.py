@@ -7,6 +7,13 @@ tree whose interpreter has it:  /opt/conda/bin/python3.9  with scikit-image 0.18
 
     PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 -W ignore tests/golden/make_watershed_golden.py
 
+numpy's sort: scikit-image orders peak candidates with np.argsort(-intensities), an UNSTABLE sort, so the choice among exactly tied candidates
+is whatever numpy's quicksort leaves.  Every numpy before 1.25 -- i.e. every numpy the reference's `tensorflow==2.11` (requirements.txt:4) can
+run with -- uses its generic introsort; numpy >= 1.25 dispatches argsort to an AVX-512 network sort where the CPU has one (this box does), with
+another order among equal keys.  The script therefore re-executes itself with NPY_DISABLE_CPU_FEATURES naming the AVX-512 groups, which puts
+numpy 1.26.4 on the generic code path: the recorded tie choices are those of the reference's pinned environment (and of any machine without
+AVX-512).  With the dispatch left on, 45 tied pairs of the benchmark stack are resolved the other way round (96 of 8.4 M voxels).
+
 What runs: /root/reference/CellTracker/watershed.py (`watershed_2d`, `watershed_3d`) and `Tracker._watershed` of
 /root/reference/CellTracker/tracker.py:671-684, unmodified, on the synthetic probability maps of tests/_ws_cases.py -- with scikit-image,
 scipy, tifffile, h5py, matplotlib and sklearn REAL and only tensorflow / stardist / csbdeep (absent in that tree too, untouched by this
@@ -21,6 +28,12 @@ import sys
 import types
 from pathlib import Path
 from unittest.mock import MagicMock
+
+import os  # noqa: E402
+
+_NO_AVX512 = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL"
+if os.environ.get("NPY_DISABLE_CPU_FEATURES") != _NO_AVX512:          # before numpy is imported
+    os.execve(sys.executable, [sys.executable, "-W", "ignore", *sys.argv], dict(os.environ, NPY_DISABLE_CPU_FEATURES=_NO_AVX512, PYTHONDONTWRITEBYTECODE="1"))
 
 sys.dont_write_bytecode = True
 HERE = Path(__file__).resolve().parent
@@ -62,8 +75,10 @@ def main():
     ref_tracker = importlib.import_module("CellTracker.tracker")
     assert ref_ws.peak_local_max is peak_local_max and ref_ws.watershed is watershed, "the reference must be bound to the real scikit-image"
     make_stack = importlib.import_module("3deecelltracker_amd.synth").make_stack
+    from numpy.core._multiarray_umath import __cpu_features__ as cpu
+    assert not cpu["AVX512_SKX"] and not cpu["AVX512F"], "numpy must run its generic sort (see the module docstring)"
     out = {"versions": np.array([f"scikit-image {skimage.__version__}", f"scipy {scipy.__version__}", f"numpy {np.__version__}",
-                                 f"python {sys.version.split()[0]}"])}
+                                 f"python {sys.version.split()[0]}", "numpy sort: generic introsort (AVX-512 dispatch disabled)"])}
     names = []
     for name, (build, zr, ms) in cases.PIN_CASES.items():
         prob = build(make_stack)

@@ -1,9 +1,9 @@
 """The marker watershed held to THE REFERENCE'S OWN CODE RUN ON THE REAL scikit-image 0.18.3 (tests/golden/watershed_skimage.npz, recorded
 by tests/golden/make_watershed_golden.py under the image's second interpreter, /opt/conda/bin/python3.9: CellTracker/watershed.py and
 Tracker._watershed unmodified, nothing of scikit-image / scipy stubbed).  CPU: the oracle's restated primitives and its composite equal
-every recorded stage.  GPU: the device path equals the recorded segmentation, sizes bookkeeping and centres on seven volumes -- compared
-with the golden directly, no oracle in between -- and on the 512 x 512 x 32 benchmark stack up to the reference's own machine-dependent
-choice among exactly tied peak candidates (isolated and proven to be the only difference on the CPU)."""
+every recorded stage incl. the choice among exactly tied peak candidates (numpy's generic introsort, restated).  GPU: the device path equals
+the recorded segmentation, sizes bookkeeping and centres on eight volumes incl. the 512 x 512 x 32 benchmark stack -- compared with the
+golden directly, no oracle in between."""
 import importlib
 
 import numpy as np
@@ -35,40 +35,56 @@ def test_golden_is_the_real_thing(pin):
     assert int(pin["headline_para"][3]) == 566 and int(pin["headline_seg_auto"].max()) == 566
 
 
-def _same_up_to_ties(got, want, values):
-    """two peak masks that may differ only in WHICH of several exactly equal candidates were kept"""
-    return got.sum() == want.sum() and np.array_equal(np.sort(values[got]), np.sort(values[want]))
+def _tied_marker_components(mask, peaks, smooth):
+    """mask components (full connectivity, as the flood sees one basin system: connectivity 1) that hold two or more markers of EXACTLY equal
+    height: there the order in which upstream's binary heap pops the equal (value, age 0) seeds decides the boundary between them"""
+    import scipy.ndimage as ndi
+    comp, n = ndi.label(mask)
+    out = np.zeros(mask.shape, bool)
+    for c in range(1, n + 1):
+        v = smooth[(comp == c) & peaks]
+        if v.size > 1 and np.unique(v).size < v.size:
+            out |= comp == c
+    return out
 
 
 @pytest.mark.parametrize("name", cases.TIE_FREE + ("random_a", "random_b", "random_c", "ties"))
 def test_restated_primitives_equal_skimage_stage_by_stage(pin, name):
-    """Every restated primitive against scikit-image's own output, each fed with the RECORDED output of the stage before it (so that the
-    machine-dependent choice among exactly tied peaks upstream -- see _ws_cases.PIN_CASES -- does not leak into the later stages):
-    peak_local_max up to ties; label + watershed, find_boundaries, the 2-D composite, label + watershed in 3-D exactly."""
+    """Every restated primitive against scikit-image's own output, each fed with the RECORDED output of the stage before it: peak_local_max
+    (incl. the choice among exactly tied candidates: numpy's introsort restated, oracle.argsort_quicksort), label + watershed, find_boundaries,
+    the 2-D composite, label + watershed in 3-D, the size bookkeeping.  The one thing left open: seeds of exactly equal height inside one
+    basin system (the designed tie volume only) -- upstream's heap pops them in an order that depends on its array layout; the oracle takes the
+    smaller raveled index.  Outside such components the flood must agree there too."""
     import scipy.ndimage as ndi
     prob, zr, ms = _case(pin, name)
     unpack = lambda key, dt=bool: np.unpackbits(pin[f"{name}_{key}"])[:prob.size].reshape(prob.shape).astype(dt)
     peaks2d, bd2d, wo2d, peaks3d = unpack("peaks2d"), unpack("bd2d"), unpack("wo2d"), unpack("peaks3d")
     labels2d = pin[f"{name}_labels2d"]
+    open_voxels = 0
     for z in range(prob.shape[2]):
         bn = prob[:, :, z] > 0.5
         smooth = ndi.gaussian_filter(ndi.distance_transform_edt(bn, sampling=[1, 1]), 2, mode="constant")
-        assert _same_up_to_ties(wr.peak_local_max_mask(smooth, 7), peaks2d[:, :, z], smooth), f"peak_local_max, slice {z}"
+        assert np.array_equal(wr.peak_local_max_mask(smooth, 7), peaks2d[:, :, z]), f"peak_local_max, slice {z}"
         lab = wr.watershed(-smooth, wr.label_full(peaks2d[:, :, z]), bn)
-        assert np.array_equal(lab, labels2d[:, :, z]), f"label + watershed, slice {z}"
-        assert np.array_equal(wr.find_boundaries_outer(lab, 2), bd2d[:, :, z]), f"find_boundaries, slice {z}"
+        tied = _tied_marker_components(bn, peaks2d[:, :, z], smooth)
+        assert np.array_equal(lab[~tied], labels2d[:, :, z][~tied]), f"label + watershed, slice {z}"
+        open_voxels += int((lab != labels2d[:, :, z]).sum())
+        assert np.array_equal(wr.find_boundaries_outer(labels2d[:, :, z], 2), bd2d[:, :, z]), f"find_boundaries, slice {z}"
+    assert open_voxels == 0 or name == "ties"          # (the touching pair of identical blobs has such seeds too and still agrees)
     wo = prob > 0.5
     wo[bd2d] = False
     assert np.array_equal(wo, wo2d)
     smooth3 = ndi.gaussian_filter(ndi.distance_transform_edt(wo2d, sampling=[1, 1, zr]), (2, 2, 0.3), mode="constant")
-    if name != "ties":          # (on a 2-D plateau of equal maxima even the NUMBER of peaks that survive the spacing rule depends on the order)
-        assert _same_up_to_ties(wr.peak_local_max_mask(smooth3, 3, exclude_border=0), peaks3d, smooth3), "peak_local_max (3-D)"
+    assert np.array_equal(wr.peak_local_max_mask(smooth3, 3, exclude_border=0), peaks3d), "peak_local_max (3-D)"
     lab3 = wr.watershed(-smooth3, wr.label_full(peaks3d), wo2d)
-    assert np.array_equal(lab3, pin[f"{name}_labels3d"]), "label + watershed (3-D)"
+    tied3 = _tied_marker_components(wo2d, peaks3d, smooth3)
+    assert np.array_equal(lab3[~tied3], pin[f"{name}_labels3d"][~tied3]), "label + watershed (3-D)"
+    assert np.array_equal(lab3, pin[f"{name}_labels3d"]) or name == "ties"
     # min_size bookkeeping, remove_small_objects, relabel_sequential on the recorded 3-D labels
-    counts = np.sort(np.bincount(lab3.ravel()))
+    rec3 = pin[f"{name}_labels3d"].astype(np.int32)
+    counts = np.sort(np.bincount(rec3.ravel()))
     assert int(np.sum(counts >= ms) - 1) == int(pin[f"{name}_para"][3])
-    assert np.array_equal(wr.relabel_sequential(wr.remove_small_objects(lab3, ms)), pin[f"{name}_seg_auto"])
+    assert np.array_equal(wr.relabel_sequential(wr.remove_small_objects(rec3, ms)), pin[f"{name}_seg_auto"])
 
 
 @pytest.mark.parametrize("name", cases.TIE_FREE)
@@ -89,44 +105,53 @@ def test_oracle_composite_equals_the_reference_on_real_skimage(pin, name):
     assert np.array_equal(centres, pin[f"{name}_centres"])
 
 
-def _recorded_peaks(pin, name, shape):
-    n = int(np.prod(shape))
-    return (np.unpackbits(pin[f"{name}_peaks2d"])[:n].reshape(shape).astype(bool), np.unpackbits(pin[f"{name}_peaks3d"])[:n].reshape(shape).astype(bool))
-
-
-def test_benchmark_stack_equals_the_reference_given_its_tie_choices(pin):
-    """512 x 512 x 32 / 566 cells.  45 of the ~4000 per-slice peak candidates come in exactly tied adjacent pairs (blobs symmetric about a
-    pixel edge); the recorded run kept the later pixel of each, the oracle keeps the earlier (machine-dependent upstream, see _ws_cases).
-    (1) With the recorded peaks in place of its own choice the oracle reproduces the reference's segmentation_auto and centres EXACTLY;
-    (2) with its own choice it differs in 96 of 8.4 M voxels (the boundary between one touching pair, one voxel elsewhere), same 566 cells."""
-    import scipy.ndimage as ndi
+def test_benchmark_stack_equals_the_reference(pin):
+    """512 x 512 x 32 / 566 cells, all 8.4 M voxels and the centres -- incl. the 45 exactly tied pairs of peak candidates (blobs symmetric about
+    a pixel edge) that numpy's introsort orders (with numpy's AVX-512 argsort, >= 1.25 on such CPUs, upstream itself keeps the other pixel of
+    each pair and 96 voxels come out differently: tests/golden/make_watershed_golden.py)."""
     prob, zr, ms = _case(pin, "headline")
-    want = pin["headline_seg_auto"]
-    p2, p3 = _recorded_peaks(pin, "headline", prob.shape)
-    labels, oms, ocn = wr.tracker_watershed(prob, zr, "min_size", ms, 0, peaks2d=p2, peaks3d=p3)
+    labels, centres, oms, ocn = wr.segment_centroids(prob, zr, "min_size", ms)
     assert (oms, ocn) == (int(pin["headline_para"][2]), 566)
-    assert np.array_equal(labels, want)
-    centres = np.asarray(ndi.center_of_mass(labels > 0, labels, range(1, 567)))
+    assert np.array_equal(labels, pin["headline_seg_auto"])
     assert np.array_equal(centres, pin["headline_centres"])
-    own, _, oms2, ocn2 = wr.segment_centroids(prob, zr, "min_size", ms)
-    assert (oms2, ocn2) == (oms, ocn) and 0 < int((own != want).sum()) < 200
-
-
-def test_exact_ties_are_resolved_by_an_unstable_sort_upstream(pin):
-    """The designed tie case (ridges of EQUAL maxima): scikit-image orders tied candidates with np.argsort(-intensities) -- unstable, on this
-    image's CPU an AVX-512 network sort -- so WHICH of the tied peaks stay is machine-dependent upstream.  What does not depend on the order
-    is pinned: per slice the same number of peaks with the same intensities (the spacing rule is `distance < min_distance`, strict)."""
+    n = prob.size
+    p2 = np.unpackbits(pin["headline_peaks2d"])[:n].reshape(prob.shape).astype(bool)
     import scipy.ndimage as ndi
-    prob, zr, ms = _case(pin, "ties")
-    want = np.unpackbits(pin["ties_peaks2d"])[:prob.size].reshape(prob.shape).astype(bool)
-    differs = 0
-    for z in range(prob.shape[2]):
+    for z in (0, 9, 17, 31):
         smooth = ndi.gaussian_filter(ndi.distance_transform_edt(prob[:, :, z] > 0.5, sampling=[1, 1]), 2, mode="constant")
-        got = wr.peak_local_max_mask(smooth, 7)
-        assert got.sum() == want[:, :, z].sum()
-        assert np.array_equal(np.sort(smooth[got]), np.sort(smooth[want[:, :, z]]))
-        differs += int((got != want[:, :, z]).any())
-    assert differs > 0, "the recorded order agrees with the oracle's everywhere: the tie case no longer exercises what it documents"
+        assert np.array_equal(wr.peak_local_max_mask(smooth, 7), p2[:, :, z])
+
+
+def test_argsort_restatement_equals_numpy_generic_sort():
+    """oracle.argsort_quicksort against np.argsort itself on the generic code path (the image's second interpreter with the AVX-512 dispatch
+    switched off): heavy ties, no ties, presorted, all-equal, organ-pipe (the heapsort fallback), sizes 0 ... 5000."""
+    import os
+    import subprocess
+    from pathlib import Path
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py):
+        pytest.skip("no second interpreter on this machine")
+    code = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from numpy.core._multiarray_umath import __cpu_features__ as cpu
+assert not cpu['AVX512_SKX']
+from oracle.watershed_ref import argsort_quicksort as aq
+rng = np.random.default_rng(0); bad = 0; total = 0
+for trial in range(600):
+    n = int(rng.integers(0, 40)) if trial % 3 == 0 else int(rng.integers(0, 4000)) if trial % 3 == 1 else int(rng.integers(0, 300))
+    k = int(rng.integers(1, 30)); mode = trial % 4
+    a = (rng.integers(0, k, n).astype(float) if mode == 0 else np.round(rng.normal(size=n), 1) if mode == 1 else rng.normal(size=n) if mode == 2
+         else -np.sort(rng.integers(0, k, n).astype(float)))
+    total += 1; bad += not np.array_equal(np.argsort(-a), aq(-a))
+for n in (16, 17, 33, 1000, 5000):
+    for a in (np.zeros(n), np.arange(n) % 2.0, np.concatenate([np.arange(n // 2), np.arange(n - n // 2, 0, -1)]).astype(float)):
+        total += 1; bad += not np.array_equal(np.argsort(-a), aq(-a))
+print('mismatches', bad, 'of', total)
+"""
+    env = dict(os.environ, NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([py, "-W", "ignore", "-c", code, str(Path(__file__).resolve().parent.parent)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "mismatches 0 of 615" in r.stdout, r.stdout[-300:] + r.stderr[-500:]
 
 
 @pytest.mark.gpu
@@ -139,12 +164,6 @@ def test_device_watershed_equals_the_reference_on_real_skimage(pin, name):
     assert (oms, ocn) == (int(pin[f"{name}_para"][2]), int(pin[f"{name}_para"][3]))
     got = labels.cpu().numpy()
     want = pin[f"{name}_seg_auto"]
-    if name == "headline":
-        # the tied-pair choices of the recorded run (previous test): the device makes the oracle's choice, and must then equal the ORACLE
-        # exactly (tests/test_watershed.py::test_device_watershed_headline_size); against the recording the same 96 voxels differ
-        own, _, _, _ = wr.segment_centroids(prob, zr, "min_size", ms)
-        assert np.array_equal(got, own) and 0 < int((got != want).sum()) < 200
-        return
     assert np.array_equal(got, want), f"{int((got != want).sum())} voxels differ"
     assert np.array_equal(centres.cpu().numpy(), pin[f"{name}_centres"])
     assert np.array_equal(sizes.cpu().numpy(), np.bincount(want.ravel())[1:])
