@@ -273,8 +273,8 @@ SegLayout seg_layout(long long V, int cap) {
 //     pair inwards, zero 'constant' borders, axis 0 then 1 (then 2), no fused multiply-add (the TU is built with -ffp-contract=off);
 //     the weights are computed by the host exactly as scipy does and passed in;
 //   * peaks: value == separable maximum over the (2 d + 1)^ndim window, none for a constant image, value > the image's minimum, border
-//     exclusion, and among EQUAL peaks closer than d the one with the smaller raveled index (skimage's ensure_spacing can only ever drop
-//     ties: inside the window two surviving maxima are equal); labels in raster order;
+//     exclusion, and among EQUAL peaks closer than d (strictly) the one numpy's generic argsort puts first (ws_aquicksort; skimage's
+//     ensure_spacing can only ever drop ties: inside the window two surviving maxima are equal); labels in raster order;
 //   * watershed: skimage's priority flood is inherently sequential (a heap of (value, age), labels given at push time).  Connected
 //     components of the mask never interact, and inside a component the order of pops only depends on the component's own entries, so
 //     every component is flooded by ONE thread with its own binary heap (value, age, raveled index): hundreds of components run side

@@ -8,8 +8,8 @@ Two region steps, both on the device:
 
 * ``watershed_centroids[_device]`` -- the reference's own marker watershed (watershed_2d per z slice, then watershed_3d, min_size /
   cell_num, relabel_sequential; ct_watershed_segment).  Held to the reference's own code running on scikit-image 0.18.3
-  (tests/golden/watershed_skimage.npz, tests/test_watershed_pin.py: seven volumes exactly, the 512 x 512 x 32 benchmark stack up to
-  upstream's machine-dependent choice among exactly tied peak candidates);
+  (tests/golden/watershed_skimage.npz, tests/test_watershed_pin.py: eight volumes incl. the 512 x 512 x 32 benchmark stack, voxel for
+  voxel, incl. numpy's sort order among exactly tied peak candidates);
   scipy's EDT / Gaussian arithmetic is reproduced operand for operand.  This is what ``Tracker._segment`` uses.
 * ``segment_centroids[_device]`` -- threshold + 3D connected components (touching cells are not split): the cheap variant SURVEY 8f#2
   names, kept as ``method="cc"`` and used by the per-frame ``FrameChain``.

@@ -14,21 +14,24 @@ not importable by the image's main interpreter, so its four functions are RESTAT
 (/opt/conda/bin/python3.9) carries scikit-image 0.18.3 (the generation `peak_local_max(indices=False)` needs): tests/golden/
 make_watershed_golden.py runs CellTracker/watershed.py and Tracker._watershed there, unmodified, and records every stage
 (tests/golden/watershed_skimage.npz); tests/test_watershed_pin.py holds each restatement to scikit-image's output exactly (fed with the
-recorded output of the stage before it), the composite to the reference's segmentation on seven volumes and -- given the recorded run's
-choice among exactly tied peaks, see below -- on the 512 x 512 x 32 benchmark stack (all 8.4 M voxels), the device path on the same.  The restatements:
+recorded output of the stage before it) and the composite to the reference's segmentation on eight volumes incl. the 512 x 512 x 32
+benchmark stack (all 8.4 M voxels), the device path on the same.  The restatements:
   * peak_local_max  -- skimage/feature/peak.py (0.18): image == maximum_filter(image, footprint (2 d + 1)^ndim, mode='constant'),
     no peaks for a trivial (constant) image, & image > threshold with threshold = image.min() (no absolute / relative threshold given),
     border of width min_distance excluded unless exclude_border is 0/False, then the peaks in descending intensity with every peak
     CLOSER THAN min_distance (Chebyshev, strict: two peaks exactly min_distance apart both stay) to an already kept one dropped
     (ensure_spacing).  Inside the maximum filter's footprint two surviving peaks can only be that close if they are EQUAL, so the last
-    step only acts on exact ties.  THE ONE THING THAT CANNOT BE PINNED: upstream orders tied candidates with np.argsort(-intensities), an
-    unstable sort (numpy >= 1.25 dispatches it to an AVX-512 network sort where the CPU has one), so which of several exactly equal
-    candidates stay is machine-dependent in the reference itself (symmetric shapes produce such ties: adjacent pixels either side of a
-    blob's centre line; the recorded run keeps the later one where this oracle keeps the earlier).  The order is fixed here as "smaller
-    raveled index first" -- one admissible outcome; the pin test compares peaks up to that choice and everything downstream exactly.
+    step only acts on exact ties -- and WHICH of several exactly equal candidates stay is decided by the order np.argsort(-intensities)
+    leaves them in: an unstable sort.  Every numpy before 1.25 (every numpy the reference's tensorflow==2.11 runs with) uses its generic
+    introsort, restated here as argsort_quicksort and checked against numpy itself; the golden vectors are recorded on that code path, and
+    the oracle equals them candidate for candidate.  (numpy >= 1.25 on a CPU with AVX-512 dispatches argsort to a network sort with another
+    order among equal keys: there the reference itself keeps the other pixel of a tied pair -- 45 pairs / 96 voxels on the benchmark stack.)
   * watershed       -- skimage/segmentation/_watershed_cy.pyx: a priority queue of (value, age), seeded with all marker pixels (age 0),
     pop the smallest, give every unlabelled in-mask neighbour (connectivity 1, in ascending raveled-offset order) the popped pixel's
-    label at PUSH time and push it with value = image[neighbour] and the next age.  Markers enter in raveled order (ages ascending).
+    label at PUSH time and push it with value = image[neighbour] and the next age.  STILL OPEN: all markers enter with age 0, so seeds of
+    EXACTLY equal height are popped in the order upstream's binary heap happens to hold them (its array layout); here: smaller raveled
+    index first.  It only matters for two equal seeds inside one basin system (the designed tie volume of the tests; not the benchmark
+    stack, not the random volumes) and then moves the boundary between them by a row.
   * find_boundaries(mode='outer') -- skimage/segmentation/boundaries.py: grey dilation != grey erosion over the connectivity-c
     structure, kept where the pixel is background or the full-connectivity neighbourhood holds two different OBJECT labels.
   * remove_small_objects on a label image (sizes by bincount of the labels as they are) and relabel_sequential.
