@@ -424,8 +424,8 @@ __global__ __launch_bounds__(256) void ws_peak_kernel(SegGeom g, int mode2d, int
 // pr - 1, the larger part pushed, ranges of <= 16 elements finished by insertion sort, heapsort for a popped range deeper than 2 floor(log2 n)
 // (numpy/core/src/npysort/quicksort.cpp aquicksort_, heapsort.cpp aheapsort_; oracle/watershed_ref.py::argsort_quicksort is the same
 // restatement, checked against numpy itself).  scikit-image orders peak candidates with it, so the choice among EXACTLY tied candidates closer
-// than min_distance is whatever this unstable sort leaves (every numpy before 1.25, later ones on CPUs without AVX-512).  One thread, LDS
-// arrays: vk[p] = key of the element at position p (moved together with ts[p] = its index, so a comparison is one LDS read, not two dependent ones).
+// than min_distance is whatever this unstable sort leaves (every numpy before 1.25, later ones on CPUs without AVX-512).  LDS arrays:
+// vk[p] = key of the element at position p (moved together with ts[p] = its index, so a comparison is one LDS read, not two dependent ones).
 __device__ void ws_aheapsort(int* vk, int* ts, int lo, int n) {
     // 1-based heap over positions lo .. lo + n - 1
 #define A_V(i) vk[lo + (i) - 1]
@@ -453,49 +453,67 @@ __device__ void ws_aheapsort(int* vk, int* ts, int lo, int n) {
 #undef A_V
 #undef A_T
 }
-__device__ void ws_aquicksort(int* vk, int* ts, int num, int* stack_lo /* LDS [3][64] */) {
-    if (num < 2) return;
-    int* stack_hi = stack_lo + 64; int* stack_depth = stack_lo + 128;
-    int sp = 0;
-    int pl = 0, pr = num - 1;
-    int cdepth = 0;
-    for (int n = num >> 1; n; n >>= 1) ++cdepth;
-    cdepth *= 2;
+// One range of the sort, by one thread, exactly as numpy's inner loop treats it: a range that comes off the stack beyond the depth limit is
+// heap-sorted; otherwise partition while it is longer than 16, hand the LARGER part on (numpy pushes it on its stack; here it joins the next
+// round's list -- ranges are disjoint, so the order in which they are processed does not change the result) and continue with the smaller
+// one, then insertion sort.
+constexpr int WS_QS_RANGES = 512;                 // >= n / 17 partitions per round at n = WS_PEAK_CAP3D
+__device__ void ws_sort_range(int* vk, int* ts, int pl, int pr, int cdepth, bool from_stack, int* nxt, int* nxt_count) {
+    if (from_stack && cdepth < 0) { ws_aheapsort(vk, ts, pl, pr - pl + 1); return; }
 #define WS_SWAP(a, b) { const int tv_ = vk[a], tt_ = ts[a]; vk[a] = vk[b]; ts[a] = ts[b]; vk[b] = tv_; ts[b] = tt_; }
-    for (;;) {
-        if (cdepth < 0) ws_aheapsort(vk, ts, pl, pr - pl + 1);
-        else {
-            while (pr - pl > 15) {
-                const int pm = pl + ((pr - pl) >> 1);
-                if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
-                if (vk[pr] < vk[pm]) WS_SWAP(pr, pm)
-                if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
-                const int vp = vk[pm];
-                int pi = pl, pj = pr - 1;
-                WS_SWAP(pm, pj)
-                for (;;) {
-                    do ++pi; while (vk[pi] < vp);
-                    do --pj; while (vp < vk[pj]);
-                    if (pi >= pj) break;
-                    WS_SWAP(pi, pj)
-                }
-                const int pk = pr - 1;
-                WS_SWAP(pi, pk)
-                --cdepth;
-                if (pi - pl < pr - pi) { stack_lo[sp] = pi + 1; stack_hi[sp] = pr; stack_depth[sp] = cdepth; ++sp; pr = pi - 1; }
-                else { stack_lo[sp] = pl; stack_hi[sp] = pi - 1; stack_depth[sp] = cdepth; ++sp; pl = pi + 1; }
-            }
-            for (int pi = pl + 1; pi <= pr; ++pi) {
-                const int vv = vk[pi], tt = ts[pi];
-                int pj = pi;
-                while (pj > pl && vv < vk[pj - 1]) { vk[pj] = vk[pj - 1]; ts[pj] = ts[pj - 1]; --pj; }
-                vk[pj] = vv; ts[pj] = tt;
-            }
+    while (pr - pl > 15) {
+        const int pm = pl + ((pr - pl) >> 1);
+        if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
+        if (vk[pr] < vk[pm]) WS_SWAP(pr, pm)
+        if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
+        const int vp = vk[pm];
+        int pi = pl, pj = pr - 1;
+        WS_SWAP(pm, pj)
+        for (;;) {
+            do ++pi; while (vk[pi] < vp);
+            do --pj; while (vp < vk[pj]);
+            if (pi >= pj) break;
+            WS_SWAP(pi, pj)
         }
-        if (sp == 0) break;
-        --sp; pl = stack_lo[sp]; pr = stack_hi[sp]; cdepth = stack_depth[sp];
+        const int pk = pr - 1;
+        WS_SWAP(pi, pk)
+        --cdepth;
+        const int k = atomicAdd(nxt_count, 1);
+        if (pi - pl < pr - pi) { nxt[3 * k] = pi + 1; nxt[3 * k + 1] = pr; nxt[3 * k + 2] = cdepth; pr = pi - 1; }
+        else { nxt[3 * k] = pl; nxt[3 * k + 1] = pi - 1; nxt[3 * k + 2] = cdepth; pl = pi + 1; }
+    }
+    for (int pi = pl + 1; pi <= pr; ++pi) {
+        const int vv = vk[pi], tt = ts[pi];
+        int pj = pi;
+        while (pj > pl && vv < vk[pj - 1]) { vk[pj] = vk[pj - 1]; ts[pj] = ts[pj - 1]; --pj; }
+        vk[pj] = vv; ts[pj] = tt;
     }
 #undef WS_SWAP
+}
+// The whole sort by a 1024-thread workgroup (every thread calls it): rounds of disjoint ranges, lane 0 of each of the 16 waves takes every
+// 16th range of the round (lanes of one wave would only serialise).  The critical path is ~3 n element steps instead of n log n (the 3-D stage
+// of the benchmark stack: 0.49 -> 0.30 ms, an element step of one thread is ~100 ns of LDS latency); same permutation as a one-thread replay.
+__device__ void ws_aquicksort_block(int* vk, int* ts, int num, int* lists /* LDS [2][3 * WS_QS_RANGES] */, int* counts /* LDS [2] */) {
+    if (num < 2) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
+        int cdepth = 0;
+        for (int n = num >> 1; n; n >>= 1) ++cdepth;
+        lists[0] = 0; lists[1] = num - 1; lists[2] = 2 * cdepth;
+        counts[0] = 1; counts[1] = 0;
+    }
+    __syncthreads();
+    for (int round = 0;; ++round) {
+        const int n_cur = counts[round & 1];
+        if (n_cur == 0) break;
+        int* cur = lists + (round & 1) * 3 * WS_QS_RANGES;
+        int* nxt = lists + ((round + 1) & 1) * 3 * WS_QS_RANGES;
+        if (lane == 0)
+            for (int j = wave; j < n_cur; j += 16) ws_sort_range(vk, ts, cur[3 * j], cur[3 * j + 1], cur[3 * j + 2], round > 0, nxt, &counts[(round + 1) & 1]);
+        __syncthreads();
+        if (threadIdx.x == 0) counts[round & 1] = 0;
+        __syncthreads();
+    }
 }
 
 // One workgroup per group: final peak test, ensure_spacing among exact ties, raster-order marker labels.
@@ -596,8 +614,8 @@ __global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mod
             ts[t] = t; kf[t] = (t < nv) ? 1 : 0;
         }
         __syncthreads();
-        __shared__ int qs_stack[3 * 64];
-        if (threadIdx.x == 0) ws_aquicksort(keep, ts, nv, qs_stack);
+        __shared__ int qs_lists[2 * 3 * WS_QS_RANGES], qs_counts[2];
+        ws_aquicksort_block(keep, ts, nv, qs_lists, qs_counts);
         __syncthreads();
         // greedy spacing inside every run of equal rank, in numpy's order (run starts in parallel)
         for (int t = threadIdx.x; t < nv; t += 1024) {
