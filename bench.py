@@ -350,7 +350,8 @@ def roofline_from_timing(ctx, args, n_patches, steps):
                 # the reference operator's flops (2 * 27 * Cin * Cout per computed voxel; one product per fp32 product) over the same
                 # duration against the peak of the pipe the kernel runs on: `frac` is pipe utilisation, this is useful work
                 "algorithmic_frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / peak_tf, 4) if dom["ms"] > 0 else None,
-                "traffic": traffic, "kernel": dom_name,
+                # contract: HBM bytes per launch of this kernel from the PMC counters (number or null); where it comes from is traffic_detail
+                "traffic": traffic["hbm_bytes_per_launch"] if traffic else None, "traffic_detail": traffic, "kernel": dom_name,
                 "math": ("f16x3 split (2 fp16 components per operand, 3 MFMA products per fp32 product, per-patch power-of-two scaling, fp32 accumulate)" if dom.get("f16") else
                          "bf16x6 split (6 bf16 MFMA products per fp32 product, fp32 accumulate)") if dom["bf"] else "f32-input MFMA",
                 "fp32_equivalent_tflops": round(dom_fp32_equiv, 2),

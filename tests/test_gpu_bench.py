@@ -37,6 +37,7 @@ def test_single_gpu_modes_share_one_schema():
         assert line["metric"].startswith("volumes/s segment+match") and "workload" in line["config"] and "model" not in line["config"]
         r = line["roofline"]
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert r["traffic"] is None or isinstance(r["traffic"], (int, float))          # bytes per launch (PMC), the contract's scalar
         assert r["hbm_bound_kernel"]["kernel"].startswith(("conv_first_f16_kernel", "conv_l0l1_fused_kernel"))   # (the first conv runs inside the second's workgroups)
         assert 0 < r["algorithmic_frac"] <= r["frac"] and 0 < r["conv_stack_hbm_frac"] < 1
         assert line["config"]["headline_excludes"] and line["config"]["rccl_ranks"]["world_size"] == 1
