@@ -503,6 +503,22 @@ def test_prgls_2000_cells_to_convergence_against_oracle():
     assert float(np.abs(moved[perm[keep]] - yn[keep]).max()) < 0.02       # the true pairs end up on top of each other
 
 
+def test_prgls_2700_cells_wide_estep_against_oracle():
+    """n = 2700: nine waves per E-step block, i.e. the 1024-thread instantiation of estep_rows_kernel (128 VGPRs, a few spilled registers);
+    the whole EM run against the reference formulation."""
+    xn, yn, corr, tracked, perm, keep = _converging_case(2700, seed=31, n_tracked=300)
+    prior, pairs = tl.simple_match(corr)
+    prior_o, pairs_o = mr.simple_match(corr)
+    assert np.array_equal(pairs, pairs_o) and np.array_equal(prior, prior_o)
+    ref, post_o, iters = mr.prgls_with_two_ref(prior_o, yn, xn, tracked, beta=3, lambda_=3, return_iters=True)
+    t = dev.torch()
+    out_l, out_n, post, iters_dev = dev.prgls_two_ref(dev.to_dev(prior.astype(np.float64), t.float64), dev.points_dev(yn), dev.points_dev(xn),
+                                                      dev.points_dev(tracked), 3, 3, 2000, want_ref=True)
+    assert int(iters_dev) == iters and 4 <= iters <= 15
+    np.testing.assert_allclose(out_l.cpu().numpy(), ref, rtol=0, atol=COORD_TOL)
+    np.testing.assert_allclose(post.cpu().numpy(), post_o, rtol=0, atol=COORD_TOL)
+
+
 def test_prgls_legacy_dialect_600_cells_against_oracle():
     """The legacy dialect (track.py:11-56: beta 1000 -> lambda 1e-5, 10 iterations, dense M-step) at the headline cell count."""
     xn, yn, corr, _, perm, keep = _converging_case(600, seed=77)
