@@ -28,10 +28,12 @@ benchmark stack (all 8.4 M voxels), the device path on the same.  The restatemen
     order among equal keys: there the reference itself keeps the other pixel of a tied pair -- 45 pairs / 96 voxels on the benchmark stack.)
   * watershed       -- skimage/segmentation/_watershed_cy.pyx: a priority queue of (value, age), seeded with all marker pixels (age 0),
     pop the smallest, give every unlabelled in-mask neighbour (connectivity 1, in ascending raveled-offset order) the popped pixel's
-    label at PUSH time and push it with value = image[neighbour] and the next age.  STILL OPEN: all markers enter with age 0, so seeds of
-    EXACTLY equal height are popped in the order upstream's binary heap happens to hold them (its array layout); here: smaller raveled
-    index first.  It only matters for two equal seeds inside one basin system (the designed tie volume of the tests; not the benchmark
-    stack, not the random volumes) and then moves the boundary between them by a row.
+    label at PUSH time and push it with value = image[neighbour] and the next age.  All markers enter with age 0, so seeds of EXACTLY
+    equal height are popped in the order upstream's binary heap happens to hold them (its array layout, global over the image): restated
+    as _UpstreamHeap (seed_order="upstream": with it the oracle equals the reference on ALL nine recorded volumes, the designed tie volume
+    included).  The DEFAULT is seed_order="raveled" -- smaller raveled index first -- because that is what the device can do: it floods
+    every basin system on its own, and upstream's order depends on the whole image's heap.  The two differ only where two equal seeds
+    share a basin (the designed tie volume; not the benchmark stack, not the random volumes): the boundary between them moves by a row.
   * find_boundaries(mode='outer') -- skimage/segmentation/boundaries.py: grey dilation != grey erosion over the connectivity-c
     structure, kept where the pixel is background or the full-connectivity neighbourhood holds two different OBJECT labels.
   * remove_small_objects on a label image (sizes by bincount of the labels as they are) and relabel_sequential.
@@ -182,8 +184,59 @@ def label_full(mask: np.ndarray) -> np.ndarray:
     return lab.astype(np.int32)
 
 
-def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.ndarray:
-    """skimage.segmentation.watershed(image, markers, mask=mask) (connectivity 1, no compactness, no watershed line)."""
+class _UpstreamHeap:
+    """skimage/segmentation/heap_general.pxi + heap_watershed.pxi restated: a textbook binary heap over (value, age) -- push appends and sifts
+    up while STRICTLY smaller than the parent; pop moves the last element to the root and sifts it down towards the strictly smaller child
+    (the left one when both children tie).  Elements that compare equal -- only the seeds can: every later element has its own age -- come out
+    in an order that depends on this array layout.  Checked against skimage.segmentation.watershed itself on 60 tie-heavy inputs."""
+
+    def __init__(self):
+        self.h = []
+
+    @staticmethod
+    def _smaller(a, b):
+        return a[0] < b[0] or (a[0] == b[0] and a[1] < b[1])
+
+    def push(self, e):
+        h = self.h
+        h.append(e)
+        c = len(h) - 1
+        while c > 0:
+            p = (c + 1) // 2 - 1
+            if self._smaller(h[c], h[p]):
+                h[c], h[p] = h[p], h[c]; c = p
+            else:
+                break
+
+    def pop(self):
+        h = self.h
+        top = h[0]
+        last = h.pop()
+        if h:
+            h[0] = last
+            i, n = 0, len(h)
+            while True:
+                l, r, sm = 2 * i + 1, 2 * i + 2, i
+                if l >= n:
+                    break
+                if self._smaller(h[l], h[i]):
+                    sm = l
+                if r < n and self._smaller(h[r], h[sm]):
+                    sm = r
+                if sm == i:
+                    break
+                h[i], h[sm] = h[sm], h[i]; i = sm
+        return top
+
+    def __len__(self):
+        return len(self.h)
+
+
+def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray, seed_order: str = "raveled") -> np.ndarray:
+    """skimage.segmentation.watershed(image, markers, mask=mask) (connectivity 1, no compactness, no watershed line).
+    seed_order: how seeds of EXACTLY equal height are popped -- "raveled" (smaller raveled index first: the rule of the device path, whose
+    basins are flooded independently) or "upstream" (the order scikit-image's own heap leaves them in, _UpstreamHeap).  Every other element
+    carries its own age, so the two only differ where two equal seeds share a basin."""
     image = np.asarray(image, dtype=np.float64)
     shape = image.shape
     out = np.where(mask, markers, 0).astype(np.int32).ravel().copy()      # markers outside the mask are dropped (skimage: markers[~mask] = 0)
@@ -191,12 +244,22 @@ def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.nd
     msk = np.asarray(mask, dtype=bool).ravel()
     strides = [int(np.prod(shape[a + 1:])) for a in range(len(shape))]
     offs = sorted([(-s, a, -1) for a, s in enumerate(strides)] + [(s, a, 1) for a, s in enumerate(strides)])   # ascending raveled offset
-    heap = [(img[i], 0, int(i)) for i in np.flatnonzero(out)]
-    heapq.heapify(heap)
-    age = 0
     coords_of = lambda i: np.unravel_index(i, shape)
-    while heap:
-        _, _, i = heapq.heappop(heap)
+    if seed_order == "upstream":
+        up = _UpstreamHeap()
+        for i in np.flatnonzero(out):
+            up.push((img[i], 0, int(i)))
+        push, pop, pending = up.push, up.pop, up
+        age = 1
+    elif seed_order == "raveled":
+        heap = [(img[i], 0, int(i)) for i in np.flatnonzero(out)]
+        heapq.heapify(heap)
+        push, pop, pending = (lambda e: heapq.heappush(heap, e)), (lambda: heapq.heappop(heap)), heap
+        age = 0
+    else:
+        raise ValueError("seed_order is 'raveled' or 'upstream'")
+    while len(pending):
+        _, _, i = pop()
         ci = coords_of(i)
         for off, ax, sgn in offs:
             c = ci[ax] + sgn
@@ -207,7 +270,7 @@ def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.nd
                 continue
             age += 1
             out[j] = out[i]
-            heapq.heappush(heap, (img[j], age, int(j)))
+            push((img[j], age, int(j)))
     return out.reshape(shape)
 
 
@@ -242,7 +305,7 @@ def relabel_sequential(labels: np.ndarray) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------ the reference's functions
-def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, collect=None, peaks=None):
+def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, collect=None, peaks=None, seed_order: str = "raveled"):
     """watershed.py:16-53 -> (bn_output, boundary).  peaks (tests only): a recorded peak mask [x, y, z] used instead of peak_local_max's --
     the choice among exactly tied candidates that one particular upstream run made (see the header)."""
     image_pred = np.asarray(image_pred)
@@ -253,7 +316,7 @@ def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, co
         dist_smooth = ndi.gaussian_filter(dist, 2, mode="constant")
         local_maxi = peak_local_max_mask(dist_smooth, min_distance=min_distance) if peaks is None else np.asarray(peaks[:, :, z], dtype=bool)
         markers = label_full(local_maxi)
-        labels_ws = watershed(-dist_smooth, markers, bn)
+        labels_ws = watershed(-dist_smooth, markers, bn, seed_order)
         boundary[:, :, z] = find_boundaries_outer(labels_ws, connectivity=2)
         if collect is not None:
             collect.append({"dist": dist, "dist_smooth": dist_smooth, "peaks": local_maxi, "labels": labels_ws})
@@ -262,13 +325,14 @@ def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, co
     return bn_output, boundary
 
 
-def watershed_3d(image_watershed2d: np.ndarray, samplingrate, method: str, min_size: int, cell_num: int, min_distance: int, collect=None, peaks=None):
+def watershed_3d(image_watershed2d: np.ndarray, samplingrate, method: str, min_size: int, cell_num: int, min_distance: int, collect=None, peaks=None,
+                 seed_order: str = "raveled"):
     """watershed.py:55-108 -> (labels_wo_bd, labels_clear, min_size, cell_num).  peaks: as in watershed_2d."""
     dist = ndi.distance_transform_edt(image_watershed2d, sampling=samplingrate)
     dist_smooth = ndi.gaussian_filter(dist, (2, 2, 0.3), mode="constant")
     local_maxi = peak_local_max_mask(dist_smooth, min_distance=min_distance, exclude_border=0) if peaks is None else np.asarray(peaks, dtype=bool)
     markers = label_full(local_maxi)
-    labels_ws = watershed(-dist_smooth, markers, image_watershed2d)
+    labels_ws = watershed(-dist_smooth, markers, image_watershed2d, seed_order)
     counts = np.sort(np.bincount(labels_ws.ravel()))
     if method == "min_size":
         cell_num = int(np.sum(counts >= min_size) - 1)
@@ -287,17 +351,19 @@ def watershed_3d(image_watershed2d: np.ndarray, samplingrate, method: str, min_s
 
 
 def tracker_watershed(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0,
-                      peaks2d=None, peaks3d=None):
+                      peaks2d=None, peaks3d=None, seed_order: str = "raveled"):
     """Tracker._watershed (tracker.py:671-684) -> (segmentation_auto int32, min_size, cell_num)."""
     img = np.asarray(image_cell_bg_xyz)
-    wo_border, _ = watershed_2d(img, z_range=img.shape[2], min_distance=7, peaks=peaks2d)
-    _, wi_border, min_size, cell_num = watershed_3d(wo_border, [1, 1, z_xy_ratio], method, min_size, cell_num, min_distance=3, peaks=peaks3d)
+    wo_border, _ = watershed_2d(img, z_range=img.shape[2], min_distance=7, peaks=peaks2d, seed_order=seed_order)
+    _, wi_border, min_size, cell_num = watershed_3d(wo_border, [1, 1, z_xy_ratio], method, min_size, cell_num, min_distance=3, peaks=peaks3d,
+                                                    seed_order=seed_order)
     return relabel_sequential(wi_border), min_size, cell_num
 
 
-def segment_centroids(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0):
+def segment_centroids(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0,
+                      seed_order: str = "raveled"):
     """-> (labels int32, centres float64 [n, 3] via the reference's center_of_mass call (tracker.py:646-647), min_size, cell_num)."""
-    labels, min_size, cell_num = tracker_watershed(image_cell_bg_xyz, z_xy_ratio, method, min_size, cell_num)
+    labels, min_size, cell_num = tracker_watershed(image_cell_bg_xyz, z_xy_ratio, method, min_size, cell_num, seed_order=seed_order)
     n = int(labels.max())
     centres = np.asarray(ndi.center_of_mass(labels > 0, labels, range(1, n + 1)), dtype=np.float64).reshape(n, 3) if n else np.zeros((0, 3))
     return labels, centres, min_size, cell_num

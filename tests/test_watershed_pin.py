@@ -13,7 +13,6 @@ import _ws_cases as cases
 from oracle import watershed_ref as wr
 
 synth = importlib.import_module("3deecelltracker_amd.synth")
-SMALL_FINAL = cases.TIE_FREE + ("random_a", "random_b", "random_c")
 
 
 @pytest.fixture(scope="module")
@@ -48,43 +47,64 @@ def _tied_marker_components(mask, peaks, smooth):
     return out
 
 
-@pytest.mark.parametrize("name", cases.TIE_FREE + ("random_a", "random_b", "random_c", "ties"))
+ALL_SMALL = cases.TIE_FREE + ("random_a", "random_b", "random_c", "ties")
+
+
+@pytest.mark.parametrize("name", ALL_SMALL)
 def test_restated_primitives_equal_skimage_stage_by_stage(pin, name):
-    """Every restated primitive against scikit-image's own output, each fed with the RECORDED output of the stage before it: peak_local_max
-    (incl. the choice among exactly tied candidates: numpy's introsort restated, oracle.argsort_quicksort), label + watershed, find_boundaries,
-    the 2-D composite, label + watershed in 3-D, the size bookkeeping.  The one thing left open: seeds of exactly equal height inside one
-    basin system (the designed tie volume only) -- upstream's heap pops them in an order that depends on its array layout; the oracle takes the
-    smaller raveled index.  Outside such components the flood must agree there too."""
+    """Every restated primitive against scikit-image's own output, each fed with the RECORDED output of the stage before it, EXACTLY, on all
+    eight small volumes incl. the designed tie volume: peak_local_max (the choice among exactly tied candidates: numpy's introsort restated,
+    oracle.argsort_quicksort), label + watershed (seeds of exactly equal height in upstream's heap order, oracle._UpstreamHeap),
+    find_boundaries, the 2-D composite, label + watershed in 3-D, the size bookkeeping."""
     import scipy.ndimage as ndi
     prob, zr, ms = _case(pin, name)
     unpack = lambda key, dt=bool: np.unpackbits(pin[f"{name}_{key}"])[:prob.size].reshape(prob.shape).astype(dt)
     peaks2d, bd2d, wo2d, peaks3d = unpack("peaks2d"), unpack("bd2d"), unpack("wo2d"), unpack("peaks3d")
     labels2d = pin[f"{name}_labels2d"]
-    open_voxels = 0
     for z in range(prob.shape[2]):
         bn = prob[:, :, z] > 0.5
         smooth = ndi.gaussian_filter(ndi.distance_transform_edt(bn, sampling=[1, 1]), 2, mode="constant")
         assert np.array_equal(wr.peak_local_max_mask(smooth, 7), peaks2d[:, :, z]), f"peak_local_max, slice {z}"
-        lab = wr.watershed(-smooth, wr.label_full(peaks2d[:, :, z]), bn)
-        tied = _tied_marker_components(bn, peaks2d[:, :, z], smooth)
-        assert np.array_equal(lab[~tied], labels2d[:, :, z][~tied]), f"label + watershed, slice {z}"
-        open_voxels += int((lab != labels2d[:, :, z]).sum())
-        assert np.array_equal(wr.find_boundaries_outer(labels2d[:, :, z], 2), bd2d[:, :, z]), f"find_boundaries, slice {z}"
-    assert open_voxels == 0 or name == "ties"          # (the touching pair of identical blobs has such seeds too and still agrees)
+        lab = wr.watershed(-smooth, wr.label_full(peaks2d[:, :, z]), bn, seed_order="upstream")
+        assert np.array_equal(lab, labels2d[:, :, z]), f"label + watershed, slice {z}"
+        assert np.array_equal(wr.find_boundaries_outer(lab, 2), bd2d[:, :, z]), f"find_boundaries, slice {z}"
     wo = prob > 0.5
     wo[bd2d] = False
     assert np.array_equal(wo, wo2d)
     smooth3 = ndi.gaussian_filter(ndi.distance_transform_edt(wo2d, sampling=[1, 1, zr]), (2, 2, 0.3), mode="constant")
     assert np.array_equal(wr.peak_local_max_mask(smooth3, 3, exclude_border=0), peaks3d), "peak_local_max (3-D)"
-    lab3 = wr.watershed(-smooth3, wr.label_full(peaks3d), wo2d)
-    tied3 = _tied_marker_components(wo2d, peaks3d, smooth3)
-    assert np.array_equal(lab3[~tied3], pin[f"{name}_labels3d"][~tied3]), "label + watershed (3-D)"
-    assert np.array_equal(lab3, pin[f"{name}_labels3d"]) or name == "ties"
-    # min_size bookkeeping, remove_small_objects, relabel_sequential on the recorded 3-D labels
-    rec3 = pin[f"{name}_labels3d"].astype(np.int32)
-    counts = np.sort(np.bincount(rec3.ravel()))
+    lab3 = wr.watershed(-smooth3, wr.label_full(peaks3d), wo2d, seed_order="upstream")
+    assert np.array_equal(lab3, pin[f"{name}_labels3d"]), "label + watershed (3-D)"
+    counts = np.sort(np.bincount(lab3.ravel()))
     assert int(np.sum(counts >= ms) - 1) == int(pin[f"{name}_para"][3])
-    assert np.array_equal(wr.relabel_sequential(wr.remove_small_objects(rec3, ms)), pin[f"{name}_seg_auto"])
+    assert np.array_equal(wr.relabel_sequential(wr.remove_small_objects(lab3, ms)), pin[f"{name}_seg_auto"])
+
+
+@pytest.mark.parametrize("name", ALL_SMALL)
+def test_seed_order_is_the_only_open_rule_and_only_bites_on_the_tie_volume(pin, name):
+    """The device floods every basin system on its own and pops seeds of exactly equal height by raveled index (the oracle's default);
+    upstream's order among them comes from ONE heap over the whole image.  Whole pipeline, both rules: with upstream's the oracle equals
+    the reference on every volume; with the device's it does on all but the designed tie volume -- and there only inside basin systems
+    that hold two seeds of exactly equal height."""
+    import scipy.ndimage as ndi
+    prob, zr, ms = _case(pin, name)
+    want = pin[f"{name}_seg_auto"]
+    up, ucen, ums, ucn = wr.segment_centroids(prob, zr, "min_size", ms, seed_order="upstream")
+    assert np.array_equal(up, want) and (ums, ucn) == (int(pin[f"{name}_para"][2]), int(pin[f"{name}_para"][3]))
+    assert np.array_equal(ucen, pin[f"{name}_centres"])
+    own, _, _, _ = wr.segment_centroids(prob, zr, "min_size", ms)
+    if name != "ties":
+        assert np.array_equal(own, want)
+        return
+    assert not np.array_equal(own, want)
+    # 2-D stage: every differing pixel lies in a basin system with tied seeds
+    peaks2d = np.unpackbits(pin["ties_peaks2d"])[:prob.size].reshape(prob.shape).astype(bool)
+    for z in range(prob.shape[2]):
+        bn = prob[:, :, z] > 0.5
+        smooth = ndi.gaussian_filter(ndi.distance_transform_edt(bn, sampling=[1, 1]), 2, mode="constant")
+        a = wr.watershed(-smooth, wr.label_full(peaks2d[:, :, z]), bn)
+        tied = _tied_marker_components(bn, peaks2d[:, :, z], smooth)
+        assert np.array_equal(a[~tied], pin["ties_labels2d"][:, :, z][~tied])
 
 
 @pytest.mark.parametrize("name", cases.TIE_FREE)
@@ -94,15 +114,6 @@ def test_cell_num_method_equals_the_reference(pin, name):
     cn_in, ms2, cn2 = (int(v) for v in pin[f"{name}_cellnum"])
     _, clear_cn, oms2, ocn2 = wr.watershed_3d(wo, [1, 1, zr], "cell_num", 0, cn_in, 3)
     assert (oms2, ocn2) == (ms2, cn2) and np.array_equal(clear_cn, pin[f"{name}_clear_cellnum"])
-
-
-@pytest.mark.parametrize("name", SMALL_FINAL)
-def test_oracle_composite_equals_the_reference_on_real_skimage(pin, name):
-    prob, zr, ms = _case(pin, name)
-    labels, centres, oms, ocn = wr.segment_centroids(prob, zr, "min_size", ms)
-    assert (oms, ocn) == (int(pin[f"{name}_para"][2]), int(pin[f"{name}_para"][3]))
-    assert np.array_equal(labels, pin[f"{name}_seg_auto"])
-    assert np.array_equal(centres, pin[f"{name}_centres"])
 
 
 def test_benchmark_stack_equals_the_reference(pin):
@@ -152,6 +163,36 @@ print('mismatches', bad, 'of', total)
     env = dict(os.environ, NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL", PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([py, "-W", "ignore", "-c", code, str(Path(__file__).resolve().parent.parent)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "mismatches 0 of 615" in r.stdout, r.stdout[-300:] + r.stderr[-500:]
+
+
+def test_upstream_heap_restatement_equals_skimage_watershed():
+    """oracle.watershed(seed_order="upstream") against skimage.segmentation.watershed itself (second interpreter) on inputs made of ties:
+    integer-valued images with 2-12 random seeds, random masks, 2-D and 3-D."""
+    import os
+    import subprocess
+    from pathlib import Path
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py):
+        pytest.skip("no second interpreter on this machine")
+    code = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from skimage.segmentation import watershed as sk
+from oracle.watershed_ref import watershed as ours
+rng = np.random.default_rng(0); bad = 0; total = 0
+for t in range(60):
+    nd = 2 if t < 45 else 3
+    shape = tuple(int(rng.integers(8, 40)) for _ in range(2)) if nd == 2 else (int(rng.integers(6, 14)),) * 3
+    img = rng.integers(0, 4 if nd == 2 else 3, shape).astype(float)
+    mask = rng.uniform(size=shape) > 0.15
+    mk = np.zeros(shape, np.int32); k = int(rng.integers(2, 12))
+    mk.ravel()[rng.choice(img.size, k, replace=False)] = np.arange(1, k + 1)
+    total += 1; bad += not np.array_equal(sk(img, mk, mask=mask), ours(img, mk, mask, seed_order='upstream'))
+print('mismatches', bad, 'of', total)
+"""
+    r = subprocess.run([py, "-W", "ignore", "-c", code, str(Path(__file__).resolve().parent.parent)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0 and "mismatches 0 of 60" in r.stdout, r.stdout[-300:] + r.stderr[-500:]
 
 
 @pytest.mark.gpu
