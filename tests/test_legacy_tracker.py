@@ -280,3 +280,22 @@ def test_device_notebook_flow_from_tiff_folders(ffn_w, tmp_path):
     assert len(trk.history.r_tracked_coordinates) == 3
     trk.save_coordinates()
     assert (tmp_path / "track_information" / "tracked_coordinates.csv").exists()
+
+
+def test_volume1_setup_equals_the_reference_on_real_skimage(golden_dir):
+    """load_manual_seg + interpolate_seg against THE REFERENCE's own run with the real scikit-image / tifffile (tests/golden/
+    make_interpolate_seg_golden.py, second interpreter): the TIFF layers written by tifffile are read with PIL, relabel_sequential is numpy,
+    skimage.filters.gaussian is scipy's gaussian_filter, skimage.measure.label is scipy's label -- label images, z range and centres identical."""
+    import types
+    tracker = importlib.import_module("3deecelltracker_amd.tracker")
+    want = np.load(golden_dir / "interpolate_seg.npz")
+    trk = tracker.Tracker.for_matching(None, siz_xyz=(40, 44, 6), z_xy_ratio=float(want["para"][0]), z_scaling=int(want["para"][1]))
+    trk.paths = types.SimpleNamespace(manual_segmentation_vol1=str(golden_dir / "manual_vol1") + "/")
+    trk.load_manual_seg()
+    assert np.array_equal(trk.segmentation_manual_relabels, want["loaded_relabelled"])
+    trk.interpolate_seg()
+    assert np.array_equal(trk.seg_cells_interpolated_corrected, want["seg_interp"])
+    assert list(trk.Z_RANGE_INTERP) == want["z_range_interp"].tolist()
+    assert np.array_equal(trk.segmentation_manual_relabels, want["manual_relabels"])
+    assert trk.cell_num_t0 == int(want["cell_num_t0"])
+    np.testing.assert_allclose(trk.r_coordinates_tracked_t0, want["r_tracked_t0"], rtol=0, atol=1e-12)
