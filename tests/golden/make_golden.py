@@ -38,7 +38,10 @@ def _stub_modules():
              "skimage.feature", "csbdeep", "csbdeep.utils", "csbdeep.utils.tf", "csbdeep.models",
              "stardist", "stardist.models", "stardist.utils", "stardist.nms", "stardist.matching",
              "stardist.models.base", "stardist.geometry", "stardist.rays3d"]
+    import importlib.machinery
     for n in names:
+        if importlib.machinery.PathFinder.find_spec(n.split(".")[0]) is not None:      # really there (the image's second interpreter has skimage / tifffile / h5py)
+            continue
         m = MagicMock(name=n)
         m.__path__ = []
         m.__name__ = n
@@ -53,6 +56,7 @@ def _stub_modules():
 
 
 _stub_modules()
+REAL_SKIMAGE = not isinstance(sys.modules.get("skimage", None), MagicMock)
 import matplotlib  # noqa: E402
 matplotlib.use("Agg")
 
@@ -313,7 +317,12 @@ def gen_legacy_tracker():
     a temp dir), cal_subregions (:1095-1112), initiate_tracking, _get_cells_onBoundary, _transform_cells_quick,
     _correction_once_interp, _accurate_correction and match (:1138-1175).
 
-    What cannot run here and is replaced, nothing else: tifffile's imread inside read_image_ts (the stack is handed over in
+    Under the image's second interpreter (/opt/conda/bin/python3.9: scikit-image 0.18.3 and tifffile real; run with
+    NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL" for numpy's generic sort) the same function writes
+    legacy_tracker_real.npz with the watershed UNPATCHED and the stack read from per-layer TIFF files by the reference's own read_image_ts;
+    tests/test_legacy_tracker.py holds the two recordings against each other (identical integers, floats within 1e-12).
+
+    What cannot run in the main interpreter and is replaced there, nothing else: tifffile's imread inside read_image_ts (the stack is handed over in
     memory), scikit-image's four primitives under the reference's own `_watershed` (restated, oracle/watershed_ref.py), the matplotlib animation of _predict_pos_once(draw=True) (draw forced off) and
     interpolate_seg (skimage; its results -- seg_cells_interpolated_corrected, Z_RANGE_INTERP, r_coordinates_tracked_t0 --
     are set from a synthetic label image with the same scipy.ndimage.center_of_mass call, :1070-1075).  The probability map
@@ -329,7 +338,7 @@ def gen_legacy_tracker():
     for ci, (seed, siz, zs, ratio, ncell, ens, margin) in enumerate(((0, (120, 136, 14), 5, 4.0, 40, False, 6.5), (1, (96, 110, 12), 3, 2.5, 30, 5, 10.0))):
         case = ct_synth.make_legacy_frame_case(seed, siz, zs, ratio, ncell, margin=margin, edge_cells=2 if margin < 10 else 0)
         tmp = tempfile.mkdtemp()
-        _, restore_ws = _reference_watershed_on_restated_skimage()
+        restore_ws = (lambda: None) if REAL_SKIMAGE else _reference_watershed_on_restated_skimage()[1]
         with contextlib.redirect_stdout(io.StringIO()):
             trk = ref_tracker.Tracker(volume_num=8, siz_xyz=siz, z_xy_ratio=ratio, z_scaling=zs, noise_level=100, min_size=20,
                                       beta_tk=300, lambda_tk=0.1, maxiter_tk=20, folder_path=tmp, image_name="img_t%04i_z%04i.tif",
@@ -349,7 +358,12 @@ def gen_legacy_tracker():
             trk.ffn_model = _FFN(ffn_w)
             trk.initiate_tracking()
             np.save(trk.paths.unet_cache + "t%06i.npy" % 7, case["prob_f16"][None, :, :, :, None])
-            ref_tracker.read_image_ts = lambda vol, path, name, z_range, print_=False: case["raw"]
+            if REAL_SKIMAGE:      # tifffile is real as well: the stack goes through per-layer TIFF files and the reference's own reader
+                import tifffile
+                for z in range(case["raw"].shape[2]):
+                    tifffile.imwrite(trk.paths.raw_image + trk.paths.image_name % (7, z + 1), case["raw"][:, :, z])
+            else:
+                ref_tracker.read_image_ts = lambda vol, path, name, z_range, print_=False: case["raw"]
 
             # _watershed (:671-684) is the reference's own code; scikit-image's primitives underneath are the restated ones
             # (_reference_watershed_on_restated_skimage): the regions of these well-separated synthetic cells are the same as the
@@ -384,7 +398,7 @@ def gen_legacy_tracker():
         out[f"lt_wild_sums_{ci}"] = np.array([int(lab_w.astype(np.int64).sum()), int(msk_w.astype(np.int64).sum()), int((msk_w > 1).sum())])
         print("legacy tracker case", ci, "cells", trk.cell_num_t0, "segmented", len(trk.segresult.r_coordinates_segment),
               "boundary", int(bd_local.sum()), "max |i_disp|", int(np.abs(i_disp).max()), "wild overlaps", int((msk_w > 1).sum()))
-    np.savez_compressed(HERE / "legacy_tracker.npz", **out)
+    np.savez_compressed(HERE / ("legacy_tracker_real.npz" if REAL_SKIMAGE else "legacy_tracker.npz"), **out)
 
 
 def _reference_watershed_on_restated_skimage():

@@ -299,3 +299,19 @@ def test_volume1_setup_equals_the_reference_on_real_skimage(golden_dir):
     assert np.array_equal(trk.segmentation_manual_relabels, want["manual_relabels"])
     assert trk.cell_num_t0 == int(want["cell_num_t0"])
     np.testing.assert_allclose(trk.r_coordinates_tracked_t0, want["r_tracked_t0"], rtol=0, atol=1e-12)
+
+
+def test_golden_recorded_with_restated_primitives_equals_the_recording_on_real_libraries(golden_dir):
+    """tests/golden/legacy_tracker.npz comes from the reference's own Tracker with scikit-image's primitives restated and the stack handed over
+    in memory (main interpreter); legacy_tracker_real.npz from the same script under the image's second interpreter, where scikit-image 0.18.3
+    and tifffile are REAL (watershed unpatched, the stack read from per-layer TIFF files by the reference's own read_image_ts; scipy 1.7.1,
+    numpy 1.26.4, scikit-learn 0.24.2).  46 arrays: every integer one identical (segment order, boundary flags, i_disp, label sums ...),
+    floating point within 1e-12 (the predicted coordinates differ by 4e-14: another BLAS)."""
+    a, b = np.load(golden_dir / "legacy_tracker.npz"), np.load(golden_dir / "legacy_tracker_real.npz")
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 40
+    for k in a.files:
+        assert a[k].shape == b[k].shape, k
+        if np.issubdtype(a[k].dtype, np.floating):
+            np.testing.assert_allclose(a[k], b[k], rtol=0, atol=1e-12, err_msg=k)
+        else:
+            assert np.array_equal(a[k], b[k]), k
