@@ -327,9 +327,8 @@ int ct_accurate_correction_legacy(const float* prob, const void* raw, int raw_dt
 /* ------------------------------------------------------------------------------------------
  * Probability map -> labelled regions -> cell centres  (tracker.py:636-648)
  * ------------------------------------------------------------------------------------------
- * Stands in for _segment's region step with threshold + 3D connected components (the reference's skimage marker
- * watershed, watershed.py:16-108, has no runnable reference in this image and is not restated -- touching cells are not
- * split), then applies the reference's own scipy.ndimage.center_of_mass(regions > 0, regions, 1..n) (tracker.py:646).
+ * The cheap variant of _segment's region step: threshold + 3D connected components (touching cells are not split; the reference's
+ * marker watershed itself is ct_watershed_segment below), then applies the reference's own scipy.ndimage.center_of_mass(regions > 0, regions, 1..n) (tracker.py:646).
  * prob [dev] fp32 [x][y][z]; foreground = prob > threshold (watershed.py:38,48: 0.5); connectivity 1/2/3 =
  * scipy.ndimage.generate_binary_structure(3, c); regions with fewer than min_size voxels are dropped
  * (skimage remove_small_objects semantics) and the rest numbered 1..n in raster order of their first voxel
@@ -353,7 +352,11 @@ int ct_segment_centroids(const float* prob, const int dims_xyz[3], float thresho
  * caller exactly as scipy does (3deecelltracker_amd/segment.py); labels_out [dev] int32 [x][y][z] or NULL; centres [dev] fp64 [cap][3] raw voxel
  * coordinates; sizes [dev] int32 [cap] or NULL; n_out [dev] int32 [3] = {number of cells, min_size in force, cell_num in force}.
  * More cells than `cap`: only the first `cap` centres are written (the caller retries with a larger table).  Synchronises the stream twice
- * (peak-table overflow flags).  CT_ESHAPE: z > 128, an axis >= 16384, or more than 2048 peaks in a slice / 8192 in the volume. */
+ * (peak-table overflow flags).  CT_ESHAPE: z > 128, an axis >= 16384, or more than 2048 peaks in a slice / 8192 in the volume.
+ * Ties, as upstream resolves them (pinned against the reference on scikit-image 0.18.3, tests/test_watershed_pin.py): peak candidates of exactly
+ * equal height closer than min_distance (strictly) are thinned in the order np.argsort(-values) leaves them -- numpy's generic introsort,
+ * replayed on the device; seeds of exactly equal height inside one connected region are flooded in raveled order (upstream: the order of its
+ * image-wide heap -- the one rule that is the device's own).                                                                                */
 size_t ct_watershed_workspace_bytes(const int dims_xyz[3], int cap);
 int    ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_ratio, int method, int min_size, int cell_num,
                             int min_distance_2d, int min_distance_3d, const double* gauss_xy, int radius_xy, const double* gauss_z, int radius_z,
