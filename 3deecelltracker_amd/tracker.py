@@ -263,21 +263,28 @@ class Tracker:
     # ------------------------------------------------------------------ unit transforms (reference :552-573)
     @staticmethod
     def _transform_disps(disp, factor):
-        new_disp = np.array(disp).copy()
-        new_disp[:, 2] = new_disp[:, 2] * factor
-        return new_disp
+        """Coordinates / displacements with their z column multiplied by `factor` (x, y untouched); always a fresh array."""
+        scaled = np.array(disp, copy=True)
+        scaled[:, 2] *= factor
+        return scaled
 
+    def _z_units(self, disp, factor, to_voxels):
+        out = self._transform_disps(disp, factor)
+        return np.rint(out).astype(int) if to_voxels else out
+
+    # the four unit changes of the reference (:557-573): "layer" = raw voxels, "real" = voxels with z in x/y units,
+    # "interpolated" = voxels of the z-upsampled image; everything that lands on a voxel grid is rounded to int
     def _transform_layer_to_real(self, voxel_disp):
-        return self._transform_disps(voxel_disp, self.z_xy_ratio)
+        return self._z_units(voxel_disp, self.z_xy_ratio, to_voxels=False)
 
     def _transform_real_to_interpolated(self, r_disp):
-        return np.rint(self._transform_disps(r_disp, self.z_scaling / self.z_xy_ratio)).astype(int)
+        return self._z_units(r_disp, self.z_scaling / self.z_xy_ratio, to_voxels=True)
 
     def _transform_real_to_layer(self, r_disp):
-        return np.rint(self._transform_disps(r_disp, 1 / self.z_xy_ratio)).astype(int)
+        return self._z_units(r_disp, 1 / self.z_xy_ratio, to_voxels=True)
 
     def _transform_interpolated_to_layer(self, r_disp):
-        return np.rint(self._transform_disps(r_disp, 1 / self.z_scaling)).astype(int)
+        return self._z_units(r_disp, 1 / self.z_scaling, to_voxels=True)
 
     # ------------------------------------------------------------------ models (reference :575-581, :1119-1122)
     def load_unet(self):
@@ -688,13 +695,15 @@ class Tracker:
         return None
 
     def _reset_tracking_state(self, from_volume):
+        """Forget everything recorded from `from_volume` on, so that tracking can restart there (reference :1462-1470: the same two
+        conditions and messages)."""
         assert from_volume >= 2, "from_volume should >= 2"
-        current_vol = len(self.history.r_displacements)
-        del self.history.r_displacements[from_volume - 1:]
-        del self.history.r_segmented_coordinates[from_volume - 1:]
-        del self.history.r_tracked_coordinates[from_volume - 1:]
-        assert len(self.history.r_displacements) == from_volume - 1, \
-            f"Currently data has been tracked until vol {current_vol}, the program cannot start from {from_volume}"
+        hist, keep = self.history, from_volume - 1
+        tracked_until = len(hist.r_displacements)
+        for series in (hist.r_displacements, hist.r_segmented_coordinates, hist.r_tracked_coordinates):
+            series[keep:] = []
+        assert len(hist.r_displacements) == keep, \
+            f"Currently data has been tracked until vol {tracked_until}, the program cannot start from {from_volume}"
 
     def track_one_vol(self, target_volume, fig=None, axc6=None, method="min_size"):
         """reference :1473-1536 without the label-image / figure outputs (skimage watershed, matplotlib)."""

@@ -414,6 +414,21 @@ def match_schedule(steps: int, partition: bool, workers: int | None, batch: int 
     return workers, max(1, min(batch, -(-steps // workers)))
 
 
+def relaunch_under_launcher(n: int):
+    """`python bench.py --gpus N` without a launcher (the shape of the driver's N = 1 command): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same argv>`,
+    one rank per GPU.  The port is one the kernel just handed out, the rendezvous address the loopback (the container's host
+    name may not resolve)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -439,8 +454,11 @@ def main():
     ap.add_argument("--realistic-partition", action="store_true", help="discriminating-FFN pass on a CU partition (--realistic-match-cus) instead of priority streams (116 vs 121 volumes/s)")
     ap.add_argument("--match-batch", type=int, default=None, help="frames whose matches share one chain of launches (ct_prgls_two_ref_batched); capped at ceil(steps / chains) so that a short run does not end on queued match batches")
     ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous only: every rank joins the process group, rank 0 prints {world_size, backend}; no GPU work (CPU test of the self-launch)")
     ap.add_argument("--cpu-patches", type=int, default=75, help="U-Net patches timed by the CPU baseline sample (default: the whole 75-patch volume, ~6 s on 32 threads: nothing is extrapolated)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_launcher(args.gpus)          # does not return
     args.match_workers, args.match_batch = match_schedule(args.steps, args.partition, args.match_workers, args.match_batch)
 
     import torch
@@ -451,11 +469,25 @@ def main():
     ctx.local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.same_device:
         ctx.local = 0
+    if args.launch_check:
+        if ctx.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(args.backend, rank=ctx.rank, world_size=ctx.world)
+            seen = [None] * ctx.world
+            dist.all_gather_object(seen, (ctx.rank, ctx.local))
+            dist.destroy_process_group()
+        else:
+            seen = [(0, 0)]
+        if ctx.rank == 0:
+            print(json.dumps({"launch_check": True, "world_size": ctx.world, "gpus": args.gpus, "backend": args.backend if ctx.world > 1 else None,
+                              "ranks": sorted(r for r, _ in seen), "local_ranks": sorted(l for _, l in seen)}))
+        return
     torch.cuda.set_device(ctx.local)
     if ctx.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=ctx.rank, world_size=ctx.world)
-    assert ctx.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}"
+    if ctx.world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={ctx.world} ranks")
     ctx.dev = f"cuda:{ctx.local}"
     world, rank, dev = ctx.world, ctx.rank, ctx.dev
 

@@ -78,6 +78,18 @@ def test_two_ranks_gloo_same_device_runs_all_sharding_passes():
     assert cfg["with_discriminating_ffn"]["prgls_iterations"] <= 30
 
 
+def test_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2 ...` as the driver would type it: bench.py starts its own ranks (torch.distributed.run)."""
+    env_keys = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+    saved = {k: os.environ.pop(k) for k in env_keys if k in os.environ}
+    try:
+        line = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--same-device",
+                     "--no-realistic-pass"], timeout=1500)
+    finally:
+        os.environ.update(saved)
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"]["world_size"] == 2 and line["value"] > 0
+
+
 def test_two_ranks_nccl():
     import torch
     if torch.cuda.device_count() < 2:
