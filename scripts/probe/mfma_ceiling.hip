@@ -29,23 +29,27 @@ __global__ __launch_bounds__(256) void spin(float* out, int iters, int operands)
             a[i] = __builtin_bit_cast(_Float16, ha); b[i] = __builtin_bit_cast(_Float16, hb);
         }
     }
+    // The matrix loop is inline assembly on purpose: written as builtins, hipcc (ROCm 7.2) rotates the accumulator tuples through the loop
+    // (a[24:27] <- a[22:25] ...) and pays ~40 v_accvgpr_read/write copies per 8 MFMAs -- the loop then measures the copies, not the pipe
+    // (that is what profiles/r03_mfma_shapes.txt's "1346 TFLOP/s" for 16x16x32 was).
     if constexpr (SHAPE == 0) {
-        f32x4 acc[8];
-        for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 c0{0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
         for (int it = 0; it < iters; ++it)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[k], 0, 0, 0);
-        float s = 0.f;
-        for (int k = 0; k < 8; ++k) s += acc[k][0];
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %8, %9, %0\n v_mfma_f32_16x16x32_f16 %1, %8, %9, %1\n"
+                         "v_mfma_f32_16x16x32_f16 %2, %8, %9, %2\n v_mfma_f32_16x16x32_f16 %3, %8, %9, %3\n"
+                         "v_mfma_f32_16x16x32_f16 %4, %8, %9, %4\n v_mfma_f32_16x16x32_f16 %5, %8, %9, %5\n"
+                         "v_mfma_f32_16x16x32_f16 %6, %8, %9, %6\n v_mfma_f32_16x16x32_f16 %7, %8, %9, %7\n"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));
+        const float s = c0[0] + c1[0] + c2[0] + c3[0] + c4[0] + c5[0] + c6[0] + c7[0];
         if (s == 12345.f) out[0] = s;
     } else {
-        f32x16 acc[4];
-        for (int k = 0; k < 4; ++k) for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+        f32x16 c0, c1, c2, c3;
+        for (int e = 0; e < 16; ++e) { c0[e] = 0.f; c1[e] = 0.f; c2[e] = 0.f; c3[e] = 0.f; }
         for (int it = 0; it < iters; ++it)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k], 0, 0, 0);
-        float s = 0.f;
-        for (int k = 0; k < 4; ++k) s += acc[k][0];
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n v_mfma_f32_32x32x16_f16 %1, %4, %5, %1\n"
+                         "v_mfma_f32_32x32x16_f16 %2, %4, %5, %2\n v_mfma_f32_32x32x16_f16 %3, %4, %5, %3\n"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));
+        const float s = c0[0] + c1[0] + c2[0] + c3[0];
         if (s == 12345.f) out[0] = s;
     }
 }
