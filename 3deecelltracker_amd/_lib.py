@@ -115,6 +115,9 @@ def lib():
     return _lib
 
 
+CT_EINVAL, CT_ESHAPE, CT_EWORKSPACE, CT_ENOTCONV = -1, -2, -3, -4      # include/ctamd.h
+
+
 def check(rc: int, what: str = "ctamd call"):
     if rc != 0:
         msg = lib().ct_error_string(rc)

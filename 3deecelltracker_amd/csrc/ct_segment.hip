@@ -844,6 +844,105 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsi
     }
 }
 
+// Do two seeds of EXACTLY equal height share a mask component?  Only then does the order in which upstream's heap releases equal seeds matter
+// (seeds are the only entries that can compare equal: every later entry carries its own age), and only then does the group (z slice in the
+// 2-D stage, the volume in the 3-D stage) take the sequential path below.  One thread per listed component (>= 2 markers).
+__global__ void ws_tie_detect_kernel(SegGeom g, int mode2d, const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots,
+                                     const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap,
+                                     int32_t* __restrict__ tie_flags) {
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *nroots) return;
+    const int root = roots[t];
+    const WsHeapEntry* h = heap + heap_off[root];
+    const int n = heap_cnt[root];
+    for (int a = 1; a < n; ++a) {
+        const double va = h[a].value;
+        for (int b = 0; b < a; ++b)
+            if (h[b].value == va) { tie_flags[mode2d ? root % g.Z : 0] = 1; return; }
+    }
+}
+
+// skimage's flood with skimage's OWN heap, for a group in which equal seeds share a component (ws_tie_detect_kernel): ONE binary heap over the
+// whole image keyed by (value, age) -- no index in the key --, every marker pushed with age 0 in raveled order, push = append + sift up while
+// STRICTLY smaller than the parent, pop = last element to the root + sift down towards the strictly smaller child (the left one when the
+// children tie) (skimage/segmentation/heap_general.pxi; oracle/watershed_ref.py::_UpstreamHeap is the same restatement, held to
+// skimage.segmentation.watershed itself).  Which of two equal seeds leaves first depends on that array's layout, i.e. on every push and pop of
+// the image before it, so the group is replayed sequentially by one thread (the heap lives in the group's slice of the queue memory); it
+// overwrites what the component-parallel flood wrote for the group.  Exact ties of the fp64 smoothed EDT between two peaks of ONE component
+// need mirror-symmetric shapes; a stack that has them pays ~2 us per foreground voxel of the group here.
+template <bool MODE2D>
+__global__ __launch_bounds__(64) void ws_flood_upstream_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth, int cap,
+                                                               const int32_t* __restrict__ marker_idx, const int32_t* __restrict__ marker_count,
+                                                               const int32_t* __restrict__ tie_flags, WsHeapEntry* __restrict__ heap_all,
+                                                               int32_t* __restrict__ labels) {
+    const int grp = blockIdx.x;
+    if (!tie_flags[grp]) return;
+    const long long gsize = MODE2D ? (long long)g.X * g.Y : g.V;
+    WsHeapEntry* const h = heap_all + (size_t)grp * gsize;
+    for (long long p = threadIdx.x; p < gsize; p += 64) labels[MODE2D ? p * g.Z + grp : p] = 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    auto smaller = [](const WsHeapEntry& a, const WsHeapEntry& b) { return a.value < b.value || (a.value == b.value && a.age < b.age); };
+    int n = 0;
+    auto push = [&](const WsHeapEntry& e) {
+        int c = n++;
+        while (c > 0) {
+            const int p = (c - 1) >> 1;
+            const WsHeapEntry hp = h[p];
+            if (!smaller(e, hp)) break;
+            h[c] = hp; c = p;
+        }
+        h[c] = e;
+    };
+    const int nm = marker_count[grp];
+    for (int k = 0; k < nm; ++k) {                                               // marker list = raveled order inside the group
+        const int id = marker_idx[(size_t)grp * cap + k];
+        if (!bn[id]) continue;                                                   // markers outside the mask are dropped, their numbers stay used
+        labels[id] = k + 1;
+        push(WsHeapEntry{-smooth[id], 0, id});
+    }
+    const long long sx = (long long)g.Y * g.Z, sy = g.Z;
+    int age = 1;
+    while (n > 0) {
+        const WsHeapEntry top = h[0];
+        const WsHeapEntry last = h[--n];
+        if (n > 0) {
+            int i = 0;
+            for (;;) {
+                const int l = 2 * i + 1;
+                if (l >= n) break;
+                int sm = i;
+                WsHeapEntry ref = last;
+                const WsHeapEntry hl = h[l];
+                if (smaller(hl, ref)) { sm = l; ref = hl; }
+                if (l + 1 < n) { const WsHeapEntry hr = h[l + 1]; if (smaller(hr, ref)) { sm = l + 1; ref = hr; } }
+                if (sm == i) break;
+                h[i] = ref; i = sm;
+            }
+            h[i] = last;
+        }
+        const int i = top.idx;
+        int x, y, z; ws_xyz(i, g, x, y, z);
+        const int lab = labels[i];
+        const long long nb[6] = {x > 0 ? i - sx : -1, y > 0 ? i - sy : -1, (!MODE2D && z > 0) ? (long long)i - 1 : -1,
+                                 (!MODE2D && z + 1 < g.Z) ? (long long)i + 1 : -1, y + 1 < g.Y ? i + sy : -1, x + 1 < g.X ? i + sx : -1};
+        bool take[6]; double val[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                                            // independent loads first, the dependent heap walk after
+            const long long j = nb[q];
+            take[q] = j >= 0 && bn[j] && labels[j] == 0;
+            val[q] = j >= 0 ? -smooth[j] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (!take[q]) continue;
+            ++age;
+            labels[nb[q]] = lab;
+            push(WsHeapEntry{val[q], age, (int)nb[q]});
+        }
+    }
+}
+
 // find_boundaries(labels, connectivity 2, mode 'outer') inside every z slice, removed from the mask (watershed.py:45-51)
 __global__ void ws_boundary2d_kernel(SegGeom g, const unsigned char* __restrict__ bn, const int32_t* __restrict__ labels, unsigned char* __restrict__ bn_out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -886,27 +985,38 @@ __global__ __launch_bounds__(1024) void ws_finish_kernel(long long V, const int3
                                                          unsigned int* __restrict__ counts, int32_t* __restrict__ newlabel, int32_t* __restrict__ n_out) {
     __shared__ int s_val[2];
     __shared__ int s_scan[1024];
-    __shared__ int s_carry;
+    __shared__ int s_carry, s_kmax;
+    __shared__ unsigned long long s_tot;
     const int K = marker_count[0];
-    if (threadIdx.x == 0) {
-        unsigned long long tot = 0;
-        for (int l = 1; l <= K; ++l) tot += counts[l];
-        counts[0] = (unsigned int)((unsigned long long)V - tot);
-        s_val[0] = 0; s_val[1] = min_size;
+    if (threadIdx.x == 0) { s_tot = 0; s_kmax = 0; s_val[0] = 0; s_val[1] = min_size; }
+    __syncthreads();
+    {   // bin 0 = V - the rest; np.bincount's last bin is the largest label PRESENT (a marker dropped outside the mask leaves an empty bin in
+        // between, but no bin after the last present label)
+        unsigned long long tot = 0; int kmax = 0;
+        for (int l = 1 + threadIdx.x; l <= K; l += 1024) { const unsigned int c = counts[l]; tot += c; if (c) kmax = l; }
+        atomicAdd(&s_tot, tot); atomicMax(&s_kmax, kmax);
     }
+    __syncthreads();
+    const int KB = s_kmax;
+    if (threadIdx.x == 0) counts[0] = (unsigned int)((unsigned long long)V - s_tot);
     __syncthreads();
     if (method == 0) {
         int c = 0;
-        for (int l = threadIdx.x; l <= K; l += 1024) c += counts[l] >= (unsigned int)min_size ? 1 : 0;
+        for (int l = threadIdx.x; l <= KB; l += 1024) c += counts[l] >= (unsigned int)min_size ? 1 : 0;
         atomicAdd(&s_val[0], c);
         __syncthreads();
         if (threadIdx.x == 0) { s_val[0] -= 1; s_val[1] = min_size; }
+    } else if (cell_num > KB) {
+        // np.sort(counts)[-cell_num - 1] with fewer than cell_num + 1 bins: the reference raises IndexError (watershed.py:92); n = -1 tells the host
+        if (threadIdx.x == 0) { n_out[0] = -1; n_out[1] = min_size; n_out[2] = cell_num; }
+        for (int l = threadIdx.x; l <= K; l += 1024) newlabel[l] = 0;
+        return;
     } else {
         // the (cell_num + 1)-th largest count = np.sort(counts)[-cell_num - 1]
-        for (int l = threadIdx.x; l <= K; l += 1024) {
+        for (int l = threadIdx.x; l <= KB; l += 1024) {
             const unsigned int c = counts[l];
             int rank = 0;
-            for (int q = 0; q <= K; ++q) { const unsigned int cq = counts[q]; rank += (cq > c || (cq == c && q < l)) ? 1 : 0; }
+            for (int q = 0; q <= KB; ++q) { const unsigned int cq = counts[q]; rank += (cq > c || (cq == c && q < l)) ? 1 : 0; }
             if (rank == cell_num) s_val[1] = (int)c;
         }
         __syncthreads();
@@ -918,7 +1028,8 @@ __global__ __launch_bounds__(1024) void ws_finish_kernel(long long V, const int3
     __syncthreads();
     for (int base = 1; base <= K; base += 1024) {
         const int l = base + threadIdx.x;
-        const int keep = (l <= K && counts[l] >= ms) ? 1 : 0;
+        const unsigned int cl = l <= K ? counts[l] : 0u;
+        const int keep = (cl > 0 && cl >= ms) ? 1 : 0;                           // relabel_sequential numbers the labels that are PRESENT
         s_scan[threadIdx.x] = keep;
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1) {
@@ -1047,6 +1158,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     int32_t* marker_count = (int32_t*)(ws + L.stats + 2048);                      // [128]
     unsigned int* bump = (unsigned int*)(ws + L.stats + 2560);                    // bump | nroots | overflow
     unsigned int* nroots = bump + 1; int* overflow = (int*)(bump + 2);
+    int32_t* tie_flags = (int32_t*)(ws + L.stats + 3072);                         // [128] groups whose equal seeds share a component
     unsigned int* counts = (unsigned int*)(ws + L.stats + 4096);                  // [WS_PEAK_CAP3D + 1]
     int32_t* newlabel = (int32_t*)(counts + WS_PEAK_CAP3D + 1);
     unsigned long long* sums = (unsigned long long*)(ws + L.sums);
@@ -1092,14 +1204,20 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         ws_marker_append_kernel<<<(unsigned)((ngroups * pcap + 255) / 256), 256, 0, st>>>(ngroups, pcap, marker_idx, marker_count, smooth, parent, heap_off,
                                                                                        heap_cnt, heap, roots, nroots, labels);
         LAUNCH_CHECK();
-        unsigned int h_nroots = 0; int h_over = 0;
-        HIPCHK(hipMemcpyAsync(&h_nroots, nroots, sizeof(h_nroots), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&h_over, overflow, sizeof(h_over), hipMemcpyDeviceToHost, st));
+        ws_tie_detect_kernel<<<(unsigned)((ngroups * pcap / 2 + 255) / 256), 256, 0, st>>>(g, mode2d ? 1 : 0, roots, nroots, heap_off, heap_cnt, heap, tie_flags);
+        LAUNCH_CHECK();
+        int32_t h_flags[256];                                                    // one copy: bump | nroots | overflow ... (+ 512 bytes) the 128 tie flags
+        HIPCHK(hipMemcpyAsync(h_flags, bump, sizeof(h_flags), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        const unsigned int h_nroots = (unsigned int)h_flags[1]; const int h_over = h_flags[2];
         if (h_over) return CT_ESHAPE;                                            // more peak candidates than the per-slice / per-volume table holds
+        bool any_tie = false;
+        for (int q = 0; q < ngroups; ++q) any_tie |= h_flags[128 + q] != 0;
+        static const bool no_upstream = getenv("CT_WS_UPSTREAM_TIES") && atoi(getenv("CT_WS_UPSTREAM_TIES")) == 0;   // (A/B: raveled order among equal seeds)
+        if (no_upstream) any_tie = false;
         ws_fill_single_kernel<<<nb, 256, 0, st>>>(V, parent, heap_off, heap_cnt, heap, labels);
         LAUNCH_CHECK();
-        if (h_nroots) {
+        if (h_nroots && !(any_tie && !mode2d)) {
             static const bool thread_flood = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 0;      // (A/B: one thread per component, binary heap)
             if (thread_flood) {
                 if (mode2d) ws_flood_kernel<true><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
@@ -1108,6 +1226,11 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
                 if (mode2d) ws_flood_wave_kernel<true><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels);
                 else ws_flood_wave_kernel<false><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels);
             }
+            LAUNCH_CHECK();
+        }
+        if (any_tie) {                                                           // equal seeds inside one component: those groups again, with upstream's heap
+            if (mode2d) ws_flood_upstream_kernel<true><<<ngroups, 64, 0, st>>>(g, mask, smooth, pcap, marker_idx, marker_count, tie_flags, heap, labels);
+            else ws_flood_upstream_kernel<false><<<1, 64, 0, st>>>(g, mask, smooth, pcap, marker_idx, marker_count, tie_flags, heap, labels);
             LAUNCH_CHECK();
         }
         return CT_OK;

@@ -84,6 +84,8 @@ def gaussian_weights(sigma: float, truncate: float = 4.0):
 
 
 _METHODS = {"min_size": 0, "cell_num": 1}
+# what ct_watershed_workspace_bytes / ct_watershed_segment refuse (csrc/ct_segment.hip: per-slice statistics tables, WS_PEAK_CAP2D / 3D)
+WATERSHED_LIMITS = "z <= 128 slices, x and y < 16384, < 2^31 voxels, <= 2048 peak candidates per z slice and <= 8192 in the volume"
 
 
 def watershed_centroids_device(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0, cap: int = 4096,
@@ -109,14 +111,21 @@ def watershed_centroids_device(prob, z_xy_ratio: float, method: str = "min_size"
         sizes = _dev.empty((cap,), t.int32, prob.device)
         nbytes = L.ct_watershed_workspace_bytes(dims, int(cap))
         if nbytes == 0:
-            raise ValueError(f"volume {tuple(prob.shape)} is outside the watershed kernels' limits (z <= 128, int32 voxel indices)")
+            raise ValueError(f"volume {tuple(prob.shape)} is outside the device watershed's limits ({WATERSHED_LIMITS}); "
+                             "threshold + connected components have none: Tracker.region_method = 'cc' / segment_centroids_device")
         ws = _dev.workspace(nbytes, prob.device)
-        _lib.check(L.ct_watershed_segment(prob.data_ptr(), dims, float(z_xy_ratio), _METHODS[method], int(min_size), int(cell_num),
-                                          int(min_distance_2d), int(min_distance_3d), w_xy.ctypes.data_as(C.c_void_p), r_xy,
-                                          w_z.ctypes.data_as(C.c_void_p), r_z, int(cap), labels.data_ptr() if want_labels else None,
-                                          centres.data_ptr(), sizes.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), ws.numel(),
-                                          _dev.stream(prob.device)), "ct_watershed_segment")
+        rc = L.ct_watershed_segment(prob.data_ptr(), dims, float(z_xy_ratio), _METHODS[method], int(min_size), int(cell_num),
+                                    int(min_distance_2d), int(min_distance_3d), w_xy.ctypes.data_as(C.c_void_p), r_xy,
+                                    w_z.ctypes.data_as(C.c_void_p), r_z, int(cap), labels.data_ptr() if want_labels else None,
+                                    centres.data_ptr(), sizes.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    _dev.stream(prob.device))
+        if rc == _lib.CT_ESHAPE:          # the shape itself was accepted above: the peak tables overflowed
+            raise ValueError(f"the probability map has more peak candidates than the device watershed's tables hold ({WATERSHED_LIMITS}): "
+                             "a map that noisy usually needs a higher noise_level; Tracker.region_method = 'cc' has no such limit")
+        _lib.check(rc, "ct_watershed_segment")
         n, ms, cn = (int(v) for v in n_dev.cpu().tolist())
+        if n < 0:                         # watershed.py:92: np.sort(counts)[-cell_num - 1] with fewer than cell_num + 1 bins
+            raise IndexError(f"index {-cell_num - 1} is out of bounds: method='cell_num' asks for {cell_num} cells, the watershed found fewer regions")
         if n <= cap:
             return labels, centres[:n], sizes[:n], ms, cn
         cap = max(2 * cap, n)

@@ -31,9 +31,11 @@ benchmark stack (all 8.4 M voxels), the device path on the same.  The restatemen
     label at PUSH time and push it with value = image[neighbour] and the next age.  All markers enter with age 0, so seeds of EXACTLY
     equal height are popped in the order upstream's binary heap happens to hold them (its array layout, global over the image): restated
     as _UpstreamHeap (seed_order="upstream": with it the oracle equals the reference on ALL nine recorded volumes, the designed tie volume
-    included).  The DEFAULT is seed_order="raveled" -- smaller raveled index first -- because that is what the device can do: it floods
-    every basin system on its own, and upstream's order depends on the whole image's heap.  The two differ only where two equal seeds
-    share a basin (the designed tie volume; not the benchmark stack, not the random volumes): the boundary between them moves by a row.
+    included).  It is the DEFAULT, and since round 4 the device follows it too: mask components in which two seeds of exactly equal height
+    meet make their group (z slice / volume) take a sequential replay of that heap on the device (ws_flood_upstream_kernel); everywhere else
+    the order among equal seeds cannot matter and the component-parallel flood runs.  seed_order="raveled" (smaller raveled index first, the
+    device's rule until round 3) is kept to show where the two differ: only where two equal seeds share a basin (the designed tie volume;
+    not the benchmark stack, not the random volumes) -- the boundary between them moves by a row.
   * find_boundaries(mode='outer') -- skimage/segmentation/boundaries.py: grey dilation != grey erosion over the connectivity-c
     structure, kept where the pixel is background or the full-connectivity neighbourhood holds two different OBJECT labels.
   * remove_small_objects on a label image (sizes by bincount of the labels as they are) and relabel_sequential.
@@ -232,11 +234,11 @@ class _UpstreamHeap:
         return len(self.h)
 
 
-def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray, seed_order: str = "raveled") -> np.ndarray:
+def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray, seed_order: str = "upstream") -> np.ndarray:
     """skimage.segmentation.watershed(image, markers, mask=mask) (connectivity 1, no compactness, no watershed line).
-    seed_order: how seeds of EXACTLY equal height are popped -- "raveled" (smaller raveled index first: the rule of the device path, whose
-    basins are flooded independently) or "upstream" (the order scikit-image's own heap leaves them in, _UpstreamHeap).  Every other element
-    carries its own age, so the two only differ where two equal seeds share a basin."""
+    seed_order: how seeds of EXACTLY equal height are popped -- "upstream" (default: the order scikit-image's own heap leaves them in,
+    _UpstreamHeap; the device path follows it since round 4) or "raveled" (smaller raveled index first: the device's rule until round 3, kept to
+    show where the two differ).  Every other element carries its own age, so the two only differ where two equal seeds share a basin."""
     image = np.asarray(image, dtype=np.float64)
     shape = image.shape
     out = np.where(mask, markers, 0).astype(np.int32).ravel().copy()      # markers outside the mask are dropped (skimage: markers[~mask] = 0)
@@ -245,6 +247,15 @@ def watershed(image: np.ndarray, markers: np.ndarray, mask: np.ndarray, seed_ord
     strides = [int(np.prod(shape[a + 1:])) for a in range(len(shape))]
     offs = sorted([(-s, a, -1) for a, s in enumerate(strides)] + [(s, a, 1) for a, s in enumerate(strides)])   # ascending raveled offset
     coords_of = lambda i: np.unravel_index(i, shape)
+    seeds = np.flatnonzero(out)
+    if seed_order == "upstream":
+        # Equal seeds only matter where they share a connectivity-1 component of the mask (components never interact, and inside one the
+        # pops of the global sequence that belong to it are ordered by its own (value, age) keys -- seeds apart, all distinct).  Without such a
+        # pair the result does not depend on the order among equal seeds and the C heapq path computes it (the same criterion sends a
+        # group to the sequential replay on the device; the pin tests hold both to scikit-image's output on every recorded volume).
+        comp = ndi.label(msk.reshape(shape))[0].ravel()[seeds]
+        if np.unique(np.stack([comp.astype(np.float64), img[seeds]], 1), axis=0).shape[0] == seeds.size:
+            seed_order = "raveled"
     if seed_order == "upstream":
         up = _UpstreamHeap()
         for i in np.flatnonzero(out):
@@ -305,7 +316,7 @@ def relabel_sequential(labels: np.ndarray) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------ the reference's functions
-def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, collect=None, peaks=None, seed_order: str = "raveled"):
+def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, collect=None, peaks=None, seed_order: str = "upstream"):
     """watershed.py:16-53 -> (bn_output, boundary).  peaks (tests only): a recorded peak mask [x, y, z] used instead of peak_local_max's --
     the choice among exactly tied candidates that one particular upstream run made (see the header)."""
     image_pred = np.asarray(image_pred)
@@ -326,7 +337,7 @@ def watershed_2d(image_pred: np.ndarray, z_range: int, min_distance: int = 7, co
 
 
 def watershed_3d(image_watershed2d: np.ndarray, samplingrate, method: str, min_size: int, cell_num: int, min_distance: int, collect=None, peaks=None,
-                 seed_order: str = "raveled"):
+                 seed_order: str = "upstream"):
     """watershed.py:55-108 -> (labels_wo_bd, labels_clear, min_size, cell_num).  peaks: as in watershed_2d."""
     dist = ndi.distance_transform_edt(image_watershed2d, sampling=samplingrate)
     dist_smooth = ndi.gaussian_filter(dist, (2, 2, 0.3), mode="constant")
@@ -351,7 +362,7 @@ def watershed_3d(image_watershed2d: np.ndarray, samplingrate, method: str, min_s
 
 
 def tracker_watershed(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0,
-                      peaks2d=None, peaks3d=None, seed_order: str = "raveled"):
+                      peaks2d=None, peaks3d=None, seed_order: str = "upstream"):
     """Tracker._watershed (tracker.py:671-684) -> (segmentation_auto int32, min_size, cell_num)."""
     img = np.asarray(image_cell_bg_xyz)
     wo_border, _ = watershed_2d(img, z_range=img.shape[2], min_distance=7, peaks=peaks2d, seed_order=seed_order)
@@ -361,7 +372,7 @@ def tracker_watershed(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: 
 
 
 def segment_centroids(image_cell_bg_xyz: np.ndarray, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0,
-                      seed_order: str = "raveled"):
+                      seed_order: str = "upstream"):
     """-> (labels int32, centres float64 [n, 3] via the reference's center_of_mass call (tracker.py:646-647), min_size, cell_num)."""
     labels, min_size, cell_num = tracker_watershed(image_cell_bg_xyz, z_xy_ratio, method, min_size, cell_num, seed_order=seed_order)
     n = int(labels.max())

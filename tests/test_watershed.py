@@ -163,3 +163,41 @@ def test_device_watershed_headline_size():
     assert np.array_equal(got_l, want_l), f"{int((got_l != want_l).sum())} voxels differ"
     assert np.array_equal(got_c, want_c)
     assert want_cn > ndi.label(prob > 0.5)[1]                   # more cells than connected components: touching cells were split
+
+
+def _hole_case():
+    """two discs over four slices, the first with a one-voxel hole through its centre: the blurred EDT peaks ON the hole, i.e. a marker on a
+    background voxel -- skimage's watershed drops it, its number stays used, and the first disc (no other marker) stays unlabelled"""
+    prob = np.zeros((64, 64, 8), np.float32)
+    g = np.stack(np.meshgrid(np.arange(64), np.arange(64), indexing="ij"), -1).astype(float)
+    for z in range(2, 6):
+        prob[:, :, z][((g - np.array([20, 20])) ** 2).sum(-1) <= 30] = 0.9
+        prob[20, 20, z] = 0.0
+        prob[:, :, z][((g - np.array([44, 44])) ** 2).sum(-1) <= 40] = 0.9
+    return prob
+
+
+def test_oracle_marker_on_background_leaves_an_empty_bin():
+    prob = _hole_case()
+    col = []
+    wo, _ = wr.watershed_2d(prob, 8)
+    wr.watershed_3d(wo, [1, 1, 2.0], "min_size", 0, 0, 3, collect=col)
+    assert (col[0]["peaks"] & ~wo).sum() == 1 and col[0]["peaks"].sum() == 2
+    labels, centres, ms, cn = wr.segment_centroids(prob, 2.0, "min_size", 0)
+    assert labels.max() == 1 and (ms, cn) == (0, 2)               # np.bincount -> [background, 0, n]: three bins >= 0, minus one
+    with pytest.raises(IndexError):
+        wr.segment_centroids(prob, 2.0, "cell_num", 0, 3)         # np.sort(counts)[-4] of three bins (watershed.py:92)
+
+
+@pytest.mark.gpu
+def test_device_marker_on_background_and_min_size_zero():
+    """(advisor, round 3) a marker dropped outside the mask leaves an EMPTY bin: relabel_sequential numbers present labels only, np.bincount
+    has no bins past the largest present label, and cell_num beyond the bins is the reference's IndexError."""
+    prob = _hole_case()
+    for method, ms, cn in (("min_size", 0, 0), ("min_size", 5, 0), ("cell_num", 0, 1), ("cell_num", 0, 2)):
+        want = wr.segment_centroids(prob, 2.0, method, ms, cn)
+        got = _device(prob, 2.0, method, ms, cn)
+        assert (got[2], got[3]) == (want[2], want[3]), (method, ms, cn)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.isfinite(got[1]).all()
+    with pytest.raises(IndexError):
+        _device(prob, 2.0, "cell_num", 0, 3)
