@@ -284,6 +284,7 @@ SegLayout seg_layout(long long V, int cap) {
 // ================================================================================================
 constexpr int WS_INF = 1 << 14;                       // "no background on this line" (volumes are < 2^14 voxels per axis)
 constexpr int WS_PEAK_CAP2D = 2048, WS_PEAK_CAP3D = 8192;
+constexpr int WS_SEL2_CAP = 2048;                  // groups of at most this many candidates take ws_peak_select2_kernel
 
 struct WsHeapEntry { double value; int age; int idx; };
 
@@ -291,9 +292,13 @@ __device__ __forceinline__ void ws_xyz(long long i, const SegGeom& g, int& x, in
     z = (int)(i % g.Z); y = (int)((i / g.Z) % g.Y); x = (int)(i / ((long long)g.Z * g.Y));
 }
 
-__global__ void ws_threshold_kernel(const float* __restrict__ prob, long long V, unsigned char* __restrict__ bn) {
+// (every kernel that produces a mask also prepares the union-find of its components: parent = own index / -1, size = 0)
+__global__ void ws_threshold_kernel(const float* __restrict__ prob, long long V, unsigned char* __restrict__ bn, int32_t* __restrict__ parent,
+                                    int32_t* __restrict__ size) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < V) bn[i] = prob[i] > 0.5f ? 1 : 0;
+    if (i >= V) return;
+    const bool fg = prob[i] > 0.5f;
+    bn[i] = fg ? 1 : 0; parent[i] = fg ? (int32_t)i : -1; size[i] = 0;
 }
 
 // distance (voxels) to the nearest background voxel along x, WS_INF if the line has none.  One thread per VOXEL searching outwards
@@ -385,6 +390,76 @@ __global__ void ws_maxfilt_kernel(SegGeom g, int axis, const double* __restrict_
     out[i] = m;
 }
 
+// ---- the same two filters as sliding windows in registers (axes 0 and 1) --------------------------------------------------------------------
+// A thread owns one line segment of WS_SEG outputs along the filter axis and keeps the 2 R + 1 inputs of the current output in registers
+// (static indices: the loop over a window's worth of outputs is unrolled, the roles rotate), so every input is loaded ONCE per segment
+// ((SEG + 2 R) / SEG = 1.25 x) instead of 2 R + 1 times through the caches (the per-voxel kernels above are bound by exactly that: 17 x 67 MB
+// per pass through L2).  Lanes run over the contiguous remainder of the index (z fastest), so each step of a wave is a 512-byte row.
+// Arithmetic: operation for operation that of ws_gauss_kernel / ws_maxfilt_kernel (zeros stand for what lies outside the image).
+constexpr int WS_SEG = 64;
+template <int AXIS> __device__ __forceinline__ bool ws_line(const SegGeom& g, long long t, long long& base, long long& stride, int& len, int& p0) {
+    const long long C = AXIS == 0 ? (long long)g.Y * g.Z : (long long)g.X * g.Z;
+    len = AXIS == 0 ? g.X : g.Y;
+    const int nseg = (len + WS_SEG - 1) / WS_SEG;
+    if (t >= C * nseg) return false;
+    const long long cc = t % C; p0 = (int)(t / C) * WS_SEG;
+    if (AXIS == 0) { base = cc; stride = (long long)g.Y * g.Z; }
+    else { base = (cc / g.Z) * (long long)g.Y * g.Z + cc % g.Z; stride = g.Z; }
+    return true;
+}
+template <int AXIS, int R>
+__global__ __launch_bounds__(256) void ws_gauss_slide_kernel(SegGeom g, const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ w) {
+    constexpr int W = 2 * R + 1;
+    long long base, stride; int len, p0;
+    if (!ws_line<AXIS>(g, (long long)blockIdx.x * 256 + threadIdx.x, base, stride, len, p0)) return;
+    const int pend = min(p0 + WS_SEG, len), qend = min(len, pend + R);
+    double wt[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; ++j) wt[j] = w[j];
+    double win[W];
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) { const int q = p0 - R + k; win[k] = (q >= 0 && q < qend) ? in[base + q * stride] : 0.0; }
+#pragma unroll 1
+    for (int gp = p0; gp < pend; gp += W) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int p = gp + k, q = p + R;
+            win[(2 * R + k) % W] = q < qend ? in[base + q * stride] : 0.0;
+            double acc = win[(R + k) % W] * wt[R];
+#pragma unroll
+            for (int j = R; j >= 1; --j) acc += (win[(R + k - j + W) % W] + win[(R + k + j) % W]) * wt[R - j];
+            if (p < pend) out[base + p * stride] = acc;
+        }
+    }
+}
+template <int AXIS, int R>
+__global__ __launch_bounds__(256) void ws_max_slide_kernel(SegGeom g, const double* __restrict__ in, double* __restrict__ out) {
+    constexpr int W = 2 * R + 1;
+    long long base, stride; int len, p0;
+    if (!ws_line<AXIS>(g, (long long)blockIdx.x * 256 + threadIdx.x, base, stride, len, p0)) return;
+    const int pend = min(p0 + WS_SEG, len), qend = min(len, pend + R);
+    double win[W];
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k) { const int q = p0 - R + k; win[k] = (q >= 0 && q < qend) ? in[base + q * stride] : 0.0; }
+#pragma unroll 1
+    for (int gp = p0; gp < pend; gp += W) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int p = gp + k, q = p + R;
+            win[(2 * R + k) % W] = q < qend ? in[base + q * stride] : 0.0;
+            // ws_maxfilt_kernel's order: the centre, (0 if the window leaves the image and the centre is negative,) then -1, +1, -2, +2, ...
+            double m = win[(R + k) % W];
+            if ((p - R < 0 || p + R >= len) && m < 0.0) m = 0.0;
+#pragma unroll
+            for (int j = 1; j <= R; ++j) {
+                if (p - j >= 0) m = fmax(m, win[(R + k - j + W) % W]);
+                if (p + j < len) m = fmax(m, win[(R + k + j) % W]);
+            }
+            if (p < pend) out[base + p * stride] = m;
+        }
+    }
+}
+
 // Peak candidates + the per-group statistics peak_local_max needs (group = z slice in 2-D mode, the whole volume in 3-D mode):
 // eq_count = #(value == window maximum), vmin = the image minimum (values are >= 0: the bit patterns order like the values).
 // A candidate is a positive local maximum outside the excluded border; "value > minimum" and "not a constant image" are applied
@@ -417,6 +492,108 @@ __global__ __launch_bounds__(256) void ws_peak_kernel(SegGeom g, int mode2d, int
     for (int t = threadIdx.x; t < ngroups && t < 128; t += 256) {
         if (s_eq[t]) atomicAdd(&eq_count[t], s_eq[t]);
         if (s_min[t] != ~0ull) atomicMin(&vmin[t], s_min[t]);
+    }
+}
+
+// The LAST pass of the window maximum fused with ws_peak_kernel's test: the window maximum is never written (vmax_out: the tests' hook) nor
+// read back, and the per-group statistics are accumulated per thread / per wave instead of two LDS atomics per voxel.
+// 2-D stage: the y pass as a sliding window (a thread's z = its group is fixed along its line).
+template <int R>
+__global__ __launch_bounds__(256) void ws_max_peak_slide_kernel(SegGeom g, int border, const double* __restrict__ in, const double* __restrict__ v,
+                                                                double* __restrict__ vmax_out, unsigned int* __restrict__ eq_count,
+                                                                unsigned long long* __restrict__ vmin, unsigned int* __restrict__ cand_count, int cap,
+                                                                unsigned long long* __restrict__ cand_val, int32_t* __restrict__ cand_idx,
+                                                                int* __restrict__ overflow) {
+    constexpr int W = 2 * R + 1;
+    __shared__ unsigned int s_eq[128];
+    __shared__ unsigned long long s_min[128];
+    for (int t = threadIdx.x; t < 128; t += 256) { s_eq[t] = 0; s_min[t] = ~0ull; }
+    __syncthreads();
+    long long base, stride; int len, p0;
+    const bool live = ws_line<1>(g, (long long)blockIdx.x * 256 + threadIdx.x, base, stride, len, p0);
+    if (live) {
+        const int z = (int)(base % g.Z), x = (int)(base / ((long long)g.Y * g.Z));
+        const int pend = min(p0 + WS_SEG, len), qend = min(len, pend + R);
+        const bool x_inside = x >= border && x < g.X - border;
+        unsigned int eqs = 0; unsigned long long mn = ~0ull;
+        double win[W];
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) { const int q = p0 - R + k; win[k] = (q >= 0 && q < qend) ? in[base + q * stride] : 0.0; }
+#pragma unroll 1
+        for (int gp = p0; gp < pend; gp += W) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const int p = gp + k, q = p + R;
+                win[(2 * R + k) % W] = q < qend ? in[base + q * stride] : 0.0;
+                double m = win[(R + k) % W];
+                if ((p - R < 0 || p + R >= len) && m < 0.0) m = 0.0;
+#pragma unroll
+                for (int j = 1; j <= R; ++j) {
+                    if (p - j >= 0) m = fmax(m, win[(R + k - j + W) % W]);
+                    if (p + j < len) m = fmax(m, win[(R + k + j) % W]);
+                }
+                if (p < pend) {
+                    const long long i = base + p * stride;
+                    const double a = v[i];
+                    if (vmax_out) vmax_out[i] = m;
+                    const bool eq = a == m;
+                    eqs += eq ? 1u : 0u;
+                    const unsigned long long ab = (unsigned long long)__double_as_longlong(a);
+                    mn = ab < mn ? ab : mn;
+                    if (eq && a > 0.0 && x_inside && p >= border && p < len - border) {
+                        const unsigned int pos = atomicAdd(&cand_count[z], 1u);
+                        if ((int)pos < cap) { cand_val[(size_t)z * cap + pos] = ab; cand_idx[(size_t)z * cap + pos] = (int32_t)i; }
+                        else *overflow = 1;
+                    }
+                }
+            }
+        }
+        if (eqs) atomicAdd(&s_eq[z & 127], eqs);
+        atomicMin(&s_min[z & 127], mn);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < g.Z && t < 128; t += 256) {
+        if (s_eq[t]) atomicAdd(&eq_count[t], s_eq[t]);
+        if (s_min[t] != ~0ull) atomicMin(&vmin[t], s_min[t]);
+    }
+}
+// 3-D stage: the z pass per voxel (z is the contiguous axis: the 2 r + 1 reads of a lane hit the line its neighbours fetch), one group.
+__global__ __launch_bounds__(256) void ws_maxz_peak_kernel(SegGeom g, int r, int border, const double* __restrict__ in, const double* __restrict__ v,
+                                                           double* __restrict__ vmax_out, unsigned int* __restrict__ eq_count,
+                                                           unsigned long long* __restrict__ vmin, unsigned int* __restrict__ cand_count, int cap,
+                                                           unsigned long long* __restrict__ cand_val, int32_t* __restrict__ cand_idx, int* __restrict__ overflow) {
+    __shared__ unsigned int s_eq;
+    __shared__ unsigned long long s_min;
+    if (threadIdx.x == 0) { s_eq = 0; s_min = ~0ull; }
+    __syncthreads();
+    unsigned int eqs = 0; unsigned long long mn = ~0ull;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < g.V; i += (long long)gridDim.x * 256) {
+        int x, y, z; ws_xyz(i, g, x, y, z);
+        double m = in[i];
+        if ((z - r < 0 || z + r >= g.Z) && m < 0.0) m = 0.0;
+        for (int j = 1; j <= r; ++j) {
+            if (z - j >= 0) m = fmax(m, in[i - j]);
+            if (z + j < g.Z) m = fmax(m, in[i + j]);
+        }
+        const double a = v[i];
+        if (vmax_out) vmax_out[i] = m;
+        const bool eq = a == m;
+        eqs += eq ? 1u : 0u;
+        const unsigned long long ab = (unsigned long long)__double_as_longlong(a);
+        mn = ab < mn ? ab : mn;
+        const bool inside = x >= border && x < g.X - border && y >= border && y < g.Y - border && z >= border && z < g.Z - border;
+        if (eq && a > 0.0 && inside) {
+            const unsigned int pos = atomicAdd(&cand_count[0], 1u);
+            if ((int)pos < cap) { cand_val[pos] = ab; cand_idx[pos] = (int32_t)i; }
+            else *overflow = 1;
+        }
+    }
+    if (eqs) atomicAdd(&s_eq, eqs);
+    atomicMin(&s_min, mn);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_eq) atomicAdd(&eq_count[0], s_eq);
+        if (s_min != ~0ull) atomicMin(&vmin[0], s_min);
     }
 }
 
@@ -521,11 +698,13 @@ __device__ void ws_aquicksort_block(int* vk, int* ts, int num, int* lists /* LDS
 __global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mode2d, int min_distance, const unsigned int* __restrict__ eq_count,
                                                               const unsigned long long* __restrict__ vmin, const unsigned int* __restrict__ cand_count,
                                                               int cap, const unsigned long long* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
-                                                              int32_t* __restrict__ labels, int32_t* __restrict__ marker_idx, int32_t* __restrict__ marker_count) {
+                                                              int32_t* __restrict__ labels, int32_t* __restrict__ marker_idx, int32_t* __restrict__ marker_count,
+                                                              int small_elsewhere) {
     extern __shared__ unsigned long long ws_sm[];
     const int grp = blockIdx.x;
     const long long gsize = mode2d ? (long long)g.X * g.Y : g.V;
     int n = (int)min(cand_count[grp], (unsigned int)cap);
+    if (small_elsewhere && n <= WS_SEL2_CAP) return;                             // ws_peak_select2_kernel's
     if (eq_count[grp] == (unsigned long long)gsize) n = 0;                       // constant image: no peaks
     int np2 = 1; while (np2 < n) np2 <<= 1;
     unsigned long long* key = ws_sm;                                             // [np2] ~value bits (descending value = ascending key)
@@ -668,6 +847,193 @@ __global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mod
     if (threadIdx.x == 0) marker_count[grp] = nkept;
 }
 
+// One range of the sort by one WAVE -- the same element moves as ws_sort_range, found in parallel.  Hoare's loop around a parked pivot vp is a
+// function of the ORIGINAL range: with L_1 < L_2 < ... the positions in [pl + 1, pr - 1] whose key is not < vp (where `do ++pi` can stop; pr - 1
+// holds vp itself) and R_1 > R_2 > ... those in [pl, pr - 2] whose key is not > vp (where `do --pj` can stop; pl holds a key <= vp), iteration
+// k swaps (L_k, R_k) as long as L_k < R_k -- both lie inside the stretch no earlier swap touched --, and after K swaps pi comes to rest on
+// min(L_{K+1}, R_K) (R_K now holds a key >= vp).  Lanes own consecutive chunks, prefix sums rank the stoppers, the lists live in scratch at the
+// range's own offsets (ranges of a round are disjoint).  A leaf (<= 16 elements) is numpy's insertion sort = a STABLE sort: every lane places
+// its element by counting.  LDS instructions of one wave execute in order; wave_barrier only pins the compiler.
+__device__ __forceinline__ int ws_wave_excl_prefix(int v, int lane, int& total) {
+    int s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(s, d); if (lane >= d) s += o; }
+    total = __shfl(s, 63);
+    return s - v;
+}
+__device__ void ws_sort_range_wave(int* vk, int* ts, int* Ls, int* Rs, int pl, int pr, int cdepth, bool from_stack, int* nxt, int* nxt_count, int lane) {
+    if (from_stack && cdepth < 0) { if (lane == 0) ws_aheapsort(vk, ts, pl, pr - pl + 1); __builtin_amdgcn_wave_barrier(); return; }
+#define WS_SWAP(a, b) { const int tv_ = vk[a], tt_ = ts[a]; vk[a] = vk[b]; ts[a] = ts[b]; vk[b] = tv_; ts[b] = tt_; }
+    while (pr - pl > 15) {
+        if (lane == 0) {
+            const int pm = pl + ((pr - pl) >> 1);
+            if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
+            if (vk[pr] < vk[pm]) WS_SWAP(pr, pm)
+            if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
+            const int pj = pr - 1;
+            WS_SWAP(pm, pj)
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int vp = vk[pr - 1];
+        const int m = pr - pl + 1, c = (m + 63) >> 6;
+        const int lo = min(pl + lane * c, pr + 1), hi = min(lo + c, pr + 1);
+        int nl = 0, nr = 0;
+        for (int q = lo; q < hi; ++q) { const int v = vk[q]; nl += (q > pl && q < pr && !(v < vp)) ? 1 : 0; nr += (q < pr - 1 && !(vp < v)) ? 1 : 0; }
+        int tot_l, tot_r;
+        int kl = ws_wave_excl_prefix(nl, lane, tot_l);
+        const int pre_r = ws_wave_excl_prefix(nr, lane, tot_r);
+        int kr = tot_r - pre_r - nr;                                             // stoppers to the right of this lane's chunk
+        for (int q = lo; q < hi; ++q) { const int v = vk[q]; if (q > pl && q < pr && !(v < vp)) Ls[pl + kl++] = q; }
+        for (int q = hi - 1; q >= lo; --q) { const int v = vk[q]; if (q < pr - 1 && !(vp < v)) Rs[pl + kr++] = q; }
+        __builtin_amdgcn_wave_barrier();
+        const int nmin = min(tot_l, tot_r);
+        int ck = 0;
+        for (int k = lane; k < nmin; k += 64) ck += Ls[pl + k] < Rs[pl + k] ? 1 : 0;
+        int K; (void)ws_wave_excl_prefix(ck, lane, K);
+        const int pi = min(Ls[pl + K], K > 0 ? Rs[pl + K - 1] : pr - 1);
+        for (int k = lane; k < K; k += 64) { const int a = Ls[pl + k], b = Rs[pl + k]; WS_SWAP(a, b) }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) { const int pk = pr - 1; WS_SWAP(pi, pk) }
+        __builtin_amdgcn_wave_barrier();
+        --cdepth;
+        int k = 0;
+        if (lane == 0) k = atomicAdd(nxt_count, 1);
+        k = __shfl(k, 0);
+        if (pi - pl < pr - pi) { if (lane == 0) { nxt[3 * k] = pi + 1; nxt[3 * k + 1] = pr; nxt[3 * k + 2] = cdepth; } pr = pi - 1; }
+        else { if (lane == 0) { nxt[3 * k] = pl; nxt[3 * k + 1] = pi - 1; nxt[3 * k + 2] = cdepth; } pl = pi + 1; }
+    }
+#undef WS_SWAP
+    const int m = pr - pl + 1;
+    if (m > 1) {
+        int myv = 0, myt = 0, pos = 0;
+        if (lane < m) {
+            myv = vk[pl + lane]; myt = ts[pl + lane];
+            for (int j = 0; j < m; ++j) { const int o = vk[pl + j]; pos += (o < myv || (o == myv && j < lane)) ? 1 : 0; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < m) { vk[pl + pos] = myv; ts[pl + pos] = myt; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ws_peak_select_kernel for groups of at most WS_SEL2_CAP candidates (every real stack): the three bitonic sorts (by value, by raveled index, by
+// raveled index again: ~55 block-wide barriers each) become counting passes -- thread t counts the candidates in front of its own, n LDS
+// broadcast reads, no barrier inside --, and a range of the introsort replay is partitioned by a whole wave (ws_sort_range_wave) instead of one
+// thread walking it element by element (2 n dependent LDS steps were 0.25 ms of the benchmark stack's 3-D stage).  Same results array for array.
+constexpr size_t WS_SEL2_LDS = (size_t)WS_SEL2_CAP * 44;
+__global__ __launch_bounds__(1024) void ws_peak_select2_kernel(SegGeom g, int mode2d, int min_distance, const unsigned int* __restrict__ eq_count,
+                                                               const unsigned long long* __restrict__ vmin, const unsigned int* __restrict__ cand_count,
+                                                               int cap, const unsigned long long* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
+                                                               int32_t* __restrict__ labels, int32_t* __restrict__ marker_idx, int32_t* __restrict__ marker_count) {
+    extern __shared__ unsigned long long ws_sel_sm[];
+    __shared__ int qs_lists[2 * 3 * WS_QS_RANGES], qs_counts[2];
+    __shared__ int tie_matters, n_valid, nkept;
+    const int grp = blockIdx.x;
+    const long long gsize = mode2d ? (long long)g.X * g.Y : g.V;
+    int n = (int)min(cand_count[grp], (unsigned int)cap);
+    if (n > WS_SEL2_CAP) return;                                                 // ws_peak_select_kernel's (launched beside this one)
+    if (eq_count[grp] == (unsigned long long)gsize) n = 0;                       // constant image: no peaks
+    unsigned long long* const val = ws_sel_sm;                                   // [CAP] value bits as appended
+    unsigned long long* const rval = val + WS_SEL2_CAP;                          // [CAP] ... in raveled order
+    int* const idx = (int*)(rval + WS_SEL2_CAP);                                 // [CAP] voxel index as appended (0x7fffffff: not a peak)
+    int* const ridx = idx + WS_SEL2_CAP;                                         // [CAP] ... in raveled order
+    int* const vk = ridx + WS_SEL2_CAP;                                          // [CAP] dense rank of -value (numpy's sort key), moved by the sort
+    int* const ts = vk + WS_SEL2_CAP;                                            // [CAP] the permutation being sorted
+    int* const kf = ts + WS_SEL2_CAP;                                            // [CAP] kept flag per sorted position, then per raveled position
+    int* const lsc = kf + WS_SEL2_CAP;                                           // [CAP] scratch of the sort: left / right stopper lists of a range
+    int* const rsc = lsc + WS_SEL2_CAP;                                          // [CAP]
+    const unsigned long long mn = vmin[grp];
+    if (threadIdx.x == 0) { tie_matters = 0; n_valid = 0; nkept = 0; }
+    for (int t = threadIdx.x; t < n; t += 1024) {
+        const unsigned long long vb = cand_val[(size_t)grp * cap + t];
+        val[t] = vb; idx[t] = vb > mn ? cand_idx[(size_t)grp * cap + t] : 0x7fffffff;      // value > image minimum
+    }
+    __syncthreads();
+    // raveled order: position = number of peaks with a smaller voxel index
+    for (int t = threadIdx.x; t < n; t += 1024) {
+        const int me = idx[t];
+        if (me == 0x7fffffff) continue;
+        int pos = 0;
+        for (int u = 0; u < n; ++u) pos += idx[u] < me ? 1 : 0;
+        ridx[pos] = me; rval[pos] = val[t];
+        atomicAdd(&n_valid, 1);
+    }
+    __syncthreads();
+    const int nv = n_valid;
+    // numpy's key = -value: dense rank = number of strictly larger values; do two EQUAL peaks lie closer than min_distance (strictly)?
+    for (int t = threadIdx.x; t < nv; t += 1024) {
+        const unsigned long long me = rval[t];
+        int xa, ya, za; ws_xyz(ridx[t], g, xa, ya, za);
+        int rank = 0; bool close = false;
+        for (int u = 0; u < nv; ++u) {
+            const unsigned long long o = rval[u];
+            rank += o > me ? 1 : 0;
+            if (o == me && u != t) {
+                int xb, yb, zb; ws_xyz(ridx[u], g, xb, yb, zb);
+                close |= max(max(abs(xa - xb), abs(ya - yb)), abs(za - zb)) < min_distance;
+            }
+        }
+        vk[t] = rank; ts[t] = t; kf[t] = 1;
+        if (close) tie_matters = 1;
+    }
+    __syncthreads();
+    if (tie_matters) {
+        // np.argsort(-intensities) over the peaks in raveled order: the replay, one thread per range of a round
+        if (nv >= 2) {
+            if (threadIdx.x == 0) {
+                int cdepth = 0;
+                for (int m = nv >> 1; m; m >>= 1) ++cdepth;
+                qs_lists[0] = 0; qs_lists[1] = nv - 1; qs_lists[2] = 2 * cdepth;
+                qs_counts[0] = 1; qs_counts[1] = 0;
+            }
+            __syncthreads();
+            for (int round = 0;; ++round) {
+                const int n_cur = qs_counts[round & 1];
+                if (n_cur == 0) break;
+                int* cur = qs_lists + (round & 1) * 3 * WS_QS_RANGES;
+                int* nxt = qs_lists + ((round + 1) & 1) * 3 * WS_QS_RANGES;
+                for (int j = threadIdx.x >> 6; j < n_cur; j += 16)
+                    ws_sort_range_wave(vk, ts, lsc, rsc, cur[3 * j], cur[3 * j + 1], cur[3 * j + 2], round > 0, nxt, &qs_counts[(round + 1) & 1], threadIdx.x & 63);
+                __syncthreads();
+                if (threadIdx.x == 0) qs_counts[round & 1] = 0;
+                __syncthreads();
+            }
+        }
+        // ensure_spacing inside every run of equal rank, in numpy's order (run starts in parallel)
+        for (int t = threadIdx.x; t < nv; t += 1024) {
+            if (t > 0 && vk[t - 1] == vk[t]) continue;
+            int e = t + 1;
+            while (e < nv && vk[e] == vk[t]) ++e;
+            for (int a = t + 1; a < e; ++a) {
+                int xa, ya, za; ws_xyz(ridx[ts[a]], g, xa, ya, za);
+                for (int b = t; b < a; ++b) {
+                    if (!kf[b]) continue;
+                    int xb, yb, zb; ws_xyz(ridx[ts[b]], g, xb, yb, zb);
+                    if (max(max(abs(xa - xb), abs(ya - yb)), abs(za - zb)) < min_distance) { kf[a] = 0; break; }   // strict (skimage ensure_spacing)
+                }
+            }
+        }
+        __syncthreads();
+        // kept flag per raveled position (vk is free now)
+        for (int t = threadIdx.x; t < nv; t += 1024) vk[ts[t]] = kf[t];
+        __syncthreads();
+        for (int t = threadIdx.x; t < nv; t += 1024) kf[t] = vk[t];
+        __syncthreads();
+    }
+    // markers numbered in raster order (skimage.morphology.label of isolated pixels)
+    for (int t = threadIdx.x; t < nv; t += 1024) {
+        if (!kf[t]) continue;
+        int before = 0;
+        for (int u = 0; u < t; ++u) before += kf[u];
+        const int id = ridx[t];
+        labels[id] = before + 1;
+        marker_idx[(size_t)grp * cap + before] = id;
+        atomicAdd(&nkept, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) marker_count[grp] = nkept;
+}
+
 // connectivity-1 components of the mask (2-D mode: inside every z slice) with the union-find of the connected-components path
 template <bool MODE2D>
 __global__ void ws_cc_init_merge_kernel(SegGeom g, const unsigned char* __restrict__ bn, int32_t* __restrict__ parent, int phase) {
@@ -763,15 +1129,59 @@ __global__ void ws_flood_kernel(SegGeom g, const unsigned char* __restrict__ bn,
     }
 }
 
+// ---- the flood of one mask component by one wave, second form: everything the loop touches lives in LDS -------------------------------------
+// wave-wide maxima by DPP (quad_perm, quad_perm, row_half_mirror, row_mirror, row_bcast:15, row_bcast:31; lane 63 holds the result): a butterfly of
+// __shfl_xor is six LDS-crossbar round trips per dword, and the queue's arg-min used to need five dwords per round
+__device__ __forceinline__ unsigned long long ws_wave_max_u64(unsigned long long k) {
+    unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+#define WS_DPPMAX64(ctrl, rmask) { const unsigned int th = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)hi, ctrl, rmask, 0xf, false), \
+                                                      tl = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)lo, ctrl, rmask, 0xf, false); \
+                                   const bool g_ = th > hi || (th == hi && tl > lo); hi = g_ ? th : hi; lo = g_ ? tl : lo; }
+    WS_DPPMAX64(0xB1, 0xf) WS_DPPMAX64(0x4E, 0xf) WS_DPPMAX64(0x141, 0xf) WS_DPPMAX64(0x140, 0xf) WS_DPPMAX64(0x142, 0xa) WS_DPPMAX64(0x143, 0xc)
+#undef WS_DPPMAX64
+    return ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)lo, 63);
+}
+__device__ __forceinline__ unsigned int ws_wave_max_u32(unsigned int v) {
+#define WS_DPPMAX32(ctrl, rmask) { const unsigned int t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false); v = t > v ? t : v; }
+    WS_DPPMAX32(0xB1, 0xf) WS_DPPMAX32(0x4E, 0xf) WS_DPPMAX32(0x141, 0xf) WS_DPPMAX32(0x140, 0xf) WS_DPPMAX32(0x142, 0xa) WS_DPPMAX32(0x143, 0xc)
+#undef WS_DPPMAX32
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // components with exactly one marker: every voxel gets that marker's label (what the flood would do, without its sequential walk)
-__global__ void ws_fill_single_kernel(long long V, const int32_t* __restrict__ parent, const int32_t* __restrict__ heap_off,
-                                      const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap, int32_t* __restrict__ labels) {
+// -- and the bounding box of every component with several markers (slot = its position in the flood's list) for ws_flood_box_kernel
+__global__ void ws_fill_single_kernel(SegGeom g, const int32_t* __restrict__ parent, const int32_t* __restrict__ heap_off,
+                                      const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap, int32_t* __restrict__ labels,
+                                      const int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V) return;
-    const int root = parent[i];
-    if (root < 0 || heap_cnt[root] != 1) return;
-    const int m = heap[heap_off[root]].idx;
-    if (m != (int)i) labels[i] = labels[m];
+    int root = -1, cnt = 0;
+    if (i < g.V) { root = parent[i]; if (root >= 0) cnt = heap_cnt[root]; }
+    if (cnt == 1) {
+        const int m = heap[heap_off[root]].idx;
+        if (m != (int)i) labels[i] = labels[m];
+    }
+    // bounding boxes: the lanes of a wave that belong to one component are reduced first (one atomic per coordinate bound, wave and component:
+    // a thread-per-voxel version spent 0.2 ms on the same-address atomics of the largest component)
+    unsigned long long todo = __ballot(cnt >= 2);
+    if (!todo) return;
+    int x = 0, y = 0, z = 0;
+    if (cnt >= 2) ws_xyz(i, g, x, y, z);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lr = __shfl(root, leader);
+        const bool mine = cnt >= 2 && root == lr;
+        const unsigned long long same = __ballot(mine) & todo;
+        const unsigned int nx = ws_wave_max_u32(mine ? 0x7fffffffu - (unsigned int)x : 0u), mx = ws_wave_max_u32(mine ? (unsigned int)x + 1u : 0u);
+        const unsigned int ny = ws_wave_max_u32(mine ? 0x7fffffffu - (unsigned int)y : 0u), my = ws_wave_max_u32(mine ? (unsigned int)y + 1u : 0u);
+        const unsigned int nz = ws_wave_max_u32(mine ? 0x7fffffffu - (unsigned int)z : 0u), mz = ws_wave_max_u32(mine ? (unsigned int)z + 1u : 0u);
+        if (lane == leader) {
+            int32_t* bb = bbox + 6 * (size_t)slot_of[lr];
+            atomicMin(bb + 0, (int)(0x7fffffffu - nx)); atomicMin(bb + 1, (int)(0x7fffffffu - ny)); atomicMin(bb + 2, (int)(0x7fffffffu - nz));
+            atomicMax(bb + 3, (int)mx - 1); atomicMax(bb + 4, (int)my - 1); atomicMax(bb + 5, (int)mz - 1);
+        }
+        todo &= ~same;
+    }
 }
 
 // skimage's priority flood of ONE mask component per WAVE.  The queue is an unsorted array (LDS when the component fits, its slice of the
@@ -780,15 +1190,24 @@ __global__ void ws_fill_single_kernel(long long V, const int32_t* __restrict__ p
 // pushed with consecutive ages in ascending raveled-offset order (ballot prefix), labels given at push time.  Per pop: one LDS sweep, one
 // butterfly, ONE global round trip (the single-thread version pays a dozen dependent ones).
 constexpr int WS_Q_LDS = 2048;                     // queue entries held in LDS (32 KB + 8 KB of labels per 64-thread block)
+constexpr int WS_BOX_CAP = 8192;                   // voxels of a component's bounding box held in LDS (64 KB smoothed EDT + 32 KB labels)
+// Which components take the LDS form: at most WS_Q_LDS voxels (the queue never holds more than the component) inside a bounding box of at
+// most WS_BOX_CAP voxels.  The others keep ws_flood_wave_kernel (queue in LDS or global memory, state in global memory).
+__device__ __forceinline__ bool ws_box_eligible(const int32_t* bb, int csize, bool mode2d) {
+    const long long vol = (long long)(bb[3] - bb[0] + 1) * (bb[4] - bb[1] + 1) * (mode2d ? 1 : (bb[5] - bb[2] + 1));
+    return csize <= WS_Q_LDS && vol <= WS_BOX_CAP && bb[3] - bb[0] < 1024 && bb[4] - bb[1] < 1024 && (mode2d || bb[5] - bb[2] < 128);
+}
 template <bool MODE2D>
 __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth,
                                                            const int32_t* __restrict__ roots, const int32_t* __restrict__ size,
                                                            const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
-                                                           WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ qlab_all, int32_t* __restrict__ labels) {
+                                                           WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ qlab_all, int32_t* __restrict__ labels,
+                                                           const int32_t* __restrict__ bbox) {
     __shared__ WsHeapEntry q_lds[WS_Q_LDS];
     __shared__ int32_t l_lds[WS_Q_LDS];
     const int lane = threadIdx.x;
     const int root = roots[blockIdx.x];
+    if (bbox && ws_box_eligible(bbox + (size_t)blockIdx.x * 6, size[root], MODE2D)) return;      // ws_flood_box_kernel's
     const bool in_lds = size[root] <= WS_Q_LDS;
     WsHeapEntry* const gq = heap_all + heap_off[root];
     int32_t* const gl = qlab_all + heap_off[root];
@@ -830,7 +1249,7 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsi
             else if (lane == 4) j = y + 1 < g.Y ? i + sy : -1; else if (lane == 5) j = x + 1 < g.X ? i + sx : -1;
         }
         bool take = false; double val = 0.0;
-        if (j >= 0) { take = bn[j] && labels[j] == 0; if (take) val = -smooth[j]; }
+        if (j >= 0) { const unsigned char b = bn[j]; const int l = labels[j]; val = -smooth[j]; take = b && l == 0; }      // three independent loads: one round trip
         const unsigned long long mask = __ballot(take);
         if (take) {
             const int rank = (int)__popcll(mask & ((1ull << lane) - 1ull));
@@ -844,15 +1263,139 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsi
     }
 }
 
+// queue entry of the LDS flood: key = bit pattern of the smoothed EDT (>= +0.0, so the patterns order like the values and the LARGEST key is the
+// smallest -smooth = the next pop), then the smaller age, then the smaller index (only seeds share an age)
+struct WsQEntry { unsigned long long key; int age; int idx; };
+__device__ __forceinline__ bool ws_qbefore(const WsQEntry& a, const WsQEntry& b) {
+    const unsigned long long ta = ((unsigned long long)(unsigned int)a.age << 32) | (unsigned int)a.idx, tb = ((unsigned long long)(unsigned int)b.age << 32) | (unsigned int)b.idx;
+    return a.key > b.key || (a.key == b.key && ta < tb);
+}
+// wave arg-min of the per-lane candidates -> every lane gets the winner's queue position and packed coordinates.  32-bit phases (a step of
+// ws_wave_max_u32 folds into ONE v_max_u32 with a DPP operand): high word of the key, low word among the lanes that hold the high maximum;
+// equal keys fall through to the age, equal ages (seeds) to the index.
+__device__ __forceinline__ void ws_wave_argmin(const WsQEntry& best, int& bpos, int& bidx, int lane) {
+    const unsigned int hi = (unsigned int)(best.key >> 32), lo = (unsigned int)best.key;
+    const bool has = bpos >= 0;
+    const unsigned int hmax = ws_wave_max_u32(has ? hi : 0u);
+    const bool c1 = has && hi == hmax;
+    const unsigned int lmax = ws_wave_max_u32(c1 ? lo : 0u);
+    unsigned long long m = __ballot(c1 && lo == lmax);
+    if (__popcll(m) > 1) {
+        const bool in = (m >> lane) & 1ull;
+        const unsigned int amax = ws_wave_max_u32(in ? ~(unsigned int)best.age : 0u);
+        m &= __ballot(in && ~(unsigned int)best.age == amax);
+        if (__popcll(m) > 1) {
+            const bool in2 = (m >> lane) & 1ull;
+            const unsigned int imax = ws_wave_max_u32(in2 ? ~(unsigned int)best.idx : 0u);
+            m &= __ballot(in2 && ~(unsigned int)best.idx == imax);
+        }
+    }
+    const int w = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+    bidx = __builtin_amdgcn_readlane(best.idx, w);
+    bpos = __builtin_amdgcn_readlane(bpos, w);
+}
+
+constexpr size_t WS_BOX_LDS = (size_t)WS_Q_LDS * sizeof(WsQEntry) + (size_t)WS_BOX_CAP * 12;
+// Local coordinates travel packed in the entry's idx (lx << 17 | ly << 7 | lz: monotone in the raveled order, so the index tie-break is
+// unchanged): a pop then needs no division by the box's runtime extents (three of them cost more than the rest of the iteration).
+template <bool MODE2D>
+__global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const double* __restrict__ smooth, const int32_t* __restrict__ parent,
+                                                          const int32_t* __restrict__ roots, const int32_t* __restrict__ size,
+                                                          const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
+                                                          const WsHeapEntry* __restrict__ heap_all, const int32_t* __restrict__ bbox, int32_t* __restrict__ labels) {
+    extern __shared__ unsigned long long ws_box_sm[];
+    const int lane = threadIdx.x;
+    const int root = roots[blockIdx.x];
+    const int32_t* bb = bbox + (size_t)blockIdx.x * 6;
+    if (!ws_box_eligible(bb, size[root], MODE2D)) return;
+    WsQEntry* const q = (WsQEntry*)ws_box_sm;                                    // [WS_Q_LDS]
+    double* const sm_box = (double*)(q + WS_Q_LDS);                              // [WS_BOX_CAP]
+    int32_t* const st_box = (int32_t*)(sm_box + WS_BOX_CAP);                     // [WS_BOX_CAP]  -1 outside the component, 0 free, > 0 label
+    const int x0 = bb[0], y0 = bb[1], z0 = MODE2D ? root % g.Z : bb[2];
+    const int BX = bb[3] - x0 + 1, BY = bb[4] - y0 + 1, BZ = MODE2D ? 1 : bb[5] - z0 + 1;
+    const int bvol = BX * BY * BZ;
+    const long long sx = (long long)g.Y * g.Z, sy = g.Z;
+    // box walk without per-voxel divisions: p advances by 64, its mixed-radix digits by (64 / (BZ BY), (64 / BZ) % BY, 64 % BZ) with carries
+    const int d64z = 64 % BZ, d64y = (64 / BZ) % BY, d64x = 64 / (BZ * BY);
+    {
+        int lz = lane % BZ, ly = (lane / BZ) % BY, lx = lane / (BZ * BY);
+        for (int p = lane; p < bvol; p += 64) {
+            const long long j = (long long)(x0 + lx) * sx + (long long)(y0 + ly) * sy + (z0 + lz);
+            const bool mine = parent[j] == root;
+            sm_box[p] = smooth[j];
+            st_box[p] = mine ? labels[j] : -1;
+            lz += d64z; if (lz >= BZ) { lz -= BZ; ++ly; }
+            ly += d64y; if (ly >= BY) { ly -= BY; ++lx; }
+            lx += d64x;
+        }
+    }
+    int n = heap_cnt[root];
+    const WsHeapEntry* gq = heap_all + heap_off[root];
+    for (int e = lane; e < n; e += 64) {
+        const WsHeapEntry t = gq[e];
+        int x, y, z; ws_xyz(t.idx, g, x, y, z);
+        q[e] = WsQEntry{(unsigned long long)__double_as_longlong(-t.value), 0, ((x - x0) << 17) | ((y - y0) << 7) | (z - z0)};
+    }
+    __syncthreads();
+    // this lane's neighbour, in ascending raveled-offset order over the lanes: x-1, y-1, (z-1, z+1,) y+1, x+1; the rest idle
+    int sh = 0, dir = 0, lim = 0, dlin = 0;
+    if (MODE2D) {
+        if (lane == 0) { sh = 17; dir = -1; lim = BX; dlin = -BY; } else if (lane == 1) { sh = 7; dir = -1; lim = BY; dlin = -1; }
+        else if (lane == 2) { sh = 7; dir = 1; lim = BY; dlin = 1; } else if (lane == 3) { sh = 17; dir = 1; lim = BX; dlin = BY; }
+    } else {
+        if (lane == 0) { sh = 17; dir = -1; lim = BX; dlin = -BY * BZ; } else if (lane == 1) { sh = 7; dir = -1; lim = BY; dlin = -BZ; }
+        else if (lane == 2) { sh = 0; dir = -1; lim = BZ; dlin = -1; } else if (lane == 3) { sh = 0; dir = 1; lim = BZ; dlin = 1; }
+        else if (lane == 4) { sh = 7; dir = 1; lim = BY; dlin = BZ; } else if (lane == 5) { sh = 17; dir = 1; lim = BX; dlin = BY * BZ; }
+    }
+    const int fmask = sh == 17 ? 1023 : (sh == 7 ? 1023 : 127), dpk = dir * (1 << sh);
+    int age = 0;
+    while (n > 0) {
+        WsQEntry best = q[lane < n ? lane : 0]; int bpos = lane < n ? lane : -1;
+        for (int e = lane + 64; e < n; e += 64) { const WsQEntry t = q[e]; if (ws_qbefore(t, best)) { best = t; bpos = e; } }
+        int c;
+        ws_wave_argmin(best, bpos, c, lane);
+        --n;
+        if (lane == 0 && bpos != n) q[bpos] = q[n];
+        const int lin = ((c >> 17) * BY + ((c >> 7) & 1023)) * BZ + (c & 127);     // uniform
+        const int lab = st_box[lin];                                             // the label a voxel got when it was pushed (seeds: their marker's)
+        const bool valid = (unsigned int)(((c >> sh) & fmask) + dir) < (unsigned int)lim;
+        const int nb = valid ? lin + dlin : lin;
+        const int st = st_box[nb]; const double sv = sm_box[nb];                 // (both reads in flight with the label's)
+        const bool take = valid && st == 0;
+        const unsigned long long mask = __ballot(take);
+        if (take) {
+            const int rank = (int)__popcll(mask & ((1ull << lane) - 1ull));
+            st_box[nb] = lab;
+            q[n + rank] = WsQEntry{(unsigned long long)__double_as_longlong(sv), age + rank + 1, c + dpk};
+        }
+        const int cnt = (int)__popcll(mask);
+        n += cnt; age += cnt;
+        // one wave: its LDS instructions execute in program order, so the next sweep sees these writes; the compiler must not move them
+        __builtin_amdgcn_wave_barrier();
+    }
+    {
+        int lz = lane % BZ, ly = (lane / BZ) % BY, lx = lane / (BZ * BY);
+        for (int p = lane; p < bvol; p += 64) {
+            const int lab = st_box[p];
+            if (lab > 0) labels[(long long)(x0 + lx) * sx + (long long)(y0 + ly) * sy + (z0 + lz)] = lab;
+            lz += d64z; if (lz >= BZ) { lz -= BZ; ++ly; }
+            ly += d64y; if (ly >= BY) { ly -= BY; ++lx; }
+            lx += d64x;
+        }
+    }
+}
+
 // Do two seeds of EXACTLY equal height share a mask component?  Only then does the order in which upstream's heap releases equal seeds matter
 // (seeds are the only entries that can compare equal: every later entry carries its own age), and only then does the group (z slice in the
 // 2-D stage, the volume in the 3-D stage) take the sequential path below.  One thread per listed component (>= 2 markers).
 __global__ void ws_tie_detect_kernel(SegGeom g, int mode2d, const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots,
                                      const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap,
-                                     int32_t* __restrict__ tie_flags) {
+                                     int32_t* __restrict__ tie_flags, int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox) {
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *nroots) return;
     const int root = roots[t];
+    slot_of[root] = (int32_t)t;                                                  // (for the bounding boxes ws_fill_single_kernel collects)
+    bbox[6 * t + 0] = bbox[6 * t + 1] = bbox[6 * t + 2] = 0x7fffffff; bbox[6 * t + 3] = bbox[6 * t + 4] = bbox[6 * t + 5] = -1;
     const WsHeapEntry* h = heap + heap_off[root];
     const int n = heap_cnt[root];
     for (int a = 1; a < n; ++a) {
@@ -944,22 +1487,27 @@ __global__ __launch_bounds__(64) void ws_flood_upstream_kernel(SegGeom g, const 
 }
 
 // find_boundaries(labels, connectivity 2, mode 'outer') inside every z slice, removed from the mask (watershed.py:45-51)
-__global__ void ws_boundary2d_kernel(SegGeom g, const unsigned char* __restrict__ bn, const int32_t* __restrict__ labels, unsigned char* __restrict__ bn_out) {
+__global__ void ws_boundary2d_kernel(SegGeom g, const unsigned char* __restrict__ bn, const int32_t* __restrict__ labels, unsigned char* __restrict__ bn_out,
+                                     int32_t* __restrict__ parent, int32_t* __restrict__ size) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.V) return;
-    int x, y, z; ws_xyz(i, g, x, y, z);
-    const int own = labels[i];
-    int mx = own, mn = own, mn_obj = own ? own : 0x7fffffff;
-    for (int dx = -1; dx <= 1; ++dx)
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int xx = x + dx, yy = y + dy;
-            if (xx < 0 || xx >= g.X || yy < 0 || yy >= g.Y) continue;
-            const int l = labels[((long long)xx * g.Y + yy) * g.Z + z];
-            mx = max(mx, l); mn = min(mn, l);
-            if (l) mn_obj = min(mn_obj, l);
-        }
-    const bool boundary = (mx != mn) && (own == 0 || mx != mn_obj);
-    bn_out[i] = (bn[i] && !boundary) ? 1 : 0;
+    bool keep = false;
+    if (bn[i]) {                                           // background stays background: only the 2 % foreground voxels look at their 3 x 3
+        int x, y, z; ws_xyz(i, g, x, y, z);
+        const int own = labels[i];
+        int mx = own, mn = own, mn_obj = own ? own : 0x7fffffff;
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int xx = x + dx, yy = y + dy;
+                if (xx < 0 || xx >= g.X || yy < 0 || yy >= g.Y) continue;
+                const int l = labels[((long long)xx * g.Y + yy) * g.Z + z];
+                mx = max(mx, l); mn = min(mn, l);
+                if (l) mn_obj = min(mn_obj, l);
+            }
+        const bool boundary = (mx != mn) && (own == 0 || mx != mn_obj);
+        keep = !boundary;
+    }
+    bn_out[i] = keep ? 1 : 0; parent[i] = keep ? (int32_t)i : -1; size[i] = 0;     // + the union-find of the 3-D stage's components
 }
 
 // bincount of the watershed labels (bins 1..K; bin 0 = V - the rest), wave-aggregated
@@ -1048,7 +1596,7 @@ __global__ __launch_bounds__(1024) void ws_finish_kernel(long long V, const int3
 }
 
 struct WsLayout { size_t bn, bn2, gx, d2, dist, tmp, smooth, vmax, labels, parent, size, heap_off, heap_cnt, heap, qlab, roots, cand_val, cand_idx, marker_idx,
-                  stats, sums, weights, total; int ngroups2d; };
+                  stats, sums, weights, bbox, total; int ngroups2d; };
 WsLayout ws_layout(long long V, int Z, int cap) {
     WsLayout L{};
     size_t o = 0;
@@ -1064,6 +1612,7 @@ WsLayout ws_layout(long long V, int Z, int cap) {
     L.stats = take(4096 + (size_t)(WS_PEAK_CAP3D + 1) * 8);       // eq_count[128] | vmin[128] | cand_count[128] | marker_count[128] | bump, nroots, overflow | counts / newlabel
     L.sums = take((size_t)cap * 4 * 8);
     L.weights = take(64 * 8);
+    L.bbox = take((ncand / 2 + 1) * 6 * 4);                       // a listed component holds >= 2 markers
     L.total = o; L.ngroups2d = Z;
     return L;
 }
@@ -1159,6 +1708,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     unsigned int* bump = (unsigned int*)(ws + L.stats + 2560);                    // bump | nroots | overflow
     unsigned int* nroots = bump + 1; int* overflow = (int*)(bump + 2);
     int32_t* tie_flags = (int32_t*)(ws + L.stats + 3072);                         // [128] groups whose equal seeds share a component
+    int32_t* bbox = (int32_t*)(ws + L.bbox);                                      // [listed component][6] bounding boxes; slot map = gx (free after the EDT)
     unsigned int* counts = (unsigned int*)(ws + L.stats + 4096);                  // [WS_PEAK_CAP3D + 1]
     int32_t* newlabel = (int32_t*)(counts + WS_PEAK_CAP3D + 1);
     unsigned long long* sums = (unsigned long long*)(ws + L.sums);
@@ -1167,36 +1717,67 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     const unsigned nb = (unsigned)((V + 255) / 256);
     // (per call: the attribute belongs to the current device's copy of the kernel, and a process may drive several devices)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_PEAK_CAP3D * 16));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_SEL2_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_box_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BOX_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_box_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BOX_LDS));
     HIPCHK(hipMemcpyAsync(w_xy, gauss_xy, (size_t)(2 * radius_xy + 1) * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(w_z, gauss_z, (size_t)(2 * radius_z + 1) * sizeof(double), hipMemcpyHostToDevice, st));
 
     // one pass of: peaks of `smooth` -> markers -> components of `mask` -> flood into `labels`
+    static const bool no_slide = getenv("CT_WS_SLIDE") && atoi(getenv("CT_WS_SLIDE")) == 0;                   // (A/B: the per-voxel filter kernels)
+    const unsigned nbx = (unsigned)(((long long)dims_xyz[1] * Z * ((dims_xyz[0] + WS_SEG - 1) / WS_SEG) + 255) / 256);      // line segments along x / along y
+    const unsigned nby = (unsigned)(((long long)dims_xyz[0] * Z * ((dims_xyz[1] + WS_SEG - 1) / WS_SEG) + 255) / 256);
+    // one pass of the Gaussian / the window maximum along axis 0 or 1
+    auto gauss_pass = [&](int axis, const double* in, double* out) {
+        if (!no_slide && radius_xy == 8) {
+            if (axis == 0) ws_gauss_slide_kernel<0, 8><<<nbx, 256, 0, st>>>(g, in, out, w_xy); else ws_gauss_slide_kernel<1, 8><<<nby, 256, 0, st>>>(g, in, out, w_xy);
+        } else ws_gauss_kernel<<<nb, 256, 0, st>>>(g, axis, in, out, w_xy, radius_xy);
+    };
+    auto max_pass = [&](int axis, const double* in, double* out, int r) {
+        if (!no_slide && r == 7) {
+            if (axis == 0) ws_max_slide_kernel<0, 7><<<nbx, 256, 0, st>>>(g, in, out); else ws_max_slide_kernel<1, 7><<<nby, 256, 0, st>>>(g, in, out);
+        } else if (!no_slide && r == 3) {
+            if (axis == 0) ws_max_slide_kernel<0, 3><<<nbx, 256, 0, st>>>(g, in, out); else ws_max_slide_kernel<1, 3><<<nby, 256, 0, st>>>(g, in, out);
+        } else ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, axis, in, out, r);
+    };
+
     auto stage = [&](bool mode2d, const unsigned char* mask, int min_distance, int border) -> int {
         const int ngroups = mode2d ? Z : 1, pcap = mode2d ? WS_PEAK_CAP2D : WS_PEAK_CAP3D;
-        // separable window maximum: smooth -> tmp -> (dist ->) vmax
-        ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, 0, smooth, tmp, min_distance);
-        LAUNCH_CHECK();
-        if (mode2d) { ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, 1, tmp, vmax, min_distance); LAUNCH_CHECK(); }
-        else {
-            ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, 1, tmp, dist, min_distance); LAUNCH_CHECK();
-            ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, 2, dist, vmax, min_distance); LAUNCH_CHECK();
-        }
+        // separable window maximum: smooth -> tmp -> (dist ->) [vmax]; the last pass carries the peak test (the maximum itself is only written
+        // for the tests' hook)
+        double* const vmax_out = (method_in & 0x300) ? vmax : nullptr;
         HIPCHK(hipMemsetAsync(ws + L.stats, 0, 4096, st));
         HIPCHK(hipMemsetAsync(vmin, 0xff, 128 * sizeof(unsigned long long), st));
         HIPCHK(hipMemsetAsync(labels, 0, (size_t)V * 4, st));
-        ws_peak_kernel<<<1024, 256, 0, st>>>(g, mode2d ? 1 : 0, border, smooth, vmax, eq_count, vmin, cand_count, pcap, cand_val, cand_idx, overflow);
-        LAUNCH_CHECK();
-        ws_peak_select_kernel<<<ngroups, 1024, (size_t)pcap * 16, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val, cand_idx,
-                                                                    labels, marker_idx, marker_count);
+        max_pass(0, smooth, tmp, min_distance);
         LAUNCH_CHECK();
         if (mode2d) {
-            ws_cc_init_merge_kernel<true><<<nb, 256, 0, st>>>(g, mask, parent, 0); LAUNCH_CHECK();
+            if (!no_slide && min_distance == 7)
+                ws_max_peak_slide_kernel<7><<<nby, 256, 0, st>>>(g, border, tmp, smooth, vmax_out, eq_count, vmin, cand_count, pcap, cand_val, cand_idx, overflow);
+            else {
+                max_pass(1, tmp, vmax, min_distance); LAUNCH_CHECK();
+                ws_peak_kernel<<<1024, 256, 0, st>>>(g, 1, border, smooth, vmax, eq_count, vmin, cand_count, pcap, cand_val, cand_idx, overflow);
+            }
+        } else {
+            max_pass(1, tmp, dist, min_distance); LAUNCH_CHECK();
+            ws_maxz_peak_kernel<<<2048, 256, 0, st>>>(g, min_distance, border, dist, smooth, vmax_out, eq_count, vmin, cand_count, pcap, cand_val, cand_idx, overflow);
+        }
+        LAUNCH_CHECK();
+static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT")) == 0;          // (A/B: the bitonic-sort form for every group)
+        if (!no_sel2) {
+            ws_peak_select2_kernel<<<ngroups, 1024, WS_SEL2_LDS, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val, cand_idx,
+                                                                       labels, marker_idx, marker_count);
+            LAUNCH_CHECK();
+        }
+        if (no_sel2 || pcap > WS_SEL2_CAP)                                       // groups with more candidates than the counting form takes
+            ws_peak_select_kernel<<<ngroups, 1024, (size_t)pcap * 16, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val, cand_idx,
+                                                                        labels, marker_idx, marker_count, no_sel2 ? 0 : 1);
+        LAUNCH_CHECK();
+        if (mode2d) {
             ws_cc_init_merge_kernel<true><<<nb, 256, 0, st>>>(g, mask, parent, 1); LAUNCH_CHECK();
         } else {
-            ws_cc_init_merge_kernel<false><<<nb, 256, 0, st>>>(g, mask, parent, 0); LAUNCH_CHECK();
             ws_cc_init_merge_kernel<false><<<nb, 256, 0, st>>>(g, mask, parent, 1); LAUNCH_CHECK();
         }
-        HIPCHK(hipMemsetAsync(size, 0, (size_t)V * 4, st));
         cc_flatten_kernel<<<nb, 256, 0, st>>>(V, parent, size);
         LAUNCH_CHECK();
         ws_heap_alloc_kernel<<<nb, 256, 0, st>>>(V, parent, size, heap_off, heap_cnt, bump);
@@ -1204,7 +1785,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         ws_marker_append_kernel<<<(unsigned)((ngroups * pcap + 255) / 256), 256, 0, st>>>(ngroups, pcap, marker_idx, marker_count, smooth, parent, heap_off,
                                                                                        heap_cnt, heap, roots, nroots, labels);
         LAUNCH_CHECK();
-        ws_tie_detect_kernel<<<(unsigned)((ngroups * pcap / 2 + 255) / 256), 256, 0, st>>>(g, mode2d ? 1 : 0, roots, nroots, heap_off, heap_cnt, heap, tie_flags);
+        ws_tie_detect_kernel<<<(unsigned)((ngroups * pcap / 2 + 255) / 256), 256, 0, st>>>(g, mode2d ? 1 : 0, roots, nroots, heap_off, heap_cnt, heap, tie_flags, gx, bbox);
         LAUNCH_CHECK();
         int32_t h_flags[256];                                                    // one copy: bump | nroots | overflow ... (+ 512 bytes) the 128 tie flags
         HIPCHK(hipMemcpyAsync(h_flags, bump, sizeof(h_flags), hipMemcpyDeviceToHost, st));
@@ -1215,7 +1796,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         for (int q = 0; q < ngroups; ++q) any_tie |= h_flags[128 + q] != 0;
         static const bool no_upstream = getenv("CT_WS_UPSTREAM_TIES") && atoi(getenv("CT_WS_UPSTREAM_TIES")) == 0;   // (A/B: raveled order among equal seeds)
         if (no_upstream) any_tie = false;
-        ws_fill_single_kernel<<<nb, 256, 0, st>>>(V, parent, heap_off, heap_cnt, heap, labels);
+        ws_fill_single_kernel<<<nb, 256, 0, st>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox);
         LAUNCH_CHECK();
         if (h_nroots && !(any_tie && !mode2d)) {
             static const bool thread_flood = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 0;      // (A/B: one thread per component, binary heap)
@@ -1223,8 +1804,14 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
                 if (mode2d) ws_flood_kernel<true><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
                 else ws_flood_kernel<false><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
             } else {
-                if (mode2d) ws_flood_wave_kernel<true><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels);
-                else ws_flood_wave_kernel<false><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels);
+                static const bool no_box = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 1;         // (A/B: every component through the global-state wave flood)
+                if (!no_box) {
+                    if (mode2d) ws_flood_box_kernel<true><<<h_nroots, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, size, heap_off, heap_cnt, heap, bbox, labels);
+                    else ws_flood_box_kernel<false><<<h_nroots, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, size, heap_off, heap_cnt, heap, bbox, labels);
+                    LAUNCH_CHECK();
+                }
+                if (mode2d) ws_flood_wave_kernel<true><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
+                else ws_flood_wave_kernel<false><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
             }
             LAUNCH_CHECK();
         }
@@ -1237,19 +1824,19 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     };
 
     // ---- watershed_2d (watershed.py:16-53), all z slices at once
-    ws_threshold_kernel<<<nb, 256, 0, st>>>(prob, V, bn);
+    ws_threshold_kernel<<<nb, 256, 0, st>>>(prob, V, bn, parent, size);
     LAUNCH_CHECK();
     ws_edt_x_kernel<<<nb, 256, 0, st>>>(g, bn, gx);
     LAUNCH_CHECK();
     ws_edt_y_kernel<true><<<nb, 256, 0, st>>>(g, gx, d2, dist);
     LAUNCH_CHECK();
-    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 0, dist, tmp, w_xy, radius_xy);
+    gauss_pass(0, dist, tmp);
     LAUNCH_CHECK();
-    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 1, tmp, smooth, w_xy, radius_xy);
+    gauss_pass(1, tmp, smooth);
     LAUNCH_CHECK();
     int rc = stage(true, bn, min_distance_2d, min_distance_2d);
     if (rc) return rc;
-    ws_boundary2d_kernel<<<nb, 256, 0, st>>>(g, bn, labels, bn2);
+    ws_boundary2d_kernel<<<nb, 256, 0, st>>>(g, bn, labels, bn2, parent, size);
     LAUNCH_CHECK();
     if (method_in & 0x100) { HIPCHK(hipMemsetAsync(n_out, 0, 3 * sizeof(int32_t), st)); return CT_OK; }     // (tests: stop after watershed_2d, see ct_watershed_read_stage)
 
@@ -1260,9 +1847,9 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     LAUNCH_CHECK();
     ws_edt_z_kernel<<<nb, 256, 0, st>>>(g, d2, z_xy_ratio, dist);
     LAUNCH_CHECK();
-    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 0, dist, tmp, w_xy, radius_xy);
+    gauss_pass(0, dist, tmp);
     LAUNCH_CHECK();
-    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 1, tmp, dist, w_xy, radius_xy);
+    gauss_pass(1, tmp, dist);
     LAUNCH_CHECK();
     ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 2, dist, smooth, w_z, radius_z);
     LAUNCH_CHECK();

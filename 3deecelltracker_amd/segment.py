@@ -156,7 +156,7 @@ def watershed_stages_device(prob, z_xy_ratio: float, stage: str = "2d", min_size
     centres = _dev.empty((cap, 3), t.float64, prob.device); sizes = _dev.empty((cap,), t.int32, prob.device)
     n_dev = _dev.empty((3,), t.int32, prob.device)
     ws = _dev.workspace(L.ct_watershed_workspace_bytes(dims, int(cap)), prob.device)
-    _lib.check(L.ct_watershed_segment(prob.data_ptr(), dims, float(z_xy_ratio), 0x100 if stage == "2d" else 0, int(min_size), 0, 7, 3,
+    _lib.check(L.ct_watershed_segment(prob.data_ptr(), dims, float(z_xy_ratio), 0x100 if stage == "2d" else 0x200, int(min_size), 0, 7, 3,
                                       w_xy.ctypes.data_as(C.c_void_p), r_xy, w_z.ctypes.data_as(C.c_void_p), r_z, int(cap), None,
                                       centres.data_ptr(), sizes.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), ws.numel(),
                                       _dev.stream(prob.device)), "ct_watershed_segment")
