@@ -1663,6 +1663,13 @@ __device__ __forceinline__ double rsqrt_nr(double x) {      // v_rsq_f64 (~2^-26
     const double e = fma(-x * y, h, 0.5);                    // 0.5 - x y^2 / 2
     return fma(y, e, y);
 }
+// S is addressed through SIX(row, col): PACK = false -> row * ld + col (odd ld spreads rows over the banks); PACK = true -> the rows of the lower
+// triangle back to back (row a holds a + 1 entries; the naug right-hand-side rows, r entries each, follow): half the LDS -- 35 instead of 68 KB
+// at rank 90 -- which is what lets the single workgroup of lr_solve_kernel start beside four resident conv workgroups of a CU as soon as ONE of
+// them retires (with 68 KB it waited for two to retire together: 137 us per launch in the pipelined benchmark against 22 alone).  Every access
+// of the two routines has col <= row (rows < r) or col < r (right-hand-side rows); the arithmetic is untouched, so results keep their bits.
+#define SIX(row, col) (PACK ? (((row) < r ? (row) * ((row) + 1) / 2 : r * (r + 1) / 2 + ((row) - r) * r) + (col)) : ((row) * ld + (col)))
+template <bool PACK>
 __device__ void chol_factor_aug_lds_fast(double* S, double* idiag, int ld, int r, int naug, int tid) {
     // All LDS reads of a phase are issued unconditionally (indices clamped into the matrix, padding selected afterwards)
     // so that they pipeline: predicated reads compile to branches and serialise at ~120 cycles apiece.  Dependent fp64
@@ -1676,7 +1683,7 @@ __device__ void chol_factor_aug_lds_fast(double* S, double* idiag, int ld, int r
 #pragma unroll
             for (int k = 0; k < LS_B; ++k) {
                 if (k <= i) {
-                    const double v = S[min(j0 + i, r - 1) * ld + j0 + min(k, nb - 1)];
+                    const double v = S[SIX(min(j0 + i, r - 1), j0 + min(k, nb - 1))];
                     Ld[i][k] = (i < nb) ? v : (i == k ? 1.0 : 0.0);
                 } else Ld[i][k] = 0.0;
             }
@@ -1695,7 +1702,7 @@ __device__ void chol_factor_aug_lds_fast(double* S, double* idiag, int ld, int r
         for (int a2 = j0 + nb + tid; a2 < ra; a2 += 256) {
             double x[LS_B];
 #pragma unroll
-            for (int k = 0; k < LS_B; ++k) { const double v = S[a2 * ld + j0 + min(k, nb - 1)]; x[k] = (k < nb) ? v : 0.0; }
+            for (int k = 0; k < LS_B; ++k) { const double v = S[SIX(a2, j0 + min(k, nb - 1))]; x[k] = (k < nb) ? v : 0.0; }
 #pragma unroll
             for (int k = 0; k < LS_B; ++k) {
                 double t = x[k];
@@ -1704,7 +1711,7 @@ __device__ void chol_factor_aug_lds_fast(double* S, double* idiag, int ld, int r
                 x[k] = t * inv[k];
             }
 #pragma unroll
-            for (int k = 0; k < LS_B; ++k) if (k < nb) S[a2 * ld + j0 + k] = x[k];
+            for (int k = 0; k < LS_B; ++k) if (k < nb) S[SIX(a2, j0 + k)] = x[k];
         }
         __syncthreads();
         if (tid == 0) {
@@ -1712,7 +1719,7 @@ __device__ void chol_factor_aug_lds_fast(double* S, double* idiag, int ld, int r
             for (int i = 0; i < LS_B; ++i) {
                 if (i < nb) idiag[j0 + i] = inv[i];
 #pragma unroll
-                for (int k = 0; k < LS_B; ++k) if (i < nb && k <= i) S[(j0 + i) * ld + j0 + k] = Ld[i][k];
+                for (int k = 0; k < LS_B; ++k) if (i < nb && k <= i) S[SIX((j0 + i), j0 + k)] = Ld[i][k];
             }
         }
         // trailing update S[a][b] -= L[a][:] . L[b][:] over the lower triangle of the remaining rows (b <= a, b < r) plus
@@ -1734,19 +1741,20 @@ __device__ void chol_factor_aug_lds_fast(double* S, double* idiag, int ld, int r
 #pragma unroll
             for (int k = 0; k < LS_B; ++k) {
                 const int ck = j0 + min(k, nb - 1);
-                const double va = S[a2 * ld + ck];
+                const double va = S[SIX(a2, ck)];
                 La[k] = (k < nb) ? va : 0.0;
-                Lb[k] = S[b2 * ld + ck];
+                Lb[k] = S[SIX(b2, ck)];
             }
-            const double cur = S[a2 * ld + b2];
+            const double cur = S[SIX(a2, b2)];
             double t0 = 0.0, t1 = 0.0;
 #pragma unroll
             for (int k = 0; k < LS_B; k += 2) { t0 = fma(La[k], Lb[k], t0); t1 = fma(La[k + 1], Lb[k + 1], t1); }
-            S[a2 * ld + b2] = cur - (t0 + t1);
+            S[SIX(a2, b2)] = cur - (t0 + t1);
         }
         __syncthreads();
     }
 }
+template <bool PACK>
 __device__ void chol_backsub3_lds_fast(double* S, const double* idiag, int ld, int r, int tid) {
     for (int j0 = ((r - 1) / LS_B) * LS_B; j0 >= 0; j0 -= LS_B) {
         const int nb = min(LS_B, r - j0);
@@ -1755,10 +1763,10 @@ __device__ void chol_backsub3_lds_fast(double* S, const double* idiag, int ld, i
 #pragma unroll
         for (int k = 0; k < LS_B; ++k) {
             const int ck = j0 + min(k, nb - 1);
-            rh[k][0] = S[(r + 0) * ld + ck]; rh[k][1] = S[(r + 1) * ld + ck]; rh[k][2] = S[(r + 2) * ld + ck];
+            rh[k][0] = S[SIX((r + 0), ck)]; rh[k][1] = S[SIX((r + 1), ck)]; rh[k][2] = S[SIX((r + 2), ck)];
             idg[k] = idiag[ck];
 #pragma unroll
-            for (int p2 = k + 1; p2 < LS_B; ++p2) Lb[p2][k] = S[(j0 + min(p2, nb - 1)) * ld + ck];
+            for (int p2 = k + 1; p2 < LS_B; ++p2) Lb[p2][k] = S[SIX((j0 + min(p2, nb - 1)), ck)];
         }
         double qv[LS_B][3];
 #pragma unroll
@@ -1775,23 +1783,24 @@ __device__ void chol_backsub3_lds_fast(double* S, const double* idiag, int ld, i
         if (tid < j0) {
             double l[LS_B];
 #pragma unroll
-            for (int k = 0; k < LS_B; ++k) l[k] = S[(j0 + min(k, nb - 1)) * ld + tid];
-            double u0 = S[(r + 0) * ld + tid], u1 = S[(r + 1) * ld + tid], u2 = S[(r + 2) * ld + tid];
+            for (int k = 0; k < LS_B; ++k) l[k] = S[SIX((j0 + min(k, nb - 1)), tid)];
+            double u0 = S[SIX((r + 0), tid)], u1 = S[SIX((r + 1), tid)], u2 = S[SIX((r + 2), tid)];
             double v0 = 0.0, v1 = 0.0, v2 = 0.0;
 #pragma unroll
             for (int k = 0; k < LS_B; k += 2) {                        // qv = 0 beyond nb
                 u0 = fma(-l[k], qv[k][0], u0); u1 = fma(-l[k], qv[k][1], u1); u2 = fma(-l[k], qv[k][2], u2);
                 v0 = fma(-l[k + 1], qv[k + 1][0], v0); v1 = fma(-l[k + 1], qv[k + 1][1], v1); v2 = fma(-l[k + 1], qv[k + 1][2], v2);
             }
-            S[(r + 0) * ld + tid] = u0 + v0; S[(r + 1) * ld + tid] = u1 + v1; S[(r + 2) * ld + tid] = u2 + v2;
+            S[SIX((r + 0), tid)] = u0 + v0; S[SIX((r + 1), tid)] = u1 + v1; S[SIX((r + 2), tid)] = u2 + v2;
         } else if (tid == j0) {
 #pragma unroll
             for (int k = 0; k < LS_B; ++k)
-                if (k < nb) { S[(r + 0) * ld + j0 + k] = qv[k][0]; S[(r + 1) * ld + j0 + k] = qv[k][1]; S[(r + 2) * ld + j0 + k] = qv[k][2]; }
+                if (k < nb) { S[SIX((r + 0), j0 + k)] = qv[k][0]; S[SIX((r + 1), j0 + k)] = qv[k][1]; S[SIX((r + 2), j0 + k)] = qv[k][2]; }
         }
         __syncthreads();
     }
 }
+#undef SIX
 
 // ---- dense path for n > DS_MAXN: blocked right-looking Cholesky of M = D^1/2 G D^1/2 + c I (NB = 32) --------------
 // The 3 right-hand sides W [3][n] ride through the factorisation as extra rows (forward substitution for free);
@@ -1944,8 +1953,9 @@ __global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict_
     if (sc[S_DONE] != 0.0) return;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int r = *rank_p;
-    const int ld = r | 1;                  // odd leading dimension (doubles): spreads rows over the LDS banks
-    double* S = sm;                        // [ra][ld]
+    const int ld = r | 1;                  // (unpacked form: odd leading dimension)
+    double* S = sm;                        // packed: rows of the lower triangle back to back, then the 3 right-hand-side rows (PSIX)
+#define PSIX(row, col) (((row) < r ? (row) * ((row) + 1) / 2 : r * (r + 1) / 2 + ((row) - r) * r) + (col))
     __shared__ double red[4];
     __shared__ double idiag[LR_RMAX];
     const int tid = threadIdx.x;
@@ -1965,9 +1975,9 @@ __global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict_
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (e0 + tid + 256 * u < r * r && bi[u] <= ai[u]) S[ai[u] * ld + bi[u]] = v[u] + (ai[u] == bi[u] ? c : 0.0);
+            if (e0 + tid + 256 * u < r * r && bi[u] <= ai[u]) S[PSIX(ai[u], bi[u])] = v[u] + (ai[u] == bi[u] ? c : 0.0);
     }
-    for (int e = tid; e < r * 3; e += 256) { const int a = e / 3, d = e - a * 3; S[(r + d) * ld + a] = yin[e]; }
+    for (int e = tid; e < r * 3; e += 256) { const int a = e / 3, d = e - a * 3; S[PSIX(r + d, a)] = yin[e]; }
     {   // sumP = sum_i d_i
         double acc = 0.0;
         for (int i0 = 0; i0 < n; i0 += 256 * 4) {
@@ -1981,9 +1991,10 @@ __global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict_
     }
     __syncthreads();
     if (tid == 0) { sc[S_SUMP] = (red[0] + red[1]) + (red[2] + red[3]); sc[S_C] = c; }
-    chol_factor_aug_lds_fast(S, idiag, ld, r, 3, tid);
-    chol_backsub3_lds_fast(S, idiag, ld, r, tid);
-    for (int e = tid; e < r * 3; e += 256) { const int a2 = e / 3, d = e - a2 * 3; qout[e] = S[(r + d) * ld + a2]; }
+    chol_factor_aug_lds_fast<true>(S, idiag, ld, r, 3, tid);
+    chol_backsub3_lds_fast<true>(S, idiag, ld, r, tid);
+    for (int e = tid; e < r * 3; e += 256) { const int a2 = e / 3, d = e - a2 * 3; qout[e] = S[PSIX(r + d, a2)]; }
+#undef PSIX
 }
 
 // Dense M-step for small n (n + 3 rows of n|1 doubles fit the LDS: n <= DS_MAXN): one workgroup finishes the column
@@ -2039,8 +2050,8 @@ __global__ __launch_bounds__(256) void dense_small_solve_kernel(const double* __
             if (e0 + tid + 256 * u < n * n && jj[u] <= ii[u]) S[ii[u] * ld + jj[u]] = sq[ii[u]] * gv[u] * sq[jj[u]] + (ii[u] == jj[u] ? c : 0.0);
     }
     __syncthreads();
-    chol_factor_aug_lds_fast(S, idiag, ld, n, 3, tid);
-    chol_backsub3_lds_fast(S, idiag, ld, n, tid);
+    chol_factor_aug_lds_fast<false>(S, idiag, ld, n, 3, tid);
+    chol_backsub3_lds_fast<false>(S, idiag, ld, n, tid);
     for (int e = tid; e < 3 * n; e += 256) { const int d = e / n, i = e - d * n; C[e] = sq[i] * S[(n + d) * ld + i]; }
 }
 
@@ -2386,7 +2397,7 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
         else
             hipLaunchKernelGGL(lr_gram_kernel, dim3((nent + 3) / 4), dim3(256), 0, st, n, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs, w.Spart, w.ypart);
         LAUNCH_CHECK();
-        const size_t lds = (size_t)(rank + 3) * (rank | 1) * sizeof(double);
+        const size_t lds = ((size_t)rank * (rank + 1) / 2 + 3 * (size_t)rank) * sizeof(double);          // packed triangle + 3 right-hand sides
         hipLaunchKernelGGL(lr_solve_kernel, dim3(1), dim3(256), lds, st, w.Spart, w.ypart, n, w.rank, lambda, w.dvec, w.sc, w.q);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(lr_coeff_kernel, dim3((n + 63) / 64), dim3(256), 0, st, w.U, n, w.rank, w.q, w.sqd, w.rhs, w.sc, w.C);
@@ -2718,7 +2729,7 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
                 hipLaunchKernelGGL(lr_gram_kernel, dim3((nent + 3) / 4, 1, zB), dim3(256), 0, st, nn, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs,
                                w.Spart, w.ypart, bt);
             LAUNCH_CHECK();
-            const size_t lds = (size_t)(rank + 3) * (rank | 1) * sizeof(double);
+            const size_t lds = ((size_t)rank * (rank + 1) / 2 + 3 * (size_t)rank) * sizeof(double);
             hipLaunchKernelGGL(lr_solve_kernel, dim3(1, 1, zB), dim3(256), lds, st, w.Spart, w.ypart, nn, w.rank, lambda, w.dvec, w.sc, w.q, bt);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(lr_coeff_kernel, dim3((nn + 63) / 64, 1, zB), dim3(256), 0, st, w.U, nn, w.rank, w.q, w.sqd, w.rhs, w.sc, w.C, bt,

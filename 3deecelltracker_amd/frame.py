@@ -3,7 +3,9 @@
     raw uint16 stack                          (already in HBM, or uploaded from a pinned host buffer)
       -> ct_normalize_image                   preprocess._normalize_image            (preprocess.py:170-188)
       -> ct_unet_predict_volume               unet3d.unet3_prediction                (unet3d.py:203-256)
-      -> ct_segment_centroids                 prob map -> regions -> centres         (tracker.py:636-648; seg/coords%06d.npy)
+      -> ct_watershed_segment                 prob map -> regions -> centres: the reference's marker watershed (tracker.py:636-648,
+                                              671-684 = watershed.py:16-108; seg/coords%06d.npy).  region_method="cc" selects the cheap
+                                              variant instead (ct_segment_centroids: threshold + connected components)
       -> normalise / kNN features / FFN / greedy prior / PR-GLS / de-normalise       (trackerlite.py:70-109)
       -> ct_accurate_correction               CoordsToImageTransformer.accurate_correction (coord_image_transformer.py:406-489)
 
@@ -18,13 +20,16 @@ import numpy as np
 from . import _dev
 from .coord_image_transformer import Coordinates, CoordsToImageTransformer
 from .preprocess import normalize_image_device
-from .segment import segment_centroids_device
+from .segment import segment_centroids_device, watershed_centroids_device
 from .trackerlite import match_device
 
 
 class FrameChain:
     def __init__(self, unet_model, ffn_model, transformer: CoordsToImageTransformer, noise_level: float, shrink=(24, 24, 2),
-                 min_size: int = 20, beta: float = 3.0, lambda_: float = 3.0, ensemble: bool = True):
+                 min_size: int = 20, beta: float = 3.0, lambda_: float = 3.0, ensemble: bool = True, region_method: str = "watershed"):
+        if region_method not in ("watershed", "cc"):
+            raise ValueError(f"unknown region_method {region_method!r}: use 'watershed' or 'cc'")
+        self.region_method = region_method
         self.unet_model = unet_model
         self.ffn_model = ffn_model
         self.transformer = transformer
@@ -47,7 +52,11 @@ class FrameChain:
             self._prob = _dev.torch().empty_like(norm)
         prob = self.unet_model.predict_volume_device(norm, self.shrink, out=self._prob)
         self._mark("unet")
-        _, centres, _ = segment_centroids_device(prob, 0.5, 1, self.min_size, want_labels=False)
+        if self.region_method == "watershed":                   # Tracker._segment's default (tracker.py:636-648): z_xy_ratio = voxel z / voxel x
+            vs = self.transformer.voxel_size
+            _, centres, _, _, _ = watershed_centroids_device(prob, float(vs[2]) / float(vs[0]), "min_size", self.min_size, 0, want_labels=False)
+        else:
+            _, centres, _ = segment_centroids_device(prob, 0.5, 1, self.min_size, want_labels=False)
         self._mark("regions")
         return prob, centres
 
@@ -102,7 +111,7 @@ class FrameChain:
 
     # ---- synthetic sequence
     @classmethod
-    def synthetic(cls, shape=(512, 512, 32), n_cells=600, seed=0, ffn_weights=None, device=None, factor=5):
+    def synthetic(cls, shape=(512, 512, 32), n_cells=600, seed=0, ffn_weights=None, device=None, factor=5, region_method="watershed"):
         """Two consecutive synthetic frames: blobs at c1 (frame t1) and at c1 + smooth motion (frame t2)."""
         from pathlib import Path
         from . import synth, unet3d
@@ -131,7 +140,7 @@ class FrameChain:
             trained = Path(__file__).resolve().parent.parent / "tests" / "golden" / "ffn_synthetic_trained.npz"
             ffn_weights = synth.load_ffn_npz(trained) if trained.exists() else synth.make_ffn_weights(0, 6.0, -3.0)
         ffn = FFN(device=device).set_weights_dict(ffn_weights)
-        chain = cls(model, ffn, tr, noise_level=100.0)
+        chain = cls(model, ffn, tr, noise_level=100.0, region_method=region_method)
         dev = "cuda" if device is None else f"cuda:{device}"
         chain.raw_t1 = t.from_numpy(stack1).to(dev)
         chain.raw_t2 = t.from_numpy(stack2).to(dev)

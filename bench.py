@@ -229,26 +229,36 @@ def measure_pcie(ctx):
 
 def measure_chained(ctx, args):
     """The chained per-frame pipeline (frame.FrameChain): the match consumes the centroids of the probability map just
-    produced and the correction runs on that map -- one frame at a time on one stream."""
+    produced and the correction runs on that map -- one frame at a time on one stream.  The region step is the reference's own marker
+    watershed (Tracker._segment's default, tracker.py:636-648, 671-684); the same chain with threshold + connected components
+    (the cheap variant) is reported beside it."""
     import torch
     frame = mod("frame")
-    chain = frame.FrameChain.synthetic(shape=tuple(args.shape), n_cells=args.cells, seed=0, device=ctx.local)
-    for _ in range(2):
-        out = chain.run()
-    chain.enable_timing()
-    torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
-    K = 5
-    for _ in range(K):
-        out = chain.run()
-    torch.cuda.synchronize(ctx.dev)
-    dt = (time.perf_counter() - t0) / K
-    err = float(np.abs(out["coords"].real - chain.true_t2 * np.array([1.0, 1.0, 4.0])).max(axis=1).mean())
-    return {"volumes_per_s": round(1.0 / dt, 2), "ms_per_frame": round(dt * 1e3, 3),
-            "stage_ms": {k: round(v, 3) for k, v in chain.stage_times().items()},
-            "cells_segmented": out["n_segmented"], "prgls_iterations": out["prgls_iterations"],
-            "correction_rounds": out["correction_rounds"], "mean_abs_error_vs_true_centres": round(err, 3),
-            "what": "raw stack -> LCN -> U-Net (pass-through weights) -> regions/centres -> FFN (synthetic-trained) + greedy + PR-GLS -> "
-                    "accurate correction on the same probability map; one frame at a time, one stream, full chip"}
+
+    def one(region_method):
+        chain = frame.FrameChain.synthetic(shape=tuple(args.shape), n_cells=args.cells, seed=0, device=ctx.local, region_method=region_method)
+        for _ in range(2):
+            out = chain.run()
+        chain.enable_timing()
+        torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
+        K = 5
+        for _ in range(K):
+            out = chain.run()
+        torch.cuda.synchronize(ctx.dev)
+        dt = (time.perf_counter() - t0) / K
+        err = float(np.abs(out["coords"].real - chain.true_t2 * np.array([1.0, 1.0, 4.0])).max(axis=1).mean())
+        return {"volumes_per_s": round(1.0 / dt, 2), "ms_per_frame": round(dt * 1e3, 3),
+                "stage_ms": {k: round(v, 3) for k, v in chain.stage_times().items()},
+                "cells_segmented": out["n_segmented"], "prgls_iterations": out["prgls_iterations"],
+                "correction_rounds": out["correction_rounds"], "mean_abs_error_vs_true_centres": round(err, 3)}
+
+    res = one("watershed")
+    cc = one("cc")
+    res["region_step"] = "ct_watershed_segment (the reference's marker watershed, bit-identical to watershed.py on scikit-image: tests/test_watershed_pin.py)"
+    res["with_connected_components_instead"] = {k: cc[k] for k in ("volumes_per_s", "ms_per_frame", "stage_ms", "cells_segmented")}
+    res["what"] = ("raw stack -> LCN -> U-Net (pass-through weights) -> marker watershed -> centres -> FFN (synthetic-trained) + greedy + PR-GLS -> "
+                   "accurate correction on the same probability map; one frame at a time, one stream, full chip")
+    return res
 
 
 def roofline_from_timing(ctx, args, n_patches, steps):
@@ -612,9 +622,9 @@ def main():
                             "cu_partition": ({"unet": ctx.pipe.n_cu - ctx.pipe.match_cus, "match": ctx.pipe.match_cus} if ctx.pipe.match_cus else
                                              {"unet": ctx.pipe.n_cu, "match": "no partition: match chains on high-priority streams"}),
                             "match_chains_in_flight": args.match_workers, "frames_per_match_chain": args.match_batch,
-                            "headline_excludes": ["regions->centres (ct_segment_centroids)", "accurate correction"] if args.mode != "ensemble" else [],
+                            "headline_excludes": ["regions->centres (ct_watershed_segment, the reference's marker watershed)", "accurate correction"] if args.mode != "ensemble" else [],
                             "headline_note": "matches take given ~600-point sets (independent units, SURVEY 8e); the dependent per-frame chain "
-                                             "incl. regions->centres and correction is config.chained",
+                                             "incl. the watershed and the correction is config.chained",
                             "rccl_ranks": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                                             "tracked_sets_gathered": ctx.gathered_sets} if world > 1 else
                                            {"world_size": 1, "backend": None, "tracked_sets_gathered": 0}),

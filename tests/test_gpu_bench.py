@@ -118,3 +118,26 @@ def test_lcn_regions_correction_are_unaffected_by_a_unet_sharing_their_cus(arran
                        text=True, timeout=600, cwd=repo)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "mismatching results: 0 of" in r.stdout, r.stdout[-1500:]
+
+
+def test_chained_frame_runs_the_reference_region_step():
+    """frame.FrameChain (bench.py's config.chained): the region step is the reference's marker watershed by default, the cheap connected-components
+    variant on request; both chains track the same synthetic cells, the watershed splits touching cells the components leave joined."""
+    import importlib
+    import numpy as np
+    frame = importlib.import_module("3deecelltracker_amd.frame")
+    seg = importlib.import_module("3deecelltracker_amd.segment")
+    res = {}
+    for method in ("watershed", "cc"):
+        chain = frame.FrameChain.synthetic(shape=(256, 256, 24), n_cells=150, seed=3, region_method=method)
+        out = chain.run()
+        prob, centres = chain.segment(chain.raw_t2)
+        if method == "watershed":                         # the chain's centres ARE ct_watershed_segment's on the map it just produced
+            _, want, _, _, _ = seg.watershed_centroids_device(prob, 4.0, "min_size", chain.min_size, 0, want_labels=False)
+            assert np.array_equal(centres.cpu().numpy(), want.cpu().numpy())
+        err = float(np.abs(out["coords"].real - chain.true_t2 * np.array([1.0, 1.0, 4.0])).max(axis=1).mean())
+        res[method] = (out["n_segmented"], err)
+    assert res["watershed"][0] >= res["cc"][0] >= 100
+    assert res["watershed"][1] < 2.0 and res["cc"][1] < 2.0
+    with pytest.raises(ValueError):
+        frame.FrameChain(None, None, None, 100.0, region_method="stardist")
