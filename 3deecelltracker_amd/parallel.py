@@ -245,13 +245,22 @@ def gather_centroids(local_coords, cap: int = 4096):
 class TrackedSetGather:
     """The "gather of centroid sets" of the frames mode: the tracked (cells, 3) sets of one match batch leave as ONE
     all_gather_into_tensor ([frames][cells][3] per rank -> [world][frames][cells][3]) on a communication stream ordered after the
-    producer; the receive buffers are kept per batch size.  `gathered` counts the sets received (world x frames per call): a SCALE
-    record shows that the collective saw every rank.  CPU tensors + gloo in the tests, RCCL on the GPUs."""
+    producer.  `gathered` counts the sets received (world x frames per call): a SCALE record shows that the collective saw every rank.
+    CPU tensors + gloo in the tests, RCCL on the GPUs.
 
-    def __init__(self, comm_stream=None):
+    Contract of the returned buffer: the CALLER's current stream already waits for the collective (an event recorded on the communication
+    stream), so kernels enqueued after the call may read it; `last_event` is that event for consumers on other streams.  Receive buffers
+    are kept per batch shape and used in rotation (`depth` of them, default 2): a returned buffer stays untouched until `depth` further
+    calls of the same shape have been made.  Every rank must pass the same number of frames and the same cell count -- it is an
+    all_gather_into_tensor; ragged tails go through gather_centroids."""
+
+    def __init__(self, comm_stream=None, depth: int = 2):
         self.comm = comm_stream
+        self.depth = max(1, int(depth))
         self.bufs = {}
+        self.turn = {}
         self.gathered = 0
+        self.last_event = None
 
     def __call__(self, tracked):
         import torch
@@ -261,18 +270,26 @@ class TrackedSetGather:
         if world == 1 or not tracked:
             return None
         cuda = tracked[0].is_cuda
-        ctx = torch.cuda.stream(self.comm) if (cuda and self.comm is not None) else _Null()
-        if cuda and self.comm is not None:
-            self.comm.wait_stream(torch.cuda.current_stream(tracked[0].device))
+        side = cuda and self.comm is not None
+        ctx = torch.cuda.stream(self.comm) if side else _Null()
+        cur = torch.cuda.current_stream(tracked[0].device) if cuda else None
+        if side:
+            self.comm.wait_stream(cur)
         with ctx:
             send = torch.stack(tracked)                      # [frames][cells][3], this rank's frames
             key = (len(tracked), tuple(send.shape[1:]), send.dtype)
-            buf = self.bufs.get(key)
-            if buf is None:
-                buf = self.bufs[key] = torch.empty((world, *send.shape), dtype=send.dtype, device=send.device)
+            ring = self.bufs.setdefault(key, [])
+            k = self.turn.get(key, 0)
+            if len(ring) <= k:
+                ring.append(torch.empty((world, *send.shape), dtype=send.dtype, device=send.device))
+            buf = ring[k]
+            self.turn[key] = (k + 1) % self.depth
             dist.all_gather_into_tensor(buf.view(-1, *send.shape[1:]), send)   # dim-0 concatenation: the form gloo accepts too
-            if cuda and self.comm is not None:
+            if side:
                 send.record_stream(self.comm)
+                self.last_event = torch.cuda.Event(); self.last_event.record(self.comm)
+        if side:
+            cur.wait_event(self.last_event)                  # consumers on the caller's stream are ordered after the collective
         self.gathered += world * len(tracked)
         return buf
 

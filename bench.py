@@ -41,6 +41,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 PKG = "3deecelltracker_amd"
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 = fp32 vector peak
 BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 dense MFMA peak (~2.5 PF; measured ceiling 2382)
+# What v_mfma_f32_16x16x32_f16 sustains for 5 s on random finite operands at the package power cap (profiles/r04_mfma_ceiling.txt: 2.05 GHz,
+# 1328 W; zero operands reach 2411 TFLOP/s at 2.39 GHz, which is the guide's condition).  Reported BESIDE roofline.peak, never instead of it.
+F16_MFMA_SUSTAINED_TF = 1981.0
 HBM_PEAK_TBS = 8.0
 NOISE_LEVEL = 100.0
 
@@ -327,6 +330,23 @@ def roofline_from_timing(ctx, args, n_patches, steps):
                        "gbps": round(abytes * cnt[i] / max(ms[i], 1e-9) / 1e6, 1),
                        "hbm_frac": round(hbm_frac, 4), "mfma_frac": round(mfma_frac, 4),
                        "binding_roof": "hbm" if hbm_frac >= mfma_frac else "mfma"})
+    # why a layer sits where it does: the committed SQ-counter digest of its kernel instantiation (scripts/prof_sq.sh + sq_summary.py on
+    # `microbench.py unet`, full chip) merged in -- matrix-pipe busy share, other instructions issued per MFMA, the clock the CUs saw
+    sq = {}
+    for cand in sorted((ROOT / "profiles").glob("r*_unet_sq_summary.json"), reverse=True):
+        try:
+            sq = json.loads(cand.read_text())["kernels"]; sq_src = f"profiles/{cand.name}"
+            break
+        except Exception:
+            pass
+    for ly in layers:
+        kk = sq.get(ly.get("kernel", ""))
+        if not kk or not ly.get("ms"):
+            continue
+        ly["pipe_busy"] = kk.get("mfma_pipe_busy"); ly["clock_GHz"] = kk.get("effective_clock_GHz")
+        if kk.get("non_mfma_insts_per_mfma") is not None:
+            ly["non_mfma_insts_per_mfma"] = kk["non_mfma_insts_per_mfma"]
+        ly["sq_source"] = sq_src
     # the fused first conv follows the family of the rest: fp16 matrix pipe with f16x3, f32-input MFMAs otherwise
     first_name = "conv_first_f16_kernel<5>" if any(k.get("f16") for k in by_kernel.values()) and os.environ.get("CT_FIRST_F16", "1") != "0" \
         else "conv_first_mfma_kernel"
@@ -355,8 +375,15 @@ def roofline_from_timing(ctx, args, n_patches, steps):
         except Exception:
             pass
     first = layers[0] if not layers[0].get("fused_into_next") else layers[1]
+    hbm_contract = round(n_patches * arch.algorithmic_bytes_per_patch() / (conv_ms_total * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if conv_ms_total else None
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4),
+                # the matrix pipe's rate on realistic operands at the power cap, and the kernel against THAT (context; `peak` stays the datasheet figure)
+                "sustained_peak": F16_MFMA_SUSTAINED_TF if dom.get("f16") else None,
+                "frac_of_sustained_peak": round(achieved / F16_MFMA_SUSTAINED_TF, 4) if dom.get("f16") else None,
+                # SURVEY 8(d)'s contract figure: the reference operator's minimum activation traffic (285.1 MB per unet3_a patch) x patches over the
+                # conv stack's time, against the 8 TB/s HBM peak -- the number the north-star's ">= 60 % HBM roofline" is read on
+                "hbm_contract_frac": hbm_contract,
                 # the reference operator's flops (2 * 27 * Cin * Cout per computed voxel; one product per fp32 product) over the same
                 # duration against the peak of the pipe the kernel runs on: `frac` is pipe utilisation, this is useful work
                 "algorithmic_frac": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / peak_tf, 4) if dom["ms"] > 0 else None,
@@ -373,7 +400,7 @@ def roofline_from_timing(ctx, args, n_patches, steps):
                 "executed_gflop_per_launch": round(dom["issued"] / max(dom["launches"], 1) / 1e9, 2),
                 "conv_stack_ms_per_volume": round(conv_ms_total, 3),
                 "conv_stack_tflops": round(n_patches * arch.flops_per_patch() / (conv_ms_total * 1e-3) / 1e12, 2) if conv_ms_total else None,
-                "conv_stack_hbm_frac": round(n_patches * arch.algorithmic_bytes_per_patch() / (conv_ms_total * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if conv_ms_total else None,
+                "conv_stack_hbm_frac": hbm_contract,          # (the name of rounds 2-3; same number as hbm_contract_frac)
                 "hbm_bound_kernel": {"kernel": first["kernel"], "layer": 0, "achieved_GBps": first["gbps"], "peak_GBps": HBM_PEAK_TBS * 1e3,
                                      "frac": first["hbm_frac"], "avg_launch_ms": first["ms"],
                                      "note": "the first conv (Cin = 1, AI 12 flop/B) is the HBM-bound instantiation; when it runs inside the second conv's "

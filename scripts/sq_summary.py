@@ -31,9 +31,15 @@ for k, c in ctr.items():
                           "issuing": round(c.get("SQ_ACTIVE_INST_ANY", 0) / w, 3)}
         if "SQ_WAIT_INST_LDS" in c:
             d["wave_time"]["of_which_lds_issue_stall"] = round(c["SQ_WAIT_INST_LDS"] / w, 3)
-    for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
+    for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_MFMA"):
         if name in c:
             d[name.lower() + "_per_dispatch"] = c[name]
+    # instructions that are not MFMAs per MFMA.  SQ_INSTS_VALU counts the MFMAs too; one v_mfma_f32_16x16x32_f16 keeps the pipe busy for 16 cycles
+    # (profiles/r04_mfma_ceiling.txt: 2411 TFLOP/s at 2.39 GHz on 1024 SIMDs), so the MFMA count of a dispatch is its busy cycles / 16.
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_INSTS_VALU" in c and c["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
+        n_mfma = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 16.0
+        d["mfma_insts_per_dispatch_est"] = round(n_mfma)
+        d["non_mfma_insts_per_mfma"] = round((c["SQ_INSTS_VALU"] - n_mfma + c.get("SQ_INSTS_SALU", 0.0) + c.get("SQ_INSTS_LDS", 0.0)) / n_mfma, 2)
     res[k] = d
 json.dump({"_comment": __doc__, "kernels": res}, open(out, "w"), indent=1)
 for k, d in res.items():

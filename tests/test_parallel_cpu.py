@@ -54,14 +54,19 @@ def _worker(rank, world, port, q):
         assert tuple(none.shape) == (0, 4, 3)
         # the frames mode's gather: a batch of tracked sets per rank in ONE all_gather_into_tensor
         g = par.TrackedSetGather()
+        kept = []
         for frames in (3, 1, 3):
             mine = [torch.full((5, 3), 10.0 * rank + f, dtype=torch.float64) for f in range(frames)]
             buf = g(mine)
+            kept.append(buf)
             assert tuple(buf.shape) == (2, frames, 5, 3)
             for r in range(2):
                 for f in range(frames):
                     assert torch.equal(buf[r, f], torch.full((5, 3), 10.0 * r + f, dtype=torch.float64))
-        assert g.gathered == 2 * (3 + 1 + 3) and len(g.bufs) == 2          # buffers are reused per batch size
+        assert g.gathered == 2 * (3 + 1 + 3) and len(g.bufs) == 2          # buffers are kept per batch shape ...
+        assert kept[0].data_ptr() != kept[2].data_ptr()                    # ... and rotate: the next call of the same shape leaves the last result alone
+        again = g([torch.zeros((5, 3), dtype=torch.float64) for _ in range(3)])
+        assert again.data_ptr() == kept[0].data_ptr() and torch.equal(kept[2][1 - rank, 1], torch.full((5, 3), 10.0 * (1 - rank) + 1, dtype=torch.float64))
         # variable-size centroid sets
         local = torch.arange((rank + 2) * 3, dtype=torch.float64).reshape(-1, 3) + 100 * rank
         sets = par.gather_centroids(local, cap=16)
