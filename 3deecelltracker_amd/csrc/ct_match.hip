@@ -246,36 +246,58 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        Bt bt = Bt{0, nullptr}) {
     BT_SHIFT(const float*, A); BT_SHIFT(float*, C); BT_DIM_N(M);         // batched: rows = the problem's reference points
     if ((int)blockIdx.y * 64 >= M) return;
-    __shared__ float As[16][64 + 1];
-    __shared__ float Bs[16][64 + 4];
+    // K in steps of GK = 32 through two LDS buffers: the next step's 64 x 32 | 32 x 64 panels are fetched into registers before the current
+    // step's FMAs and parked after them, one barrier per step (the first version waited a full L2 round trip per 16-deep step with nothing
+    // else in flight: 60 us per 600 x 512 x 512 product, four of them per match).  Every output still accumulates fmaf(a, b, acc) over k = 0,
+    // 1, 2, ... : the same bits.
+    constexpr int GK = 32;
+    __shared__ float As[2][GK][64 + 1];
+    __shared__ float Bs[2][GK][64 + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        for (int e = tid; e < 64 * 16; e += 256) {
-            const int r = e >> 4, kk = e & 15;
-            const int gm = m0 + r, gk = k0 + kk;
-            As[kk][r] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
-        }
-        for (int e = tid; e < 16 * 64; e += 256) {
-            const int kk = e >> 6, c = e & 63;
-            const int gk = k0 + kk, gn = n0 + c;
-            Bs[kk][c] = (gk < K && gn < N) ? B[(size_t)gk * N + gn] : 0.f;
-        }
-        __syncthreads();
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            const int r = e >> 5, kk = e & 31;                       // A panel: 64 rows x 32 k
+            const int gm = m0 + r, gk = k0 + kk;
+            ra[u] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
+            const int kb = e >> 6, c = e & 63;                       // B panel: 32 k x 64 columns
+            const int gkb = k0 + kb, gn = n0 + c;
+            rb[u] = (gkb < K && gn < N) ? B[(size_t)gkb * N + gn] : 0.f;
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            As[buf][e & 31][e >> 5] = ra[u];
+            Bs[buf][e >> 6][e & 63] = rb[u];
+        }
+    };
+    fetch(0); park(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        const bool more = k0 + GK < K;
+        if (more) fetch(k0 + GK);
+#pragma unroll
+        for (int kk = 0; kk < GK; ++kk) {
             float a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+            for (int i = 0; i < 4; ++i) a[i] = As[buf][kk][ty * 4 + i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+            for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kk][tx * 4 + j];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
         }
+        if (more) park(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1195,7 +1217,8 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
 static inline int prgls_chunk(int enq, int total) { const int c = enq < 16 ? 8 : 16; return (total - enq) < c ? (total - enq) : c; }
 
 constexpr int LR_RMAX = 128;
-constexpr int LR_PF = 8;                       // rows of U fetched together in lowrank_factor_kernel's update loop
+constexpr int LR_PF = 8;                       // rows of U fetched together in lowrank_factor_kernel's update loop (general path)
+constexpr int LR_REG = 24, LR_PF2 = 16;        // n <= 1024: rows of a thread's column of U kept in registers; rows fetched together beyond them
 
 // pivoted Cholesky of the symmetric PSD matrix G (n x n); single workgroup.
 // U [LR_RMAX][n] (row k contiguous).  The factorisation is nested (row k does not depend on later rows), so one run to the fine
@@ -1206,11 +1229,70 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
                                                               int* __restrict__ rank_out, Bt bt = Bt{0, nullptr}) {
     BT_SHIFT(const double*, G); BT_SHIFT(double*, U); BT_SHIFT(double*, resid); BT_SHIFT(int*, rank_out);
     if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
-    __shared__ double redv[16];
-    __shared__ int redi[16];
+    __shared__ double redv[2][16];
+    __shared__ int redi[2][16];
     __shared__ double pivv; __shared__ int pivi;
-    __shared__ double urow[LR_RMAX + LR_PF];    // U[0..k-1][p], zero padded
+    __shared__ double urow[LR_RMAX + LR_PF2];   // U[0..k-1][p], zero padded
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n <= 1024) {
+        // One point per thread (every match of the per-frame path): the thread's residual and the first LR_REG rows of its column of U stay in
+        // REGISTERS -- those rows are read at every later step, and fetching them from L2 was the step's cost (k / LR_PF dependent round trips:
+        // 0.4 ms per 600-point factorisation, a fifth of a chained frame's match) --, rows beyond come LR_PF2 at a time, the wave partials of the
+        // arg-max are combined by every thread (one barrier less), and thread p hands over its registers for urow.  Same operations in the same
+        // order per element as the general loop below.
+        const int i = tid; const bool act = i < n;
+        double res = act ? G[(size_t)i * n + i] : -1.0;
+        double ureg[LR_REG];
+#pragma unroll
+        for (int j = 0; j < LR_REG; ++j) ureg[j] = 0.0;
+        int k = 0, k_coarse = -1;
+        for (; k < LR_RMAX; ++k) {
+            const bool cand = act && res > -1.0;                  // (the general loop's `d > best` from best = -1)
+            double best = cand ? res : -1.0; int bi = cand ? i : 0x7fffffff;
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) {
+                const double od = shfl_xor_d(best, mk); const int oi = __shfl_xor(bi, mk);
+                if (od > best || (od == best && oi < bi)) { best = od; bi = oi; }
+            }
+            double (&rv)[16] = redv[k & 1]; int (&ri)[16] = redi[k & 1];      // (two sets: a wave may run ahead into the next step's partials)
+            if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
+            __syncthreads();
+            double pv = rv[0]; int p = ri[0];
+#pragma unroll
+            for (int w = 1; w < 16; ++w) { const double b = rv[w]; const int ix = ri[w]; if (b > pv || (b == pv && ix < p)) { pv = b; p = ix; } }
+            if (k_coarse < 0 && !(pv > tol_coarse)) k_coarse = k;
+            if (!(pv > tol)) break;
+            const double piv = sqrt(pv);
+            if (tid == p) {
+#pragma unroll
+                for (int j = 0; j < LR_REG; ++j) urow[j] = ureg[j];          // (rows >= k are still zero)
+            }
+            if (tid >= LR_REG && tid < LR_RMAX + LR_PF2) urow[tid] = tid < k ? U[(size_t)tid * n + p] : 0.0;
+            __syncthreads();
+            if (act) {
+                double u = G[(size_t)p * n + i];
+#pragma unroll
+                for (int j = 0; j < LR_REG; ++j) u -= ureg[j] * urow[j];
+                for (int j0 = LR_REG; j0 < k; j0 += LR_PF2) {
+                    double t[LR_PF2];
+#pragma unroll
+                    for (int q = 0; q < LR_PF2; ++q) t[q] = U[(size_t)min(j0 + q, k - 1) * n + i];
+#pragma unroll
+                    for (int q = 0; q < LR_PF2; ++q) u -= t[q] * urow[j0 + q];
+                }
+                u /= piv;
+                U[(size_t)k * n + i] = u;
+#pragma unroll
+                for (int j = 0; j < LR_REG; ++j) ureg[j] = (j == k) ? u : ureg[j];
+                res = (i == p) ? 0.0 : res - u * u;
+            }
+            __syncthreads();                                   // row k is visible to the threads that fetch U[k][p] next step
+        }
+        if (act) resid[i] = res;
+        if (tid == 0) { rank_out[0] = k_coarse; rank_out[1] = k; }
+        return;
+    }
+    double (&redv0)[16] = redv[0]; int (&redi0)[16] = redi[0];
     for (int i = tid; i < n; i += 1024) resid[i] = G[(size_t)i * n + i];
     __syncthreads();
     int k = 0, k_coarse = -1;
@@ -1222,11 +1304,11 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
             const double od = shfl_xor_d(best, mk); const int oi = __shfl_xor(bi, mk);
             if (od > best || (od == best && oi < bi)) { best = od; bi = oi; }
         }
-        if (lane == 0) { redv[wave] = best; redi[wave] = bi; }
+        if (lane == 0) { redv0[wave] = best; redi0[wave] = bi; }
         __syncthreads();
         if (tid == 0) {
-            double b = redv[0]; int ix = redi[0];
-            for (int w = 1; w < 16; ++w) if (redv[w] > b || (redv[w] == b && redi[w] < ix)) { b = redv[w]; ix = redi[w]; }
+            double b = redv0[0]; int ix = redi0[0];
+            for (int w = 1; w < 16; ++w) if (redv0[w] > b || (redv0[w] == b && redi0[w] < ix)) { b = redv0[w]; ix = redi0[w]; }
             pivv = b; pivi = ix;
         }
         __syncthreads();
