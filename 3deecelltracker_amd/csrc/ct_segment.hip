@@ -359,7 +359,9 @@ __global__ void ws_edt_z_kernel(SegGeom g, const int32_t* __restrict__ d2, doubl
 }
 
 // scipy.ndimage correlate1d, symmetric kernel w[0..2r], 'constant' (0) borders, along the axis with element stride `stride`
-__global__ void ws_gauss_kernel(SegGeom g, int axis, const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ w, int r) {
+struct WsWeights { double w[48]; };                   // a kernel argument (384 bytes): no device copy of the host's weights per call
+__global__ void ws_gauss_kernel(SegGeom g, int axis, const double* __restrict__ in, double* __restrict__ out, const WsWeights ww, int r) {
+    const double* w = ww.w;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.V) return;
     int x, y, z; ws_xyz(i, g, x, y, z);
@@ -408,7 +410,8 @@ template <int AXIS> __device__ __forceinline__ bool ws_line(const SegGeom& g, lo
     return true;
 }
 template <int AXIS, int R>
-__global__ __launch_bounds__(256) void ws_gauss_slide_kernel(SegGeom g, const double* __restrict__ in, double* __restrict__ out, const double* __restrict__ w) {
+__global__ __launch_bounds__(256) void ws_gauss_slide_kernel(SegGeom g, const double* __restrict__ in, double* __restrict__ out, const WsWeights ww) {
+    const double* w = ww.w;
     constexpr int W = 2 * R + 1;
     long long base, stride; int len, p0;
     if (!ws_line<AXIS>(g, (long long)blockIdx.x * 256 + threadIdx.x, base, stride, len, p0)) return;
@@ -1712,7 +1715,9 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     unsigned int* counts = (unsigned int*)(ws + L.stats + 4096);                  // [WS_PEAK_CAP3D + 1]
     int32_t* newlabel = (int32_t*)(counts + WS_PEAK_CAP3D + 1);
     unsigned long long* sums = (unsigned long long*)(ws + L.sums);
-    double* w_xy = (double*)(ws + L.weights); double* w_z = w_xy + 48;
+    WsWeights w_xy{}, w_z{};
+    for (int j = 0; j <= 2 * radius_xy; ++j) w_xy.w[j] = gauss_xy[j];
+    for (int j = 0; j <= 2 * radius_z; ++j) w_z.w[j] = gauss_z[j];
     const SegGeom g{dims_xyz[0], dims_xyz[1], dims_xyz[2], V};
     const unsigned nb = (unsigned)((V + 255) / 256);
     // (per call: the attribute belongs to the current device's copy of the kernel, and a process may drive several devices)
@@ -1720,8 +1725,6 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_SEL2_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_box_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BOX_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_box_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BOX_LDS));
-    HIPCHK(hipMemcpyAsync(w_xy, gauss_xy, (size_t)(2 * radius_xy + 1) * sizeof(double), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(w_z, gauss_z, (size_t)(2 * radius_z + 1) * sizeof(double), hipMemcpyHostToDevice, st));
 
     // one pass of: peaks of `smooth` -> markers -> components of `mask` -> flood into `labels`
     static const bool no_slide = getenv("CT_WS_SLIDE") && atoi(getenv("CT_WS_SLIDE")) == 0;                   // (A/B: the per-voxel filter kernels)

@@ -355,8 +355,10 @@ int ct_segment_centroids(const float* prob, const int dims_xyz[3], float thresho
  * (peak-table overflow flags).  CT_ESHAPE: z > 128, an axis >= 16384, or more than 2048 peaks in a slice / 8192 in the volume.
  * Ties, as upstream resolves them (pinned against the reference on scikit-image 0.18.3, tests/test_watershed_pin.py): peak candidates of exactly
  * equal height closer than min_distance (strictly) are thinned in the order np.argsort(-values) leaves them -- numpy's generic introsort,
- * replayed on the device; seeds of exactly equal height inside one connected region are flooded in raveled order (upstream: the order of its
- * image-wide heap -- the one rule that is the device's own).                                                                                */
+ * replayed on the device; seeds of exactly equal height inside one connected region are popped in the order upstream's image-wide binary heap
+ * leaves them in: a z slice / volume that holds such a pair is replayed sequentially with that heap (heap_general.pxi restated; ~2 us per
+ * foreground voxel of the group, mirror-symmetric shapes only), everything else is flooded component by component in parallel.
+ * n_out[0] = -1: method "cell_num" asked for more cells than np.bincount has bins (the reference's IndexError, watershed.py:92).            */
 size_t ct_watershed_workspace_bytes(const int dims_xyz[3], int cap);
 int    ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_ratio, int method, int min_size, int cell_num,
                             int min_distance_2d, int min_distance_3d, const double* gauss_xy, int radius_xy, const double* gauss_z, int radius_z,

@@ -2,7 +2,7 @@
 # the U-Net alone, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate PMC passes), SQ counters, the match chain, the bench line.
 #   usage: bash scripts/evidence.sh r02
 set -u
-R=${1:-r03}
+R=${1:-r04}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3
@@ -16,6 +16,8 @@ bash scripts/prof_sq.sh unetB_$R "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_
 bash scripts/prof_sq.sh unetC_$R "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" $GRAFT_REPO_ROOT/scripts/microbench.py unet | tail -1
 cd $GRAFT_REPO_ROOT
 python scripts/sq_summary.py gpurun_out/prof/unet_${R}_kernel_stats.csv gpurun_out/prof/${R}_unet_sq_summary.json gpurun_out/prof/unetA_${R}_sq.csv gpurun_out/prof/unetB_${R}_sq.csv gpurun_out/prof/unetC_${R}_sq.csv
+bash scripts/prof.sh watershed_$R $GRAFT_REPO_ROOT/scripts/microbench.py watershed | head -3
+bash scripts/prof.sh frame_$R $GRAFT_REPO_ROOT/scripts/microbench.py frame | head -3
 bash scripts/prof.sh match600_$R $GRAFT_REPO_ROOT/scripts/microbench.py match 600 | head -3
 bash scripts/prof.sh batched_$R $GRAFT_REPO_ROOT/scripts/microbench.py batched 600 16 | head -3
 cd $GRAFT_REPO_ROOT
