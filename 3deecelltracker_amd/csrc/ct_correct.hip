@@ -35,10 +35,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // movement of every cell on the interpolated grid: round((coords - vol1) * (1, 1, factor)), numpy half-to-even
+// (`done` != 0: an earlier round already met the stopping rule -- rounds enqueued ahead of the host's look at the flags do nothing)
 __global__ void movements_kernel(const float* __restrict__ coords, const float* __restrict__ vol1, int n, int factor,
-                                 int32_t* __restrict__ mov) {
+                                 int32_t* __restrict__ mov, const int* __restrict__ done) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * n) return;
+    if (i >= 3 * n || *done) return;
     const float d = coords[i] - vol1[i];                       // Coordinates.__sub__ : float32 raw difference
     const double s = (i % 3 == 2) ? (double)factor : 1.0;
     mov[i] = (int32_t)rint((double)d * s);
@@ -72,9 +73,10 @@ __device__ __forceinline__ void for_cell_voxels(const CorrGeom g, const int32_t*
 
 __global__ __launch_bounds__(256) void scatter_counts_kernel(CorrGeom g, const int32_t* __restrict__ bbox, const uint8_t* __restrict__ subs,
                                                              const long long* __restrict__ offs, const uint8_t* __restrict__ missed,
-                                                             const int32_t* __restrict__ mov, unsigned int* __restrict__ cnt, int* __restrict__ err) {
+                                                             const int32_t* __restrict__ mov, unsigned int* __restrict__ cnt, int* __restrict__ err,
+                                                             const int* __restrict__ done) {
     const int i = blockIdx.x;
-    if (missed[i]) return;
+    if (missed[i] || *done) return;
     for_cell_voxels(g, bbox + 6 * i, subs + offs[i], mov + 3 * i, err,
                     [&](int x, int y, int k) { atomicAdd(&cnt[((size_t)x * g.Y + y) * g.Z + k], 1u); });
 }
@@ -85,9 +87,10 @@ __global__ __launch_bounds__(256) void centre_of_mass_kernel(CorrGeom g, const f
                                                              const uint8_t* __restrict__ subs, const long long* __restrict__ offs,
                                                              const uint8_t* __restrict__ missed, const int32_t* __restrict__ mov,
                                                              const unsigned int* __restrict__ cnt, float* __restrict__ coords,
-                                                             unsigned int* __restrict__ flag, int* __restrict__ err) {
+                                                             unsigned int* __restrict__ flag, int* __restrict__ err, const int* __restrict__ done) {
     __shared__ double red[4][4];
     const int i = blockIdx.x;
+    if (*done) return;
     double sw = 0.0, swx = 0.0, swy = 0.0, swz = 0.0;
     if (!missed[i])
         for_cell_voxels(g, bbox + 6 * i, subs + offs[i], mov + 3 * i, err, [&](int x, int y, int k) {
@@ -217,6 +220,14 @@ __global__ __launch_bounds__(256) void legacy_com_kernel(LegacyGeom g, double ra
     }
 }
 
+// closes round `it`: np.max(delta.interp) < 0.5 (the flag holds the signed maximum + 2^30) -> done = it; the round's flag words are kept for the
+// host in hist[it & 1] (it looks every second round)
+__global__ void correction_round_end_kernel(const unsigned int* __restrict__ flag, int it, int* __restrict__ done, unsigned int* __restrict__ hist) {
+    if (*done) return;
+    hist[2 * (it & 1)] = flag[0]; hist[2 * (it & 1) + 1] = flag[16];
+    if ((int)flag[0] - (1 << 30) < 1 || flag[16]) *done = it;                   // (an out-of-image box also ends the loop: the host reports it)
+}
+
 }  // namespace
 
 extern "C" {
@@ -239,25 +250,37 @@ int ct_accurate_correction(const float* prob, const int dims[3], int factor, int
     unsigned int* cnt = (unsigned int*)ws; ws += align_up(nvox * 4, 256);
     int32_t* mov = (int32_t*)ws; ws += align_up((size_t)n_cells * 12, 256);
     unsigned int* flag = (unsigned int*)ws; int* err = (int*)(ws + 64);
-    int it = 0;
-    for (it = 1; it <= max_repetition; ++it) {
-        HIPCHK(hipMemsetAsync(cnt, 0, nvox * 4, st));
-        HIPCHK(hipMemsetAsync(flag, 0, 128, st));
-        hipLaunchKernelGGL(movements_kernel, dim3((3 * n_cells + 255) / 256), dim3(256), 0, st, coords_raw, coord_vol1_raw, n_cells, factor, mov);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(scatter_counts_kernel, dim3(n_cells), dim3(256), 0, st, g, bbox, subimages, sub_offsets, missed, mov, cnt, err);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(centre_of_mass_kernel, dim3(n_cells), dim3(256), 0, st, g, prob, bbox, subimages, sub_offsets, missed, mov, cnt,
-                           coords_raw, flag, err);
-        LAUNCH_CHECK();
-        unsigned int h[32];
-        HIPCHK(hipMemcpyAsync(h, flag, sizeof(h), hipMemcpyDeviceToHost, st));
+    int* done = (int*)(ws + 256); unsigned int* hist = (unsigned int*)(ws + 320);      // (behind the per-round flag block)
+    HIPCHK(hipMemsetAsync(done, 0, 128, st));
+    // Rounds are enqueued two at a time: the device closes each round itself (correction_round_end_kernel) and a round enqueued after the
+    // stopping rule was met does nothing, so the host waits once per two rounds instead of once per round (a frame's four rounds: two idle gaps
+    // instead of four).  Same rounds, same results, same iteration count.
+    int it = 0, finished = 0;
+    for (it = 1; it <= max_repetition && !finished; ) {
+        const int first = it;
+        for (int k = 0; k < 2 && it <= max_repetition; ++k, ++it) {
+            HIPCHK(hipMemsetAsync(cnt, 0, nvox * 4, st));
+            HIPCHK(hipMemsetAsync(flag, 0, 128, st));
+            hipLaunchKernelGGL(movements_kernel, dim3((3 * n_cells + 255) / 256), dim3(256), 0, st, coords_raw, coord_vol1_raw, n_cells, factor, mov, done);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(scatter_counts_kernel, dim3(n_cells), dim3(256), 0, st, g, bbox, subimages, sub_offsets, missed, mov, cnt, err, done);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(centre_of_mass_kernel, dim3(n_cells), dim3(256), 0, st, g, prob, bbox, subimages, sub_offsets, missed, mov, cnt,
+                               coords_raw, flag, err, done);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(correction_round_end_kernel, dim3(1), dim3(1), 0, st, flag, it, done, hist);
+            LAUNCH_CHECK();
+        }
+        unsigned int h[32];                                            // done | ... | hist[4] at + 16 words
+        HIPCHK(hipMemcpyAsync(h, done, sizeof(h), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (((int*)h)[16]) return CT_ESHAPE;                           // a moved bounding box left the image (reference: ValueError)
-        const int mx = (int)h[0] - (1 << 30);
-        if (mx < 1) break;                                             // np.max(delta.interp) < 0.5  (signed max, as in the reference)
+        const int d = (int)h[0];
+        if (d) {
+            if (h[16 + 2 * (d & 1) + 1]) return CT_ESHAPE;             // a moved bounding box left the image (reference: ValueError)
+            finished = d;
+        } else (void)first;
     }
-    if (iterations) *iterations = it > max_repetition ? max_repetition : it;
+    if (iterations) *iterations = finished ? finished : max_repetition;
     return CT_OK;
 }
 

@@ -1084,8 +1084,7 @@ template <bool MODE2D>
 __global__ void ws_flood_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth, const int32_t* __restrict__ roots,
                                 const unsigned int* __restrict__ nroots, const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
                                 WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ labels) {
-    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *nroots) return;
+    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < *nroots; t += gridDim.x * blockDim.x) {
     const int root = roots[t];
     WsHeapEntry* h = heap_all + heap_off[root];
     int n = heap_cnt[root];
@@ -1129,6 +1128,7 @@ __global__ void ws_flood_kernel(SegGeom g, const unsigned char* __restrict__ bn,
             }
             h[k] = e;
         }
+    }
     }
 }
 
@@ -1202,15 +1202,17 @@ __device__ __forceinline__ bool ws_box_eligible(const int32_t* bb, int csize, bo
 }
 template <bool MODE2D>
 __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth,
-                                                           const int32_t* __restrict__ roots, const int32_t* __restrict__ size,
+                                                           const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots, const int32_t* __restrict__ size,
                                                            const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
                                                            WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ qlab_all, int32_t* __restrict__ labels,
                                                            const int32_t* __restrict__ bbox) {
     __shared__ WsHeapEntry q_lds[WS_Q_LDS];
     __shared__ int32_t l_lds[WS_Q_LDS];
     const int lane = threadIdx.x;
-    const int root = roots[blockIdx.x];
-    if (bbox && ws_box_eligible(bbox + (size_t)blockIdx.x * 6, size[root], MODE2D)) return;      // ws_flood_box_kernel's
+    for (unsigned int slot = blockIdx.x; slot < *nroots; slot += gridDim.x) {   // (the host no longer waits for the list's length: a fixed grid walks it)
+    const int root = roots[slot];
+    if (bbox && ws_box_eligible(bbox + (size_t)slot * 6, size[root], MODE2D)) continue;      // ws_flood_box_kernel's
+    __syncthreads();                                       // (one wave) the previous component's queue is done with
     const bool in_lds = size[root] <= WS_Q_LDS;
     WsHeapEntry* const gq = heap_all + heap_off[root];
     int32_t* const gl = qlab_all + heap_off[root];
@@ -1264,6 +1266,7 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsi
         n += cnt; age += cnt;
         __syncthreads();                                   // one wave: orders this iteration's queue writes before the next sweep
     }
+    }
 }
 
 // queue entry of the LDS flood: key = bit pattern of the smoothed EDT (>= +0.0, so the patterns order like the values and the LARGEST key is the
@@ -1281,8 +1284,11 @@ __device__ __forceinline__ void ws_wave_argmin(const WsQEntry& best, int& bpos, 
     const bool has = bpos >= 0;
     const unsigned int hmax = ws_wave_max_u32(has ? hi : 0u);
     const bool c1 = has && hi == hmax;
-    const unsigned int lmax = ws_wave_max_u32(c1 ? lo : 0u);
-    unsigned long long m = __ballot(c1 && lo == lmax);
+    unsigned long long m = __ballot(c1);
+    if (__popcll(m) > 1) {                                    // (two keys within 2^-20 of each other: rare -- the low word decides)
+        const unsigned int lmax = ws_wave_max_u32(c1 ? lo : 0u);
+        m = __ballot(c1 && lo == lmax);
+    }
     if (__popcll(m) > 1) {
         const bool in = (m >> lane) & 1ull;
         const unsigned int amax = ws_wave_max_u32(in ? ~(unsigned int)best.age : 0u);
@@ -1303,14 +1309,16 @@ constexpr size_t WS_BOX_LDS = (size_t)WS_Q_LDS * sizeof(WsQEntry) + (size_t)WS_B
 // unchanged): a pop then needs no division by the box's runtime extents (three of them cost more than the rest of the iteration).
 template <bool MODE2D>
 __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const double* __restrict__ smooth, const int32_t* __restrict__ parent,
-                                                          const int32_t* __restrict__ roots, const int32_t* __restrict__ size,
+                                                          const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots, const int32_t* __restrict__ size,
                                                           const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
                                                           const WsHeapEntry* __restrict__ heap_all, const int32_t* __restrict__ bbox, int32_t* __restrict__ labels) {
     extern __shared__ unsigned long long ws_box_sm[];
     const int lane = threadIdx.x;
-    const int root = roots[blockIdx.x];
-    const int32_t* bb = bbox + (size_t)blockIdx.x * 6;
-    if (!ws_box_eligible(bb, size[root], MODE2D)) return;
+    for (unsigned int slot = blockIdx.x; slot < *nroots; slot += gridDim.x) {   // a fixed grid walks the list (its length stays on the device)
+    const int root = roots[slot];
+    const int32_t* bb = bbox + (size_t)slot * 6;
+    if (!ws_box_eligible(bb, size[root], MODE2D)) continue;
+    __builtin_amdgcn_wave_barrier();
     WsQEntry* const q = (WsQEntry*)ws_box_sm;                                    // [WS_Q_LDS]
     double* const sm_box = (double*)(q + WS_Q_LDS);                              // [WS_BOX_CAP]
     int32_t* const st_box = (int32_t*)(sm_box + WS_BOX_CAP);                     // [WS_BOX_CAP]  -1 outside the component, 0 free, > 0 label
@@ -1386,6 +1394,7 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
             lx += d64x;
         }
     }
+    }
 }
 
 // Do two seeds of EXACTLY equal height share a mask component?  Only then does the order in which upstream's heap releases equal seeds matter
@@ -1393,8 +1402,10 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
 // 2-D stage, the volume in the 3-D stage) take the sequential path below.  One thread per listed component (>= 2 markers).
 __global__ void ws_tie_detect_kernel(SegGeom g, int mode2d, const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots,
                                      const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap,
-                                     int32_t* __restrict__ tie_flags, int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox) {
+                                     int32_t* __restrict__ tie_flags, int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox,
+                                     const int* __restrict__ overflow, int32_t* __restrict__ latch) {
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && *overflow) latch[0] = 1;                                       // (the per-stage flag is cleared with the next stage's statistics)
     if (t >= *nroots) return;
     const int root = roots[t];
     slot_of[root] = (int32_t)t;                                                  // (for the bounding boxes ws_fill_single_kernel collects)
@@ -1533,12 +1544,18 @@ __global__ void ws_bincount_kernel(long long V, const int32_t* __restrict__ labe
 // watershed.py:88-96: cell_num from min_size or min_size from cell_num (both over ALL bins, the background's included, like
 // np.bincount), labels smaller than min_size dropped, the rest renumbered in order (relabel_sequential).  One workgroup.
 __global__ __launch_bounds__(1024) void ws_finish_kernel(long long V, const int32_t* __restrict__ marker_count, int method, int min_size, int cell_num,
-                                                         unsigned int* __restrict__ counts, int32_t* __restrict__ newlabel, int32_t* __restrict__ n_out) {
+                                                         unsigned int* __restrict__ counts, int32_t* __restrict__ newlabel, int32_t* __restrict__ n_out,
+                                                         const int32_t* __restrict__ latch) {
     __shared__ int s_val[2];
     __shared__ int s_scan[1024];
     __shared__ int s_carry, s_kmax;
     __shared__ unsigned long long s_tot;
     const int K = marker_count[0];
+    if (*latch) {                                              // a peak table overflowed in one of the stages: nothing below means anything
+        if (threadIdx.x == 0) { n_out[0] = -2; n_out[1] = min_size; n_out[2] = cell_num; }
+        for (int l = threadIdx.x; l <= K; l += 1024) newlabel[l] = 0;
+        return;
+    }
     if (threadIdx.x == 0) { s_tot = 0; s_kmax = 0; s_val[0] = 0; s_val[1] = min_size; }
     __syncthreads();
     {   // bin 0 = V - the rest; np.bincount's last bin is the largest label PRESENT (a marker dropped outside the mask leaves an empty bin in
@@ -1711,6 +1728,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     unsigned int* bump = (unsigned int*)(ws + L.stats + 2560);                    // bump | nroots | overflow
     unsigned int* nroots = bump + 1; int* overflow = (int*)(bump + 2);
     int32_t* tie_flags = (int32_t*)(ws + L.stats + 3072);                         // [128] groups whose equal seeds share a component
+    int32_t* latch = (int32_t*)(ws + L.stats + 3584);                             // peak-table overflow of either stage (outside the per-stage clear)
     int32_t* bbox = (int32_t*)(ws + L.bbox);                                      // [listed component][6] bounding boxes; slot map = gx (free after the EDT)
     unsigned int* counts = (unsigned int*)(ws + L.stats + 4096);                  // [WS_PEAK_CAP3D + 1]
     int32_t* newlabel = (int32_t*)(counts + WS_PEAK_CAP3D + 1);
@@ -1749,7 +1767,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         // separable window maximum: smooth -> tmp -> (dist ->) [vmax]; the last pass carries the peak test (the maximum itself is only written
         // for the tests' hook)
         double* const vmax_out = (method_in & 0x300) ? vmax : nullptr;
-        HIPCHK(hipMemsetAsync(ws + L.stats, 0, 4096, st));
+        HIPCHK(hipMemsetAsync(ws + L.stats, 0, 3584, st));
         HIPCHK(hipMemsetAsync(vmin, 0xff, 128 * sizeof(unsigned long long), st));
         HIPCHK(hipMemsetAsync(labels, 0, (size_t)V * 4, st));
         max_pass(0, smooth, tmp, min_distance);
@@ -1788,37 +1806,34 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
         ws_marker_append_kernel<<<(unsigned)((ngroups * pcap + 255) / 256), 256, 0, st>>>(ngroups, pcap, marker_idx, marker_count, smooth, parent, heap_off,
                                                                                        heap_cnt, heap, roots, nroots, labels);
         LAUNCH_CHECK();
-        ws_tie_detect_kernel<<<(unsigned)((ngroups * pcap / 2 + 255) / 256), 256, 0, st>>>(g, mode2d ? 1 : 0, roots, nroots, heap_off, heap_cnt, heap, tie_flags, gx, bbox);
+        ws_tie_detect_kernel<<<(unsigned)((ngroups * pcap / 2 + 255) / 256), 256, 0, st>>>(g, mode2d ? 1 : 0, roots, nroots, heap_off, heap_cnt, heap, tie_flags, gx, bbox,
+                                                                                           overflow, latch);
         LAUNCH_CHECK();
-        int32_t h_flags[256];                                                    // one copy: bump | nroots | overflow ... (+ 512 bytes) the 128 tie flags
-        HIPCHK(hipMemcpyAsync(h_flags, bump, sizeof(h_flags), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        const unsigned int h_nroots = (unsigned int)h_flags[1]; const int h_over = h_flags[2];
-        if (h_over) return CT_ESHAPE;                                            // more peak candidates than the per-slice / per-volume table holds
-        bool any_tie = false;
-        for (int q = 0; q < ngroups; ++q) any_tie |= h_flags[128 + q] != 0;
+        // No host round trip: the flood kernels walk the device-side list with fixed grids, the groups whose equal seeds share a component are
+        // replayed by a kernel that looks at its own flag, and a peak-table overflow is latched and reported through n_out (-2) by ws_finish_kernel.
+        // (Until round 4 each stage copied list length and flags to the host and waited: two idle gaps per call.)
         static const bool no_upstream = getenv("CT_WS_UPSTREAM_TIES") && atoi(getenv("CT_WS_UPSTREAM_TIES")) == 0;   // (A/B: raveled order among equal seeds)
-        if (no_upstream) any_tie = false;
         ws_fill_single_kernel<<<nb, 256, 0, st>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox);
         LAUNCH_CHECK();
-        if (h_nroots && !(any_tie && !mode2d)) {
+        {
             static const bool thread_flood = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 0;      // (A/B: one thread per component, binary heap)
+            constexpr unsigned FLOOD_GRID = 512;
             if (thread_flood) {
-                if (mode2d) ws_flood_kernel<true><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
-                else ws_flood_kernel<false><<<(h_nroots + 63) / 64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
+                if (mode2d) ws_flood_kernel<true><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
+                else ws_flood_kernel<false><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
             } else {
                 static const bool no_box = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 1;         // (A/B: every component through the global-state wave flood)
                 if (!no_box) {
-                    if (mode2d) ws_flood_box_kernel<true><<<h_nroots, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, size, heap_off, heap_cnt, heap, bbox, labels);
-                    else ws_flood_box_kernel<false><<<h_nroots, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, size, heap_off, heap_cnt, heap, bbox, labels);
+                    if (mode2d) ws_flood_box_kernel<true><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels);
+                    else ws_flood_box_kernel<false><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels);
                     LAUNCH_CHECK();
                 }
-                if (mode2d) ws_flood_wave_kernel<true><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
-                else ws_flood_wave_kernel<false><<<h_nroots, 64, 0, st>>>(g, mask, smooth, roots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
+                if (mode2d) ws_flood_wave_kernel<true><<<FLOOD_GRID, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
+                else ws_flood_wave_kernel<false><<<FLOOD_GRID, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
             }
             LAUNCH_CHECK();
         }
-        if (any_tie) {                                                           // equal seeds inside one component: those groups again, with upstream's heap
+        if (!no_upstream) {                                                      // equal seeds inside one component: those groups again, with upstream's heap
             if (mode2d) ws_flood_upstream_kernel<true><<<ngroups, 64, 0, st>>>(g, mask, smooth, pcap, marker_idx, marker_count, tie_flags, heap, labels);
             else ws_flood_upstream_kernel<false><<<1, 64, 0, st>>>(g, mask, smooth, pcap, marker_idx, marker_count, tie_flags, heap, labels);
             LAUNCH_CHECK();
@@ -1826,6 +1841,7 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
         return CT_OK;
     };
 
+    HIPCHK(hipMemsetAsync(latch, 0, 16, st));
     // ---- watershed_2d (watershed.py:16-53), all z slices at once
     ws_threshold_kernel<<<nb, 256, 0, st>>>(prob, V, bn, parent, size);
     LAUNCH_CHECK();
@@ -1841,7 +1857,14 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
     if (rc) return rc;
     ws_boundary2d_kernel<<<nb, 256, 0, st>>>(g, bn, labels, bn2, parent, size);
     LAUNCH_CHECK();
-    if (method_in & 0x100) { HIPCHK(hipMemsetAsync(n_out, 0, 3 * sizeof(int32_t), st)); return CT_OK; }     // (tests: stop after watershed_2d, see ct_watershed_read_stage)
+    if (method_in & 0x100) {                                                      // (tests: stop after watershed_2d, see ct_watershed_read_stage)
+        int32_t h_latch = 0;
+        HIPCHK(hipMemcpyAsync(&h_latch, latch, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h_latch) return CT_ESHAPE;
+        HIPCHK(hipMemsetAsync(n_out, 0, 3 * sizeof(int32_t), st));
+        return CT_OK;
+    }
 
     // ---- watershed_3d (watershed.py:55-108)
     ws_edt_x_kernel<<<nb, 256, 0, st>>>(g, bn2, gx);
@@ -1864,7 +1887,7 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
     HIPCHK(hipMemsetAsync(sums, 0, (size_t)cap * 4 * 8, st));
     ws_bincount_kernel<<<nb, 256, 0, st>>>(V, labels, WS_PEAK_CAP3D, counts);
     LAUNCH_CHECK();
-    ws_finish_kernel<<<1, 1024, 0, st>>>(V, marker_count, method, min_size, cell_num, counts, newlabel, n_out);
+    ws_finish_kernel<<<1, 1024, 0, st>>>(V, marker_count, method, min_size, cell_num, counts, newlabel, n_out, latch);
     LAUNCH_CHECK();
     cc_label_kernel<<<nb, 256, 0, st>>>(g, labels, newlabel, labels_out, cap, sums);
     LAUNCH_CHECK();

@@ -119,11 +119,11 @@ def watershed_centroids_device(prob, z_xy_ratio: float, method: str = "min_size"
                                     w_z.ctypes.data_as(C.c_void_p), r_z, int(cap), labels.data_ptr() if want_labels else None,
                                     centres.data_ptr(), sizes.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), ws.numel(),
                                     _dev.stream(prob.device))
-        if rc == _lib.CT_ESHAPE:          # the shape itself was accepted above: the peak tables overflowed
+        _lib.check(rc, "ct_watershed_segment")
+        n, ms, cn = (int(v) for v in n_dev.cpu().tolist())          # the call's only host round trip
+        if n == -2:                       # a peak table overflowed in one of the stages (latched on the device, nothing was waited for)
             raise ValueError(f"the probability map has more peak candidates than the device watershed's tables hold ({WATERSHED_LIMITS}): "
                              "a map that noisy usually needs a higher noise_level; Tracker.region_method = 'cc' has no such limit")
-        _lib.check(rc, "ct_watershed_segment")
-        n, ms, cn = (int(v) for v in n_dev.cpu().tolist())
         if n < 0:                         # watershed.py:92: np.sort(counts)[-cell_num - 1] with fewer than cell_num + 1 bins
             raise IndexError(f"index {-cell_num - 1} is out of bounds: method='cell_num' asks for {cell_num} cells, the watershed found fewer regions")
         if n <= cap:

@@ -351,8 +351,9 @@ int ct_segment_centroids(const float* prob, const int dims_xyz[3], float thresho
  * gauss_xy / gauss_z [host]: the 2 r + 1 correlation weights of scipy's gaussian_filter1d for sigma 2 / 0.3 (truncate 4), computed by the
  * caller exactly as scipy does (3deecelltracker_amd/segment.py); labels_out [dev] int32 [x][y][z] or NULL; centres [dev] fp64 [cap][3] raw voxel
  * coordinates; sizes [dev] int32 [cap] or NULL; n_out [dev] int32 [3] = {number of cells, min_size in force, cell_num in force}.
- * More cells than `cap`: only the first `cap` centres are written (the caller retries with a larger table).  Synchronises the stream twice
- * (peak-table overflow flags).  CT_ESHAPE: z > 128, an axis >= 16384, or more than 2048 peaks in a slice / 8192 in the volume.
+ * More cells than `cap`: only the first `cap` centres are written (the caller retries with a larger table).  Asynchronous: nothing is waited
+ * for (component lists and flags stay on the device).  CT_ESHAPE: z > 128 or an axis >= 16384.  More than 2048 peak candidates in a slice /
+ * 8192 in the volume are latched on the device and reported as n_out[0] = -2 (labels / centres are meaningless then).
  * Ties, as upstream resolves them (pinned against the reference on scikit-image 0.18.3, tests/test_watershed_pin.py): peak candidates of exactly
  * equal height closer than min_distance (strictly) are thinned in the order np.argsort(-values) leaves them -- numpy's generic introsort,
  * replayed on the device; seeds of exactly equal height inside one connected region are popped in the order upstream's image-wide binary heap

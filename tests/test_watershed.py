@@ -201,3 +201,17 @@ def test_device_marker_on_background_and_min_size_zero():
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.isfinite(got[1]).all()
     with pytest.raises(IndexError):
         _device(prob, 2.0, "cell_num", 0, 3)
+
+
+@pytest.mark.gpu
+def test_device_peak_table_overflow_is_reported():
+    """A map of pure speckle has more 3-D peak candidates than the device tables hold: the condition is latched on the device (the call itself
+    waits for nothing) and surfaces as the wrapper's ValueError naming the limits and the connected-components opt-out."""
+    rng = np.random.default_rng(5)
+    prob = (rng.uniform(size=(400, 400, 32)) > 0.45).astype(np.float32) * 0.9
+    with pytest.raises(ValueError, match="peak candidates"):
+        _device(prob, 4.0, "min_size", 0, 0)
+    # and the next call on a sane map is unaffected (the latch is per call)
+    got = _device(touching_case(), 3.0, "min_size", 40, 0)
+    want = wr.segment_centroids(touching_case(), 3.0, "min_size", 40)
+    assert np.array_equal(got[0], want[0])
