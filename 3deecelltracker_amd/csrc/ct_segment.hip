@@ -1079,13 +1079,28 @@ __device__ __forceinline__ bool ws_less(const WsHeapEntry& a, const WsHeapEntry&
     return a.value < b.value || (a.value == b.value && (a.age < b.age || (a.age == b.age && a.idx < b.idx)));
 }
 
+constexpr int WS_Q_LDS = 2048;                     // queue entries held in LDS (32 KB + 8 KB of labels per 64-thread block)
+constexpr int WS_HEAP_MIN = 8192;                 // components larger than this are flooded with a binary heap (one thread), not a swept queue
+constexpr int WS_BOX_CAP = 8192;                   // voxels of a component's bounding box held in LDS (64 KB smoothed EDT + 32 KB labels)
+// Which components take the LDS form: a bounding box of at most WS_BOX_CAP voxels (and a frontier that fits the WS_Q_LDS queue entries: a
+// component whose queue would overflow is handed back untouched, its box marked ineligible).  The others keep ws_flood_wave_kernel (state in
+// global memory; up to WS_HEAP_MIN voxels) or, beyond that, ws_flood_kernel's binary heap (a linear sweep per pop does not scale to clumps of
+// tens of thousands of voxels).
+__device__ __forceinline__ bool ws_box_eligible(const int32_t* bb, int csize, bool mode2d) {
+    const long long vol = (long long)(bb[3] - bb[0] + 1) * (bb[4] - bb[1] + 1) * (mode2d ? 1 : (bb[5] - bb[2] + 1));
+    (void)csize;                                           // (the queue holds the FRONTIER: a component larger than the queue usually fits; see the overflow exit)
+    return vol <= WS_BOX_CAP && bb[3] - bb[0] < 1024 && bb[4] - bb[1] < 1024 && (mode2d || bb[5] - bb[2] < 128);
+}
 // skimage's priority flood of ONE mask component per thread (see the header of this section)
 template <bool MODE2D>
 __global__ void ws_flood_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth, const int32_t* __restrict__ roots,
                                 const unsigned int* __restrict__ nroots, const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
-                                WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ labels) {
+                                WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ labels, const int32_t* __restrict__ size, int larger_than,
+                                const int32_t* __restrict__ bbox) {
     for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < *nroots; t += gridDim.x * blockDim.x) {
     const int root = roots[t];
+    if (size[root] <= larger_than) continue;               // (the wave kernels' share)
+    if (bbox && ws_box_eligible(bbox + (size_t)t * 6, size[root], MODE2D) && heap_cnt[root] <= WS_Q_LDS) continue;      // ws_flood_box_kernel's
     WsHeapEntry* h = heap_all + heap_off[root];
     int n = heap_cnt[root];
     auto sift_down = [&](int k) {
@@ -1192,14 +1207,6 @@ __global__ void ws_fill_single_kernel(SegGeom g, const int32_t* __restrict__ par
 // ws_flood_kernel, so the same pops in the same sequence --, the popped pixel's 4 / 6 neighbours are fetched by as many lanes at once and
 // pushed with consecutive ages in ascending raveled-offset order (ballot prefix), labels given at push time.  Per pop: one LDS sweep, one
 // butterfly, ONE global round trip (the single-thread version pays a dozen dependent ones).
-constexpr int WS_Q_LDS = 2048;                     // queue entries held in LDS (32 KB + 8 KB of labels per 64-thread block)
-constexpr int WS_BOX_CAP = 8192;                   // voxels of a component's bounding box held in LDS (64 KB smoothed EDT + 32 KB labels)
-// Which components take the LDS form: at most WS_Q_LDS voxels (the queue never holds more than the component) inside a bounding box of at
-// most WS_BOX_CAP voxels.  The others keep ws_flood_wave_kernel (queue in LDS or global memory, state in global memory).
-__device__ __forceinline__ bool ws_box_eligible(const int32_t* bb, int csize, bool mode2d) {
-    const long long vol = (long long)(bb[3] - bb[0] + 1) * (bb[4] - bb[1] + 1) * (mode2d ? 1 : (bb[5] - bb[2] + 1));
-    return csize <= WS_Q_LDS && vol <= WS_BOX_CAP && bb[3] - bb[0] < 1024 && bb[4] - bb[1] < 1024 && (mode2d || bb[5] - bb[2] < 128);
-}
 template <bool MODE2D>
 __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth,
                                                            const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots, const int32_t* __restrict__ size,
@@ -1211,7 +1218,8 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsi
     const int lane = threadIdx.x;
     for (unsigned int slot = blockIdx.x; slot < *nroots; slot += gridDim.x) {   // (the host no longer waits for the list's length: a fixed grid walks it)
     const int root = roots[slot];
-    if (bbox && ws_box_eligible(bbox + (size_t)slot * 6, size[root], MODE2D)) continue;      // ws_flood_box_kernel's
+    if (bbox && ws_box_eligible(bbox + (size_t)slot * 6, size[root], MODE2D) && heap_cnt[root] <= WS_Q_LDS) continue;      // ws_flood_box_kernel's
+    if (size[root] > WS_HEAP_MIN) continue;                // ws_flood_kernel's (binary heap)
     __syncthreads();                                       // (one wave) the previous component's queue is done with
     const bool in_lds = size[root] <= WS_Q_LDS;
     WsHeapEntry* const gq = heap_all + heap_off[root];
@@ -1311,13 +1319,13 @@ template <bool MODE2D>
 __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const double* __restrict__ smooth, const int32_t* __restrict__ parent,
                                                           const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots, const int32_t* __restrict__ size,
                                                           const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
-                                                          const WsHeapEntry* __restrict__ heap_all, const int32_t* __restrict__ bbox, int32_t* __restrict__ labels) {
+                                                          const WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ bbox, int32_t* __restrict__ labels) {
     extern __shared__ unsigned long long ws_box_sm[];
     const int lane = threadIdx.x;
     for (unsigned int slot = blockIdx.x; slot < *nroots; slot += gridDim.x) {   // a fixed grid walks the list (its length stays on the device)
     const int root = roots[slot];
-    const int32_t* bb = bbox + (size_t)slot * 6;
-    if (!ws_box_eligible(bb, size[root], MODE2D)) continue;
+    int32_t* bb = bbox + (size_t)slot * 6;
+    if (!ws_box_eligible(bb, size[root], MODE2D) || heap_cnt[root] > WS_Q_LDS) continue;
     __builtin_amdgcn_wave_barrier();
     WsQEntry* const q = (WsQEntry*)ws_box_sm;                                    // [WS_Q_LDS]
     double* const sm_box = (double*)(q + WS_Q_LDS);                              // [WS_BOX_CAP]
@@ -1359,7 +1367,7 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
         else if (lane == 4) { sh = 7; dir = 1; lim = BY; dlin = BZ; } else if (lane == 5) { sh = 17; dir = 1; lim = BX; dlin = BY * BZ; }
     }
     const int fmask = sh == 17 ? 1023 : (sh == 7 ? 1023 : 127), dpk = dir * (1 << sh);
-    int age = 0;
+    int age = 0; bool overflowed = false;
     while (n > 0) {
         WsQEntry best = q[lane < n ? lane : 0]; int bpos = lane < n ? lane : -1;
         for (int e = lane + 64; e < n; e += 64) { const WsQEntry t = q[e]; if (ws_qbefore(t, best)) { best = t; bpos = e; } }
@@ -1374,6 +1382,7 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
         const int st = st_box[nb]; const double sv = sm_box[nb];                 // (both reads in flight with the label's)
         const bool take = valid && st == 0;
         const unsigned long long mask = __ballot(take);
+        if (n + (int)__popcll(mask) > WS_Q_LDS) { overflowed = true; break; }   // (uniform) frontier beyond the queue: hand the component back
         if (take) {
             const int rank = (int)__popcll(mask & ((1ull << lane) - 1ull));
             st_box[nb] = lab;
@@ -1383,6 +1392,10 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
         n += cnt; age += cnt;
         // one wave: its LDS instructions execute in program order, so the next sweep sees these writes; the compiler must not move them
         __builtin_amdgcn_wave_barrier();
+    }
+    if (overflowed) {                                      // nothing was written to global memory: the global-state kernels start from the markers
+        if (lane == 0) bb[3] = 0x7fffffff;                    // (x extent >= 1024: ineligible for them to see)
+        continue;
     }
     {
         int lz = lane % BZ, ly = (lane / BZ) % BY, lx = lane / (BZ * BY);
@@ -1819,10 +1832,13 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
             static const bool thread_flood = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 0;      // (A/B: one thread per component, binary heap)
             constexpr unsigned FLOOD_GRID = 512;
             if (thread_flood) {
-                if (mode2d) ws_flood_kernel<true><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
-                else ws_flood_kernel<false><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels);
+                if (mode2d) ws_flood_kernel<true><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels, size, -1, nullptr);
+                else ws_flood_kernel<false><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels, size, -1, nullptr);
             } else {
-                static const bool no_box = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 1;         // (A/B: every component through the global-state wave flood)
+                // every listed component is flooded by exactly one of three kernels: its bounding box fits LDS -> ws_flood_box_kernel (which hands a
+                // component back, box marked, if its frontier outgrows the queue); else up to WS_HEAP_MIN voxels -> ws_flood_wave_kernel (swept queue,
+                // state in global memory); else -> ws_flood_kernel (one thread, binary heap: O(log n) per pop for clumps of tens of thousands of voxels)
+                static const bool no_box = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 1;         // (A/B: no LDS-resident flood)
                 if (!no_box) {
                     if (mode2d) ws_flood_box_kernel<true><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels);
                     else ws_flood_box_kernel<false><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels);
@@ -1830,6 +1846,9 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
                 }
                 if (mode2d) ws_flood_wave_kernel<true><<<FLOOD_GRID, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
                 else ws_flood_wave_kernel<false><<<FLOOD_GRID, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
+                LAUNCH_CHECK();
+                if (mode2d) ws_flood_kernel<true><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels, size, WS_HEAP_MIN, no_box ? nullptr : bbox);
+                else ws_flood_kernel<false><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels, size, WS_HEAP_MIN, no_box ? nullptr : bbox);
             }
             LAUNCH_CHECK();
         }

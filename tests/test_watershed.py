@@ -205,13 +205,32 @@ def test_device_marker_on_background_and_min_size_zero():
 
 @pytest.mark.gpu
 def test_device_peak_table_overflow_is_reported():
-    """A map of pure speckle has more 3-D peak candidates than the device tables hold: the condition is latched on the device (the call itself
-    waits for nothing) and surfaces as the wrapper's ValueError naming the limits and the connected-components opt-out."""
-    rng = np.random.default_rng(5)
-    prob = (rng.uniform(size=(400, 400, 32)) > 0.45).astype(np.float32) * 0.9
+    """More peak candidates than the device tables hold (a lattice of isolated 3 x 3 specks: 4096 per slice, 20 000 in the volume -- single-marker
+    components, nothing to flood): the condition is latched on the device (the call itself waits for nothing) and surfaces as the wrapper's
+    ValueError naming the limits and the connected-components opt-out.  The latch is per call."""
+    prob = np.zeros((384, 384, 32), np.float32)
+    for dx in range(3):
+        for dy in range(3):
+            prob[2 + dx::6, 2 + dy::6, 1::6] = 0.9
     with pytest.raises(ValueError, match="peak candidates"):
         _device(prob, 4.0, "min_size", 0, 0)
-    # and the next call on a sane map is unaffected (the latch is per call)
     got = _device(touching_case(), 3.0, "min_size", 40, 0)
     want = wr.segment_centroids(touching_case(), 3.0, "min_size", 40)
     assert np.array_equal(got[0], want[0])
+
+
+@pytest.mark.gpu
+def test_device_watershed_on_a_large_clump():
+    """One connected clump of 60 overlapping blobs (> 8192 voxels, a bounding box far beyond the LDS tile): the component takes the
+    binary-heap flood, its neighbours the LDS-resident one -- labels equal the oracle's."""
+    rng = np.random.default_rng(9)
+    c = np.stack([rng.uniform(20, 100, 60), rng.uniform(20, 100, 60), rng.uniform(4, 12, 60)], 1)
+    prob = blobs((120, 120, 16), c, rng.uniform(7, 10, 60), level=0.8)
+    prob += rng.uniform(0, 0.15, prob.shape).astype(np.float32) * (prob > 0)
+    lab, n = ndi.label(prob > 0.5)
+    assert np.bincount(lab.ravel())[1:].max() > 8192
+    want = wr.segment_centroids(prob, 3.0, "min_size", 20)
+    got = _device(prob, 3.0, "min_size", 20, 0)
+    assert (got[2], got[3]) == (want[2], want[3]) and want[0].max() >= 10
+    assert np.array_equal(got[0], want[0]), f"{int((got[0] != want[0]).sum())} voxels differ"
+    assert np.array_equal(got[1], want[1])
