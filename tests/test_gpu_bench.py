@@ -38,6 +38,10 @@ def test_single_gpu_modes_share_one_schema():
         r = line["roofline"]
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
         assert r["traffic"] is None or isinstance(r["traffic"], (int, float))          # bytes per launch (PMC), the contract's scalar
+        # the block explains itself: the SURVEY 8(d) contract figure, the measured sustained matrix-pipe rate beside the datasheet peak
+        assert 0.0 < r["hbm_contract_frac"] < 1.0 and r["hbm_contract_frac"] == r["conv_stack_hbm_frac"]
+        assert r["sustained_peak"] < r["peak"] and abs(r["frac_of_sustained_peak"] - r["achieved"] / r["sustained_peak"]) < 1e-3
+        assert any("pipe_busy" in ly for ly in line["layers"])                            # SQ digest merged per layer
         assert r["hbm_bound_kernel"]["kernel"].startswith(("conv_first_f16_kernel", "conv_l0l1_fused_kernel"))   # (the first conv runs inside the second's workgroups)
         assert 0 < r["algorithmic_frac"] <= r["frac"] and 0 < r["conv_stack_hbm_frac"] < 1
         assert line["config"]["headline_excludes"] and line["config"]["rccl_ranks"]["world_size"] == 1
