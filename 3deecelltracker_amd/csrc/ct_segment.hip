@@ -1319,13 +1319,15 @@ template <bool MODE2D>
 __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const double* __restrict__ smooth, const int32_t* __restrict__ parent,
                                                           const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots, const int32_t* __restrict__ size,
                                                           const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
-                                                          const WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ bbox, int32_t* __restrict__ labels) {
+                                                          const WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ bbox, int32_t* __restrict__ labels,
+                                                          int qcap /* queue entries usable (<= WS_Q_LDS; smaller in the hand-back test) */) {
     extern __shared__ unsigned long long ws_box_sm[];
     const int lane = threadIdx.x;
     for (unsigned int slot = blockIdx.x; slot < *nroots; slot += gridDim.x) {   // a fixed grid walks the list (its length stays on the device)
     const int root = roots[slot];
     int32_t* bb = bbox + (size_t)slot * 6;
     if (!ws_box_eligible(bb, size[root], MODE2D) || heap_cnt[root] > WS_Q_LDS) continue;
+    if (heap_cnt[root] > qcap) { if (lane == 0) bb[3] = 0x7fffffff; continue; }     // (only with a reduced qcap: hand back before touching anything)
     __builtin_amdgcn_wave_barrier();
     WsQEntry* const q = (WsQEntry*)ws_box_sm;                                    // [WS_Q_LDS]
     double* const sm_box = (double*)(q + WS_Q_LDS);                              // [WS_BOX_CAP]
@@ -1382,7 +1384,7 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
         const int st = st_box[nb]; const double sv = sm_box[nb];                 // (both reads in flight with the label's)
         const bool take = valid && st == 0;
         const unsigned long long mask = __ballot(take);
-        if (n + (int)__popcll(mask) > WS_Q_LDS) { overflowed = true; break; }   // (uniform) frontier beyond the queue: hand the component back
+        if (n + (int)__popcll(mask) > qcap) { overflowed = true; break; }       // (uniform) frontier beyond the queue: hand the component back
         if (take) {
             const int rank = (int)__popcll(mask & ((1ull << lane) - 1ull));
             st_box[nb] = lab;
@@ -1840,8 +1842,9 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
                 // state in global memory); else -> ws_flood_kernel (one thread, binary heap: O(log n) per pop for clumps of tens of thousands of voxels)
                 static const bool no_box = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 1;         // (A/B: no LDS-resident flood)
                 if (!no_box) {
-                    if (mode2d) ws_flood_box_kernel<true><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels);
-                    else ws_flood_box_kernel<false><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels);
+                    static const int qcap = getenv("CT_WS_QCAP") ? (atoi(getenv("CT_WS_QCAP")) < WS_Q_LDS ? atoi(getenv("CT_WS_QCAP")) : WS_Q_LDS) : WS_Q_LDS;   // (tests: force the hand-back)
+                    if (mode2d) ws_flood_box_kernel<true><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels, qcap);
+                    else ws_flood_box_kernel<false><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels, qcap);
                     LAUNCH_CHECK();
                 }
                 if (mode2d) ws_flood_wave_kernel<true><<<FLOOD_GRID, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);

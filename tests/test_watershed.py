@@ -2,6 +2,8 @@
 on the GPU.  The oracle restates four scikit-image functions (pinned against scikit-image 0.18.3 itself in tests/test_watershed_pin.py); scipy's
 functions are the reference's own."""
 import importlib
+import sys
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -9,6 +11,7 @@ import scipy.ndimage as ndi
 
 from oracle import watershed_ref as wr
 
+REPO = Path(__file__).resolve().parent.parent
 synth = importlib.import_module("3deecelltracker_amd.synth")
 seg = importlib.import_module("3deecelltracker_amd.segment")
 
@@ -234,3 +237,32 @@ def test_device_watershed_on_a_large_clump():
     assert (got[2], got[3]) == (want[2], want[3]) and want[0].max() >= 10
     assert np.array_equal(got[0], want[0]), f"{int((got[0] != want[0]).sum())} voxels differ"
     assert np.array_equal(got[1], want[1])
+
+
+_ALT_PATHS = [{"CT_WS_FLOOD": "0"}, {"CT_WS_FLOOD": "1"}, {"CT_WS_QCAP": "8"}, {"CT_WS_SLIDE": "0"}, {"CT_WS_SELECT": "0"}]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", _ALT_PATHS, ids=lambda e: "-".join(f"{k}={v}" for k, v in e.items()))
+def test_device_watershed_alternative_paths_give_the_same_labels(env):
+    """Every switchable path of the device watershed -- binary-heap flood for all components, global-state wave flood, the LDS flood handing
+    components back when its queue is (artificially) too short, per-voxel filters, bitonic-sort peak selection -- produces the oracle's labels
+    (the switches are read once per process: each variant runs in its own interpreter)."""
+    import os
+    import subprocess
+    code = """
+import sys, importlib, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from _ws_cases import touching_case, random_case, tie_case
+from oracle import watershed_ref as wr
+seg = importlib.import_module("3deecelltracker_amd.segment")
+bad = 0
+for prob, zr, ms in ((touching_case(), 3.0, 40), (random_case((120, 100, 16), 40, 1), 4.0, 20), (tie_case(), 2.0, 5)):
+    want = wr.segment_centroids(prob, zr, "min_size", ms)
+    got = seg.watershed_centroids(prob, zr, "min_size", ms, 0)
+    bad += int(not np.array_equal(got[0], want[0])) + int(not np.array_equal(got[1], want[1]))
+print("mismatches", bad)
+"""
+    repo = str(REPO)
+    r = subprocess.run([sys.executable, "-c", code, repo], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-300:] + r.stderr[-800:]
