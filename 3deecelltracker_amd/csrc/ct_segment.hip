@@ -277,8 +277,12 @@ SegLayout seg_layout(long long V, int cap) {
 //     ensure_spacing can only ever drop ties: inside the window two surviving maxima are equal); labels in raster order;
 //   * watershed: skimage's priority flood is inherently sequential (a heap of (value, age), labels given at push time).  Connected
 //     components of the mask never interact, and inside a component the order of pops only depends on the component's own entries, so
-//     every component is flooded by ONE thread with its own binary heap (value, age, raveled index): hundreds of components run side
-//     by side, the result is the sequential algorithm's, bit for bit.
+//     every component is flooded on its own, hundreds side by side, with the sequential algorithm's result bit for bit: a component with ONE
+//     marker is filled with its label; one with several gets a wave whose queue, smoothed EDT and label state live in LDS (its bounding box:
+//     ws_flood_box_kernel), or -- too large for that -- a wave with the state in global memory (ws_flood_wave_kernel) or a thread with a binary
+//     heap (ws_flood_kernel, clumps beyond 8192 voxels).  Seeds of EXACTLY equal height inside one component leave upstream's heap in an
+//     order that depends on the whole image: the groups (z slice / volume) that hold such a pair are replayed sequentially with upstream's
+//     own heap (ws_flood_upstream_kernel).  Nothing is copied to the host on the way: lists and flags stay on the device.
 // All volume arrays are [x][y][z] like the probability map; threads run over z fastest so that every 1-D pass along x or y is a
 // coalesced sweep.
 // ================================================================================================
