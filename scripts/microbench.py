@@ -55,8 +55,20 @@ def norm_pair(n, seed=100, box=(512, 512, 32)):
 def cmd_unet(args):
     synth, unet3d, arch = mod("synth"), mod("unet3d"), mod("arch").UNET3_A
     shape = tuple(int(v) for v in args[:3]) if len(args) >= 3 else (512, 512, 32)
-    model = unet3d.unet3_a().set_weights_dict(synth.make_unet_weights("unet3_a", 0))
+    # --passthrough: the chained frame's weights (synth.make_passthrough_unet_weights) instead of the Glorot ones; --gaps: one volume at a
+    # time with an idle pause in between (what a dependent frame's U-Net sees: the chip's clocks after a low-power phase)
+    w = synth.make_passthrough_unet_weights("unet3_a", 0) if "--passthrough" in args else synth.make_unet_weights("unet3_a", 0)
+    model = unet3d.unet3_a().set_weights_dict(w)
     vol = torch.randn(*shape, device="cuda"); out = torch.zeros_like(vol)
+    if "--gaps" in args:
+        import time
+        ts = []
+        for _ in range(12):
+            torch.cuda.synchronize(); time.sleep(0.004)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); model.predict_volume_device(vol, out=out); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        print(f"one volume at a time after a 4-ms idle pause: {np.median(ts[2:]):.2f} ms/vol (min {min(ts[2:]):.2f}, max {max(ts[2:]):.2f})")
     dt, _ = timeit(lambda: model.predict_volume_device(vol, out=out))
     _, grid = unet3d.tile_plan(shape, arch.input_shape, (24, 24, 2))
     npatch = grid[0] * grid[1] * grid[2]
