@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/ctamd.h"
 
@@ -38,9 +39,17 @@ struct SelState { uint32_t prefix, mask; unsigned long long rank; };
 // Both order statistics of np.median ((n-1)/2 and n/2) are selected in the same passes: st[0] / st[1] share one histogram
 // while their prefixes agree (almost always -- they are neighbours in sorted order) and get separate ones once they differ.
 // hist: [2][256].  A wave whose 64 keys fall into one bin (background voxels in the high-byte pass) adds once.
+#ifndef CT_RADIX_PEEL
+#define CT_RADIX_PEEL 0
+#endif
+#ifndef CT_RADIX_BATCH
+#define CT_RADIX_BATCH 4
+#endif
 __global__ __launch_bounds__(256) void radix_hist_kernel(const void* __restrict__ data, int dtype, size_t n, int shift,
-                                                         const SelState* __restrict__ st, unsigned int* __restrict__ hist) {
+                                                         const SelState* __restrict__ st, unsigned int* __restrict__ hist, int nrep) {
     __shared__ unsigned int h[2][256];
+    hist += (size_t)(blockIdx.x % nrep) * 512;                 // same-address atomics serialise in L2: 1024 workgroups on one [2][256] table
+                                                              // were a 1024-deep chain per bin (20 us); nrep tables make it 1024 / nrep deep
     h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
     __syncthreads();
     const uint32_t p0 = st[0].prefix, p1 = st[1].prefix, mask = st[0].mask;      // the masks are always equal
@@ -48,6 +57,18 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const void* __restrict_
     auto count = [&](bool live, uint32_t k) {
         const int d = (int)((k >> shift) & 0xFF);
         const bool m0 = live && (k & mask) == p0, m1 = live && !same && (k & mask) == p1;
+#if CT_RADIX_PEEL > 0
+        unsigned long long rem = __ballot(m0);
+#pragma unroll 1
+        for (int it = 0; it < CT_RADIX_PEEL && rem; ++it) {
+            const int lead = __ffsll((long long)rem) - 1;
+            const int dl = __shfl(d, lead);
+            const unsigned long long grp = __ballot(m0 && d == dl) & rem;
+            if ((int)(threadIdx.x & 63) == lead) atomicAdd(&h[0][dl], (unsigned)__popcll(grp));
+            rem &= ~grp;
+        }
+        if ((rem >> (threadIdx.x & 63)) & 1) atomicAdd(&h[0][d], 1u);
+#else
         const unsigned long long b0 = __ballot(m0);
         if (b0) {
             const int lead = __ffsll((long long)b0) - 1;
@@ -55,21 +76,29 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const void* __restrict_
             if (__ballot(m0 && d == dl) == b0) { if ((int)(threadIdx.x & 63) == lead) atomicAdd(&h[0][dl], (unsigned)__popcll(b0)); }
             else if (m0) atomicAdd(&h[0][d], 1u);
         }
+#endif
         if (m1) atomicAdd(&h[1][d], 1u);
     };
     // 16 bytes per thread and load (8 uint16 or 4 float keys): a 2-byte load per key left the pass at 0.4 TB/s
     const int kpv = dtype == 0 ? 8 : 4;
     const size_t nvec = ((uintptr_t)data & 15) == 0 ? n / kpv : 0;            // (an unaligned view takes the key-by-key loop below)
     const size_t nround = (nvec + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);
-    for (size_t rnd = 0; rnd < nround; ++rnd) {
-        const size_t v = (rnd * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        const bool live = v < nvec;
-        uint4 q = live ? reinterpret_cast<const uint4*>(data)[v] : uint4{0u, 0u, 0u, 0u};
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    for (size_t rnd = 0; rnd < nround; rnd += CT_RADIX_BATCH) {  // CT_RADIX_BATCH independent loads in flight per thread
+        uint4 q[CT_RADIX_BATCH]; bool live[CT_RADIX_BATCH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (dtype == 0) { count(live, w[e] & 0xFFFFu); count(live, w[e] >> 16); }
-            else count(live, w[e] ^ ((w[e] >> 31) ? 0xFFFFFFFFu : 0x80000000u));
+        for (int b = 0; b < CT_RADIX_BATCH; ++b) {
+            const size_t v = ((rnd + b) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+            live[b] = rnd + b < nround && v < nvec;
+            q[b] = live[b] ? reinterpret_cast<const uint4*>(data)[v] : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int b = 0; b < CT_RADIX_BATCH; ++b) {
+            const uint32_t w[4] = {q[b].x, q[b].y, q[b].z, q[b].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (dtype == 0) { count(live[b], w[e] & 0xFFFFu); count(live[b], w[e] >> 16); }
+                else count(live[b], w[e] ^ ((w[e] >> 31) ? 0xFFFFFFFFu : 0x80000000u));
+            }
         }
     }
     {                                                         // the keys behind the last full vector
@@ -85,21 +114,35 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const void* __restrict_
     if (h[1][threadIdx.x]) atomicAdd(&hist[256 + threadIdx.x], h[1][threadIdx.x]);
 }
 
-__global__ void radix_pick_kernel(unsigned int* __restrict__ hist, int shift, SelState* __restrict__ st) {
-    if (threadIdx.x == 0) {
-        const bool same = st[0].prefix == st[1].prefix;
-        for (int q = 0; q < 2; ++q) {
-            const unsigned int* hq = hist + ((q == 1 && !same) ? 256 : 0);
-            unsigned long long r = st[q].rank, acc = 0; int d = 0;
-            for (; d < 256; ++d) { if (acc + hq[d] > r) break; acc += hq[d]; }
-            if (d > 255) d = 255;
-            st[q].rank = r - acc;
-            st[q].prefix |= ((uint32_t)d << shift);
-            st[q].mask |= (0xFFu << shift);
-        }
+__global__ void radix_pick_kernel(unsigned int* __restrict__ hist, int nrep, int shift, SelState* __restrict__ st) {
+    __shared__ unsigned int h[512];
+    for (int b = threadIdx.x; b < 512; b += blockDim.x) {
+        unsigned int c = 0;
+        for (int r = 0; r < nrep; ++r) { c += hist[r * 512 + b]; hist[r * 512 + b] = 0; }      // summed, and ready for the next pass
+        h[b] = c;
     }
     __syncthreads();
-    hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;          // ready for the next pass (blockDim = 256)
+    if (threadIdx.x < 64) {                                   // one wave: lane l owns bins 4 l .. 4 l + 3 (a serial walk of 256 LDS words took 10 us)
+        const int lane = threadIdx.x;
+        const bool same = st[0].prefix == st[1].prefix;
+        for (int q = 0; q < 2; ++q) {
+            const unsigned int* hq = h + ((q == 1 && !same) ? 256 : 0);
+            unsigned long long c[4], tot = 0;
+            for (int k = 0; k < 4; ++k) { c[k] = hq[4 * lane + k]; tot += c[k]; }
+            unsigned long long incl = tot;
+            for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            const unsigned long long r = st[q].rank, excl = incl - tot;
+            const unsigned long long owner = __ballot(r >= excl && r < incl);
+            if (owner ? lane == __ffsll((long long)owner) - 1 : lane == 63) {
+                unsigned long long acc = excl; int k = 0;
+                for (; k < 4; ++k) { if (acc + c[k] > r) break; acc += c[k]; }
+                const int d = k < 4 ? 4 * lane + k : 255;     // (a rank beyond the total cannot occur: the last bin, as the serial walk did)
+                st[q].rank = r - acc;
+                st[q].prefix |= ((uint32_t)d << shift);
+                st[q].mask |= (0xFFu << shift);
+            }
+        }
+    }
 }
 
 __global__ void median_finish_kernel(const SelState* __restrict__ lo, const SelState* __restrict__ hi, int dtype,
@@ -191,10 +234,58 @@ __global__ __launch_bounds__(256) void box1d_run_kernel(const float* __restrict_
     }
 }
 
+// Plane form of the same walk: a workgroup first copies one whole plane of lines (every position along `axis` x ZT consecutive z, for one
+// value of the other axis) into LDS -- each input element is fetched from memory exactly once, by loads that are all independent of one
+// another -- and then the threads walk BOX_SEG-long segments of the lines out of LDS.  box1d_run_kernel fetched 2.8 values per output
+// through the caches with two waves per SIMD and sat at 2 TB/s of effective traffic; keeping the window in registers instead made 1.4
+// fetches per output and 6 % of the time, i.e. the passes wait on the latency of dependent global loads, not on bytes.  The sums are the
+// ones box1d_run_kernel forms (same segments, same order, double accumulator), so the result is bit-identical to it.
+constexpr int BOX_PLANE_THREADS = 512, BOX_PLANE_WORDS = 16384;                 // 64 KB of LDS: two planes per CU
+template <int SRC, int EPI>
+__global__ __launch_bounds__(BOX_PLANE_THREADS) void box1d_plane_kernel(const float* __restrict__ in, float* __restrict__ out, int X, int Y,
+                                                                        int Z, int axis, int half, int mode, int ZT, LcnIO io) {
+    extern __shared__ float plane[];                          // [len][ZT]
+    const int len = axis == 0 ? X : Y;
+    const int nzc = (Z + ZT - 1) / ZT;
+    const int other = (int)(blockIdx.x / nzc), z0 = (int)(blockIdx.x % nzc) * ZT;
+    const int zt = min(ZT, Z - z0);
+    const size_t stride = axis == 0 ? (size_t)Y * Z : (size_t)Z;
+    const size_t base = (axis == 0 ? (size_t)other * Z : (size_t)other * Y * Z) + z0;
+    for (int e = threadIdx.x; e < len * ZT; e += BOX_PLANE_THREADS) {
+        const int p = e / ZT, z = e - p * ZT;
+        plane[e] = z < zt ? box_src<SRC>(in, io, base + (size_t)p * stride + z) : 0.f;
+    }
+    __syncthreads();
+    const int z = threadIdx.x % ZT, seg = threadIdx.x / ZT;
+    const int nseg_blk = BOX_PLANE_THREADS / ZT;
+    if (z >= zt || seg >= nseg_blk) return;
+    auto tap = [&](int q) { q = box_fold(q, len, mode); return q < 0 ? 0.f : plane[q * ZT + z]; };
+    for (int p0 = seg * BOX_SEG; p0 < len; p0 += nseg_blk * BOX_SEG) {
+        const int p1 = min(p0 + BOX_SEG, len);
+        double acc = 0.0;
+        for (int d = -half; d <= half; ++d) acc += (double)tap(p0 + d);
+        box_emit<EPI>(out, io, base + (size_t)p0 * stride + z, acc);
+        for (int p = p0 + 1; p < p1; ++p) {
+            acc += (double)tap(p + half) - (double)tap(p - 1 - half);
+            box_emit<EPI>(out, io, base + (size_t)p * stride + z, acc);
+        }
+    }
+}
+
 template <int SRC, int EPI>
 int launch_box_pass(bool run, const float* in, float* out, const int dims[3], int ax, int half, int mode, const LcnIO& io, hipStream_t s) {
     const size_t n = (size_t)dims[0] * dims[1] * dims[2];
-    if (run) {
+    static const bool plane_on = !(getenv("CT_LCN_PLANE") && atoi(getenv("CT_LCN_PLANE")) == 0);
+    int zt = dims[ax] <= BOX_PLANE_WORDS ? BOX_PLANE_WORDS / dims[ax] : 0;
+    if (zt > dims[2]) zt = dims[2];
+    static const int zt_cap = getenv("CT_LCN_ZT") ? atoi(getenv("CT_LCN_ZT")) : 16;   // 16 z per plane: 32 KB of LDS for 512-long lines, so four
+    if (zt > zt_cap) zt = zt_cap;                            // planes per CU are in different phases (load / walk + store): 0.206 ms per frame against
+                                                             // 0.220 with 32 (all workgroups load, then all store) and 0.267 with 8 (32-byte rows)
+    if (run && plane_on && (zt >= 8 || zt == dims[2])) {     // a plane of lines fits in LDS
+        const unsigned nblk = (unsigned)(dims[ax == 0 ? 1 : 0] * ((dims[2] + zt - 1) / zt));
+        hipLaunchKernelGGL((box1d_plane_kernel<SRC, EPI>), dim3(nblk), dim3(BOX_PLANE_THREADS), (size_t)dims[ax] * zt * sizeof(float), s, in,
+                           out, dims[0], dims[1], dims[2], ax, half, mode, zt, io);
+    } else if (run) {
         const size_t nthreads = (n / dims[ax]) * (size_t)((dims[ax] + BOX_SEG - 1) / BOX_SEG);
         hipLaunchKernelGGL((box1d_run_kernel<SRC, EPI>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, in, out, dims[0], dims[1],
                            dims[2], ax, half, mode, io);
@@ -215,16 +306,21 @@ int box_pass(int src, int epi, bool run, const float* in, float* out, const int 
     }
 }
 
+#ifndef CT_MEDIAN_TABLES
+#define CT_MEDIAN_TABLES 16
+#endif
+constexpr int MEDIAN_TABLES = CT_MEDIAN_TABLES;
+constexpr size_t MEDIAN_WS = 256 + MEDIAN_TABLES * 2048 + 256 + 64;   // what ct_median uses at most (+ the median itself behind it)
 int select_two_ranks(const void* data, int dtype, size_t n, unsigned long long rank_lo, unsigned long long rank_hi, SelState* st,
-                     unsigned int* hist, hipStream_t s) {
+                     unsigned int* hist, int nrep, hipStream_t s) {
     SelState init[2] = {{0u, 0u, rank_lo}, {0u, 0u, rank_hi}};
     HIPCHK(hipMemcpyAsync(st, init, sizeof(init), hipMemcpyHostToDevice, s));
     const int top = dtype == 0 ? 8 : 24;
     const unsigned nblk = (unsigned)((n + 256 * 32 - 1) / (256 * 32) < 2048 ? (n + 256 * 32 - 1) / (256 * 32) : 2048);
     for (int shift = top; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk ? nblk : 1), dim3(256), 0, s, data, dtype, n, shift, st, hist);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk ? nblk : 1), dim3(256), 0, s, data, dtype, n, shift, st, hist, nrep);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, s, hist, shift, st);
+        hipLaunchKernelGGL(radix_pick_kernel, dim3(1), dim3(256), 0, s, hist, nrep, shift, st);
         LAUNCH_CHECK();
     }
     return CT_OK;
@@ -237,7 +333,7 @@ extern "C" {
 size_t ct_normalize_workspace_bytes(const int dims[3]) {
     if (!dims || dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0) return 0;
     const size_t n = (size_t)dims[0] * dims[1] * dims[2];
-    return 4 * align_up(n * sizeof(float), 256) + 4096 + 512;
+    return 4 * align_up(n * sizeof(float), 256) + MEDIAN_WS + 512;
 }
 
 int ct_median(const void* data, int dtype, size_t n, double* median_out, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
@@ -245,11 +341,14 @@ int ct_median(const void* data, int dtype, size_t n, double* median_out, void* w
     if (workspace_bytes < 4096) return CT_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    unsigned int* hist = (unsigned int*)ws;                       // 2 x 256 bins
-    SelState* st = (SelState*)(ws + 2048);                         // [2]: ranks (n-1)/2 and n/2
-    HIPCHK(hipMemsetAsync(hist, 0, 2048, s));
+    const size_t usable = workspace_bytes - (size_t)(ws - (unsigned char*)workspace);
+    SelState* st = (SelState*)ws;                                  // [2]: ranks (n-1)/2 and n/2
+    unsigned int* hist = (unsigned int*)(ws + 256);                // nrep x [2][256] bins: as many tables as the workspace holds, up to 16
+    int nrep = (int)((usable - 256) / 2048);
+    nrep = nrep < 1 ? 1 : (nrep > MEDIAN_TABLES ? MEDIAN_TABLES : nrep);
+    HIPCHK(hipMemsetAsync(hist, 0, (size_t)nrep * 2048, s));
     int rc;
-    if ((rc = select_two_ranks(data, dtype, n, (unsigned long long)((n - 1) / 2), (unsigned long long)(n / 2), st, hist, s))) return rc;
+    if ((rc = select_two_ranks(data, dtype, n, (unsigned long long)((n - 1) / 2), (unsigned long long)(n / 2), st, hist, nrep, s))) return rc;
     hipLaunchKernelGGL(median_finish_kernel, dim3(1), dim3(1), 0, s, st, st + 1, dtype, median_out);
     LAUNCH_CHECK();
     return CT_OK;
@@ -266,9 +365,9 @@ int ct_normalize_image(const void* img, int dtype, const int dims[3], double noi
     const size_t slab = align_up(n * sizeof(float), 256);
     float* A = (float*)(ws + slab); float* T1 = (float*)(ws + 2 * slab); float* T2 = (float*)(ws + 3 * slab);   // (slab 0: spare)
     unsigned char* tail = ws + 4 * slab;
-    double* median = (double*)(tail + 3072);
+    double* median = (double*)(tail + MEDIAN_WS - 64);
     if (subtract_median) {
-        int rc = ct_median(img, dtype, n, median, tail, 4096, stream);
+        int rc = ct_median(img, dtype, n, median, tail, MEDIAN_WS - 64, stream);
         if (rc) return rc;
     }
     LcnIO io{img, dtype, subtract_median ? median : (const double*)nullptr, A, 1.0f / (float)(filter[0] * filter[1] * filter[2]), (float)noise_level};

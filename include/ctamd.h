@@ -281,6 +281,7 @@ int ct_trim_mean(const double* stack, int k, int n3, double cut, double* out, ct
  * ------------------------------------------------------------------------------------------
  * dtype: 0 = uint16, 1 = float32.  img/data [dev], [x][y][z].
  * ct_median: np.median (mean of the two middle order statistics) by radix select; median_out [dev] fp64.
+ *   workspace [dev]: at least 4096 bytes; up to 33.5 KB are used (16 histogram tables, which shortens the atomic chains).
  * ct_normalize_image: subtract_median = 1 -> _normalize_image (:170-188: x = max(img - median, 0), then LCN);
  *   mode 0 = zero padding (lcn_gpu :136-167, the Keras ones-kernel Conv3D), mode 1 = scipy 'reflect' (lcn_cpu :85-114);
  *   filter: odd window sizes (reference default 27, 27, 1); out [dev] fp32 [x][y][z].                       */

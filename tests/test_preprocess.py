@@ -114,3 +114,36 @@ def test_device_lcn_filter_shapes_against_oracle(fs):
         got = pre.normalize_image_device(torch.from_numpy(raw).cuda(), 7.0, filter_size=fs).cpu().numpy()
         x = np.maximum(raw.astype(np.float64) - np.median(raw), 0.0)
         np.testing.assert_allclose(got, pr.lcn(x, 7.0, fs, "constant"), rtol=0, atol=3e-4)
+
+
+@pytest.mark.gpu
+def test_device_lcn_plane_pass_is_bit_identical_to_the_line_walk():
+    """The LDS-plane box pass (default) forms exactly the sums of the per-thread line walk it replaced (CT_LCN_PLANE=0, read once per
+    process: the line walk runs in its own interpreter): same bits on an odd-sized stack (partial z chunk, ragged last segment), on a
+    stack whose planes need several z chunks, and on the 512-long lines of the headline frame -- both border modes."""
+    import os
+    import subprocess
+    import sys
+    import hashlib
+    from pathlib import Path
+    code = """
+import sys, importlib, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+pre = importlib.import_module("3deecelltracker_amd.preprocess")
+rng = np.random.default_rng(5)
+h = hashlib.sha256()
+for shape in ((70, 45, 9), (300, 200, 70), (512, 512, 4)):
+    raw = rng.integers(90, 4000, shape).astype(np.uint16)
+    h.update(pre.normalize_image_device(torch.from_numpy(raw).cuda(), 50.0).cpu().numpy().tobytes())
+    img = raw.astype(np.float32)
+    h.update(np.ascontiguousarray(pre.lcn_gpu(img, noise_level=5.0, filter_size=(27, 27, 1))).tobytes())
+    h.update(np.ascontiguousarray(pre.lcn_cpu(img, noise_level=5.0, filter_size=(9, 27, 3))).tobytes())
+print("digest", h.hexdigest())
+"""
+    repo = str(Path(__file__).resolve().parents[1])
+    outs = []
+    for env in ({}, {"CT_LCN_PLANE": "0"}):
+        r = subprocess.run([sys.executable, "-c", code, repo], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "digest" in r.stdout, r.stdout[-300:] + r.stderr[-800:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
