@@ -95,7 +95,27 @@ def greedy_match(corr_d, threshold, mode, want_prior=True):
     return pairs, npairs, prior
 
 
-def prgls_two_ref(prior_d, tgt_d, ref_d, tracked_d, beta, lambda_, max_iteration, want_posterior=True, want_ref=False):
+class PreparedRef:
+    """What prgls_two_ref needs of the reference set alone (ct_prgls_prepare_ref): made ahead of the match, e.g. on a second stream while
+    the next volume's U-Net runs.  `event` marks its completion on the stream it was enqueued on."""
+
+    def __init__(self, ref_d, beta, buf, event):
+        self.ref_d, self.beta, self.buf, self.event = ref_d, float(beta), buf, event
+
+
+def prgls_prepare_ref(ref_d, beta):
+    """Enqueue (asynchronously, on the current stream) the Gram matrix of ref_d fp64 [n][3] and its low-rank factor -> PreparedRef."""
+    t = torch(); L = _lib.lib()
+    n = int(ref_d.shape[0])
+    if n > PRGLS_MAX_POINTS:
+        raise ValueError(f"PR-GLS: {n} reference points exceed the dense M-step limit of {PRGLS_MAX_POINTS}")
+    buf = workspace(L.ct_prgls_prepared_bytes(n), ref_d.device)
+    _lib.check(L.ct_prgls_prepare_ref(ref_d.data_ptr(), n, float(beta), buf.data_ptr(), buf.numel(), stream(ref_d.device)), "ct_prgls_prepare_ref")
+    ev = t.cuda.Event(); ev.record()
+    return PreparedRef(ref_d, beta, buf, ev)
+
+
+def prgls_two_ref(prior_d, tgt_d, ref_d, tracked_d, beta, lambda_, max_iteration, want_posterior=True, want_ref=False, prepared=None):
     t = torch(); L = _lib.lib()
     m, n = prior_d.shape
     if n > PRGLS_MAX_POINTS:
@@ -107,11 +127,19 @@ def prgls_two_ref(prior_d, tgt_d, ref_d, tracked_d, beta, lambda_, max_iteration
     post = empty((m, n), t.float64, dev) if want_posterior else None
     ws = workspace(L.ct_prgls_workspace_bytes(m, n, l), dev)
     iters = C.c_int(0)
-    _lib.check(L.ct_prgls_two_ref(prior_d.data_ptr(), tgt_d.data_ptr(), m, ref_d.data_ptr(), n,
-                                  tracked_d.data_ptr() if l else None, l, float(beta), float(lambda_), int(max_iteration),
-                                  out_l.data_ptr() if l else None, out_n.data_ptr() if want_ref else None,
-                                  post.data_ptr() if want_posterior else None, C.byref(iters), ws.data_ptr(), ws.numel(),
-                                  stream(dev)), "ct_prgls_two_ref")
+    args = (prior_d.data_ptr(), tgt_d.data_ptr(), m, ref_d.data_ptr(), n,
+            tracked_d.data_ptr() if l else None, l, float(beta), float(lambda_), int(max_iteration),
+            out_l.data_ptr() if l else None, out_n.data_ptr() if want_ref else None,
+            post.data_ptr() if want_posterior else None, C.byref(iters), ws.data_ptr(), ws.numel())
+    if prepared is not None:
+        if prepared.ref_d is not ref_d or prepared.beta != float(beta):
+            raise ValueError("prgls_two_ref: `prepared` was made for another reference set or beta")
+        cur = t.cuda.current_stream(dev)
+        cur.wait_event(prepared.event)                          # (made on another stream)
+        prepared.buf.record_stream(cur); prepared.ref_d.record_stream(cur)
+        _lib.check(L.ct_prgls_two_ref_prepared(*args, prepared.buf.data_ptr(), prepared.buf.numel(), stream(dev)), "ct_prgls_two_ref_prepared")
+    else:
+        _lib.check(L.ct_prgls_two_ref(*args, stream(dev)), "ct_prgls_two_ref")
     return out_l, out_n, post, iters.value
 
 

@@ -61,6 +61,9 @@ SIGNATURES = {
     "ct_greedy_match": (_i, [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ct_prgls_workspace_bytes": (_sz, [_i, _i, _i]),
     "ct_prgls_two_ref": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _ip, _vp, _sz, _vp]),
+    "ct_prgls_prepared_bytes": (_sz, [_i]),
+    "ct_prgls_prepare_ref": (_i, [_vp, _i, _d, _vp, _sz, _vp]),
+    "ct_prgls_two_ref_prepared": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _ip, _vp, _sz, _vp, _sz, _vp]),
     "ct_prgls_batched_workspace_bytes": (_sz, [_i, _ip, _ip, _ip]),
     "ct_prgls_two_ref_batched": (_i, [_i, _vp, _vp, _ip, _vp, _ip, _vp, _ip, _d, _d, _i, _vp, _vp, _vp, _ip, _vp, _sz, _vp]),
     "ct_prgls_legacy": (_i, [_vp, _i, _vp, _i, _vp, _d, _i, _d, _d, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -2573,18 +2573,40 @@ size_t ct_prgls_workspace_bytes(int m, int n, int l) {
            + align_up((size_t)n * 8 + 4, 256) + ct_greedy_workspace_bytes(m, n) + 1024;
 }
 
-int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double* ref, int n, const double* tracked, int l,
-                     double beta, double lambda, int max_iteration, double* out_tracked, double* out_ref, double* posterior,
-                     int* iters, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+// What ct_prgls_two_ref needs of the reference set alone: Gram matrix, its pivoted-Cholesky factor, the two ranks (ct_prgls_prepare_ref)
+namespace {
+constexpr unsigned long long PREP_MAGIC = 0x3153474c52505443ull;      // "CTPRGLS1"
+struct PreparedHdr { unsigned long long magic; int n; int pad; double beta; int rank[2]; };
+struct PreparedRef { PreparedHdr* hdr; double* G; double* U; double* resid; };
+size_t prepared_layout(int n, unsigned char* base, PreparedRef* p) {
+    size_t off = 256;
+    auto take = [&](size_t count) { double* q = base ? (double*)(base + off) : nullptr; off += align_up(count * sizeof(double), 256); return q; };
+    PreparedRef t{};
+    t.hdr = (PreparedHdr*)base; t.G = take((size_t)n * n); t.U = take((size_t)LR_RMAX * n); t.resid = take(n);
+    if (p) *p = t;
+    return off;
+}
+
+int prgls_two_ref_impl(const double* prior, const double* tgt, int m, const double* ref, int n, const double* tracked, int l,
+                       double beta, double lambda, int max_iteration, double* out_tracked, double* out_ref, double* posterior,
+                       int* iters, void* workspace, size_t workspace_bytes, const void* prepared, size_t prepared_bytes, ct_stream_t stream) {
     if (!prior || !tgt || !ref || !workspace || m <= 0 || n <= 0 || l < 0 || (l > 0 && (!tracked || !out_tracked))) return CT_EINVAL;
     if (workspace_bytes < ct_prgls_workspace_bytes(m, n, l)) return CT_EWORKSPACE;
+    if (prepared && (((uintptr_t)prepared & 255) || prepared_bytes < prepared_layout(n, nullptr, nullptr))) return CT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     PrglsWs w;
     prgls_layout(m, n, l, (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), &w);
+    PreparedRef prep{};
     const size_t nn = (size_t)n * n;
     // init (trackerlite.py:319-325): gamma 0.05, Gram matrices with beta^2, sigma2 = mean d2 / 3, T(X) = X
-    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ref, n, ref, n, 2.0 * beta * beta, w.G, 0);
-    LAUNCH_CHECK();
+    if (prepared) {                                           // the kernels below only read G, U: they may live in the caller's buffer
+        prepared_layout(n, (unsigned char*)prepared, &prep);
+        w.G = prep.G; w.U = prep.U;
+        HIPCHK(hipMemcpyAsync(w.rank, prep.hdr->rank, 2 * sizeof(int), hipMemcpyDeviceToDevice, st));     // (the residual monitor raises ITS copy)
+    } else {
+        hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ref, n, ref, n, 2.0 * beta * beta, w.G, 0);
+        LAUNCH_CHECK();
+    }
     if (l > 0) {   // tracked-set kernel stored transposed [l][n] so that the field application reads rows
         const size_t nl = (size_t)n * l;
         hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, ref, n, tracked, l, 2.0 * beta * beta, w.Gln, 0);
@@ -2602,7 +2624,14 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
     // `rank` sizes the launches (grids, LDS) for the finest rank; the kernels read the rank in force from w.rank[0], which
     // starts at the coarse rank and is raised on the device by the residual monitor (scalars_kernel)
     int rank = 0, rank_coarse = 0, rc;
-    if ((rc = lowrank_prepare(w, n, st, &rank_coarse, &rank))) return rc;
+    if (prepared) {                                           // the ranks (and the tag that says whose they are) come from the prepared header
+        PreparedHdr h{};
+        HIPCHK(hipMemcpyAsync(&h, prep.hdr, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h.magic != PREP_MAGIC || h.n != n || h.beta != beta) return CT_EINVAL;     // not what ct_prgls_prepare_ref wrote for this n / beta
+        ENSURE_BIG_LDS(lr_solve_kernel);
+        rank_coarse = h.rank[0]; rank = h.rank[1];
+    } else if ((rc = lowrank_prepare(w, n, st, &rank_coarse, &rank))) return rc;
     if (rank_coarse <= 0 || getenv("CT_PRGLS_DENSE")) rank = 0;
     // EM iterations are enqueued in chunks; every kernel returns immediately once the device-side
     // convergence flag is set, the host looks at the flag once per chunk (trackerlite.py:353-356).
@@ -2687,6 +2716,41 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
     if (out_ref) HIPCHK(hipMemcpyAsync(out_ref, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (posterior) HIPCHK(hipMemcpyAsync(posterior, w.P, (size_t)m * n * sizeof(double), hipMemcpyDeviceToDevice, st));
     return CT_OK;
+}
+}  // namespace
+
+int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double* ref, int n, const double* tracked, int l,
+                     double beta, double lambda, int max_iteration, double* out_tracked, double* out_ref, double* posterior,
+                     int* iters, void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    return prgls_two_ref_impl(prior, tgt, m, ref, n, tracked, l, beta, lambda, max_iteration, out_tracked, out_ref, posterior, iters, workspace,
+                              workspace_bytes, nullptr, 0, stream);
+}
+
+size_t ct_prgls_prepared_bytes(int n) { return n > 0 ? prepared_layout(n, nullptr, nullptr) : 0; }
+
+int ct_prgls_prepare_ref(const double* ref, int n, double beta, void* prepared, size_t prepared_bytes, ct_stream_t stream) {
+    if (!ref || !prepared || n <= 0 || ((uintptr_t)prepared & 255)) return CT_EINVAL;
+    if (prepared_bytes < prepared_layout(n, nullptr, nullptr)) return CT_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    PreparedRef p;
+    prepared_layout(n, (unsigned char*)prepared, &p);
+    const PreparedHdr h{PREP_MAGIC, n, 0, beta, {0, 0}};
+    HIPCHK(hipMemcpyAsync(p.hdr, &h, sizeof(h), hipMemcpyHostToDevice, st));      // (pageable source: staged before the call returns)
+    const size_t nn = (size_t)n * n;
+    hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ref, n, ref, n, 2.0 * beta * beta, p.G, 0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1), dim3(1024), 0, st, p.G, n, kLowRankTol, kLowRankTolTight, p.U, p.resid, p.hdr->rank);
+    LAUNCH_CHECK();
+    return CT_OK;
+}
+
+int ct_prgls_two_ref_prepared(const double* prior, const double* tgt, int m, const double* ref, int n, const double* tracked, int l,
+                              double beta, double lambda, int max_iteration, double* out_tracked, double* out_ref, double* posterior,
+                              int* iters, void* workspace, size_t workspace_bytes, const void* prepared, size_t prepared_bytes,
+                              ct_stream_t stream) {
+    if (!prepared) return CT_EINVAL;
+    return prgls_two_ref_impl(prior, tgt, m, ref, n, tracked, l, beta, lambda, max_iteration, out_tracked, out_ref, posterior, iters, workspace,
+                              workspace_bytes, prepared, prepared_bytes, stream);
 }
 
 size_t ct_prgls_batched_workspace_bytes(int B, const int* m, const int* n, const int* l) {

@@ -26,10 +26,13 @@ from .trackerlite import match_device
 
 class FrameChain:
     def __init__(self, unet_model, ffn_model, transformer: CoordsToImageTransformer, noise_level: float, shrink=(24, 24, 2),
-                 min_size: int = 20, beta: float = 3.0, lambda_: float = 3.0, ensemble: bool = True, region_method: str = "watershed"):
+                 min_size: int = 20, beta: float = 3.0, lambda_: float = 3.0, ensemble: bool = True, region_method: str = "watershed",
+                 prefetch_ref: bool = True):
         if region_method not in ("watershed", "cc"):
             raise ValueError(f"unknown region_method {region_method!r}: use 'watershed' or 'cc'")
         self.region_method = region_method
+        self.prefetch_ref = bool(prefetch_ref)
+        self._side = None
         self.unet_model = unet_model
         self.ffn_model = ffn_model
         self.transformer = transformer
@@ -44,21 +47,30 @@ class FrameChain:
         self.seg_real_t1 = None
         self.confirmed_real_t1 = None
 
-    def segment(self, raw_d):
-        """raw stack -> (prob fp32 [x,y,z], centres fp64 [n,3] voxel units), both on the device."""
+    def probability_map(self, raw_d):
+        """raw stack -> prob fp32 [x,y,z] on the device (LCN + U-Net; asynchronous)."""
         norm = normalize_image_device(raw_d, self.noise_level, (27, 27, 1), mode=0, subtract_median=True)
         self._mark("lcn")
         if self._prob is None or self._prob.shape != norm.shape:
             self._prob = _dev.torch().empty_like(norm)
         prob = self.unet_model.predict_volume_device(norm, self.shrink, out=self._prob)
         self._mark("unet")
+        return prob
+
+    def regions(self, prob):
+        """prob map -> centres fp64 [n,3] (voxel units) on the device."""
         if self.region_method == "watershed":                   # Tracker._segment's default (tracker.py:636-648): z_xy_ratio = voxel z / voxel x
             vs = self.transformer.voxel_size
             _, centres, _, _, _ = watershed_centroids_device(prob, float(vs[2]) / float(vs[0]), "min_size", self.min_size, 0, want_labels=False)
         else:
             _, centres, _ = segment_centroids_device(prob, 0.5, 1, self.min_size, want_labels=False)
         self._mark("regions")
-        return prob, centres
+        return centres
+
+    def segment(self, raw_d):
+        """raw stack -> (prob fp32 [x,y,z], centres fp64 [n,3] voxel units), both on the device."""
+        prob = self.probability_map(raw_d)
+        return prob, self.regions(prob)
 
     def run(self, raw_d=None, seg_real_t1=None, confirmed_real_t1=None):
         """One frame: segment `raw_d` (t2), match it against frame t1's segmentation, move t1's confirmed cells, correct them on
@@ -69,15 +81,38 @@ class FrameChain:
         seg_real_t1 = self.seg_real_t1 if seg_real_t1 is None else seg_real_t1
         confirmed_real_t1 = self.confirmed_real_t1 if confirmed_real_t1 is None else confirmed_real_t1
         self._mark(None)
-        prob, centres = self.segment(raw_d)
+        main = t.cuda.current_stream()
+        conf_d = _dev.points_dev(confirmed_real_t1, raw_d.device)
+        s1_d = _dev.points_dev(seg_real_t1, raw_d.device)
+        if self.prefetch_ref:
+            if self._side is None:
+                self._side = t.cuda.Stream(device=raw_d.device)
+                self._inputs_ready = t.cuda.Event()
+            self._inputs_ready.record(main)                      # (the side stream must not wait for the U-Net: only for the two point sets)
+        prob = self.probability_map(raw_d)
+        # what the match needs of frame t1 alone (normalisation, the Gram matrix of its segmentation and that matrix's low-rank factor) is
+        # enqueued on a second stream -- after the U-Net's launches, so that the host's enqueue time is hidden too -- and runs beside the
+        # U-Net: ~0.35 ms of mostly single-workgroup work leave the frame's dependent chain
+        if self.prefetch_ref:
+            self._side.wait_event(self._inputs_ready)
+            with t.cuda.stream(self._side):
+                conf_n, para = _dev.normalize_points(conf_d)
+                s1, _ = _dev.normalize_points(s1_d, apply_para=para)
+                prepared = _dev.prgls_prepare_ref(s1, self.beta)
+        centres = self.regions(prob)
         vs = t.as_tensor(np.asarray(self.transformer.voxel_size, dtype=np.float64), device=centres.device)
         seg_real_t2 = centres * vs
-        conf_d = _dev.points_dev(confirmed_real_t1, centres.device)
-        conf_n, para = _dev.normalize_points(conf_d)
+        if self.prefetch_ref:
+            main.wait_stream(self._side)
+            for x in (conf_d, s1_d, conf_n, para, s1):
+                x.record_stream(main)
+        else:
+            conf_n, para = _dev.normalize_points(conf_d)
+            s1, _ = _dev.normalize_points(s1_d, apply_para=para)
+            prepared = None
         s2, _ = _dev.normalize_points(seg_real_t2, apply_para=para)
-        s1, _ = _dev.normalize_points(_dev.points_dev(seg_real_t1, centres.device), apply_para=para)
         _dev.check_match_sizes(s1.shape[0], s2.shape[0], 20, "FrameChain")
-        tracked_n, iters = match_device(self.ffn_model, s1, s2, conf_n, self.beta, self.lambda_)
+        tracked_n, iters = match_device(self.ffn_model, s1, s2, conf_n, self.beta, self.lambda_, prepared=prepared)
         tracked = _dev.denormalize_points(tracked_n, para)
         self._mark("match")
         coords = Coordinates(tracked.cpu().numpy(), self.transformer.interpolation_factor, self.transformer.voxel_size, dtype="real")
@@ -111,7 +146,8 @@ class FrameChain:
 
     # ---- synthetic sequence
     @classmethod
-    def synthetic(cls, shape=(512, 512, 32), n_cells=600, seed=0, ffn_weights=None, device=None, factor=5, region_method="watershed"):
+    def synthetic(cls, shape=(512, 512, 32), n_cells=600, seed=0, ffn_weights=None, device=None, factor=5, region_method="watershed",
+                  prefetch_ref=True):
         """Two consecutive synthetic frames: blobs at c1 (frame t1) and at c1 + smooth motion (frame t2)."""
         from pathlib import Path
         from . import synth, unet3d
@@ -140,7 +176,7 @@ class FrameChain:
             trained = Path(__file__).resolve().parent.parent / "tests" / "golden" / "ffn_synthetic_trained.npz"
             ffn_weights = synth.load_ffn_npz(trained) if trained.exists() else synth.make_ffn_weights(0, 6.0, -3.0)
         ffn = FFN(device=device).set_weights_dict(ffn_weights)
-        chain = cls(model, ffn, tr, noise_level=100.0, region_method=region_method)
+        chain = cls(model, ffn, tr, noise_level=100.0, region_method=region_method, prefetch_ref=prefetch_ref)
         dev = "cuda" if device is None else f"cuda:{device}"
         chain.raw_t1 = t.from_numpy(stack1).to(dev)
         chain.raw_t2 = t.from_numpy(stack2).to(dev)

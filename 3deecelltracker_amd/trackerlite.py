@@ -157,13 +157,15 @@ def get_volumes_list(current_vol: int, skip_volumes: List[int], sampling_number:
 
 # --------------------------------------------------------------------------------- device pipeline
 def match_device(ffn_model: FFN, seg_t1_n, seg_t2_m, confirmed_l, beta, lambda_, max_iteration=MAX_ITERATION,
-                 k=K_POINTS, threshold=0.1):
+                 k=K_POINTS, threshold=0.1, prepared=None):
     """All-device TrackerLite step on *normalised* fp64 device points:
-    FFN scores (seg_t1 vs seg_t2) -> greedy prior -> PR-GLS moving `confirmed_l` -> (l,3) device tensor."""
+    FFN scores (seg_t1 vs seg_t2) -> greedy prior -> PR-GLS moving `confirmed_l` -> (l,3) device tensor.
+    `prepared`: _dev.prgls_prepare_ref(seg_t1_n, beta) made ahead of the call (same results, the factorisation of seg_t1's Gram matrix is
+    then not part of this chain)."""
     corr = initial_matching_device(ffn_model, seg_t1_n, seg_t2_m, k)
     _, _, prior = _dev.greedy_match(corr, threshold, 0)
     out_l, _, _, iters = _dev.prgls_two_ref(prior, seg_t2_m, seg_t1_n, confirmed_l, beta, lambda_, max_iteration,
-                                            want_posterior=False)
+                                            want_posterior=False, prepared=prepared)
     return out_l, iters
 
 

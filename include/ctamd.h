@@ -195,6 +195,21 @@ int ct_prgls_two_ref(const double* prior, const double* tgt, int m, const double
                      double* out_tracked, double* out_ref, double* posterior, int* iters,
                      void* workspace, size_t workspace_bytes, ct_stream_t stream);
 
+/* The part of ct_prgls_two_ref that depends on the reference set ALONE, computed ahead of the call: the Gram matrix of `ref` (beta), its
+ * pivoted-Cholesky factor and the two ranks of the low-rank M-step.  In a frame loop `ref` (the previous volume's segmentation,
+ * trackerlite.py:86-93) is known before the current volume's U-Net starts, so ct_prgls_prepare_ref can run on a second stream beside it and
+ * the ~0.3 ms single-workgroup factorisation leaves the frame's dependent chain.  Asynchronous; `prepared` [dev], 256-byte aligned, at least
+ * ct_prgls_prepared_bytes(n) bytes, is written by ct_prgls_prepare_ref and only read by ct_prgls_two_ref_prepared (any number of times; the
+ * caller orders the two streams).  ct_prgls_two_ref_prepared = ct_prgls_two_ref with the same arguments and the same results bit for bit;
+ * CT_EINVAL if `prepared` does not carry what ct_prgls_prepare_ref wrote for this n and beta (the caller vouches for `ref` itself).      */
+size_t ct_prgls_prepared_bytes(int n);
+int ct_prgls_prepare_ref(const double* ref, int n, double beta, void* prepared, size_t prepared_bytes, ct_stream_t stream);
+int ct_prgls_two_ref_prepared(const double* prior, const double* tgt, int m, const double* ref, int n,
+                              const double* tracked, int l, double beta, double lambda, int max_iteration,
+                              double* out_tracked, double* out_ref, double* posterior, int* iters,
+                              void* workspace, size_t workspace_bytes, const void* prepared, size_t prepared_bytes,
+                              ct_stream_t stream);
+
 /* B independent prgls_with_two_ref problems (ragged sizes) in ONE chain of launches: problem b = blockIdx.z of every EM kernel.
  * A match is a chain of ~10 tiny dependent kernels per EM iteration and the GPU retires such kernels at a few hundred
  * thousand per second however many streams issue them, so the matches of independent frames (or of one ensemble prediction,

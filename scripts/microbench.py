@@ -346,7 +346,7 @@ def cmd_hbmwrite(args):
 def cmd_frame(args):
     """The chained per-frame pipeline (frame.FrameChain): raw stack -> LCN -> U-Net -> regions/centres -> match -> correction."""
     synth, frame = mod("synth"), mod("frame")
-    chain = frame.FrameChain.synthetic(shape=(512, 512, 32), n_cells=600, seed=0)
+    chain = frame.FrameChain.synthetic(shape=(512, 512, 32), n_cells=600, seed=0, prefetch_ref="--no-prefetch" not in args)
     chain.run(); chain.enable_timing()
     dt, out = timeit(lambda: chain.run(), reps=5, warm=1)
     print(f"chained frame 512x512x32: {dt*1e3:.2f} ms  ({out['n_segmented']} cells segmented, {out['prgls_iterations']} PR-GLS iterations, "

@@ -145,3 +145,20 @@ def test_chained_frame_runs_the_reference_region_step():
     assert res["watershed"][1] < 2.0 and res["cc"][1] < 2.0
     with pytest.raises(ValueError):
         frame.FrameChain(None, None, None, 100.0, region_method="stardist")
+
+
+@pytest.mark.gpu
+def test_chained_frame_with_the_reference_set_prepared_beside_the_unet_is_unchanged():
+    """FrameChain enqueues what the match needs of frame t1 alone (normalisation, Gram matrix, low-rank factor: ct_prgls_prepare_ref) on a second
+    stream beside the U-Net; the frame's results are those of the serial chain bit for bit."""
+    import importlib
+    import numpy as np
+    frame = importlib.import_module("3deecelltracker_amd.frame")
+    outs = []
+    for prefetch in (True, False):
+        chain = frame.FrameChain.synthetic(shape=(256, 256, 24), n_cells=150, seed=4, prefetch_ref=prefetch)
+        a = chain.run(); b = chain.run()
+        assert np.array_equal(a["coords"].real, b["coords"].real)
+        outs.append(b)
+    assert outs[0]["prgls_iterations"] == outs[1]["prgls_iterations"] and outs[0]["n_segmented"] == outs[1]["n_segmented"]
+    assert np.array_equal(outs[0]["coords"].real, outs[1]["coords"].real)

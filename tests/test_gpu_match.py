@@ -323,6 +323,41 @@ def test_prgls_converging_prior_against_oracle(n):
     assert float(np.abs(got[perm[keep]] - yn[keep]).max()) < 0.02          # the true pairs end up on top of each other
 
 
+@pytest.mark.parametrize("n,rep", ((150, 1), (600, 3)))
+def test_prgls_with_a_prepared_reference_set_is_bit_identical(n, rep):
+    """ct_prgls_prepare_ref (Gram matrix of the reference set + its low-rank factor, made ahead on ANOTHER stream) followed by
+    ct_prgls_two_ref_prepared gives exactly what ct_prgls_two_ref gives (moved sets, posterior, iteration count), also when one prepared
+    buffer serves several matches; a buffer prepared for another beta or size is refused."""
+    import ctypes as C
+    import torch
+    lib_mod = importlib.import_module("3deecelltracker_amd._lib")
+    rng = np.random.default_rng(70 + n)
+    xn = mr.normalize_points(rng.uniform(0, 1, (n, 3)) * np.array([512.0, 512.0, 128.0]))
+    side = torch.cuda.Stream()
+    ref_d = dev.to_dev(xn, torch.float64)
+    with torch.cuda.stream(side):
+        prepared = dev.prgls_prepare_ref(ref_d, 3.0)
+    for r in range(rep):
+        a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.2
+        yn = (xn @ a + (rng.uniform(0, 1, xn.shape) - 0.5) * 0.004)[rng.permutation(n)][: n - 7 * r]
+        corr = rng.uniform(0, 1, (len(yn), n)).astype(np.float32)
+        prior, _ = tl.simple_match(corr)
+        args = (dev.to_dev(prior, torch.float64), dev.to_dev(yn, torch.float64), ref_d, dev.to_dev(xn[: n // 2], torch.float64), 3.0, 3.0, 20)
+        want = dev.prgls_two_ref(*args, want_posterior=True, want_ref=True)
+        got = dev.prgls_two_ref(*args, want_posterior=True, want_ref=True, prepared=prepared)
+        assert got[3] == want[3] and got[3] >= 2
+        for a_, b_ in zip(got[:3], want[:3]):
+            assert torch.equal(a_, b_)
+    with pytest.raises(ValueError):
+        dev.prgls_two_ref(*args, prepared=dev.PreparedRef(ref_d, 2.0, prepared.buf, prepared.event))
+    L = lib_mod.lib()
+    iters = C.c_int(0)
+    ws = dev.workspace(L.ct_prgls_workspace_bytes(len(yn), n, 0), ref_d.device)
+    rc = L.ct_prgls_two_ref_prepared(args[0].data_ptr(), args[1].data_ptr(), len(yn), ref_d.data_ptr(), n, None, 0, 2.0, 3.0, 20, None, None, None,
+                                     C.byref(iters), ws.data_ptr(), ws.numel(), prepared.buf.data_ptr(), prepared.buf.numel(), dev.stream(ref_d.device))
+    assert rc == lib_mod.CT_EINVAL
+
+
 @pytest.mark.parametrize("n", (150, 400))
 def test_end_to_end_with_a_discriminating_ffn(golden_dir, n):
     """Whole match (features -> FFN -> greedy -> PR-GLS) with the small FFN trained on synthetic pairs
