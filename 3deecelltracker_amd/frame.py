@@ -20,7 +20,7 @@ import numpy as np
 from . import _dev
 from .coord_image_transformer import Coordinates, CoordsToImageTransformer
 from .preprocess import normalize_image_device
-from .segment import segment_centroids_device, watershed_centroids_device
+from .segment import segment_centroids_device, watershed_centroids_device, watershed_centroids_enqueue
 from .trackerlite import match_device
 
 
@@ -33,6 +33,7 @@ class FrameChain:
         self.region_method = region_method
         self.prefetch_ref = bool(prefetch_ref)
         self._side = None
+        self._seq = None
         self.unet_model = unet_model
         self.ffn_model = ffn_model
         self.transformer = transformer
@@ -47,15 +48,22 @@ class FrameChain:
         self.seg_real_t1 = None
         self.confirmed_real_t1 = None
 
-    def probability_map(self, raw_d):
+    def probability_map(self, raw_d, out=None):
         """raw stack -> prob fp32 [x,y,z] on the device (LCN + U-Net; asynchronous)."""
         norm = normalize_image_device(raw_d, self.noise_level, (27, 27, 1), mode=0, subtract_median=True)
         self._mark("lcn")
-        if self._prob is None or self._prob.shape != norm.shape:
-            self._prob = _dev.torch().empty_like(norm)
-        prob = self.unet_model.predict_volume_device(norm, self.shrink, out=self._prob)
+        if out is None:
+            if self._prob is None or self._prob.shape != norm.shape:
+                self._prob = _dev.torch().empty_like(norm)
+            out = self._prob
+        prob = self.unet_model.predict_volume_device(norm, self.shrink, out=out)
         self._mark("unet")
         return prob
+
+    def regions_enqueue(self, prob):
+        """The watershed of `prob` enqueued on the current stream without its host round trip -> object whose .result()[1] are the centres."""
+        vs = self.transformer.voxel_size
+        return watershed_centroids_enqueue(prob, float(vs[2]) / float(vs[0]), "min_size", self.min_size, 0, want_labels=False)
 
     def regions(self, prob):
         """prob map -> centres fp64 [n,3] (voxel units) on the device."""
@@ -99,16 +107,27 @@ class FrameChain:
                 conf_n, para = _dev.normalize_points(conf_d)
                 s1, _ = _dev.normalize_points(s1_d, apply_para=para)
                 prepared = _dev.prgls_prepare_ref(s1, self.beta)
-        centres = self.regions(prob)
-        vs = t.as_tensor(np.asarray(self.transformer.voxel_size, dtype=np.float64), device=centres.device)
-        seg_real_t2 = centres * vs
         if self.prefetch_ref:
             main.wait_stream(self._side)
             for x in (conf_d, s1_d, conf_n, para, s1):
                 x.record_stream(main)
+            return self.track(prob, s1_d, conf_d, pre=(conf_n, para, s1, prepared))
+        return self.track(prob, s1_d, conf_d)
+
+    def track(self, prob, seg_real_t1, confirmed_real_t1, pre=None, centres=None):
+        """The part of a frame behind the U-Net, on the current stream: regions -> centres of `prob` (unless given), match against frame t1's
+        segmentation, move t1's confirmed cells, correct them on `prob`.  `pre`: (normalised confirmed set, its parameters, normalised t1
+        segmentation, PreparedRef) when they were made ahead."""
+        t = _dev.torch()
+        if centres is None:
+            centres = self.regions(prob)
+        vs = t.as_tensor(np.asarray(self.transformer.voxel_size, dtype=np.float64), device=centres.device)
+        seg_real_t2 = centres * vs
+        if pre is not None:
+            conf_n, para, s1, prepared = pre
         else:
-            conf_n, para = _dev.normalize_points(conf_d)
-            s1, _ = _dev.normalize_points(s1_d, apply_para=para)
+            conf_n, para = _dev.normalize_points(_dev.points_dev(confirmed_real_t1, centres.device))
+            s1, _ = _dev.normalize_points(_dev.points_dev(seg_real_t1, centres.device), apply_para=para)
             prepared = None
         s2, _ = _dev.normalize_points(seg_real_t2, apply_para=para)
         _dev.check_match_sizes(s1.shape[0], s2.shape[0], 20, "FrameChain")
@@ -120,6 +139,83 @@ class FrameChain:
         self._mark("correction")
         return {"coords": corrected, "n_segmented": int(centres.shape[0]), "prgls_iterations": int(iters),
                 "correction_rounds": int(self.transformer.last_iterations), "seg_real_t2": seg_real_t2}
+
+    def run_sequence(self, raws, seg_real_t0, confirmed_real_t0):
+        """A sequence of frames as the reference's loop over volumes sees them (TrackerLite tracks from segmentations made beforehand,
+        trackerlite.py:33-109: a volume's segmentation does not depend on the tracking of the volumes before it): every frame runs the whole
+        chain with ITS OWN predecessor's results -- frame i is matched against frame i-1's segmentation and moves frame i-1's corrected
+        cells.  Three streams, one host thread: the LCN + U-Net of frame i+2 (stream S) and the marker watershed of frame i+1 (stream W,
+        enqueued without its host round trip) run beside the match + correction of frame i (stream T, whose steps the host synchronises
+        with); three probability-map buffers.  `raws`: device uint16 stacks.  Yields run()'s dict per frame; same values as calling
+        run(raw_i, seg_{i-1}, corrected_{i-1}) frame after frame."""
+        t = _dev.torch()
+        raws = list(raws)
+        if not raws:
+            return
+        dev = raws[0].device
+        NB = 3
+        if self._seq is None:
+            self._seq = {"S": t.cuda.Stream(device=dev), "W": t.cuda.Stream(device=dev, priority=-1), "T": t.cuda.Stream(device=dev, priority=-1),
+                         "prob": [t.empty(tuple(raws[0].shape), dtype=t.float32, device=dev) for _ in range(NB)],
+                         "ready": [t.cuda.Event() for _ in range(NB)], "free": [None] * NB}
+        q = self._seq
+        q["spans"] = []                                          # (stream-local spans of the last sequence: sequence_spans())
+        S, W, T = q["S"], q["W"], q["T"]
+        entry = t.cuda.current_stream(dev)
+        for st in (S, W, T):
+            st.wait_stream(entry)
+        pending = {}
+
+        def span(name, stream, fn):
+            e0 = t.cuda.Event(enable_timing=True); e0.record(stream)
+            r = fn()
+            e1 = t.cuda.Event(enable_timing=True); e1.record(stream)
+            q["spans"].append((name, e0, e1))
+            return r, e1
+
+        def enqueue_unet(j):
+            b = j % NB
+            if q["free"][b] is not None:
+                S.wait_event(q["free"][b])                       # frame j-3's correction has read this buffer
+            with t.cuda.stream(S):
+                span("unet", S, lambda: self.probability_map(raws[j], out=q["prob"][b]))
+                q["ready"][b].record(S)
+
+        def enqueue_regions(j):
+            if self.region_method != "watershed":
+                return                                           # (the cheap variant has its round trip inside: it runs with the match)
+            with t.cuda.stream(W):
+                W.wait_event(q["ready"][j % NB])
+                pending[j], _ = span("regions", W, lambda: self.regions_enqueue(q["prob"][j % NB]))
+
+        seg_prev, conf_prev = seg_real_t0, confirmed_real_t0
+        enqueue_unet(0)
+        if len(raws) > 1:
+            enqueue_unet(1)
+        enqueue_regions(0)
+        for i in range(len(raws)):
+            if i + 2 < len(raws):
+                enqueue_unet(i + 2)                              # everything asynchronous is queued before this frame's host-synchronous steps
+            if i + 1 < len(raws):
+                enqueue_regions(i + 1)
+            b = i % NB
+            with t.cuda.stream(T):
+                T.wait_event(q["ready"][b])
+                centres = pending.pop(i).result()[1] if i in pending else None
+                out, ev = span("match+correction", T, lambda: self.track(q["prob"][b], seg_prev, conf_prev, centres=centres))
+                q["free"][b] = ev
+            seg_prev, conf_prev = out["seg_real_t2"], out["coords"].real
+            yield out
+        for st in (S, W, T):
+            entry.wait_stream(st)
+
+    def sequence_spans(self):
+        """Mean ms of the LCN + U-Net spans (stream S) and of the regions/match/correction spans (stream T) of the last run_sequence."""
+        _dev.torch().cuda.synchronize()
+        acc = {}
+        for name, e0, e1 in (self._seq or {}).get("spans", []):
+            acc.setdefault(name, []).append(e0.elapsed_time(e1))
+        return {k: sum(v) / len(v) for k, v in acc.items()}
 
     # ---- optional per-stage timing (HIP events on the current stream)
     def enable_timing(self, on=True):

@@ -88,47 +88,85 @@ _METHODS = {"min_size": 0, "cell_num": 1}
 WATERSHED_LIMITS = "z <= 128 slices, x and y < 16384, < 2^31 voxels, <= 2048 peak candidates per z slice and <= 8192 in the volume"
 
 
-def watershed_centroids_device(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0, cap: int = 4096,
-                               want_labels: bool = True, min_distance_2d: int = 7, min_distance_3d: int = 3):
-    """Tracker._watershed (reference tracker.py:671-684 = watershed.py:16-108) + relabel_sequential + center_of_mass on the device.
-    prob: contiguous float32 cuda tensor [x, y, z] -> (labels int32 cuda | None, centres fp64 cuda [n, 3], sizes int32 cuda [n],
-    min_size in force, cell_num in force)."""
-    import ctypes as C
-    t = _dev.torch(); L = _lib.lib()
+class PendingWatershed:
+    """ct_watershed_segment enqueued on a stream (watershed_centroids_enqueue); result() makes the call's only host round trip (the region
+    count), re-running with larger tables in the rare case that `cap` regions were not enough."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def _enqueue(self):
+        import ctypes as C
+        t = _dev.torch(); L = _lib.lib()
+        prob, cap = self.prob, self.cap
+        dims = _lib.ivec(prob.shape)
+        self.centres = _dev.empty((cap, 3), t.float64, prob.device)
+        self.sizes = _dev.empty((cap,), t.int32, prob.device)
+        nbytes = L.ct_watershed_workspace_bytes(dims, int(cap))
+        if nbytes == 0:
+            raise ValueError(f"volume {tuple(prob.shape)} is outside the device watershed's limits ({WATERSHED_LIMITS}); "
+                             "threshold + connected components have none: Tracker.region_method = 'cc' / segment_centroids_device")
+        self.ws = _dev.workspace(nbytes, prob.device)
+        rc = L.ct_watershed_segment(prob.data_ptr(), dims, float(self.z_xy_ratio), _METHODS[self.method], int(self.min_size), int(self.cell_num),
+                                    int(self.min_distance_2d), int(self.min_distance_3d), self.w_xy.ctypes.data_as(C.c_void_p), self.r_xy,
+                                    self.w_z.ctypes.data_as(C.c_void_p), self.r_z, int(cap), self.labels.data_ptr() if self.labels is not None else None,
+                                    self.centres.data_ptr(), self.sizes.data_ptr(), self.n_dev.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                    _dev.stream(prob.device))
+        _lib.check(rc, "ct_watershed_segment")
+        self.stream = t.cuda.current_stream(prob.device)
+        self.event = t.cuda.Event(); self.event.record(self.stream)
+
+    def result(self):
+        """-> (labels int32 cuda | None, centres fp64 cuda [n, 3], sizes int32 cuda [n], min_size in force, cell_num in force); usable on the
+        stream that is current when result() is called."""
+        t = _dev.torch()
+        while True:
+            self.event.synchronize()
+            cur = t.cuda.current_stream(self.prob.device)
+            if cur != self.stream:
+                for x in (self.centres, self.sizes, self.n_dev, self.labels):
+                    if x is not None:
+                        x.record_stream(cur)
+            n, ms, cn = (int(v) for v in self.n_dev.cpu().tolist())          # the call's only host round trip
+            if n == -2:                       # a peak table overflowed in one of the stages (latched on the device, nothing was waited for)
+                raise ValueError(f"the probability map has more peak candidates than the device watershed's tables hold ({WATERSHED_LIMITS}): "
+                                 "a map that noisy usually needs a higher noise_level; Tracker.region_method = 'cc' has no such limit")
+            if n < 0:                         # watershed.py:92: np.sort(counts)[-cell_num - 1] with fewer than cell_num + 1 bins
+                raise IndexError(f"index {-self.cell_num - 1} is out of bounds: method='cell_num' asks for {self.cell_num} cells, the watershed found fewer regions")
+            if n <= self.cap:
+                return self.labels, self.centres[:n], self.sizes[:n], ms, cn
+            self.cap = max(2 * self.cap, n)
+            with t.cuda.stream(self.stream):
+                self._enqueue()
+
+
+def watershed_centroids_enqueue(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0, cap: int = 4096,
+                                want_labels: bool = True, min_distance_2d: int = 7, min_distance_3d: int = 3) -> PendingWatershed:
+    """watershed_centroids_device without its host round trip: the kernels are enqueued on the current stream, `.result()` waits for them.
+    `prob` must stay untouched until result() has returned."""
+    t = _dev.torch()
     if prob.dim() != 3 or not prob.is_cuda or not prob.is_contiguous() or prob.dtype != t.float32:
         raise ValueError("expected a contiguous float32 cuda tensor (x, y, z)")
     if method not in _METHODS:
         raise ValueError("The method parameter should be either min_size or cell_num")        # watershed.py:93
     if min_size < 0 or cell_num < 0 or cap <= 0:
         raise ValueError("min_size / cell_num must be >= 0 and cap positive")
-    dims = _lib.ivec(prob.shape)
     w_xy, r_xy = gaussian_weights(2.0)
     w_z, r_z = gaussian_weights(0.3)
-    labels = _dev.empty(tuple(prob.shape), t.int32, prob.device) if want_labels else None
-    n_dev = _dev.empty((3,), t.int32, prob.device)
-    while True:
-        centres = _dev.empty((cap, 3), t.float64, prob.device)
-        sizes = _dev.empty((cap,), t.int32, prob.device)
-        nbytes = L.ct_watershed_workspace_bytes(dims, int(cap))
-        if nbytes == 0:
-            raise ValueError(f"volume {tuple(prob.shape)} is outside the device watershed's limits ({WATERSHED_LIMITS}); "
-                             "threshold + connected components have none: Tracker.region_method = 'cc' / segment_centroids_device")
-        ws = _dev.workspace(nbytes, prob.device)
-        rc = L.ct_watershed_segment(prob.data_ptr(), dims, float(z_xy_ratio), _METHODS[method], int(min_size), int(cell_num),
-                                    int(min_distance_2d), int(min_distance_3d), w_xy.ctypes.data_as(C.c_void_p), r_xy,
-                                    w_z.ctypes.data_as(C.c_void_p), r_z, int(cap), labels.data_ptr() if want_labels else None,
-                                    centres.data_ptr(), sizes.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), ws.numel(),
-                                    _dev.stream(prob.device))
-        _lib.check(rc, "ct_watershed_segment")
-        n, ms, cn = (int(v) for v in n_dev.cpu().tolist())          # the call's only host round trip
-        if n == -2:                       # a peak table overflowed in one of the stages (latched on the device, nothing was waited for)
-            raise ValueError(f"the probability map has more peak candidates than the device watershed's tables hold ({WATERSHED_LIMITS}): "
-                             "a map that noisy usually needs a higher noise_level; Tracker.region_method = 'cc' has no such limit")
-        if n < 0:                         # watershed.py:92: np.sort(counts)[-cell_num - 1] with fewer than cell_num + 1 bins
-            raise IndexError(f"index {-cell_num - 1} is out of bounds: method='cell_num' asks for {cell_num} cells, the watershed found fewer regions")
-        if n <= cap:
-            return labels, centres[:n], sizes[:n], ms, cn
-        cap = max(2 * cap, n)
+    p = PendingWatershed(prob=prob, z_xy_ratio=z_xy_ratio, method=method, min_size=min_size, cell_num=cell_num, cap=cap,
+                         min_distance_2d=min_distance_2d, min_distance_3d=min_distance_3d, w_xy=w_xy, r_xy=r_xy, w_z=w_z, r_z=r_z,
+                         labels=_dev.empty(tuple(prob.shape), t.int32, prob.device) if want_labels else None,
+                         n_dev=_dev.empty((3,), t.int32, prob.device))
+    p._enqueue()
+    return p
+
+
+def watershed_centroids_device(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0, cap: int = 4096,
+                               want_labels: bool = True, min_distance_2d: int = 7, min_distance_3d: int = 3):
+    """Tracker._watershed (reference tracker.py:671-684 = watershed.py:16-108) + relabel_sequential + center_of_mass on the device.
+    prob: contiguous float32 cuda tensor [x, y, z] -> (labels int32 cuda | None, centres fp64 cuda [n, 3], sizes int32 cuda [n],
+    min_size in force, cell_num in force)."""
+    return watershed_centroids_enqueue(prob, z_xy_ratio, method, min_size, cell_num, cap, want_labels, min_distance_2d, min_distance_3d).result()
 
 
 def watershed_centroids(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0):

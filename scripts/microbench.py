@@ -353,6 +353,15 @@ def cmd_frame(args):
           f"{out['correction_rounds']} correction rounds)")
     for k, v in chain.stage_times().items():
         print(f"  {k}: {v:.3f} ms")
+    chain.enable_timing(False)
+    raws = [chain.raw_t2, chain.raw_t1] * 6
+    list(chain.run_sequence(raws[:4], chain.seg_real_t1, chain.confirmed_real_t1))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    outs = list(chain.run_sequence(raws, chain.seg_real_t1, chain.confirmed_real_t1))
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / len(raws)
+    print(f"frame sequence, U-Net of frame i+1 beside the tail of frame i: {dt*1e3:.2f} ms per frame ({1/dt:.1f} volumes/s), "
+          f"{[o['n_segmented'] for o in outs[:4]]} cells, {[o['prgls_iterations'] for o in outs[:4]]} PR-GLS iterations")
+    print("   spans on their own streams (ms):", {k: round(v, 2) for k, v in chain.sequence_spans().items()})
 
 
 def cmd_trace(args):

@@ -162,3 +162,28 @@ def test_chained_frame_with_the_reference_set_prepared_beside_the_unet_is_unchan
         outs.append(b)
     assert outs[0]["prgls_iterations"] == outs[1]["prgls_iterations"] and outs[0]["n_segmented"] == outs[1]["n_segmented"]
     assert np.array_equal(outs[0]["coords"].real, outs[1]["coords"].real)
+
+
+@pytest.mark.gpu
+def test_frame_sequence_with_overlapped_unet_equals_the_serial_frames():
+    """FrameChain.run_sequence: every frame is matched against ITS predecessor's segmentation and moves its predecessor's corrected cells; only
+    the LCN + U-Net of the next frame overlaps (second stream, two probability buffers).  Same values as run() frame after frame."""
+    import importlib
+    import numpy as np
+    frame = importlib.import_module("3deecelltracker_amd.frame")
+    chain = frame.FrameChain.synthetic(shape=(256, 256, 24), n_cells=150, seed=5)
+    raws = [chain.raw_t2, chain.raw_t1, chain.raw_t2, chain.raw_t1, chain.raw_t2]
+    seg, conf = chain.seg_real_t1, chain.confirmed_real_t1
+    want = []
+    for r in raws:
+        o = chain.run(r, seg, conf)
+        want.append(o); seg, conf = o["seg_real_t2"], o["coords"].real
+    for _ in range(2):                                            # (the second pass reuses the streams and buffers of the first)
+        got = list(chain.run_sequence(raws, chain.seg_real_t1, chain.confirmed_real_t1))
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g["n_segmented"] == w["n_segmented"] and g["prgls_iterations"] == w["prgls_iterations"]
+            assert np.array_equal(g["seg_real_t2"].cpu().numpy(), w["seg_real_t2"].cpu().numpy())
+            assert np.array_equal(g["coords"].real, w["coords"].real)
+    assert len({o["n_segmented"] for o in want}) >= 1 and want[0]["n_segmented"] >= 100
+    assert list(chain.run_sequence([], seg, conf)) == []
