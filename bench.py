@@ -255,12 +255,34 @@ def measure_chained(ctx, args):
                 "cells_segmented": out["n_segmented"], "prgls_iterations": out["prgls_iterations"],
                 "correction_rounds": out["correction_rounds"], "mean_abs_error_vs_true_centres": round(err, 3)}
 
+    def sequence():
+        """FrameChain.run_sequence: the same frames as a software pipeline -- frame i is matched against frame i-1's segmentation and moves
+        frame i-1's corrected cells (every dependency of the reference's loop over volumes kept), the U-Net of frame i+2 and the watershed of
+        frame i+1 run beside the match + correction of frame i.  Values identical to serial frames (tests/test_gpu_bench.py)."""
+        chain = frame.FrameChain.synthetic(shape=tuple(args.shape), n_cells=args.cells, seed=0, device=ctx.local)
+        raws = [chain.raw_t2, chain.raw_t1] * 8
+        list(chain.run_sequence(raws[:4], chain.seg_real_t1, chain.confirmed_real_t1))
+        torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
+        outs = list(chain.run_sequence(raws, chain.seg_real_t1, chain.confirmed_real_t1))
+        torch.cuda.synchronize(ctx.dev)
+        dt = (time.perf_counter() - t0) / len(raws)
+        return {"volumes_per_s": round(1.0 / dt, 2), "ms_per_frame": round(dt * 1e3, 3), "frames": len(raws),
+                "stream_spans_ms": {k: round(v, 3) for k, v in chain.sequence_spans().items()},
+                "cells_segmented": [o["n_segmented"] for o in outs[:2]], "prgls_iterations": [o["prgls_iterations"] for o in outs[:2]],
+                "what": "every frame: LCN -> U-Net -> marker watershed -> match against the PREVIOUS frame's segmentation -> correction of the previous "
+                        "frame's corrected cells; three HIP streams, one host thread (fill and drain of the pipeline inside the timed region)"}
+
     res = one("watershed")
     cc = one("cc")
+    try:                                       # (an informative pass: a failure here must not cost the headline line)
+        res["frame_sequence"] = sequence()
+    except Exception as e:  # noqa: BLE001
+        res["frame_sequence"] = {"error": repr(e)[:300]}
     res["region_step"] = "ct_watershed_segment (the reference's marker watershed, bit-identical to watershed.py on scikit-image: tests/test_watershed_pin.py)"
     res["with_connected_components_instead"] = {k: cc[k] for k in ("volumes_per_s", "ms_per_frame", "stage_ms", "cells_segmented")}
     res["what"] = ("raw stack -> LCN -> U-Net (pass-through weights) -> marker watershed -> centres -> FFN (synthetic-trained) + greedy + PR-GLS -> "
-                   "accurate correction on the same probability map; one frame at a time, one stream, full chip")
+                   "accurate correction on the same probability map; one frame at a time (what depends only on frame t1 -- its Gram matrix's "
+                   "low-rank factor -- is prepared on a second stream beside the U-Net), full chip")
     return res
 
 
@@ -651,7 +673,8 @@ def main():
                             "match_chains_in_flight": args.match_workers, "frames_per_match_chain": args.match_batch,
                             "headline_excludes": ["regions->centres (ct_watershed_segment, the reference's marker watershed)", "accurate correction"] if args.mode != "ensemble" else [],
                             "headline_note": "matches take given ~600-point sets (independent units, SURVEY 8e); the dependent per-frame chain "
-                                             "incl. the watershed and the correction is config.chained",
+                                             "incl. the watershed and the correction is config.chained (one frame's latency) and "
+                                             "config.chained.frame_sequence (a sequence of such frames, software-pipelined)",
                             "rccl_ranks": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                                             "tracked_sets_gathered": ctx.gathered_sets} if world > 1 else
                                            {"world_size": 1, "backend": None, "tracked_sets_gathered": 0}),
