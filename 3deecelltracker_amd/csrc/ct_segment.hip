@@ -1380,12 +1380,17 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
         int c;
         ws_wave_argmin(best, bpos, c, lane);
         --n;
-        if (lane == 0 && bpos != n) q[bpos] = q[n];
+        // ONE LDS round trip for everything the rest of the iteration reads: the queue's last entry (it fills the winner's slot), the popped
+        // voxel's label, the neighbour's state and height.  Left to the compiler these were three dependent round trips (lane 0's read in front
+        // of its store; the neighbour's state; label and height only inside `if (take)`): ~400 of a pop's 1300 cycles.
+        const WsQEntry last = q[n];
         const int lin = ((c >> 17) * BY + ((c >> 7) & 1023)) * BZ + (c & 127);     // uniform
         const int lab = st_box[lin];                                             // the label a voxel got when it was pushed (seeds: their marker's)
         const bool valid = (unsigned int)(((c >> sh) & fmask) + dir) < (unsigned int)lim;
         const int nb = valid ? lin + dlin : lin;
-        const int st = st_box[nb]; const double sv = sm_box[nb];                 // (both reads in flight with the label's)
+        const int st = st_box[nb]; const double sv = sm_box[nb];
+        asm volatile("" :: "v"(last.key), "v"(last.age), "v"(last.idx), "v"(lab), "v"(st), "v"(sv));      // (all six loads issued before the first use)
+        if (lane == 0 && bpos != n) q[bpos] = last;
         const bool take = valid && st == 0;
         const unsigned long long mask = __ballot(take);
         if (n + (int)__popcll(mask) > qcap) { overflowed = true; break; }       // (uniform) frontier beyond the queue: hand the component back
