@@ -12,8 +12,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/ctamd.h"
+#include "ct_fill.h"
+
+
+// Words one kernel writes and a LATER launch reads at a wave-uniform address (a cell's coordinates, updated in place round after round; the
+// `done` word) are read with agent-scope loads.  As plain loads the compiler turns them into scalar loads, and the centre-of-mass kernel then
+// saw the coordinates of TWO rounds ago now and then -- only while kernels of another stream (the U-Net, a GEMM) were running, 10-50 % of
+// the calls on every box tried, never on an idle GPU: the flag said "still moving", the correction ran a round too many and one cell ended
+// 0.3 voxel away (scripts/probe/corr_beside_unet.py; FrameChain.run_sequence is what runs the correction beside a U-Net).  Which cache kept
+// the old word was not established (the scalar cache is the suspect: per-thread vector loads of the same array, in movements_kernel, were
+// never stale); the sc1 loads below do not depend on the answer.
+__device__ __forceinline__ float fresh_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int fresh_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -24,14 +38,16 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct CorrGeom { int X, Y, Z, factor, zstart; };        // original grid, z interpolation factor, first original slice
 
+// Sum over the wave (read through lane 63): DPP steps on the two halves of the double -- the same pairs in the same order as an xor
+// butterfly (quad 1, quad 2, half-row mirror, row mirror, row 15 -> next row, lane 31 -> upper half; a + b == b + a, so the same bits)
+// without the butterfly's twelve ds_bpermute round trips.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
-        v += __hiloint2double(hi, lo);
-    }
-    return v;
+#define CT_DPP_ADD64(ctrl, rmask) { int lo = __double2loint(v), hi = __double2hiint(v);                                              \
+                                    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, rmask, 0xf, false);                                  \
+                                    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, rmask, 0xf, false); v += __hiloint2double(hi, lo); }
+    CT_DPP_ADD64(0xB1, 0xf) CT_DPP_ADD64(0x4E, 0xf) CT_DPP_ADD64(0x141, 0xf) CT_DPP_ADD64(0x140, 0xf) CT_DPP_ADD64(0x142, 0xa) CT_DPP_ADD64(0x143, 0xc)
+#undef CT_DPP_ADD64
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // movement of every cell on the interpolated grid: round((coords - vol1) * (1, 1, factor)), numpy half-to-even
@@ -39,7 +55,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 __global__ void movements_kernel(const float* __restrict__ coords, const float* __restrict__ vol1, int n, int factor,
                                  int32_t* __restrict__ mov, const int* __restrict__ done) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * n || *done) return;
+    if (i >= 3 * n || fresh_i32(done)) return;
     const float d = coords[i] - vol1[i];                       // Coordinates.__sub__ : float32 raw difference
     const double s = (i % 3 == 2) ? (double)factor : 1.0;
     mov[i] = (int32_t)rint((double)d * s);
@@ -50,7 +66,7 @@ template <typename F>
 __device__ __forceinline__ void for_cell_voxels(const CorrGeom g, const int32_t* bbox, const uint8_t* sub, const int32_t* mov,
                                                 int* err, F&& f) {
     const int bx = bbox[0], by = bbox[1], bz = bbox[2], sx = bbox[3], sy = bbox[4], sz = bbox[5];
-    const int ox = bx + mov[0], oy = by + mov[1], oz = bz + mov[2];
+    const int ox = bx + fresh_i32(mov), oy = by + fresh_i32(mov + 1), oz = bz + fresh_i32(mov + 2);      // (rewritten every round: see fresh_i32)
     const int ZI = g.Z * g.factor;
     // clipped ranges (reference raises ValueError when a clipped range is empty)
     if (max(ox, 0) >= min(ox + sx, g.X) || max(oy, 0) >= min(oy + sy, g.Y) || max(oz, 0) >= min(oz + sz, ZI)) {
@@ -76,7 +92,7 @@ __global__ __launch_bounds__(256) void scatter_counts_kernel(CorrGeom g, const i
                                                              const int32_t* __restrict__ mov, unsigned int* __restrict__ cnt, int* __restrict__ err,
                                                              const int* __restrict__ done) {
     const int i = blockIdx.x;
-    if (missed[i] || *done) return;
+    if (missed[i] || fresh_i32(done)) return;
     for_cell_voxels(g, bbox + 6 * i, subs + offs[i], mov + 3 * i, err,
                     [&](int x, int y, int k) { atomicAdd(&cnt[((size_t)x * g.Y + y) * g.Z + k], 1u); });
 }
@@ -90,7 +106,7 @@ __global__ __launch_bounds__(256) void centre_of_mass_kernel(CorrGeom g, const f
                                                              unsigned int* __restrict__ flag, int* __restrict__ err, const int* __restrict__ done) {
     __shared__ double red[4][4];
     const int i = blockIdx.x;
-    if (*done) return;
+    if (fresh_i32(done)) return;
     double sw = 0.0, swx = 0.0, swy = 0.0, swz = 0.0;
     if (!missed[i])
         for_cell_voxels(g, bbox + 6 * i, subs + offs[i], mov + 3 * i, err, [&](int x, int y, int k) {
@@ -110,11 +126,12 @@ __global__ __launch_bounds__(256) void centre_of_mass_kernel(CorrGeom g, const f
         float nw[3];
         const double cx = t[1] / t[0];
         if (cx != cx || t[0] == 0.0) {            // 0/0 -> NaN in the reference: "lost" cell keeps its rounded position
-            for (int d = 0; d < 3; ++d) nw[d] = (float)(int)rintf(coords[3 * i + d]);
+            for (int d = 0; d < 3; ++d) nw[d] = (float)(int)rintf(fresh_f32(&coords[3 * i + d]));
         } else { nw[0] = (float)cx; nw[1] = (float)(t[2] / t[0]); nw[2] = (float)(t[3] / t[0]); }
         int mx = -(1 << 29);
         for (int d = 0; d < 3; ++d) {
-            const float delta = nw[d] - coords[3 * i + d];
+            const float oldc = fresh_f32(&coords[3 * i + d]);
+            const float delta = nw[d] - oldc;
             const int di = (int)rint((double)delta * (d == 2 ? (double)g.factor : 1.0));
             mx = max(mx, di);
             coords[3 * i + d] = nw[d];
@@ -138,7 +155,7 @@ struct LegacyGeom { int X, Y, Z, zs, ZI, padx, pady, padz; };
 template <typename F>
 __device__ __forceinline__ bool for_cell_voxels_legacy(const LegacyGeom g, const int32_t* bbox, const uint8_t* sub, const int32_t* disp, F&& f) {
     const int sx = bbox[3], sy = bbox[4], sz = bbox[5];
-    const int ox = bbox[0] + disp[0], oy = bbox[1] + disp[1], oz = bbox[2] + disp[2];
+    const int ox = bbox[0] + fresh_i32(disp), oy = bbox[1] + fresh_i32(disp + 1), oz = bbox[2] + fresh_i32(disp + 2);   // (rewritten every other round)
     // padded-image slice [o + pad, o + pad + s) must lie inside [0, dim + 2 pad): otherwise numpy returns a slice of another
     // shape and the reference skips the cell (a start below zero would wrap around in numpy; treated as skipped as well)
     if (ox + g.padx < 0 || ox + sx > g.X + g.padx || oy + g.pady < 0 || oy + sy > g.Y + g.pady ||
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(256) void legacy_com_kernel(LegacyGeom g, double ra
         const bool lost = (com[0] != com[0]);
         bool big = false;
         for (int d = 0; d < 3; ++d) {
-            const double id = (double)disp_in[3 * i + d];
+            const double id = (double)fresh_i32(&disp_in[3 * i + d]);
             const double lc = (d == 2) ? t0[3 * i + 2] * inv_ratio + id * inv_zs : t0[3 * i + d] + id;
             double corr = lost ? 0.0 : com[d] - lc;
             if (d == 2) corr = corr * ratio;
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(256) void legacy_com_kernel(LegacyGeom g, double ra
 // closes round `it`: np.max(delta.interp) < 0.5 (the flag holds the signed maximum + 2^30) -> done = it; the round's flag words are kept for the
 // host in hist[it & 1] (it looks every second round)
 __global__ void correction_round_end_kernel(const unsigned int* __restrict__ flag, int it, int* __restrict__ done, unsigned int* __restrict__ hist) {
-    if (*done) return;
+    if (fresh_i32(done)) return;
     hist[2 * (it & 1)] = flag[0]; hist[2 * (it & 1) + 1] = flag[16];
     if ((int)flag[0] - (1 << 30) < 1 || flag[16]) *done = it;                   // (an out-of-image box also ends the loop: the host reports it)
 }
@@ -251,16 +268,17 @@ int ct_accurate_correction(const float* prob, const int dims[3], int factor, int
     int32_t* mov = (int32_t*)ws; ws += align_up((size_t)n_cells * 12, 256);
     unsigned int* flag = (unsigned int*)ws; int* err = (int*)(ws + 64);
     int* done = (int*)(ws + 256); unsigned int* hist = (unsigned int*)(ws + 320);      // (behind the per-round flag block)
-    HIPCHK(hipMemsetAsync(done, 0, 128, st));
+    HIPCHK(ct_fill_async(done, 0, 128, st));
     // Rounds are enqueued two at a time: the device closes each round itself (correction_round_end_kernel) and a round enqueued after the
     // stopping rule was met does nothing, so the host waits once per two rounds instead of once per round (a frame's four rounds: two idle gaps
     // instead of four).  Same rounds, same results, same iteration count.
     int it = 0, finished = 0;
     for (it = 1; it <= max_repetition && !finished; ) {
         const int first = it;
-        for (int k = 0; k < 2 && it <= max_repetition; ++k, ++it) {
-            HIPCHK(hipMemsetAsync(cnt, 0, nvox * 4, st));
-            HIPCHK(hipMemsetAsync(flag, 0, 128, st));
+        static const int per_sync = (getenv("CT_CORR_PAIR") && atoi(getenv("CT_CORR_PAIR")) == 0) ? 1 : 2;
+        for (int k = 0; k < per_sync && it <= max_repetition; ++k, ++it) {
+            HIPCHK(ct_fill_async(cnt, 0, nvox * 4, st));
+            HIPCHK(ct_fill_async(flag, 0, 128, st));
             hipLaunchKernelGGL(movements_kernel, dim3((3 * n_cells + 255) / 256), dim3(256), 0, st, coords_raw, coord_vol1_raw, n_cells, factor, mov, done);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(scatter_counts_kernel, dim3(n_cells), dim3(256), 0, st, g, bbox, subimages, sub_offsets, missed, mov, cnt, err, done);
@@ -270,11 +288,28 @@ int ct_accurate_correction(const float* prob, const int dims[3], int factor, int
             LAUNCH_CHECK();
             hipLaunchKernelGGL(correction_round_end_kernel, dim3(1), dim3(1), 0, st, flag, it, done, hist);
             LAUNCH_CHECK();
+            static const bool trace = getenv("CT_CORR_TRACE") != nullptr;      // debugging aid: hashes of the round's state on stderr (synchronises)
+            if (trace) {
+                float* hc = (float*)malloc((size_t)n_cells * 12); int32_t* hm = (int32_t*)malloc((size_t)n_cells * 12);
+                unsigned int* hcnt = (unsigned int*)malloc(nvox * 4); unsigned int hf[32];
+                HIPCHK(hipMemcpyAsync(hc, coords_raw, (size_t)n_cells * 12, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(hm, mov, (size_t)n_cells * 12, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(hcnt, cnt, nvox * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(hf, flag, 128, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                auto fnv = [](const void* p, size_t n) { unsigned long long h = 1469598103934665603ull; for (size_t i = 0; i < n; ++i) { h ^= ((const unsigned char*)p)[i]; h *= 1099511628211ull; } return h; };
+                fprintf(stderr, "[corr] round %d flag %d err %u coords %016llx mov %016llx cnt %016llx\n", it, (int)hf[0] - (1 << 30), hf[16],
+                        fnv(hc, (size_t)n_cells * 12), fnv(hm, (size_t)n_cells * 12), fnv(hcnt, nvox * 4));
+                free(hc); free(hm); free(hcnt);
+            }
         }
         unsigned int h[32];                                            // done | ... | hist[4] at + 16 words
         HIPCHK(hipMemcpyAsync(h, done, sizeof(h), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         const int d = (int)h[0];
+        if (getenv("CT_DEBUG"))
+            fprintf(stderr, "[ct_accurate_correction] rounds %d..%d: done %d, flags (max delta + 2^30, err) even round %d %u, odd round %d %u\n", first, it - 1, d,
+                    (int)h[16] - (1 << 30), h[17], (int)h[18] - (1 << 30), h[19]);
         if (d) {
             if (h[16 + 2 * (d & 1) + 1]) return CT_ESHAPE;             // a moved bounding box left the image (reference: ValueError)
             finished = d;
@@ -311,8 +346,8 @@ int ct_accurate_correction_legacy(const float* prob, const void* raw, int raw_dt
     LAUNCH_CHECK();
     int it = 0;
     for (it = 1; it <= max_repetition; ++it) {
-        HIPCHK(hipMemsetAsync(cnt, 0, nvox * 4, st));
-        HIPCHK(hipMemsetAsync(flag, 0, 64, st));
+        HIPCHK(ct_fill_async(cnt, 0, nvox * 4, st));
+        HIPCHK(ct_fill_async(flag, 0, 64, st));
         hipLaunchKernelGGL(legacy_scatter_kernel, dim3(n_cells), dim3(256), 0, st, g, bbox, subimages, sub_offsets, da, cnt);
         LAUNCH_CHECK();
         if (raw && raw_dtype == 1)

@@ -165,13 +165,15 @@ def test_chained_frame_with_the_reference_set_prepared_beside_the_unet_is_unchan
 
 
 @pytest.mark.gpu
-def test_frame_sequence_with_overlapped_unet_equals_the_serial_frames():
-    """FrameChain.run_sequence: every frame is matched against ITS predecessor's segmentation and moves its predecessor's corrected cells; only
-    the LCN + U-Net of the next frame overlaps (second stream, two probability buffers).  Same values as run() frame after frame."""
+@pytest.mark.parametrize("region_method", ("watershed", "cc"))
+def test_frame_sequence_with_overlapped_unet_equals_the_serial_frames(region_method):
+    """FrameChain.run_sequence: every frame is matched against ITS predecessor's segmentation and moves its predecessor's corrected cells; the
+    LCN + U-Net of frame i+2 and the watershed of frame i+1 run on their own streams beside frame i's match + correction (three probability
+    buffers; with the connected-components variant the region step stays with the match).  Same values as run() frame after frame."""
     import importlib
     import numpy as np
     frame = importlib.import_module("3deecelltracker_amd.frame")
-    chain = frame.FrameChain.synthetic(shape=(256, 256, 24), n_cells=150, seed=5)
+    chain = frame.FrameChain.synthetic(shape=(256, 256, 24), n_cells=150, seed=5, region_method=region_method)
     raws = [chain.raw_t2, chain.raw_t1, chain.raw_t2, chain.raw_t1, chain.raw_t2]
     seg, conf = chain.seg_real_t1, chain.confirmed_real_t1
     want = []

@@ -67,3 +67,19 @@ def test_packed_victim_is_corrupted_beside_the_double_k_mfma():
         pytest.xfail("the hazard no longer reproduces (packed-fp32 victim exact beside v_mfma_f32_32x32x16_f16 of another process): driver / "
                      "firmware changed -- the -fno-slp-vectorize fence of csrc/Makefile can be reconsidered")
     assert q0 == q1 == q2 == 0 and q3 == bad, f"corruption left lanes 48-63 (target rows mod 4: {q0} {q1} {q2} {q3})"
+
+
+@pytest.mark.gpu
+def test_every_stage_is_reproducible_beside_a_busy_stream():
+    """LCN, U-Net, watershed, connected components, match and accurate correction, each on its own stream while another stream runs a U-Net or a
+    rocBLAS GEMM: the bits of an idle GPU (scripts/probe/repro_beside_load.py).  The accurate correction failed this in 10-50 % of its calls --
+    a round too many, one cell 0.3 voxel off -- until the words it re-reads at wave-uniform addresses launch after launch (a cell's
+    coordinates, its movement, the `done` word) became agent-scope loads (csrc/ct_correct.hip, fresh_i32); FrameChain.run_sequence is the
+    caller that runs it beside a U-Net."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(repo / "scripts" / "probe" / "repro_beside_load.py"), "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "TOTAL 0" in r.stdout, r.stdout[-1500:]

@@ -266,3 +266,22 @@ print("mismatches", bad)
     repo = str(REPO)
     r = subprocess.run([sys.executable, "-c", code, repo], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
     assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout[-300:] + r.stderr[-800:]
+
+
+@pytest.mark.gpu
+def test_device_watershed_enqueued_on_another_stream_and_with_too_small_a_table():
+    """watershed_centroids_enqueue: the kernels run on the stream that was current at the call, result() may be taken on another stream (and
+    later); a centre table that turns out too small (cap < regions) is grown and the call repeated inside result().  Same regions either way."""
+    import torch
+    from _ws_cases import random_case
+    prob = torch.from_numpy(random_case((120, 100, 16), 40, 1)).cuda()
+    want = seg.watershed_centroids_device(prob, 4.0, "min_size", 20)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pend = seg.watershed_centroids_enqueue(prob, 4.0, "min_size", 20, cap=8)      # fewer slots than regions: regrown in result()
+        pend2 = seg.watershed_centroids_enqueue(prob, 4.0, "min_size", 20, want_labels=False)
+    got, got2 = pend.result(), pend2.result()
+    assert len(want[1]) > 8 and pend.cap >= len(want[1])
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and got[3:] == want[3:]
+    assert got2[0] is None and torch.equal(got2[1], want[1])
