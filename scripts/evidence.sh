@@ -17,6 +17,7 @@ bash scripts/prof_sq.sh unetC_$R "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIV
 cd $GRAFT_REPO_ROOT
 python scripts/sq_summary.py gpurun_out/prof/unet_${R}_kernel_stats.csv gpurun_out/prof/${R}_unet_sq_summary.json gpurun_out/prof/unetA_${R}_sq.csv gpurun_out/prof/unetB_${R}_sq.csv gpurun_out/prof/unetC_${R}_sq.csv
 bash scripts/prof.sh watershed_$R $GRAFT_REPO_ROOT/scripts/microbench.py watershed | head -3
+bash scripts/prof.sh lcn_$R $GRAFT_REPO_ROOT/scripts/microbench.py lcn | head -3
 bash scripts/prof.sh frame_$R $GRAFT_REPO_ROOT/scripts/microbench.py frame | head -3
 bash scripts/prof.sh match600_$R $GRAFT_REPO_ROOT/scripts/microbench.py match 600 | head -3
 bash scripts/prof.sh batched_$R $GRAFT_REPO_ROOT/scripts/microbench.py batched 600 16 | head -3
@@ -25,3 +26,4 @@ python scripts/hbm_traffic.py gpurun_out/prof/unet_${R}_FETCH_SIZE.csv gpurun_ou
 for s in unet "unet --layers" lcn segment watershed correction "match 600" "goodprior 600" legacy ensemble frame pcie; do timeout 300 python scripts/microbench.py $s 2>&1 | grep -v amdgpu.ids | tail -16; done > gpurun_out/microbench_$R.txt 2>&1
 tail -60 gpurun_out/microbench_$R.txt
 timeout 900 python bench.py > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err; tail -c 400 gpurun_out/bench_$R.err; head -c 1500 gpurun_out/bench_$R.json
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${R}_steps20.json 2>> gpurun_out/bench_$R.err; head -c 300 gpurun_out/bench_${R}_steps20.json
