@@ -1,10 +1,9 @@
 // ct_fill.h -- stream-ordered fills by a kernel of this library (every translation unit gets its own copy).
 //
-// Why not hipMemsetAsync: a hipMemsetAsync of a few bytes (a 128-byte flag block cleared between two kernels of one stream) was observed to
-// take effect OUT OF ORDER with its neighbours while another stream kept the GPU busy -- the accurate correction then saw the previous
-// round's flags and ran a round more or less (scripts/probe/corr_beside_unet.py: 80 of 80 calls beside a stream of torch fill_ kernels,
-// 10-30 % beside the U-Net, never on an idle GPU; gone when the same words are cleared by a kernel).  Kernels of one stream do run in
-// order, so every clear the results depend on is a kernel.
+// Used where a few flag words are cleared between two kernels of one stream and the result depends on it (csrc/ct_correct.hip).  While
+// the correction's irreproducibility beside other streams was being hunted, one box showed it in 80 of 80 calls with
+// hipMemsetAsync clearing the flag block and in none with this kernel; other boxes did not repeat that, and the cause that was finally
+// pinned down lies elsewhere (stale wave-uniform loads).  The clears stay kernels of the library: same cost, one unknown less.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
