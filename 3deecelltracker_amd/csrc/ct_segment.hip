@@ -25,6 +25,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "../../include/ctamd.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -1174,14 +1176,15 @@ __device__ __forceinline__ unsigned int ws_wave_max_u32(unsigned int v) {
 // -- and the bounding box of every component with several markers (slot = its position in the flood's list) for ws_flood_box_kernel
 __global__ void ws_fill_single_kernel(SegGeom g, const int32_t* __restrict__ parent, const int32_t* __restrict__ heap_off,
                                       const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap, int32_t* __restrict__ labels,
-                                      const int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox) {
+                                      const int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox, int what /* 1 fill | 2 boxes */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int root = -1, cnt = 0;
     if (i < g.V) { root = parent[i]; if (root >= 0) cnt = heap_cnt[root]; }
-    if (cnt == 1) {
+    if (cnt == 1 && (what & 1)) {
         const int m = heap[heap_off[root]].idx;
         if (m != (int)i) labels[i] = labels[m];
     }
+    if (!(what & 2)) return;
     // bounding boxes: the lanes of a wave that belong to one component are reduced first (one atomic per coordinate bound, wave and component:
     // a thread-per-voxel version spent 0.2 ms on the same-address atomics of the largest component)
     unsigned long long todo = __ballot(cnt >= 2);
@@ -1661,6 +1664,27 @@ WsLayout ws_layout(long long V, int Z, int cap) {
     return L;
 }
 
+// A helper stream per device: the sweeps that depend on the MASK alone (components of the mask: union-find merges, flatten, queue offsets,
+// 100-125 us) run beside the peak selection (one workgroup per group: 40-130 us during which the chip would idle), and the fill of the
+// single-marker components beside the sequential flood of the others.  (Sweeps beside sweeps gain nothing -- measured: the chain beside the
+// EDT / Gaussian / maximum passes left the call at 1.76 ms.)  The events are reused; the mutex covers one call's enqueue
+// (hipStreamWaitEvent takes the record made before it in host order), not the work itself.
+struct WsAux { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+std::mutex ws_aux_mutex;
+WsAux* ws_aux_for_current_device() {
+    static WsAux aux[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    WsAux& a = aux[dev];
+    if (!a.ok) {
+        if (hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        a.ok = true;
+    }
+    return &a;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1786,14 +1810,40 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         } else ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, axis, in, out, r);
     };
 
+    // Serial form (CT_WS_FORK=0) or the helper stream; the lock is held while this call enqueues.
+    static const bool no_fork = getenv("CT_WS_FORK") && atoi(getenv("CT_WS_FORK")) == 0;
+    std::unique_lock<std::mutex> aux_lock(ws_aux_mutex, std::defer_lock);
+    WsAux* aux = nullptr;
+    if (!no_fork) { aux_lock.lock(); aux = ws_aux_for_current_device(); if (!aux) aux_lock.unlock(); }
+    // the per-stage clears
+    auto stage_clear = [&]() -> int {
+        HIPCHK(hipMemsetAsync(ws + L.stats, 0, 3584, st));
+        HIPCHK(hipMemsetAsync(vmin, 0xff, 128 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(labels, 0, (size_t)V * 4, st));
+        return CT_OK;
+    };
+    // connectivity-1 components of `mask` (whose producer initialised parent / size), flattened, with queue space per component: everything
+    // here depends on the mask alone and runs on the helper stream beside the peak selection of the same stage
+    auto stage_components = [&](bool mode2d, const unsigned char* mask) -> int {
+        hipStream_t sc = aux ? aux->stream : st;
+        if (aux) { HIPCHK(hipEventRecord(aux->fork, st)); HIPCHK(hipStreamWaitEvent(sc, aux->fork, 0)); }
+        if (mode2d) ws_cc_init_merge_kernel<true><<<nb, 256, 0, sc>>>(g, mask, parent, 1);
+        else ws_cc_init_merge_kernel<false><<<nb, 256, 0, sc>>>(g, mask, parent, 1);
+        LAUNCH_CHECK();
+        cc_flatten_kernel<<<nb, 256, 0, sc>>>(V, parent, size);
+        LAUNCH_CHECK();
+        ws_heap_alloc_kernel<<<nb, 256, 0, sc>>>(V, parent, size, heap_off, heap_cnt, bump);
+        LAUNCH_CHECK();
+        if (aux) HIPCHK(hipEventRecord(aux->join, sc));
+        return CT_OK;
+    };
+
     auto stage = [&](bool mode2d, const unsigned char* mask, int min_distance, int border) -> int {
         const int ngroups = mode2d ? Z : 1, pcap = mode2d ? WS_PEAK_CAP2D : WS_PEAK_CAP3D;
         // separable window maximum: smooth -> tmp -> (dist ->) [vmax]; the last pass carries the peak test (the maximum itself is only written
         // for the tests' hook)
         double* const vmax_out = (method_in & 0x300) ? vmax : nullptr;
-        HIPCHK(hipMemsetAsync(ws + L.stats, 0, 3584, st));
-        HIPCHK(hipMemsetAsync(vmin, 0xff, 128 * sizeof(unsigned long long), st));
-        HIPCHK(hipMemsetAsync(labels, 0, (size_t)V * 4, st));
+        { const int rcc = stage_clear(); if (rcc) return rcc; }
         max_pass(0, smooth, tmp, min_distance);
         LAUNCH_CHECK();
         if (mode2d) {
@@ -1808,6 +1858,9 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
             ws_maxz_peak_kernel<<<2048, 256, 0, st>>>(g, min_distance, border, dist, smooth, vmax_out, eq_count, vmin, cand_count, pcap, cand_val, cand_idx, overflow);
         }
         LAUNCH_CHECK();
+        // the peak selection is one workgroup per group (40 us for 32 slices, 130 us for the volume: the chip idles); the components of the
+        // mask go beside it
+        { const int rcc = stage_components(mode2d, mask); if (rcc) return rcc; }
 static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT")) == 0;          // (A/B: the bitonic-sort form for every group)
         if (!no_sel2) {
             ws_peak_select2_kernel<<<ngroups, 1024, WS_SEL2_LDS, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val, cand_idx,
@@ -1818,15 +1871,7 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
             ws_peak_select_kernel<<<ngroups, 1024, (size_t)pcap * 16, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val, cand_idx,
                                                                         labels, marker_idx, marker_count, no_sel2 ? 0 : 1);
         LAUNCH_CHECK();
-        if (mode2d) {
-            ws_cc_init_merge_kernel<true><<<nb, 256, 0, st>>>(g, mask, parent, 1); LAUNCH_CHECK();
-        } else {
-            ws_cc_init_merge_kernel<false><<<nb, 256, 0, st>>>(g, mask, parent, 1); LAUNCH_CHECK();
-        }
-        cc_flatten_kernel<<<nb, 256, 0, st>>>(V, parent, size);
-        LAUNCH_CHECK();
-        ws_heap_alloc_kernel<<<nb, 256, 0, st>>>(V, parent, size, heap_off, heap_cnt, bump);
-        LAUNCH_CHECK();
+        if (aux) HIPCHK(hipStreamWaitEvent(st, aux->join, 0));                    // the components of the mask (stage_components, helper stream)
         ws_marker_append_kernel<<<(unsigned)((ngroups * pcap + 255) / 256), 256, 0, st>>>(ngroups, pcap, marker_idx, marker_count, smooth, parent, heap_off,
                                                                                        heap_cnt, heap, roots, nroots, labels);
         LAUNCH_CHECK();
@@ -1837,8 +1882,16 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
         // replayed by a kernel that looks at its own flag, and a peak-table overflow is latched and reported through n_out (-2) by ws_finish_kernel.
         // (Until round 4 each stage copied list length and flags to the host and waited: two idle gaps per call.)
         static const bool no_upstream = getenv("CT_WS_UPSTREAM_TIES") && atoi(getenv("CT_WS_UPSTREAM_TIES")) == 0;   // (A/B: raveled order among equal seeds)
-        ws_fill_single_kernel<<<nb, 256, 0, st>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox);
+        // the boxes first (the LDS flood needs them); the fill of the single-marker components touches no voxel of a listed component and runs
+        // on the helper stream beside the floods (a handful of waves walking sequentially for 70-310 us)
+        ws_fill_single_kernel<<<nb, 256, 0, st>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, aux ? 2 : 3);
         LAUNCH_CHECK();
+        if (aux) {
+            HIPCHK(hipEventRecord(aux->fork, st)); HIPCHK(hipStreamWaitEvent(aux->stream, aux->fork, 0));
+            ws_fill_single_kernel<<<nb, 256, 0, aux->stream>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, 1);
+            LAUNCH_CHECK();
+            HIPCHK(hipEventRecord(aux->join, aux->stream));
+        }
         {
             static const bool thread_flood = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 0;      // (A/B: one thread per component, binary heap)
             constexpr unsigned FLOOD_GRID = 512;
@@ -1864,6 +1917,7 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
             }
             LAUNCH_CHECK();
         }
+        if (aux) HIPCHK(hipStreamWaitEvent(st, aux->join, 0));                    // (the replay below clears and refloods whole groups)
         if (!no_upstream) {                                                      // equal seeds inside one component: those groups again, with upstream's heap
             if (mode2d) ws_flood_upstream_kernel<true><<<ngroups, 64, 0, st>>>(g, mask, smooth, pcap, marker_idx, marker_count, tie_flags, heap, labels);
             else ws_flood_upstream_kernel<false><<<1, 64, 0, st>>>(g, mask, smooth, pcap, marker_idx, marker_count, tie_flags, heap, labels);
