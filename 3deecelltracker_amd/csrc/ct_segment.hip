@@ -1424,6 +1424,264 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
     }
 }
 
+// ---- the LDS flood, batched: several pops per round, the sequential algorithm's result ----------------------------------------------------------
+// ws_flood_box_kernel pays ~1300 cycles per pop (one wave's dependent instruction stream), 540 pops for the largest component of the benchmark
+// stack.  Most consecutive pops do not depend on each other.  With KB = the largest key (= smallest -smooth) among the still unlabelled
+// in-component neighbours of ALL queue entries, every entry the sequential flood pushes from now on is one of those neighbours or a later
+// one's, i.e. has key <= KB; so the entries with key > KB -- strictly: an equal key would fall through to the ages -- leave the heap in key
+// order before anything that is pushed meanwhile, whatever is pushed meanwhile.  A round pops them together (at most 64, the first 64 in pop
+// order: a prefix of a valid batch is valid; the entry at the top of the heap always pops, with or without company):
+//   A  every entry's bound is refreshed lazily (it remembers WHICH neighbour gave it: while that one is unlabelled the bound is exact; else the
+//      six neighbours are looked at again; an entry without unlabelled neighbours never gets one back), KB and the top entry by wave reductions;
+//   B  the members are collected, ranked in pop order (key, age, index) by counting, lane r takes the member of rank r;
+//   C  the members leave the queue (in-place compaction);
+//   D  a neighbour voxel goes to the FIRST pop that touches it: claims by LDS atomicMin of (rank, direction) in the voxel's state word;
+//   E  the winner labels the voxel and pushes it with age = round base + rank * 8 + direction: the sequential flood's ages are the running
+//      count of pushes, ordered by (pop order, direction order) -- these are not the same numbers but the same ORDER, and only the order
+//      of ages is ever read (to break exact ties of the key).
+// An offline model of this rule on the benchmark stack's stages reproduces the sequential labels with 239 rounds for 7329 pops (3-D stage; 31
+// rounds for the component that sets the time) and 49 for 597 (2-D stage).  When nothing unlabelled is left next to the queue the remaining pops
+// cannot push: the walk ends there.  Overflow of the queue hands the component back untouched, as before.
+constexpr int WS_BATCH_MEM = 256;                  // members ranked per round (more: the round pops the top entry alone)
+constexpr int WS_CM = 0x07ffffff;                  // packed coordinates inside an entry's idx; bits 27-29: which neighbour gave the entry's bound
+constexpr size_t WS_BATCH_LDS = (size_t)WS_Q_LDS * (sizeof(WsQEntry) + 8 + 2) + (size_t)WS_BATCH_MEM * 8 + 64 * 4 + (size_t)WS_BOX_CAP * 12;
+__device__ __forceinline__ bool ws_qbefore_c(const WsQEntry& a, const WsQEntry& b) {          // ws_qbefore on the coordinates alone
+    const unsigned long long ta = ((unsigned long long)(unsigned int)a.age << 32) | (unsigned int)(a.idx & WS_CM),
+                             tb = ((unsigned long long)(unsigned int)b.age << 32) | (unsigned int)(b.idx & WS_CM);
+    return a.key > b.key || (a.key == b.key && ta < tb);
+}
+template <bool MODE2D>
+__global__ __launch_bounds__(64) void ws_flood_batch_kernel(SegGeom g, const double* __restrict__ smooth, const int32_t* __restrict__ parent,
+                                                            const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots, const int32_t* __restrict__ size,
+                                                            const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
+                                                            const WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ bbox, int32_t* __restrict__ labels,
+                                                            int qcap) {
+    extern __shared__ unsigned long long ws_box_sm[];
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (unsigned int slot = blockIdx.x; slot < *nroots; slot += gridDim.x) {
+    const int root = roots[slot];
+    int32_t* bb = bbox + (size_t)slot * 6;
+    if (!ws_box_eligible(bb, size[root], MODE2D) || heap_cnt[root] > WS_Q_LDS) continue;
+    if (heap_cnt[root] > qcap) { if (lane == 0) bb[3] = 0x7fffffff; continue; }
+    __builtin_amdgcn_wave_barrier();
+    WsQEntry* const q = (WsQEntry*)ws_box_sm;                                    // [WS_Q_LDS]
+    double* const sm_box = (double*)(q + WS_Q_LDS);                              // [WS_BOX_CAP]
+    int32_t* const st_box = (int32_t*)(sm_box + WS_BOX_CAP);                     // [WS_BOX_CAP]  -1 outside, 0 free, > 0 label, < -1 a claim in flight
+    unsigned long long* const qn = (unsigned long long*)(st_box + WS_BOX_CAP);   // [WS_Q_LDS]    an entry's bound: largest key among its unlabelled neighbours
+    unsigned long long* const skey = qn + WS_Q_LDS;                              // [WS_BATCH_MEM] the round's members' keys
+    unsigned short* const slist = (unsigned short*)(skey + WS_BATCH_MEM);        // [WS_Q_LDS]    their queue positions
+    int* const bposs = (int*)(slist + WS_Q_LDS);                                 // [64]          queue position of the member of rank r / fillers
+    const int x0 = bb[0], y0 = bb[1], z0 = MODE2D ? root % g.Z : bb[2];
+    const int BX = bb[3] - x0 + 1, BY = bb[4] - y0 + 1, BZ = MODE2D ? 1 : bb[5] - z0 + 1;
+    const int bvol = BX * BY * BZ;
+    const long long sx = (long long)g.Y * g.Z, sy = g.Z;
+    const int d64z = 64 % BZ, d64y = (64 / BZ) % BY, d64x = 64 / (BZ * BY);
+    {
+        int lz = lane % BZ, ly = (lane / BZ) % BY, lx = lane / (BZ * BY);
+        for (int p = lane; p < bvol; p += 64) {
+            const long long j = (long long)(x0 + lx) * sx + (long long)(y0 + ly) * sy + (z0 + lz);
+            const bool mine = parent[j] == root;
+            sm_box[p] = smooth[j];
+            st_box[p] = mine ? labels[j] : -1;
+            lz += d64z; if (lz >= BZ) { lz -= BZ; ++ly; }
+            ly += d64y; if (ly >= BY) { ly -= BY; ++lx; }
+            lx += d64x;
+        }
+    }
+    int n = heap_cnt[root];
+    const WsHeapEntry* gq = heap_all + heap_off[root];
+    for (int e = lane; e < n; e += 64) {
+        const WsHeapEntry t = gq[e];
+        int x, y, z; ws_xyz(t.idx, g, x, y, z);
+        q[e] = WsQEntry{(unsigned long long)__double_as_longlong(-t.value), 0, ((x - x0) << 17) | ((y - y0) << 7) | (z - z0) | (7 << 27)};
+        qn[e] = 0ull;
+    }
+    __syncthreads();
+    const int SXB = BY * BZ;
+    // neighbour d of the voxel with packed coordinates c / box index lin, in ascending raveled-offset order: x-1, y-1, z-1, z+1, y+1, x+1
+    auto nbr = [&](int c, int lin, int d, int& nb, int& cn) -> bool {
+        const int lx = c >> 17, ly = (c >> 7) & 1023, lz = c & 127;
+        bool v; int dl, dc;
+        if (d == 0) { v = lx > 0; dl = -SXB; dc = -(1 << 17); }
+        else if (d == 1) { v = ly > 0; dl = -BZ; dc = -(1 << 7); }
+        else if (d == 2) { v = lz > 0; dl = -1; dc = -1; }
+        else if (d == 3) { v = lz + 1 < BZ; dl = 1; dc = 1; }
+        else if (d == 4) { v = ly + 1 < BY; dl = BZ; dc = 1 << 7; }
+        else { v = lx + 1 < BX; dl = SXB; dc = 1 << 17; }
+        nb = v ? lin + dl : lin; cn = c + dc;
+        return v;
+    };
+    auto lin_of = [&](int c) { return ((c >> 17) * BY + ((c >> 7) & 1023)) * BZ + (c & 127); };
+    int base = 1; bool overflowed = false, single = false;
+    while (n > 0) {
+        // ---- A: bounds (lazily refreshed), top entry; entries without an unlabelled neighbour leave the queue here: their pop labels and
+        //         pushes nothing, whenever it happens (the sweep compacts in place: an entry moves to a position <= its own, reads first)
+        WsQEntry best{0ull, 0, 0}; int bpos = -1; unsigned long long kb = 0ull;
+        {
+            int w = 0;
+            for (int b0 = 0; b0 < n; b0 += 64) {
+                const int e = b0 + lane;
+                WsQEntry t{0ull, 0, 0}; int d = 6; unsigned long long nk = 0ull;
+                if (e < n) {
+                    t = q[e];
+                    d = (t.idx >> 27) & 7;
+                    t.idx &= WS_CM;
+                    const int lin = lin_of(t.idx);
+                    bool fresh = false;
+                    if (d < 6) { int nb, cn; (void)nbr(t.idx, lin, d, nb, cn); const int st = st_box[nb]; nk = qn[e]; fresh = st == 0; }
+                    if (!fresh) {
+                        int st6[6]; unsigned long long k6[6]; bool v6[6];
+#pragma unroll
+                        for (int dd = 0; dd < 6; ++dd) {
+                            int nb, cn; v6[dd] = nbr(t.idx, lin, dd, nb, cn);
+                            st6[dd] = st_box[nb]; k6[dd] = (unsigned long long)__double_as_longlong(sm_box[nb]);
+                        }
+                        nk = 0ull; d = 6;
+#pragma unroll
+                        for (int dd = 0; dd < 6; ++dd) {
+                            if (MODE2D && (dd == 2 || dd == 3)) continue;
+                            if (v6[dd] && st6[dd] == 0 && (d == 6 || k6[dd] > nk)) { nk = k6[dd]; d = dd; }
+                        }
+                    }
+                }
+                const bool keep = d != 6;
+                const unsigned long long mk = __ballot(keep);
+                if (keep) {
+                    const int p = w + (int)__popcll(mk & lt);
+                    q[p] = WsQEntry{t.key, t.age, t.idx | (d << 27)}; qn[p] = nk;
+                    kb = nk > kb ? nk : kb;
+                    if (bpos < 0 || ws_qbefore(t, best)) { best = t; bpos = p; }
+                }
+                w += (int)__popcll(mk);
+            }
+            n = w;
+        }
+        if (n == 0) break;                                   // (uniform) nothing unlabelled beside the queue: the remaining pops push nothing
+        const unsigned long long KB = single ? ~0ull : ws_wave_max_u64(kb);
+        single = false;
+        int c1;
+        ws_wave_argmin(best, bpos, c1, lane);
+        // ---- B: the members (key > KB, and the top entry), ranked in pop order by counting
+        int m = 0;
+        for (int b0 = 0; b0 < n; b0 += 64) {
+            const int e = b0 + lane;
+            unsigned long long k = 0ull;
+            if (e < n) k = q[e].key;
+            const bool mem = e < n && (k > KB || e == bpos);
+            const unsigned long long mk = __ballot(mem);
+            if (mem) { const int j = m + (int)__popcll(mk & lt); slist[j] = (unsigned short)e; if (j < WS_BATCH_MEM) skey[j] = k; }
+            m += (int)__popcll(mk);
+        }
+        if (m > WS_BATCH_MEM) { single = true; continue; }   // (uniform; rare) more members than the table ranks: this round pops the top entry alone
+        __builtin_amdgcn_wave_barrier();
+        const int bc = m < 64 ? m : 64;
+        {
+            bool tie = false;
+            if (m <= 64) {                                   // the usual case: member j's key sits in lane j, the others' arrive by v_readlane
+                const unsigned long long mine = lane < m ? skey[lane] : 0ull;
+                const int mh = (int)(mine >> 32), ml = (int)mine;
+                int r = 0, eq = 0;
+                for (int k = 0; k < m; ++k) {
+                    const unsigned long long o = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(mh, k) << 32) | (unsigned int)__builtin_amdgcn_readlane(ml, k);
+                    r += o > mine ? 1 : 0; eq += o == mine ? 1 : 0;
+                }
+                tie = lane < m && eq > 1;
+                if (lane < m) bposs[r] = (int)slist[lane];
+            } else {
+                for (int j = lane; j < m; j += 64) {
+                    const unsigned long long mine = skey[j];
+                    int r = 0, eq = 0;
+                    for (int k = 0; k < m; ++k) { const unsigned long long o = skey[k]; r += o > mine ? 1 : 0; eq += o == mine ? 1 : 0; }
+                    tie = tie || eq > 1;
+                    if (r < 64) bposs[r] = (int)slist[j];
+                }
+            }
+            if (__ballot(tie) != 0ull) {                     // (uniform; exact ties of the key among the members) the full order: key, age, index
+                for (int j = lane; j < m; j += 64) {
+                    const WsQEntry mine = q[slist[j]];
+                    int r = 0;
+                    for (int k = 0; k < m; ++k) { const WsQEntry o = q[slist[k]]; r += ws_qbefore_c(o, mine) ? 1 : 0; }
+                    if (r < 64) bposs[r] = (int)slist[j];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        int mypos = 0, mc = 0, mlin = 0, mlab = 0;
+        const bool act = lane < bc;
+        if (act) { mypos = bposs[lane]; mc = q[mypos].idx & WS_CM; mlin = lin_of(mc); mlab = st_box[mlin]; }
+        // ---- C: they leave the queue: the holes below the new length are filled from the tail
+        if (act) q[mypos].age = -1;
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int n2 = n - bc;
+            const int fpos = n2 + lane;
+            const bool isf = act && q[fpos].age != -1;
+            const bool ish = act && mypos < n2;
+            const unsigned long long fm = __ballot(isf), hm = __ballot(ish);
+            if (isf) bposs[(int)__popcll(fm & lt)] = fpos;
+            __builtin_amdgcn_wave_barrier();
+            if (ish) { const int src = bposs[(int)__popcll(hm & lt)]; q[mypos] = q[src]; qn[mypos] = qn[src]; }
+            n = n2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- D: claims: a neighbour goes to the first pop that touches it
+        const int cvb = -(1 << 30) + lane * 8;
+        int nb6[6], cn6[6]; bool v6[6];
+        {
+            int st6[6];
+#pragma unroll
+            for (int dd = 0; dd < 6; ++dd) { v6[dd] = act && nbr(mc, mlin, dd, nb6[dd], cn6[dd]); st6[dd] = st_box[act ? nb6[dd] : 0]; }
+#pragma unroll
+            for (int dd = 0; dd < 6; ++dd) {
+                if (MODE2D && (dd == 2 || dd == 3)) { v6[dd] = false; continue; }
+                v6[dd] = v6[dd] && (st6[dd] == 0 || st6[dd] < -1);
+                if (v6[dd]) atomicMin(&st_box[nb6[dd]], cvb + dd);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- E: the winners label and push
+        {
+            int st6[6]; unsigned long long k6[6];
+#pragma unroll
+            for (int dd = 0; dd < 6; ++dd) { st6[dd] = st_box[act ? nb6[dd] : 0]; k6[dd] = (unsigned long long)__double_as_longlong(sm_box[act ? nb6[dd] : 0]); }
+#pragma unroll
+            for (int dd = 0; dd < 6; ++dd) {
+                if (MODE2D && (dd == 2 || dd == 3)) continue;
+                const bool won = v6[dd] && st6[dd] == cvb + dd;
+                const unsigned long long mk = __ballot(won);
+                const int cnt = (int)__popcll(mk);
+                if (n + cnt > qcap) { overflowed = true; break; }
+                if (won) {
+                    const int p = n + (int)__popcll(mk & lt);
+                    st_box[nb6[dd]] = mlab;
+                    q[p] = WsQEntry{k6[dd], base + lane * 8 + dd, cn6[dd] | (7 << 27)};
+                    qn[p] = 0ull;
+                }
+                n += cnt;
+            }
+        }
+        if (overflowed) break;
+        base += 512;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (overflowed) {
+        if (lane == 0) bb[3] = 0x7fffffff;
+        continue;
+    }
+    {
+        int lz = lane % BZ, ly = (lane / BZ) % BY, lx = lane / (BZ * BY);
+        for (int p = lane; p < bvol; p += 64) {
+            const int lab = st_box[p];
+            if (lab > 0) labels[(long long)(x0 + lx) * sx + (long long)(y0 + ly) * sy + (z0 + lz)] = lab;
+            lz += d64z; if (lz >= BZ) { lz -= BZ; ++ly; }
+            ly += d64y; if (ly >= BY) { ly -= BY; ++lx; }
+            lx += d64x;
+        }
+    }
+    }
+}
+
 // Do two seeds of EXACTLY equal height share a mask component?  Only then does the order in which upstream's heap releases equal seeds matter
 // (seeds are the only entries that can compare equal: every later entry carries its own age), and only then does the group (z slice in the
 // 2-D stage, the volume in the 3-D stage) take the sequential path below.  One thread per listed component (>= 2 markers).
@@ -1791,6 +2049,8 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_SEL2_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_box_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BOX_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_box_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BOX_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_batch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BATCH_LDS));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_batch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BATCH_LDS));
 
     // one pass of: peaks of `smooth` -> markers -> components of `mask` -> flood into `labels`
     static const bool no_slide = getenv("CT_WS_SLIDE") && atoi(getenv("CT_WS_SLIDE")) == 0;                   // (A/B: the per-voxel filter kernels)
@@ -1904,9 +2164,16 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
                 // state in global memory); else -> ws_flood_kernel (one thread, binary heap: O(log n) per pop for clumps of tens of thousands of voxels)
                 static const bool no_box = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 1;         // (A/B: no LDS-resident flood)
                 if (!no_box) {
-                    static const int qcap = getenv("CT_WS_QCAP") ? (atoi(getenv("CT_WS_QCAP")) < WS_Q_LDS ? atoi(getenv("CT_WS_QCAP")) : WS_Q_LDS) : WS_Q_LDS;   // (tests: force the hand-back)
-                    if (mode2d) ws_flood_box_kernel<true><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels, qcap);
-                    else ws_flood_box_kernel<false><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels, qcap);
+                    static const int qcap0 = getenv("CT_WS_QCAP") ? (atoi(getenv("CT_WS_QCAP")) < WS_Q_LDS ? atoi(getenv("CT_WS_QCAP")) : WS_Q_LDS) : WS_Q_LDS;   // (tests: force the hand-back)
+                    static const int qcap = qcap0;
+                    static const bool no_batch = getenv("CT_WS_BATCH") && atoi(getenv("CT_WS_BATCH")) == 0;          // (A/B: one pop per round)
+                    if (no_batch) {
+                        if (mode2d) ws_flood_box_kernel<true><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels, qcap);
+                        else ws_flood_box_kernel<false><<<FLOOD_GRID, 64, WS_BOX_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels, qcap);
+                    } else {
+                        if (mode2d) ws_flood_batch_kernel<true><<<FLOOD_GRID, 64, WS_BATCH_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels, qcap);
+                        else ws_flood_batch_kernel<false><<<FLOOD_GRID, 64, WS_BATCH_LDS, st>>>(g, smooth, parent, roots, nroots, size, heap_off, heap_cnt, heap, bbox, labels, qcap);
+                    }
                     LAUNCH_CHECK();
                 }
                 if (mode2d) ws_flood_wave_kernel<true><<<FLOOD_GRID, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
