@@ -34,6 +34,14 @@ def tie_case():
     return prob
 
 
+def wide_front_case():
+    """Two large overlapping discs per slice (one component of ~4500 pixels inside a 100 x 60 box, two markers): the flood's frontier grows to a
+    few hundred entries, i.e. rounds of the batched LDS flood with more members than lanes; a ragged plateau keeps the distances irregular."""
+    prob = blobs((128, 96, 4), [(42, 48, 1.5), (84, 48, 1.5)], [29, 27], z_flat=1.0, level=0.8)
+    prob += np.random.default_rng(3).uniform(0, 0.2, prob.shape).astype(np.float32) * (prob > 0)
+    return prob
+
+
 def random_case(shape, n, seed, specks=True):
     rng = np.random.default_rng(seed)
     lo = np.array([8, 8, 2]); hi = np.array([shape[0] - 8, shape[1] - 8, shape[2] - 2])

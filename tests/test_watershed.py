@@ -239,25 +239,28 @@ def test_device_watershed_on_a_large_clump():
     assert np.array_equal(got[1], want[1])
 
 
-_ALT_PATHS = [{"CT_WS_FLOOD": "0"}, {"CT_WS_FLOOD": "1"}, {"CT_WS_QCAP": "8"}, {"CT_WS_SLIDE": "0"}, {"CT_WS_SELECT": "0"}]
+_ALT_PATHS = [{"CT_WS_FLOOD": "0"}, {"CT_WS_FLOOD": "1"}, {"CT_WS_QCAP": "8"}, {"CT_WS_SLIDE": "0"}, {"CT_WS_SELECT": "0"},
+              {"CT_WS_BATCH": "0"}, {"CT_WS_BATCH": "0", "CT_WS_QCAP": "8"}, {"CT_WS_FORK": "0"}, {"CT_WS_MCAP": "3"}]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", _ALT_PATHS, ids=lambda e: "-".join(f"{k}={v}" for k, v in e.items()))
 def test_device_watershed_alternative_paths_give_the_same_labels(env):
     """Every switchable path of the device watershed -- binary-heap flood for all components, global-state wave flood, the LDS flood handing
-    components back when its queue is (artificially) too short, per-voxel filters, bitonic-sort peak selection -- produces the oracle's labels
+    components back when its queue is (artificially) too short (batched and one pop per round), per-voxel filters, bitonic-sort peak selection,
+    the one-pop-per-round LDS flood, the serial form without the helper stream, batched rounds whose member table is (artificially) three
+    entries long -- produces the oracle's labels
     (the switches are read once per process: each variant runs in its own interpreter)."""
     import os
     import subprocess
     code = """
 import sys, importlib, numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
-from _ws_cases import touching_case, random_case, tie_case
+from _ws_cases import touching_case, random_case, tie_case, wide_front_case
 from oracle import watershed_ref as wr
 seg = importlib.import_module("3deecelltracker_amd.segment")
 bad = 0
-for prob, zr, ms in ((touching_case(), 3.0, 40), (random_case((120, 100, 16), 40, 1), 4.0, 20), (tie_case(), 2.0, 5)):
+for prob, zr, ms in ((touching_case(), 3.0, 40), (random_case((120, 100, 16), 40, 1), 4.0, 20), (tie_case(), 2.0, 5), (wide_front_case(), 3.0, 40)):
     want = wr.segment_centroids(prob, zr, "min_size", ms)
     got = seg.watershed_centroids(prob, zr, "min_size", ms, 0)
     bad += int(not np.array_equal(got[0], want[0])) + int(not np.array_equal(got[1], want[1]))
