@@ -1099,11 +1099,12 @@ __device__ __forceinline__ bool ws_box_eligible(const int32_t* bb, int csize, bo
 }
 // skimage's priority flood of ONE mask component per thread (see the header of this section)
 template <bool MODE2D>
-__global__ void ws_flood_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth, const int32_t* __restrict__ roots,
+__device__ __forceinline__ void ws_flood_heap_body(unsigned int bid, unsigned int nblk, SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth,
+                                                   const int32_t* __restrict__ roots,
                                 const unsigned int* __restrict__ nroots, const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
                                 WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ labels, const int32_t* __restrict__ size, int larger_than,
                                 const int32_t* __restrict__ bbox) {
-    for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < *nroots; t += gridDim.x * blockDim.x) {
+    for (unsigned int t = bid * blockDim.x + threadIdx.x; t < *nroots; t += nblk * blockDim.x) {
     const int root = roots[t];
     if (size[root] <= larger_than) continue;               // (the wave kernels' share)
     if (bbox && ws_box_eligible(bbox + (size_t)t * 6, size[root], MODE2D) && heap_cnt[root] <= WS_Q_LDS) continue;      // ws_flood_box_kernel's
@@ -1215,7 +1216,7 @@ __global__ void ws_fill_single_kernel(SegGeom g, const int32_t* __restrict__ par
 // pushed with consecutive ages in ascending raveled-offset order (ballot prefix), labels given at push time.  Per pop: one LDS sweep, one
 // butterfly, ONE global round trip (the single-thread version pays a dozen dependent ones).
 template <bool MODE2D>
-__global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth,
+__device__ __forceinline__ void ws_flood_wave_body(unsigned int bid, unsigned int nblk, SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth,
                                                            const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots, const int32_t* __restrict__ size,
                                                            const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
                                                            WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ qlab_all, int32_t* __restrict__ labels,
@@ -1223,7 +1224,7 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsi
     __shared__ WsHeapEntry q_lds[WS_Q_LDS];
     __shared__ int32_t l_lds[WS_Q_LDS];
     const int lane = threadIdx.x;
-    for (unsigned int slot = blockIdx.x; slot < *nroots; slot += gridDim.x) {   // (the host no longer waits for the list's length: a fixed grid walks it)
+    for (unsigned int slot = bid; slot < *nroots; slot += nblk) {               // (the host no longer waits for the list's length: a fixed grid walks it)
     const int root = roots[slot];
     if (bbox && ws_box_eligible(bbox + (size_t)slot * 6, size[root], MODE2D) && heap_cnt[root] <= WS_Q_LDS) continue;      // ws_flood_box_kernel's
     if (size[root] > WS_HEAP_MIN) continue;                // ws_flood_kernel's (binary heap)
@@ -1282,6 +1283,27 @@ __global__ __launch_bounds__(64) void ws_flood_wave_kernel(SegGeom g, const unsi
         __syncthreads();                                   // one wave: orders this iteration's queue writes before the next sweep
     }
     }
+}
+
+template <bool MODE2D>
+__global__ void ws_flood_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth, const int32_t* __restrict__ roots,
+                                const unsigned int* __restrict__ nroots, const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
+                                WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ labels, const int32_t* __restrict__ size, int larger_than,
+                                const int32_t* __restrict__ bbox) {
+    ws_flood_heap_body<MODE2D>(blockIdx.x, gridDim.x, g, bn, smooth, roots, nroots, heap_off, heap_cnt, heap_all, labels, size, larger_than, bbox);
+}
+// the components the LDS flood does not take, one launch: blocks [0, WS_REST_WAVE) walk the list as ws_flood_wave_body (one wave per component, swept
+// queue), blocks [WS_REST_WAVE, WS_REST_WAVE + WS_REST_HEAP) as ws_flood_heap_body (one thread per component, binary heap); every listed component
+// belongs to exactly one of them (two mostly empty launches were 9 us of every stage)
+constexpr unsigned WS_REST_WAVE = 512, WS_REST_HEAP = 64;
+template <bool MODE2D>
+__global__ __launch_bounds__(64) void ws_flood_rest_kernel(SegGeom g, const unsigned char* __restrict__ bn, const double* __restrict__ smooth,
+                                                           const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots, const int32_t* __restrict__ size,
+                                                           const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
+                                                           WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ qlab_all, int32_t* __restrict__ labels,
+                                                           const int32_t* __restrict__ bbox, int larger_than) {
+    if (blockIdx.x < WS_REST_WAVE) ws_flood_wave_body<MODE2D>(blockIdx.x, WS_REST_WAVE, g, bn, smooth, roots, nroots, size, heap_off, heap_cnt, heap_all, qlab_all, labels, bbox);
+    else ws_flood_heap_body<MODE2D>(blockIdx.x - WS_REST_WAVE, WS_REST_HEAP, g, bn, smooth, roots, nroots, heap_off, heap_cnt, heap_all, labels, size, larger_than, bbox);
 }
 
 // queue entry of the LDS flood: key = bit pattern of the smoothed EDT (>= +0.0, so the patterns order like the values and the LARGEST key is the
@@ -2030,6 +2052,13 @@ __global__ void ws_relabel8_kernel(SegGeom g, const unsigned char* __restrict__ 
     }
 }
 
+struct WsClear { unsigned long long* p[5]; unsigned int n[5]; unsigned long long v[5]; };          // up to five DISJOINT ranges of 8-byte words and their fill
+__global__ void ws_clear_kernel(WsClear c) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n[r]; i += gridDim.x * blockDim.x) c.p[r][i] = c.v[r];
+}
+
 struct WsLayout { size_t bn, bn2, gx, d2, dist, tmp, smooth, vmax, labels, parent, size, heap_off, heap_cnt, heap, qlab, roots, cand_val, cand_idx, marker_idx,
                   stats, sums, weights, bbox, total; int ngroups2d; };
 WsLayout ws_layout(long long V, int Z, int cap) {
@@ -2209,9 +2238,20 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     WsAux* aux = nullptr;
     if (!no_fork) { aux_lock.lock(); aux = ws_aux_for_current_device(); if (!aux) aux_lock.unlock(); }
     // the per-stage clears
-    auto stage_clear = [&]() -> int {
-        HIPCHK(hipMemsetAsync(ws + L.stats, 0, 3584, st));
-        HIPCHK(hipMemsetAsync(vmin, 0xff, 128 * sizeof(unsigned long long), st));
+    // (the small clears of a stage are one launch: five memsets of a few KB each were 25 us of a call; the first stage's carries the latch, the
+    // second's the tables of the final bookkeeping, which nothing touches before)
+    auto stage_clear = [&](bool first) -> int {
+        WsClear c{};
+        c.p[0] = (unsigned long long*)(ws + L.stats); c.n[0] = 512 / 8; c.v[0] = 0ull;                 // eq_count
+        c.p[1] = vmin; c.n[1] = 128; c.v[1] = ~0ull;                                                  // (stats + 512 .. + 1536)
+        c.p[2] = (unsigned long long*)(ws + L.stats + 1536); c.n[2] = (3584 - 1536) / 8; c.v[2] = 0ull;
+        if (first) { c.p[3] = (unsigned long long*)latch; c.n[3] = 2; c.v[3] = 0ull; }
+        else {
+            c.p[3] = (unsigned long long*)counts; c.n[3] = (unsigned int)(WS_PEAK_CAP3D + 1); c.v[3] = 0ull;
+            c.p[4] = sums; c.n[4] = (unsigned int)cap * 4u; c.v[4] = 0ull;
+        }
+        ws_clear_kernel<<<16, 256, 0, st>>>(c);
+        LAUNCH_CHECK();
         HIPCHK(hipMemsetAsync(labels, 0, (size_t)V * 4, st));
         return CT_OK;
     };
@@ -2246,7 +2286,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         // separable window maximum: smooth -> tmp -> (dist ->) [vmax]; the last pass carries the peak test (the maximum itself is only written
         // for the tests' hook)
         double* const vmax_out = (method_in & 0x300) ? vmax : nullptr;
-        { const int rcc = stage_clear(); if (rcc) return rcc; }
+        { const int rcc = stage_clear(mode2d); if (rcc) return rcc; }
         max_pass(0, smooth, tmp, min_distance);
         LAUNCH_CHECK();
         if (mode2d) {
@@ -2324,11 +2364,10 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
                     }
                     LAUNCH_CHECK();
                 }
-                if (mode2d) ws_flood_wave_kernel<true><<<FLOOD_GRID, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
-                else ws_flood_wave_kernel<false><<<FLOOD_GRID, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels, no_box ? nullptr : bbox);
-                LAUNCH_CHECK();
-                if (mode2d) ws_flood_kernel<true><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels, size, WS_HEAP_MIN, no_box ? nullptr : bbox);
-                else ws_flood_kernel<false><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels, size, WS_HEAP_MIN, no_box ? nullptr : bbox);
+                if (mode2d) ws_flood_rest_kernel<true><<<WS_REST_WAVE + WS_REST_HEAP, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels,
+                                                                                                  no_box ? nullptr : bbox, WS_HEAP_MIN);
+                else ws_flood_rest_kernel<false><<<WS_REST_WAVE + WS_REST_HEAP, 64, 0, st>>>(g, mask, smooth, roots, nroots, size, heap_off, heap_cnt, heap, qlab, labels,
+                                                                                             no_box ? nullptr : bbox, WS_HEAP_MIN);
             }
             LAUNCH_CHECK();
         }
@@ -2341,7 +2380,6 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
         return CT_OK;
     };
 
-    HIPCHK(hipMemsetAsync(latch, 0, 16, st));
     // ---- watershed_2d (watershed.py:16-53), all z slices at once
     ws_threshold_kernel<<<nb, 256, 0, st>>>(prob, V, bn, parent, size);
     LAUNCH_CHECK();
@@ -2383,8 +2421,6 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
     if (rc) return rc;
 
     // ---- sizes, min_size / cell_num, small objects dropped, sequential labels, centres (watershed.py:88-96, tracker.py:680, :646-647)
-    HIPCHK(hipMemsetAsync(counts, 0, (size_t)(WS_PEAK_CAP3D + 1) * 8, st));
-    HIPCHK(hipMemsetAsync(sums, 0, (size_t)cap * 4 * 8, st));
     if (sparse) ws_bincount8_kernel<<<nb8, 256, 0, st>>>(V, bn2, labels, WS_PEAK_CAP3D, counts);
     else ws_bincount_kernel<<<nb, 256, 0, st>>>(V, labels, WS_PEAK_CAP3D, counts);
     LAUNCH_CHECK();
