@@ -281,10 +281,12 @@ SegLayout seg_layout(long long V, int cap) {
 //     components of the mask never interact, and inside a component the order of pops only depends on the component's own entries, so
 //     every component is flooded on its own, hundreds side by side, with the sequential algorithm's result bit for bit: a component with ONE
 //     marker is filled with its label; one with several gets a wave whose queue, smoothed EDT and label state live in LDS (its bounding box:
-//     ws_flood_box_kernel), or -- too large for that -- a wave with the state in global memory (ws_flood_wave_kernel) or a thread with a binary
-//     heap (ws_flood_kernel, clumps beyond 8192 voxels).  Seeds of EXACTLY equal height inside one component leave upstream's heap in an
+//     ws_flood_batch_kernel -- several pops per round where they provably do not depend on each other, the sequential labels bit for bit;
+//     ws_flood_box_kernel is the one-pop-per-round form), or -- too large for that -- a wave with the state in global memory or a thread with a
+//     binary heap (ws_flood_rest_kernel = ws_flood_wave_body / ws_flood_heap_body, clumps beyond 8192 voxels).  Seeds of EXACTLY equal height inside one component leave upstream's heap in an
 //     order that depends on the whole image: the groups (z slice / volume) that hold such a pair are replayed sequentially with upstream's
-//     own heap (ws_flood_upstream_kernel).  Nothing is copied to the host on the way: lists and flags stay on the device.
+//     own heap (ws_flood_upstream_kernel).  Nothing is copied to the host on the way: lists and flags stay on the device.  The sweeps that
+//     depend on the mask alone (its components) run on a helper stream beside the peak selection, the fill beside the floods (WsAux).
 // All volume arrays are [x][y][z] like the probability map; threads run over z fastest so that every 1-D pass along x or y is a
 // coalesced sweep.
 // ================================================================================================
@@ -2088,13 +2090,17 @@ WsLayout ws_layout(long long V, int Z, int cap) {
 // (hipStreamWaitEvent takes the record made before it in host order), not the work itself.
 struct WsAux { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
 std::mutex ws_aux_mutex;
-WsAux* ws_aux_for_current_device() {
-    static WsAux aux[64];
-    int dev = 0;
+// one helper per device and PRIORITY of the caller's stream: a frame loop runs the watershed on a high-priority stream beside the U-Net, and a
+// helper of normal priority would queue the caller's dependencies behind the U-Net's workgroups (measured: the sequence of frames 6.8 -> 7.7 ms)
+WsAux* ws_aux_for(hipStream_t caller) {
+    static WsAux aux[64][8];
+    int dev = 0, prio = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    WsAux& a = aux[dev];
+    if (hipStreamGetPriority(caller, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
+    const int slot = prio + 4 < 0 ? 0 : (prio + 4 > 7 ? 7 : prio + 4);
+    WsAux& a = aux[dev][slot];
     if (!a.ok) {
-        if (hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithPriority(&a.stream, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
         a.ok = true;
@@ -2236,7 +2242,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     static const bool no_fork = getenv("CT_WS_FORK") && atoi(getenv("CT_WS_FORK")) == 0;
     std::unique_lock<std::mutex> aux_lock(ws_aux_mutex, std::defer_lock);
     WsAux* aux = nullptr;
-    if (!no_fork) { aux_lock.lock(); aux = ws_aux_for_current_device(); if (!aux) aux_lock.unlock(); }
+    if (!no_fork) { aux_lock.lock(); aux = ws_aux_for(st); if (!aux) aux_lock.unlock(); }
     // the per-stage clears
     // (the small clears of a stage are one launch: five memsets of a few KB each were 25 us of a call; the first stage's carries the latch, the
     // second's the tables of the final bookkeeping, which nothing touches before)
