@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
 // An offline model of this rule on the benchmark stack's stages reproduces the sequential labels with 239 rounds for 7329 pops (3-D stage; 31
 // rounds for the component that sets the time) and 49 for 597 (2-D stage).  When nothing unlabelled is left next to the queue the remaining pops
 // cannot push: the walk ends there.  Overflow of the queue hands the component back untouched, as before.
-constexpr int WS_BATCH_MEM = 256;                  // members ranked per round (more: the round pops the top entry alone)
+constexpr int WS_BATCH_MEM = 256;                  // members ranked per round (more qualify: the threshold is tightened until they fit)
 constexpr int WS_CM = 0x07ffffff;                  // packed coordinates inside an entry's idx; bits 27-29: which neighbour gave the entry's bound
 constexpr size_t WS_BATCH_LDS = (size_t)WS_Q_LDS * (sizeof(WsQEntry) + 8 + 2) + (size_t)WS_BATCH_MEM * 8 + 64 * 4 + (size_t)WS_BOX_CAP * 12;
 __device__ __forceinline__ bool ws_qbefore_c(const WsQEntry& a, const WsQEntry& b) {          // ws_qbefore on the coordinates alone
@@ -1539,7 +1539,7 @@ __global__ __launch_bounds__(64) void ws_flood_batch_kernel(SegGeom g, const dou
         return v;
     };
     auto lin_of = [&](int c) { return ((c >> 17) * BY + ((c >> 7) & 1023)) * BZ + (c & 127); };
-    int base = 1; bool overflowed = false, single = false;
+    int base = 1; bool overflowed = false;
     while (n > 0) {
         // ---- A: bounds (lazily refreshed), top entry; entries without an unlabelled neighbour leave the queue here: their pop labels and
         //         pushes nothing, whenever it happens (the sweep compacts in place: an entry moves to a position <= its own, reads first)
@@ -1584,22 +1584,28 @@ __global__ __launch_bounds__(64) void ws_flood_batch_kernel(SegGeom g, const dou
             n = w;
         }
         if (n == 0) break;                                   // (uniform) nothing unlabelled beside the queue: the remaining pops push nothing
-        const unsigned long long KB = single ? ~0ull : ws_wave_max_u64(kb);
-        single = false;
+        unsigned long long KB = ws_wave_max_u64(kb);
         int c1;
         ws_wave_argmin(best, bpos, c1, lane);
-        // ---- B: the members (key > KB, and the top entry), ranked in pop order by counting
+        // ---- B: the members (key > KB, and the top entry), ranked in pop order by counting.  More members than the table ranks (a very wide
+        //         front): any stricter threshold still selects a prefix of the pop order -- KB moves half way to the top entry's key until they fit
         int m = 0;
-        for (int b0 = 0; b0 < n; b0 += 64) {
-            const int e = b0 + lane;
-            unsigned long long k = 0ull;
-            if (e < n) k = q[e].key;
-            const bool mem = e < n && (k > KB || e == bpos);
-            const unsigned long long mk = __ballot(mem);
-            if (mem) { const int j = m + (int)__popcll(mk & lt); slist[j] = (unsigned short)e; if (j < WS_BATCH_MEM) skey[j] = k; }
-            m += (int)__popcll(mk);
+        for (;;) {
+            m = 0;
+            for (int b0 = 0; b0 < n; b0 += 64) {
+                const int e = b0 + lane;
+                unsigned long long k = 0ull;
+                if (e < n) k = q[e].key;
+                const bool mem = e < n && (k > KB || e == bpos);
+                const unsigned long long mk = __ballot(mem);
+                if (mem) { const int j = m + (int)__popcll(mk & lt); slist[j] = (unsigned short)e; if (j < WS_BATCH_MEM) skey[j] = k; }
+                m += (int)__popcll(mk);
+            }
+            if (m <= mcap) break;                            // (uniform)
+            const unsigned long long topkey = q[bpos].key;
+            KB = topkey > KB ? KB + ((topkey - KB + 1ull) >> 1) : ~0ull;
+            __builtin_amdgcn_wave_barrier();
         }
-        if (m > mcap) { single = true; continue; }   // (uniform; rare) more members than the table ranks: this round pops the top entry alone
         __builtin_amdgcn_wave_barrier();
         const int bc = m < 64 ? m : 64;
         {
@@ -1926,134 +1932,6 @@ __global__ __launch_bounds__(1024) void ws_finish_kernel(long long V, const int3
     if (threadIdx.x == 0) { n_out[0] = s_carry; n_out[1] = s_val[1]; n_out[2] = s_val[0]; }
 }
 
-// ---- sparse sweeps (V % 8 == 0): a thread owns 8 consecutive voxels and leaves at once when the mask has none of them --------------------------------
-// The union-find, queue-offset, fill, box and counting passes only do something on foreground voxels (2 % of the benchmark stack) but were one
-// thread per voxel over 8.4 M voxels: 15-85 us each, bound by the number of waves, not by what they do.  Here a thread reads its 8 mask bytes as
-// one word; 19 of 20 threads stop there.  Same arithmetic per foreground voxel; counts are integer atomics (order-free).
-__device__ __forceinline__ unsigned long long ws_mask8(const unsigned char* __restrict__ bn, long long t) {
-    return *reinterpret_cast<const unsigned long long*>(bn + 8 * t);
-}
-#define WS_FOR_EACH_SET_BYTE(m, k) for (int k; (m) != 0ull && ((k = (__ffsll((long long)(m)) - 1) >> 3), (m) &= ~(0xffull << (8 * k)), true);)
-
-template <bool MODE2D>
-__global__ void ws_cc_merge8_kernel(SegGeom g, const unsigned char* __restrict__ bn, int32_t* __restrict__ parent) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (8 * t >= g.V) return;
-    unsigned long long m = ws_mask8(bn, t);
-    WS_FOR_EACH_SET_BYTE(m, k) {
-        const long long i = 8 * t + k;
-        int x, y, z; ws_xyz(i, g, x, y, z);
-        if (x + 1 < g.X && bn[i + (long long)g.Y * g.Z]) unite(parent, (int)i, (int)(i + (long long)g.Y * g.Z));
-        if (y + 1 < g.Y && bn[i + g.Z]) unite(parent, (int)i, (int)(i + g.Z));
-        if (!MODE2D && z + 1 < g.Z && bn[i + 1]) unite(parent, (int)i, (int)(i + 1));
-    }
-}
-
-__global__ void ws_flatten8_kernel(long long V, const unsigned char* __restrict__ bn, int32_t* __restrict__ parent, int32_t* __restrict__ size) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (8 * t >= V) return;
-    unsigned long long m = ws_mask8(bn, t);
-    int prev = -1, cnt = 0;
-    WS_FOR_EACH_SET_BYTE(m, k) {
-        const long long i = 8 * t + k;
-        const int root = find_root(parent, (int)i);
-        __atomic_store_n(parent + i, root, __ATOMIC_RELAXED);                     // (root is an ancestor of i: walks through i stay valid)
-        if (root == prev) ++cnt;
-        else { if (cnt) atomicAdd(size + prev, cnt); prev = root; cnt = 1; }
-    }
-    if (cnt) atomicAdd(size + prev, cnt);
-}
-
-__global__ void ws_heap_alloc8_kernel(long long V, const unsigned char* __restrict__ bn, const int32_t* __restrict__ parent, const int32_t* __restrict__ size,
-                                      int32_t* __restrict__ heap_off, int32_t* __restrict__ heap_cnt, unsigned int* __restrict__ bump) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (8 * t >= V) return;
-    unsigned long long m = ws_mask8(bn, t);
-    WS_FOR_EACH_SET_BYTE(m, k) {
-        const long long i = 8 * t + k;
-        if (parent[i] == (int32_t)i) { heap_off[i] = (int32_t)atomicAdd(bump, (unsigned int)size[i]); heap_cnt[i] = 0; }
-    }
-}
-
-// ws_fill_single_kernel's two halves; the boxes' bounds only ever shrink / grow, so a bound that a plain read already finds good enough needs
-// no atomic (a stale read can only cause a superfluous one)
-__global__ void ws_fill_single8_kernel(SegGeom g, const unsigned char* __restrict__ bn, const int32_t* __restrict__ parent, const int32_t* __restrict__ heap_off,
-                                       const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap, int32_t* __restrict__ labels,
-                                       const int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox, int what /* 1 fill | 2 boxes */) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (8 * t >= g.V) return;
-    unsigned long long m = ws_mask8(bn, t);
-    WS_FOR_EACH_SET_BYTE(m, k) {
-        const long long i = 8 * t + k;
-        const int root = parent[i];
-        const int cnt = heap_cnt[root];
-        if (cnt == 1 && (what & 1)) {
-            const int mi = heap[heap_off[root]].idx;
-            if (mi != (int)i) labels[i] = labels[mi];
-        }
-        if (cnt >= 2 && (what & 2)) {
-            int x, y, z; ws_xyz(i, g, x, y, z);
-            int32_t* bb = bbox + 6 * (size_t)slot_of[root];
-            if (x < __atomic_load_n(bb + 0, __ATOMIC_RELAXED)) atomicMin(bb + 0, x);
-            if (y < __atomic_load_n(bb + 1, __ATOMIC_RELAXED)) atomicMin(bb + 1, y);
-            if (z < __atomic_load_n(bb + 2, __ATOMIC_RELAXED)) atomicMin(bb + 2, z);
-            if (x > __atomic_load_n(bb + 3, __ATOMIC_RELAXED)) atomicMax(bb + 3, x);
-            if (y > __atomic_load_n(bb + 4, __ATOMIC_RELAXED)) atomicMax(bb + 4, y);
-            if (z > __atomic_load_n(bb + 5, __ATOMIC_RELAXED)) atomicMax(bb + 5, z);
-        }
-    }
-}
-
-__global__ void ws_bincount8_kernel(long long V, const unsigned char* __restrict__ bn, const int32_t* __restrict__ labels, int K, unsigned int* __restrict__ counts) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (8 * t >= V) return;
-    unsigned long long m = ws_mask8(bn, t);
-    int prev = 0; unsigned int cnt = 0;
-    WS_FOR_EACH_SET_BYTE(m, k) {
-        int lab = labels[8 * t + k];
-        if (lab < 0 || lab > K) lab = 0;
-        if (lab == prev) ++cnt;
-        else { if (cnt && prev) atomicAdd(&counts[prev], cnt); prev = lab; cnt = 1; }
-    }
-    if (cnt && prev) atomicAdd(&counts[prev], cnt);
-}
-
-// cc_label_kernel for the watershed's final labels (labels -> newlabel[labels], per-label count and coordinate sums); labels are zero outside bn
-template <bool VEC>
-__global__ void ws_relabel8_kernel(SegGeom g, const unsigned char* __restrict__ bn, const int32_t* __restrict__ labels, const int32_t* __restrict__ newlabel,
-                                   int32_t* __restrict__ labels_out, int cap, unsigned long long* __restrict__ sums) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (8 * t >= g.V) return;
-    unsigned long long m = ws_mask8(bn, t);
-    int out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int prev = 0; unsigned int cnt = 0, sx = 0, sy = 0, sz = 0;
-    auto flush = [&]() {
-        if (cnt && prev > 0 && prev <= cap) {
-            unsigned long long* s = sums + (size_t)(prev - 1) * 4;
-            atomicAdd(s + 0, (unsigned long long)cnt); atomicAdd(s + 1, (unsigned long long)sx); atomicAdd(s + 2, (unsigned long long)sy); atomicAdd(s + 3, (unsigned long long)sz);
-        }
-    };
-    WS_FOR_EACH_SET_BYTE(m, k) {
-        const long long i = 8 * t + k;
-        const int lab = newlabel[labels[i]];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (u == k) out[u] = lab;
-        int x, y, z; ws_xyz(i, g, x, y, z);
-        if (lab != prev) { flush(); prev = lab; cnt = 0; sx = sy = sz = 0; }
-        ++cnt; sx += (unsigned int)x; sy += (unsigned int)y; sz += (unsigned int)z;
-    }
-    flush();
-    if (labels_out) {
-        if (VEC) {
-            int4* o = reinterpret_cast<int4*>(labels_out + 8 * t);
-            o[0] = int4{out[0], out[1], out[2], out[3]}; o[1] = int4{out[4], out[5], out[6], out[7]};
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) labels_out[8 * t + u] = out[u];
-        }
-    }
-}
-
 struct WsClear { unsigned long long* p[5]; unsigned int n[5]; unsigned long long v[5]; };          // up to five DISJOINT ranges of 8-byte words and their fill
 __global__ void ws_clear_kernel(WsClear c) {
 #pragma unroll
@@ -2235,9 +2113,6 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         } else ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, axis, in, out, r);
     };
 
-    static const bool no_sparse = getenv("CT_WS_SPARSE") && atoi(getenv("CT_WS_SPARSE")) == 0;                 // (A/B: one thread per voxel everywhere)
-    const bool sparse = !no_sparse && V % 8 == 0;
-    const unsigned nb8 = (unsigned)((V / 8 + 255) / 256);
     // Serial form (CT_WS_FORK=0) or the helper stream; the lock is held while this call enqueues.
     static const bool no_fork = getenv("CT_WS_FORK") && atoi(getenv("CT_WS_FORK")) == 0;
     std::unique_lock<std::mutex> aux_lock(ws_aux_mutex, std::defer_lock);
@@ -2266,23 +2141,13 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     auto stage_components = [&](bool mode2d, const unsigned char* mask) -> int {
         hipStream_t sc = aux ? aux->stream : st;
         if (aux) { HIPCHK(hipEventRecord(aux->fork, st)); HIPCHK(hipStreamWaitEvent(sc, aux->fork, 0)); }
-        if (sparse) {
-            if (mode2d) ws_cc_merge8_kernel<true><<<nb8, 256, 0, sc>>>(g, mask, parent);
-            else ws_cc_merge8_kernel<false><<<nb8, 256, 0, sc>>>(g, mask, parent);
-            LAUNCH_CHECK();
-            ws_flatten8_kernel<<<nb8, 256, 0, sc>>>(V, mask, parent, size);
-            LAUNCH_CHECK();
-            ws_heap_alloc8_kernel<<<nb8, 256, 0, sc>>>(V, mask, parent, size, heap_off, heap_cnt, bump);
-            LAUNCH_CHECK();
-        } else {
-            if (mode2d) ws_cc_init_merge_kernel<true><<<nb, 256, 0, sc>>>(g, mask, parent, 1);
-            else ws_cc_init_merge_kernel<false><<<nb, 256, 0, sc>>>(g, mask, parent, 1);
-            LAUNCH_CHECK();
-            cc_flatten_kernel<<<nb, 256, 0, sc>>>(V, parent, size);
-            LAUNCH_CHECK();
-            ws_heap_alloc_kernel<<<nb, 256, 0, sc>>>(V, parent, size, heap_off, heap_cnt, bump);
-            LAUNCH_CHECK();
-        }
+        if (mode2d) ws_cc_init_merge_kernel<true><<<nb, 256, 0, sc>>>(g, mask, parent, 1);
+        else ws_cc_init_merge_kernel<false><<<nb, 256, 0, sc>>>(g, mask, parent, 1);
+        LAUNCH_CHECK();
+        cc_flatten_kernel<<<nb, 256, 0, sc>>>(V, parent, size);
+        LAUNCH_CHECK();
+        ws_heap_alloc_kernel<<<nb, 256, 0, sc>>>(V, parent, size, heap_off, heap_cnt, bump);
+        LAUNCH_CHECK();
         if (aux) HIPCHK(hipEventRecord(aux->join, sc));
         return CT_OK;
     };
@@ -2333,13 +2198,11 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
         static const bool no_upstream = getenv("CT_WS_UPSTREAM_TIES") && atoi(getenv("CT_WS_UPSTREAM_TIES")) == 0;   // (A/B: raveled order among equal seeds)
         // the boxes first (the LDS flood needs them); the fill of the single-marker components touches no voxel of a listed component and runs
         // on the helper stream beside the floods (a handful of waves walking sequentially for 70-310 us)
-        if (sparse) ws_fill_single8_kernel<<<nb8, 256, 0, st>>>(g, mask, parent, heap_off, heap_cnt, heap, labels, gx, bbox, aux ? 2 : 3);
-        else ws_fill_single_kernel<<<nb, 256, 0, st>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, aux ? 2 : 3);
+        ws_fill_single_kernel<<<nb, 256, 0, st>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, aux ? 2 : 3);
         LAUNCH_CHECK();
         if (aux) {
             HIPCHK(hipEventRecord(aux->fork, st)); HIPCHK(hipStreamWaitEvent(aux->stream, aux->fork, 0));
-            if (sparse) ws_fill_single8_kernel<<<nb8, 256, 0, aux->stream>>>(g, mask, parent, heap_off, heap_cnt, heap, labels, gx, bbox, 1);
-            else ws_fill_single_kernel<<<nb, 256, 0, aux->stream>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, 1);
+            ws_fill_single_kernel<<<nb, 256, 0, aux->stream>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, 1);
             LAUNCH_CHECK();
             HIPCHK(hipEventRecord(aux->join, aux->stream));
         }
@@ -2427,15 +2290,11 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
     if (rc) return rc;
 
     // ---- sizes, min_size / cell_num, small objects dropped, sequential labels, centres (watershed.py:88-96, tracker.py:680, :646-647)
-    if (sparse) ws_bincount8_kernel<<<nb8, 256, 0, st>>>(V, bn2, labels, WS_PEAK_CAP3D, counts);
-    else ws_bincount_kernel<<<nb, 256, 0, st>>>(V, labels, WS_PEAK_CAP3D, counts);
+    ws_bincount_kernel<<<nb, 256, 0, st>>>(V, labels, WS_PEAK_CAP3D, counts);
     LAUNCH_CHECK();
     ws_finish_kernel<<<1, 1024, 0, st>>>(V, marker_count, method, min_size, cell_num, counts, newlabel, n_out, latch);
     LAUNCH_CHECK();
-    if (sparse) {
-        if (((uintptr_t)labels_out & 15) == 0) ws_relabel8_kernel<true><<<nb8, 256, 0, st>>>(g, bn2, labels, newlabel, labels_out, cap, sums);
-        else ws_relabel8_kernel<false><<<nb8, 256, 0, st>>>(g, bn2, labels, newlabel, labels_out, cap, sums);
-    } else cc_label_kernel<<<nb, 256, 0, st>>>(g, labels, newlabel, labels_out, cap, sums);
+    cc_label_kernel<<<nb, 256, 0, st>>>(g, labels, newlabel, labels_out, cap, sums);
     LAUNCH_CHECK();
     cc_centroid_kernel<<<(cap + 255) / 256, 256, 0, st>>>(n_out, cap, sums, centres, sizes);
     LAUNCH_CHECK();

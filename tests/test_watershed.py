@@ -249,7 +249,7 @@ def test_device_watershed_alternative_paths_give_the_same_labels(env):
     """Every switchable path of the device watershed -- binary-heap flood for all components, global-state wave flood, the LDS flood handing
     components back when its queue is (artificially) too short (batched and one pop per round), per-voxel filters, bitonic-sort peak selection,
     the one-pop-per-round LDS flood, the serial form without the helper stream, batched rounds whose member table is (artificially) three
-    entries long -- produces the oracle's labels
+    entries long (the threshold is tightened until the members fit) -- produces the oracle's labels
     (the switches are read once per process: each variant runs in its own interpreter)."""
     import os
     import subprocess
