@@ -8,6 +8,9 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
+# more hardware queues than the HIP default of 4 (only effective if the process has not touched the GPU yet): the
+# frame loop's streams must not alias
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LIB_PATH = Path(os.environ.get("CTAMD_LIB", _HERE / "libctamd.so"))    # CTAMD_LIB: A/B builds of the same ABI (dev)
 
 

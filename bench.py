@@ -37,6 +37,11 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP streams share 4 hardware queues by default; the frame loop keeps five to six streams busy (U-Net, watershed + its helper, match +
+# correction, the reference-set preparation) and two of them landing on one queue serialises them (measured: the frame sequence 6.8 ms or
+# 7.8-9.3 ms per frame depending on the order in which the process created its streams; 6.8 ms every time with 16 queues; the headline
+# line does not move).  Read by the HIP runtime when it initialises, i.e. it has to be set before the first GPU call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 PKG = "3deecelltracker_amd"
 FP32_MFMA_PEAK_TF = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 = fp32 vector peak

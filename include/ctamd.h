@@ -375,7 +375,11 @@ int ct_segment_centroids(const float* prob, const int dims_xyz[3], float thresho
  * replayed on the device; seeds of exactly equal height inside one connected region are popped in the order upstream's image-wide binary heap
  * leaves them in: a z slice / volume that holds such a pair is replayed sequentially with that heap (heap_general.pxi restated; ~2 us per
  * foreground voxel of the group, mirror-symmetric shapes only), everything else is flooded component by component in parallel.
- * n_out[0] = -1: method "cell_num" asked for more cells than np.bincount has bins (the reference's IndexError, watershed.py:92).            */
+ * n_out[0] = -1: method "cell_num" asked for more cells than np.bincount has bins (the reference's IndexError, watershed.py:92).
+ * Streams: everything is ordered on `stream` as seen from outside (work enqueued on it after the call sees the results).  Inside, the sweeps
+ * that depend on the mask alone run on a helper stream the library keeps per device and priority of `stream` (fork / join by events, no host
+ * wait; CT_WS_FORK=0 keeps everything on `stream`).  The call may be issued from several host threads (the helper's events are taken under a
+ * lock for the duration of the enqueue); two calls must not share a workspace unless they are ordered on one stream.                        */
 size_t ct_watershed_workspace_bytes(const int dims_xyz[3], int cap);
 int    ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_ratio, int method, int min_size, int cell_num,
                             int min_distance_2d, int min_distance_3d, const double* gauss_xy, int radius_xy, const double* gauss_z, int radius_z,
