@@ -265,7 +265,7 @@ def measure_chained(ctx, args):
         frame i-1's corrected cells (every dependency of the reference's loop over volumes kept), the U-Net of frame i+2 and the watershed of
         frame i+1 run beside the match + correction of frame i.  Values identical to serial frames (tests/test_gpu_bench.py)."""
         chain = frame.FrameChain.synthetic(shape=tuple(args.shape), n_cells=args.cells, seed=0, device=ctx.local)
-        raws = [chain.raw_t2, chain.raw_t1] * 8
+        raws = [chain.raw_t2, chain.raw_t1] * 16               # 32 frames (16 until the end of round 4: fill and drain, ~8 ms, are inside the timed region)
         list(chain.run_sequence(raws[:4], chain.seg_real_t1, chain.confirmed_real_t1))
         torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
         outs = list(chain.run_sequence(raws, chain.seg_real_t1, chain.confirmed_real_t1))

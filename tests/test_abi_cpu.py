@@ -3,6 +3,7 @@ host-only entry points (no kernel launches) behave."""
 import ctypes as C
 import importlib
 import re
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -99,3 +100,18 @@ def test_no_packed_fp32_outside_the_conv_kernels(L):
     nm = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
     exported = [l.split()[-1] for l in nm.splitlines() if l.strip()]
     assert exported and all(n.startswith("ct_") for n in exported), [n for n in exported if not n.startswith("ct_")][:5]
+
+
+def test_package_asks_for_more_hardware_queues_unless_told_otherwise():
+    """The frame loop keeps five to six HIP streams busy; on the runtime's default of four hardware queues they alias.  Importing the
+    package sets GPU_MAX_HW_QUEUES=16 -- before the HIP runtime initialises in a process that has not touched the GPU -- and leaves a value the
+    user exported alone."""
+    import os
+    import subprocess
+    code = ("import sys, os, importlib; sys.path.insert(0, sys.argv[1]); importlib.import_module('3deecelltracker_amd._lib'); "
+            "print('Q=' + os.environ.get('GPU_MAX_HW_QUEUES', 'unset'))")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, "-c", code, str(REPO)], capture_output=True, text=True, timeout=120, env=env)
+    assert "Q=16" in r.stdout, r.stdout + r.stderr[-300:]
+    r = subprocess.run([sys.executable, "-c", code, str(REPO)], capture_output=True, text=True, timeout=120, env=dict(env, GPU_MAX_HW_QUEUES="6"))
+    assert "Q=6" in r.stdout, r.stdout + r.stderr[-300:]
