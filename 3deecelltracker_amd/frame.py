@@ -32,6 +32,7 @@ class FrameChain:
             raise ValueError(f"unknown region_method {region_method!r}: use 'watershed' or 'cc'")
         self.region_method = region_method
         self.prefetch_ref = bool(prefetch_ref)
+        self.lcn_beside_unet = True                              # run_sequence: a frame's LCN on the watershed's stream (False: in front of its U-Net)
         self._side = None
         self._seq = None
         self.unet_model = unet_model
@@ -48,9 +49,14 @@ class FrameChain:
         self.seg_real_t1 = None
         self.confirmed_real_t1 = None
 
-    def probability_map(self, raw_d, out=None):
-        """raw stack -> prob fp32 [x,y,z] on the device (LCN + U-Net; asynchronous)."""
-        norm = normalize_image_device(raw_d, self.noise_level, (27, 27, 1), mode=0, subtract_median=True)
+    def normalized(self, raw_d):
+        """raw stack -> the LCN-normalised volume the U-Net takes (asynchronous)."""
+        return normalize_image_device(raw_d, self.noise_level, (27, 27, 1), mode=0, subtract_median=True)
+
+    def probability_map(self, raw_d, out=None, norm=None):
+        """raw stack -> prob fp32 [x,y,z] on the device (LCN + U-Net; asynchronous).  norm: the stack already normalised (normalized())."""
+        if norm is None:
+            norm = self.normalized(raw_d)
         self._mark("lcn")
         if out is None:
             if self._prob is None or self._prob.shape != norm.shape:
@@ -173,12 +179,23 @@ class FrameChain:
             q["spans"].append((name, e0, e1))
             return r, e1
 
+        lcn_on_w = self.lcn_beside_unet and self.region_method == "watershed"
+
         def enqueue_unet(j):
             b = j % NB
+            norm = None
+            if lcn_on_w:
+                # the LCN (bandwidth-bound sweeps) of frame j on the watershed's stream, which has ~3 ms of slack per frame, beside the
+                # power-bound U-Net of the frame before: the U-Net stream is the pipeline's bottleneck and loses 0.25 ms per frame
+                with t.cuda.stream(W):
+                    norm = self.normalized(raws[j])
+                    ev = t.cuda.Event(); ev.record(W)
+                S.wait_event(ev)
+                norm.record_stream(S)
             if q["free"][b] is not None:
                 S.wait_event(q["free"][b])                       # frame j-3's correction has read this buffer
             with t.cuda.stream(S):
-                span("unet", S, lambda: self.probability_map(raws[j], out=q["prob"][b]))
+                span("unet", S, lambda: self.probability_map(raws[j], out=q["prob"][b], norm=norm))
                 q["ready"][b].record(S)
 
         def enqueue_regions(j):
