@@ -239,6 +239,46 @@ def test_device_watershed_on_a_large_clump():
     assert np.array_equal(got[1], want[1])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_device_watershed_crowded_volumes_equal_the_oracle(seed):
+    """Crowded random volumes (cells packed closely enough that most mask components hold several markers: the batched LDS flood does nearly all
+    the labelling), different shapes incl. a single slice and odd extents, the wide-front case: labels, sizes and centres equal the oracle's."""
+    rng = np.random.default_rng(100 + seed)
+    shapes = [(64, 64, 8), (96, 70, 12), (57, 83, 9), (120, 120, 1), (80, 80, 6), (40, 150, 10), (110, 64, 16), (72, 72, 5)]
+    shape = shapes[seed]
+    n = int(np.prod(shape) / 900) + 3
+    lo = np.array([4, 4, 0]); hi = np.array([shape[0] - 4, shape[1] - 4, max(shape[2] - 1, 1)])
+    c = rng.uniform(lo, hi, (n, 3))
+    prob = blobs(shape, c, rng.uniform(4, 9, n), z_flat=float(rng.uniform(1.5, 4.0)), level=0.8)
+    prob += rng.uniform(0, 0.2, shape).astype(np.float32) * (prob > 0)
+    zr, ms = float(rng.uniform(1.0, 5.0)), int(rng.integers(0, 30))
+    want = wr.segment_centroids(prob, zr, "min_size", ms)
+    got = _device(prob, zr, "min_size", ms, 0)
+    comp = ndi.label(prob > 0.5)[1]
+    assert (got[2], got[3]) == (want[2], want[3])
+    assert np.array_equal(got[0], want[0]), f"{int((got[0] != want[0]).sum())} voxels differ ({comp} components, {want[3]} cells)"
+    assert np.array_equal(got[1], want[1])
+
+
+def test_crowded_volumes_have_multi_marker_components():
+    """(what the test above relies on: in these volumes the watershed finds clearly more cells than the mask has components)"""
+    more = 0
+    for seed in range(8):
+        rng = np.random.default_rng(100 + seed)
+        shapes = [(64, 64, 8), (96, 70, 12), (57, 83, 9), (120, 120, 1), (80, 80, 6), (40, 150, 10), (110, 64, 16), (72, 72, 5)]
+        shape = shapes[seed]
+        n = int(np.prod(shape) / 900) + 3
+        lo = np.array([4, 4, 0]); hi = np.array([shape[0] - 4, shape[1] - 4, max(shape[2] - 1, 1)])
+        c = rng.uniform(lo, hi, (n, 3))
+        prob = blobs(shape, c, rng.uniform(4, 9, n), z_flat=float(rng.uniform(1.5, 4.0)), level=0.8)
+        prob += rng.uniform(0, 0.2, shape).astype(np.float32) * (prob > 0)
+        zr, ms = float(rng.uniform(1.0, 5.0)), int(rng.integers(0, 30))
+        want = wr.segment_centroids(prob, zr, "min_size", ms)
+        more += int(want[3] > ndi.label(prob > 0.5)[1])
+    assert more >= 4, more
+
+
 _ALT_PATHS = [{"CT_WS_FLOOD": "0"}, {"CT_WS_FLOOD": "1"}, {"CT_WS_QCAP": "8"}, {"CT_WS_SLIDE": "0"}, {"CT_WS_SELECT": "0"},
               {"CT_WS_BATCH": "0"}, {"CT_WS_BATCH": "0", "CT_WS_QCAP": "8"}, {"CT_WS_FORK": "0"}, {"CT_WS_MCAP": "3"}]
 
