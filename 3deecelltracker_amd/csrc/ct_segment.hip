@@ -1504,15 +1504,25 @@ __global__ __launch_bounds__(64) void ws_flood_batch_kernel(SegGeom g, const dou
     const long long sx = (long long)g.Y * g.Z, sy = g.Z;
     const int d64z = 64 % BZ, d64y = (64 / BZ) % BY, d64x = 64 / (BZ * BY);
     {
+        // four box positions per lane and step: twelve independent global loads in flight (one position per step left every step waiting for
+        // its own three: 28 of the 3-D flood's 140 us on the benchmark stack)
         int lz = lane % BZ, ly = (lane / BZ) % BY, lx = lane / (BZ * BY);
-        for (int p = lane; p < bvol; p += 64) {
-            const long long j = (long long)(x0 + lx) * sx + (long long)(y0 + ly) * sy + (z0 + lz);
-            const bool mine = parent[j] == root;
-            sm_box[p] = smooth[j];
-            st_box[p] = mine ? labels[j] : -1;
-            lz += d64z; if (lz >= BZ) { lz -= BZ; ++ly; }
-            ly += d64y; if (ly >= BY) { ly -= BY; ++lx; }
-            lx += d64x;
+        for (int p = lane; p < bvol; p += 256) {
+            long long jj[4]; bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ok[u] = p + 64 * u < bvol;
+                jj[u] = ok[u] ? (long long)(x0 + lx) * sx + (long long)(y0 + ly) * sy + (z0 + lz) : (long long)root;
+                lz += d64z; if (lz >= BZ) { lz -= BZ; ++ly; }
+                ly += d64y; if (ly >= BY) { ly -= BY; ++lx; }
+                lx += d64x;
+            }
+            int pr[4], lb[4]; double sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { pr[u] = parent[jj[u]]; sv[u] = smooth[jj[u]]; lb[u] = labels[jj[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u]) { sm_box[p + 64 * u] = sv[u]; st_box[p + 64 * u] = pr[u] == root ? lb[u] : -1; }
         }
     }
     int n = heap_cnt[root];
