@@ -280,14 +280,14 @@ def test_crowded_volumes_have_multi_marker_components():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,n,zr,ms", [((256, 256, 64), 300, 2.0, 20), ((768, 640, 8), 500, 5.0, 10), ((333, 217, 37), 260, 3.0, 15), ((128, 128, 128), 200, 1.0, 25)],
+@pytest.mark.parametrize("shape,n,zr,ms", [((160, 160, 64), 120, 2.0, 20), ((512, 384, 8), 200, 5.0, 10), ((233, 117, 37), 90, 3.0, 15), ((96, 96, 128), 110, 1.0, 25)],
                          ids=["deep", "wide_thin", "odd", "z128"])
 def test_device_watershed_other_extents(shape, n, zr, ms):
     """A deep stack, a wide thin one, odd extents and the largest z the device takes (128): labels, sizes and centres equal the oracle's."""
     prob = random_case(shape, n, seed=sum(shape), specks=False)
     want = wr.segment_centroids(prob, zr, "min_size", ms)
     got = _device(prob, zr, "min_size", ms, 0)
-    assert (got[2], got[3]) == (want[2], want[3]) and want[3] > 100
+    assert (got[2], got[3]) == (want[2], want[3]) and want[3] > 50
     assert np.array_equal(got[0], want[0]), f"{int((got[0] != want[0]).sum())} voxels differ"
     assert np.array_equal(got[1], want[1])
 
