@@ -2170,6 +2170,10 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         { const int rcc = stage_clear(mode2d); if (rcc) return rcc; }
         max_pass(0, smooth, tmp, min_distance);
         LAUNCH_CHECK();
+        // 2-D stage: the components chain (~100 us) is longer than the 32 slices' peak selection (40 us): it starts one pass earlier, beside the
+        // last maximum pass as well (3-D stage: chain and selection are both ~130 us, the fork stays in front of the selection)
+        static const bool early_fork = !(getenv("CT_WS_EARLY_FORK") && atoi(getenv("CT_WS_EARLY_FORK")) == 0);
+        if (mode2d && early_fork) { const int rcc = stage_components(mode2d, mask); if (rcc) return rcc; }
         if (mode2d) {
             if (!no_slide && min_distance == 7)
                 ws_max_peak_slide_kernel<7><<<nby, 256, 0, st>>>(g, border, tmp, smooth, vmax_out, eq_count, vmin, cand_count, pcap, cand_val, cand_idx, overflow);
@@ -2184,7 +2188,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
         LAUNCH_CHECK();
         // the peak selection is one workgroup per group (40 us for 32 slices, 130 us for the volume: the chip idles); the components of the
         // mask go beside it
-        { const int rcc = stage_components(mode2d, mask); if (rcc) return rcc; }
+        if (!(mode2d && early_fork)) { const int rcc = stage_components(mode2d, mask); if (rcc) return rcc; }
 static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT")) == 0;          // (A/B: the bitonic-sort form for every group)
         if (!no_sel2) {
             ws_peak_select2_kernel<<<ngroups, 1024, WS_SEL2_LDS, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val, cand_idx,

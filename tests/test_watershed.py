@@ -293,7 +293,7 @@ def test_device_watershed_other_extents(shape, n, zr, ms):
 
 
 _ALT_PATHS = [{"CT_WS_FLOOD": "0"}, {"CT_WS_FLOOD": "1"}, {"CT_WS_QCAP": "8"}, {"CT_WS_SLIDE": "0"}, {"CT_WS_SELECT": "0"},
-              {"CT_WS_BATCH": "0"}, {"CT_WS_BATCH": "0", "CT_WS_QCAP": "8"}, {"CT_WS_FORK": "0"}, {"CT_WS_MCAP": "3"}]
+              {"CT_WS_BATCH": "0"}, {"CT_WS_BATCH": "0", "CT_WS_QCAP": "8"}, {"CT_WS_FORK": "0"}, {"CT_WS_MCAP": "3"}, {"CT_WS_EARLY_FORK": "0"}]
 
 
 @pytest.mark.gpu
