@@ -111,7 +111,7 @@ def prgls_prepare_ref(ref_d, beta):
         raise ValueError(f"PR-GLS: {n} reference points exceed the dense M-step limit of {PRGLS_MAX_POINTS}")
     buf = workspace(L.ct_prgls_prepared_bytes(n), ref_d.device)
     _lib.check(L.ct_prgls_prepare_ref(ref_d.data_ptr(), n, float(beta), buf.data_ptr(), buf.numel(), stream(ref_d.device)), "ct_prgls_prepare_ref")
-    ev = t.cuda.Event(); ev.record()
+    ev = t.cuda.Event(); ev.record(t.cuda.current_stream(ref_d.device))     # (the stream the call above was enqueued on, not the current DEVICE's)
     return PreparedRef(ref_d, beta, buf, ev)
 
 

@@ -8,14 +8,34 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-# more hardware queues than the HIP default of 4 (only effective if the process has not touched the GPU yet): the
-# frame loop's streams must not alias
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LIB_PATH = Path(os.environ.get("CTAMD_LIB", _HERE / "libctamd.so"))    # CTAMD_LIB: A/B builds of the same ABI (dev)
 
 
 class CtamdError(RuntimeError):
     pass
+
+
+_warned_queues = False
+
+
+def check_hw_queues(what: str = "the frame loop") -> bool:
+    """HIP streams share 4 hardware queues per process unless GPU_MAX_HW_QUEUES (a ROCm runtime variable, read when the runtime
+    initialises) says otherwise; the frame loop keeps five to six streams busy, and two of them on one queue serialise (measured:
+    6.6-9.3 ms per frame depending on the order in which the process created its streams, 6.8 ms every time with 16 queues:
+    INTEGRATION.md).  The package does NOT touch the host application's environment: this warns, once, when the variable is missing
+    or below 8, and returns whether it was fine.  bench.py, the tests and the probes export it themselves."""
+    global _warned_queues
+    try:
+        ok = int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8
+    except ValueError:
+        ok = False
+    if not ok and not _warned_queues:
+        import warnings
+        _warned_queues = True
+        warnings.warn(f"GPU_MAX_HW_QUEUES is {os.environ.get('GPU_MAX_HW_QUEUES', 'not set')!s} (HIP default: 4 hardware queues): {what} keeps 5-6 HIP "
+                      "streams busy and they will share queues, i.e. partly serialise.  Export GPU_MAX_HW_QUEUES=16 before the process makes "
+                      "its first GPU call (it cannot be changed afterwards).", RuntimeWarning, stacklevel=3)
+    return ok
 
 
 _lib = None

@@ -17,17 +17,10 @@
 
 #include "../../include/ctamd.h"
 #include "ct_fill.h"
+#include "ct_fresh.h"
 
 
-// Words one kernel writes and a LATER launch reads at a wave-uniform address (a cell's coordinates, updated in place round after round; the
-// `done` word) are read with agent-scope loads.  As plain loads the compiler turns them into scalar loads, and the centre-of-mass kernel then
-// saw the coordinates of TWO rounds ago now and then -- only while kernels of another stream (the U-Net, a GEMM) were running, 10-50 % of
-// the calls on every box tried, never on an idle GPU: the flag said "still moving", the correction ran a round too many and one cell ended
-// 0.3 voxel away (scripts/probe/corr_beside_unet.py; FrameChain.run_sequence is what runs the correction beside a U-Net).  Which cache kept
-// the old word was not established (the scalar cache is the suspect: per-thread vector loads of the same array, in movements_kernel, were
-// never stale); the sc1 loads below do not depend on the answer.
-__device__ __forceinline__ float fresh_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int fresh_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (control words written by one launch and read by a later one at wave-uniform addresses go through fresh_f32 / fresh_i32: ct_fresh.h)
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -2578,6 +2578,8 @@ namespace {
 constexpr unsigned long long PREP_MAGIC = 0x3153474c52505443ull;      // "CTPRGLS1"
 struct PreparedHdr { unsigned long long magic; int n; int pad; double beta; int rank[2]; };
 struct PreparedRef { PreparedHdr* hdr; double* G; double* U; double* resid; };
+// the header travels as a kernel argument: a hipMemcpyAsync from a stack struct is only safe because pageable copies are staged synchronously
+__global__ void prepared_hdr_kernel(PreparedHdr* dst, const PreparedHdr h) { *dst = h; }
 size_t prepared_layout(int n, unsigned char* base, PreparedRef* p) {
     size_t off = 256;
     auto take = [&](size_t count) { double* q = base ? (double*)(base + off) : nullptr; off += align_up(count * sizeof(double), 256); return q; };
@@ -2735,7 +2737,8 @@ int ct_prgls_prepare_ref(const double* ref, int n, double beta, void* prepared, 
     PreparedRef p;
     prepared_layout(n, (unsigned char*)prepared, &p);
     const PreparedHdr h{PREP_MAGIC, n, 0, beta, {0, 0}};
-    HIPCHK(hipMemcpyAsync(p.hdr, &h, sizeof(h), hipMemcpyHostToDevice, st));      // (pageable source: staged before the call returns)
+    hipLaunchKernelGGL(prepared_hdr_kernel, dim3(1), dim3(1), 0, st, p.hdr, h);
+    LAUNCH_CHECK();
     const size_t nn = (size_t)n * n;
     hipLaunchKernelGGL(gauss_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ref, n, ref, n, 2.0 * beta * beta, p.G, 0);
     LAUNCH_CHECK();

@@ -28,6 +28,7 @@
 #include <mutex>
 
 #include "../../include/ctamd.h"
+#include "ct_fresh.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -1074,7 +1075,7 @@ __global__ void ws_marker_append_kernel(int ngroups, int cap, const int32_t* __r
                                         unsigned int* __restrict__ nroots, int32_t* __restrict__ labels) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = t / cap, k = t - grp * cap;
-    if (grp >= ngroups || k >= marker_count[grp]) return;
+    if (grp >= ngroups || k >= fresh_i32(&marker_count[grp])) return;
     const int id = marker_idx[(size_t)grp * cap + k];
     const int root = parent[id];
     if (root < 0) { labels[id] = 0; return; }                                    // a peak of the blurred EDT on a background pixel: skimage's watershed drops markers outside the mask (their numbers stay used)
@@ -1106,7 +1107,8 @@ __device__ __forceinline__ void ws_flood_heap_body(unsigned int bid, unsigned in
                                 const unsigned int* __restrict__ nroots, const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt,
                                 WsHeapEntry* __restrict__ heap_all, int32_t* __restrict__ labels, const int32_t* __restrict__ size, int larger_than,
                                 const int32_t* __restrict__ bbox) {
-    for (unsigned int t = bid * blockDim.x + threadIdx.x; t < *nroots; t += nblk * blockDim.x) {
+    const unsigned int nroots_now = fresh_u32(nroots);       // (written by an earlier launch: ct_fresh.h)
+    for (unsigned int t = bid * blockDim.x + threadIdx.x; t < nroots_now; t += nblk * blockDim.x) {
     const int root = roots[t];
     if (size[root] <= larger_than) continue;               // (the wave kernels' share)
     if (bbox && ws_box_eligible(bbox + (size_t)t * 6, size[root], MODE2D) && heap_cnt[root] <= WS_Q_LDS) continue;      // ws_flood_box_kernel's
@@ -1226,7 +1228,8 @@ __device__ __forceinline__ void ws_flood_wave_body(unsigned int bid, unsigned in
     __shared__ WsHeapEntry q_lds[WS_Q_LDS];
     __shared__ int32_t l_lds[WS_Q_LDS];
     const int lane = threadIdx.x;
-    for (unsigned int slot = bid; slot < *nroots; slot += nblk) {               // (the host no longer waits for the list's length: a fixed grid walks it)
+    const unsigned int nroots_now = fresh_u32(nroots);       // (written by an earlier launch: ct_fresh.h)
+    for (unsigned int slot = bid; slot < nroots_now; slot += nblk) {               // (the host no longer waits for the list's length: a fixed grid walks it)
     const int root = roots[slot];
     if (bbox && ws_box_eligible(bbox + (size_t)slot * 6, size[root], MODE2D) && heap_cnt[root] <= WS_Q_LDS) continue;      // ws_flood_box_kernel's
     if (size[root] > WS_HEAP_MIN) continue;                // ws_flood_kernel's (binary heap)
@@ -1354,7 +1357,8 @@ __global__ __launch_bounds__(64) void ws_flood_box_kernel(SegGeom g, const doubl
                                                           int qcap /* queue entries usable (<= WS_Q_LDS; smaller in the hand-back test) */) {
     extern __shared__ unsigned long long ws_box_sm[];
     const int lane = threadIdx.x;
-    for (unsigned int slot = blockIdx.x; slot < *nroots; slot += gridDim.x) {   // a fixed grid walks the list (its length stays on the device)
+    const unsigned int nroots_now = fresh_u32(nroots);       // (written by an earlier launch: ct_fresh.h)
+    for (unsigned int slot = blockIdx.x; slot < nroots_now; slot += gridDim.x) {   // a fixed grid walks the list (its length stays on the device)
     const int root = roots[slot];
     int32_t* bb = bbox + (size_t)slot * 6;
     if (!ws_box_eligible(bb, size[root], MODE2D) || heap_cnt[root] > WS_Q_LDS) continue;
@@ -1485,7 +1489,8 @@ __global__ __launch_bounds__(64) void ws_flood_batch_kernel(SegGeom g, const dou
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int mcap = qcap >> 16;                             // members ranked per round (<= WS_BATCH_MEM; smaller in the tests)
     qcap &= 0xffff;
-    for (unsigned int slot = blockIdx.x; slot < *nroots; slot += gridDim.x) {
+    const unsigned int nroots_now = fresh_u32(nroots);       // (written by an earlier launch: ct_fresh.h)
+    for (unsigned int slot = blockIdx.x; slot < nroots_now; slot += gridDim.x) {
     const int root = roots[slot];
     int32_t* bb = bbox + (size_t)slot * 6;
     if (!ws_box_eligible(bb, size[root], MODE2D) || heap_cnt[root] > WS_Q_LDS) continue;
@@ -1732,8 +1737,8 @@ __global__ void ws_tie_detect_kernel(SegGeom g, int mode2d, const int32_t* __res
                                      int32_t* __restrict__ tie_flags, int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox,
                                      const int* __restrict__ overflow, int32_t* __restrict__ latch) {
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0 && *overflow) latch[0] = 1;                                       // (the per-stage flag is cleared with the next stage's statistics)
-    if (t >= *nroots) return;
+    if (t == 0 && fresh_i32(overflow)) latch[0] = 1;                                       // (the per-stage flag is cleared with the next stage's statistics)
+    if (t >= fresh_u32(nroots)) return;
     const int root = roots[t];
     slot_of[root] = (int32_t)t;                                                  // (for the bounding boxes ws_fill_single_kernel collects)
     bbox[6 * t + 0] = bbox[6 * t + 1] = bbox[6 * t + 2] = 0x7fffffff; bbox[6 * t + 3] = bbox[6 * t + 4] = bbox[6 * t + 5] = -1;
@@ -1760,7 +1765,7 @@ __global__ __launch_bounds__(64) void ws_flood_upstream_kernel(SegGeom g, const 
                                                                const int32_t* __restrict__ tie_flags, WsHeapEntry* __restrict__ heap_all,
                                                                int32_t* __restrict__ labels) {
     const int grp = blockIdx.x;
-    if (!tie_flags[grp]) return;
+    if (!fresh_i32(&tie_flags[grp])) return;
     const long long gsize = MODE2D ? (long long)g.X * g.Y : g.V;
     WsHeapEntry* const h = heap_all + (size_t)grp * gsize;
     for (long long p = threadIdx.x; p < gsize; p += 64) labels[MODE2D ? p * g.Z + grp : p] = 0;
@@ -1778,7 +1783,7 @@ __global__ __launch_bounds__(64) void ws_flood_upstream_kernel(SegGeom g, const 
         }
         h[c] = e;
     };
-    const int nm = marker_count[grp];
+    const int nm = fresh_i32(&marker_count[grp]);
     for (int k = 0; k < nm; ++k) {                                               // marker list = raveled order inside the group
         const int id = marker_idx[(size_t)grp * cap + k];
         if (!bn[id]) continue;                                                   // markers outside the mask are dropped, their numbers stay used
@@ -1877,8 +1882,8 @@ __global__ __launch_bounds__(1024) void ws_finish_kernel(long long V, const int3
     __shared__ int s_scan[1024];
     __shared__ int s_carry, s_kmax;
     __shared__ unsigned long long s_tot;
-    const int K = marker_count[0];
-    if (*latch) {                                              // a peak table overflowed in one of the stages: nothing below means anything
+    const int K = fresh_i32(&marker_count[0]);
+    if (fresh_i32(latch)) {                                              // a peak table overflowed in one of the stages: nothing below means anything
         if (threadIdx.x == 0) { n_out[0] = -2; n_out[1] = min_size; n_out[2] = cell_num; }
         for (int l = threadIdx.x; l <= K; l += 1024) newlabel[l] = 0;
         return;
@@ -1983,18 +1988,39 @@ std::mutex ws_aux_mutex;
 WsAux* ws_aux_for(hipStream_t caller) {
     static WsAux aux[64][8];
     int dev = 0, prio = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    // the device the CALLER'S STREAM lives on (a process may drive several devices and launch on a stream of another one than the current)
+    if (hipStreamGetDevice(caller, &dev) != hipSuccess) { (void)hipGetLastError(); if (hipGetDevice(&dev) != hipSuccess) return nullptr; }
+    if (dev < 0 || dev >= 64) return nullptr;
     if (hipStreamGetPriority(caller, &prio) != hipSuccess) { (void)hipGetLastError(); prio = 0; }
     const int slot = prio + 4 < 0 ? 0 : (prio + 4 > 7 ? 7 : prio + 4);
     WsAux& a = aux[dev][slot];
     if (!a.ok) {
-        if (hipStreamCreateWithPriority(&a.stream, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        a.ok = true;
+        // all three or nothing: a partial set is destroyed again (the call then runs in its serial form, and a later call may retry)
+        hipStream_t s = nullptr; hipEvent_t f = nullptr, j = nullptr;
+        int cur = -1;
+        const bool switched = hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess;
+        const bool made = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio) == hipSuccess &&
+                          hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess;
+        if (switched) (void)hipSetDevice(cur);
+        if (!made) {
+            (void)hipGetLastError();
+            if (j) (void)hipEventDestroy(j);
+            if (f) (void)hipEventDestroy(f);
+            if (s) (void)hipStreamDestroy(s);
+            return nullptr;
+        }
+        a.stream = s; a.fork = f; a.join = j; a.ok = true;
     }
     return &a;
 }
+
+// A call that returns an error after it has forked must not leave helper-stream kernels running on the caller's workspace (the caller frees
+// it on error, and the caller's stream never waited for `join`): the helper stream is drained on every exit that was not marked complete.
+struct WsAuxDrain {
+    WsAux* aux; bool complete = false;
+    ~WsAuxDrain() { if (aux && !complete) (void)hipStreamSynchronize(aux->stream); }
+};
 
 }  // namespace
 
@@ -2128,6 +2154,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     std::unique_lock<std::mutex> aux_lock(ws_aux_mutex, std::defer_lock);
     WsAux* aux = nullptr;
     if (!no_fork) { aux_lock.lock(); aux = ws_aux_for(st); if (!aux) aux_lock.unlock(); }
+    WsAuxDrain aux_drain{aux};                                                   // (declared after the lock: drains before the lock is released)
     // the per-stage clears
     // (the small clears of a stage are one launch: five memsets of a few KB each were 25 us of a call; the first stage's carries the latch, the
     // second's the tables of the final bookkeeping, which nothing touches before)
@@ -2284,6 +2311,7 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
         HIPCHK(hipStreamSynchronize(st));
         if (h_latch) return CT_ESHAPE;
         HIPCHK(hipMemsetAsync(n_out, 0, 3 * sizeof(int32_t), st));
+        aux_drain.complete = true;
         return CT_OK;
     }
 
@@ -2312,6 +2340,7 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
     LAUNCH_CHECK();
     cc_centroid_kernel<<<(cap + 255) / 256, 256, 0, st>>>(n_out, cap, sums, centres, sizes);
     LAUNCH_CHECK();
+    aux_drain.complete = true;                                                    // (every fork above has been joined by `st`)
     return CT_OK;
 }
 

@@ -11,12 +11,17 @@
 //     every epilogue store is a run of full 128-B lines;
 //   * a 3x3x3 conv is an implicit GEMM  D[cout][voxel] = sum_k W[cout][k] * A[k][voxel],  k = (tap, cin); a 16-voxel
 //     MFMA column is one (x,y) column x 16 z; the A tile (halo included) is staged in LDS once per 8-channel chunk,
-//     weights stream L2 -> registers (1 KiB per wave-load, coalesced).  Two kernel families share this structure:
-//       - conv3_bf16x6_kernel (default): every fp32 operand is split exactly into three bf16 parts and multiplied on
-//         the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, six products, fp32 accumulate) -- fp32-faithful results at
-//         2.5x fewer matrix-pipe cycles than the f32-input instruction;
+//     weights stream L2 -> registers (1 KiB per wave-load, coalesced).  Three arithmetic families share this structure (CT_CONV_MATH,
+//     read when a model is created):
+//       - conv3_split_kernel<F16 = true> "f16x3" (THE DEFAULT; the first pair of unet3_a's volume path runs in conv_l0l1_fused_kernel): every
+//         fp32 operand is split into two fp16 parts after an exact per-patch power-of-two scaling and multiplied on the fp16 matrix pipe
+//         (v_mfma_f32_16x16x32_f16, three products hi*hi + hi*lo + lo*hi, fp32 accumulate) -- fp32-faithful results (<= 2.2e-6 per conv
+//         block against fp64) at a fifth of the matrix-pipe cycles of the f32-input instruction;
+//       - conv3_split_kernel<F16 = false> "bf16x6" (CT_CONV_MATH=bf16x6, round 1's default): three exact bf16 parts, six products on
+//         v_mfma_f32_16x16x32_bf16;
 //       - conv3_mfma_kernel / _fold / _c8 (CT_CONV_MATH=f32): the exact-fp32 instruction v_mfma_f32_16x16x4_f32
 //         (an fmaf chain bit-for-bit; 157 TF peak = the fp32 vector peak);
+//     the two non-default families are kept as tested references (tests/test_gpu_unet_modes.py);
 //     decoder convs fold the taps that coincide after nearest-neighbour upsampling (12 of 27 per upsampled channel);
 //   * bias + LeakyReLU/ReLU + BatchNorm-affine run in the accumulator registers; max-pool, the
 //     nearest-upsample + concat of the decoder and the 1x1x1 sigmoid head are fused into the

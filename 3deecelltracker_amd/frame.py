@@ -158,13 +158,20 @@ class FrameChain:
         raws = list(raws)
         if not raws:
             return
+        from . import _lib
+        _lib.check_hw_queues("FrameChain.run_sequence")
         dev = raws[0].device
         NB = 3
-        if self._seq is None:
-            self._seq = {"S": t.cuda.Stream(device=dev), "W": t.cuda.Stream(device=dev, priority=-1), "T": t.cuda.Stream(device=dev, priority=-1),
-                         "prob": [t.empty(tuple(raws[0].shape), dtype=t.float32, device=dev) for _ in range(NB)],
-                         "ready": [t.cuda.Event() for _ in range(NB)], "free": [None] * NB}
+        key = (tuple(raws[0].shape), str(dev))
+        if any(tuple(r.shape) != key[0] or r.device != dev for r in raws):
+            raise ValueError("run_sequence: every volume of a sequence must have the same shape and live on the same device")
+        if self._seq is None or self._seq["key"] != key:       # (streams and probability-map buffers belong to one volume shape on one device)
+            self._seq = {"key": key, "S": t.cuda.Stream(device=dev), "W": t.cuda.Stream(device=dev, priority=-1),
+                         "T": t.cuda.Stream(device=dev, priority=-1),
+                         "prob": [t.empty(key[0], dtype=t.float32, device=dev) for _ in range(NB)],
+                         "ready": [t.cuda.Event() for _ in range(NB)]}
         q = self._seq
+        q["free"] = [None] * NB
         q["spans"] = []                                          # (stream-local spans of the last sequence: sequence_spans())
         S, W, T = q["S"], q["W"], q["T"]
         entry = t.cuda.current_stream(dev)
@@ -206,25 +213,29 @@ class FrameChain:
                 pending[j], _ = span("regions", W, lambda: self.regions_enqueue(q["prob"][j % NB]))
 
         seg_prev, conf_prev = seg_real_t0, confirmed_real_t0
-        enqueue_unet(0)
-        if len(raws) > 1:
-            enqueue_unet(1)
-        enqueue_regions(0)
-        for i in range(len(raws)):
-            if i + 2 < len(raws):
-                enqueue_unet(i + 2)                              # everything asynchronous is queued before this frame's host-synchronous steps
-            if i + 1 < len(raws):
-                enqueue_regions(i + 1)
-            b = i % NB
-            with t.cuda.stream(T):
-                T.wait_event(q["ready"][b])
-                centres = pending.pop(i).result()[1] if i in pending else None
-                out, ev = span("match+correction", T, lambda: self.track(q["prob"][b], seg_prev, conf_prev, centres=centres))
-                q["free"][b] = ev
-            seg_prev, conf_prev = out["seg_real_t2"], out["coords"].real
-            yield out
-        for st in (S, W, T):
-            entry.wait_stream(st)
+        try:
+            enqueue_unet(0)
+            if len(raws) > 1:
+                enqueue_unet(1)
+            enqueue_regions(0)
+            for i in range(len(raws)):
+                if i + 2 < len(raws):
+                    enqueue_unet(i + 2)                          # everything asynchronous is queued before this frame's host-synchronous steps
+                if i + 1 < len(raws):
+                    enqueue_regions(i + 1)
+                b = i % NB
+                with t.cuda.stream(T):
+                    T.wait_event(q["ready"][b])
+                    centres = pending.pop(i).result()[1] if i in pending else None
+                    out, ev = span("match+correction", T, lambda: self.track(q["prob"][b], seg_prev, conf_prev, centres=centres))
+                    q["free"][b] = ev
+                seg_prev, conf_prev = out["seg_real_t2"], out["coords"].real
+                yield out
+        finally:
+            # also when the consumer stops early or a frame raises (GeneratorExit / the exception passes through here): the U-Nets and
+            # watersheds already enqueued keep writing the cached buffers, so the caller's stream is ordered behind all three streams
+            for st in (S, W, T):
+                entry.wait_stream(st)
 
     def sequence_spans(self):
         """Mean ms of the LCN + U-Net spans (stream S) and of the regions/match/correction spans (stream T) of the last run_sequence."""

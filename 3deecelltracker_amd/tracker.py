@@ -263,9 +263,11 @@ class Tracker:
     # ------------------------------------------------------------------ unit transforms (reference :552-573)
     @staticmethod
     def _transform_disps(disp, factor):
-        """Coordinates / displacements with their z column multiplied by `factor` (x, y untouched); always a fresh array."""
+        """Coordinates / displacements with their z column multiplied by `factor` (x, y untouched); always a fresh array of the
+        input's dtype: an integer array (the reference feeds _transform_real_to_interpolated's output back in, :307, :451) gets its
+        scaled column truncated on assignment, as numpy does for the reference (:553-556) -- an in-place `*=` would raise instead."""
         scaled = np.array(disp, copy=True)
-        scaled[:, 2] *= factor
+        scaled[:, 2] = scaled[:, 2] * factor
         return scaled
 
     def _z_units(self, disp, factor, to_voxels):

@@ -9,6 +9,8 @@ REPO = Path(__file__).resolve().parent.parent
 if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the frame-loop tests keep 5-6 HIP streams busy: more hardware queues than the default 4 (read when HIP initialises; the package itself only warns)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def pytest_configure(config):

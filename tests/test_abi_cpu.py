@@ -102,16 +102,22 @@ def test_no_packed_fp32_outside_the_conv_kernels(L):
     assert exported and all(n.startswith("ct_") for n in exported), [n for n in exported if not n.startswith("ct_")][:5]
 
 
-def test_package_asks_for_more_hardware_queues_unless_told_otherwise():
-    """The frame loop keeps five to six HIP streams busy; on the runtime's default of four hardware queues they alias.  Importing the
-    package sets GPU_MAX_HW_QUEUES=16 -- before the HIP runtime initialises in a process that has not touched the GPU -- and leaves a value the
-    user exported alone."""
+def test_package_leaves_the_environment_alone_and_warns_about_hardware_queues():
+    """The frame loop keeps five to six HIP streams busy; on the runtime's default of four hardware queues they alias.  The package
+    must not set GPU_MAX_HW_QUEUES behind the host application's back (a process-global side effect that is silently ineffective once HIP is
+    initialised): importing it leaves the environment alone, and _lib.check_hw_queues() -- what FrameChain.run_sequence calls -- warns once
+    when the variable is missing or too small."""
     import os
     import subprocess
-    code = ("import sys, os, importlib; sys.path.insert(0, sys.argv[1]); importlib.import_module('3deecelltracker_amd._lib'); "
-            "print('Q=' + os.environ.get('GPU_MAX_HW_QUEUES', 'unset'))")
+    code = ("import sys, os, importlib, warnings; sys.path.insert(0, sys.argv[1]); L = importlib.import_module('3deecelltracker_amd._lib'); "
+            "print('Q=' + os.environ.get('GPU_MAX_HW_QUEUES', 'unset'))\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always'); ok1 = L.check_hw_queues(); ok2 = L.check_hw_queues()\n"
+            "print('OK=%s/%s W=%d' % (ok1, ok2, sum('GPU_MAX_HW_QUEUES' in str(x.message) for x in w)))")
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     r = subprocess.run([sys.executable, "-c", code, str(REPO)], capture_output=True, text=True, timeout=120, env=env)
-    assert "Q=16" in r.stdout, r.stdout + r.stderr[-300:]
+    assert "Q=unset" in r.stdout and "OK=False/False W=1" in r.stdout, r.stdout + r.stderr[-300:]
     r = subprocess.run([sys.executable, "-c", code, str(REPO)], capture_output=True, text=True, timeout=120, env=dict(env, GPU_MAX_HW_QUEUES="6"))
-    assert "Q=6" in r.stdout, r.stdout + r.stderr[-300:]
+    assert "Q=6" in r.stdout and "OK=False/False W=1" in r.stdout, r.stdout + r.stderr[-300:]
+    r = subprocess.run([sys.executable, "-c", code, str(REPO)], capture_output=True, text=True, timeout=120, env=dict(env, GPU_MAX_HW_QUEUES="16"))
+    assert "Q=16" in r.stdout and "OK=True/True W=0" in r.stdout, r.stdout + r.stderr[-300:]

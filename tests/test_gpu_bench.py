@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 REPO = Path(__file__).resolve().parent.parent
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-        "config", "roofline", "cpu_baseline"}
+        "config", "roofline", "cpu_baseline", "value_spread"}
 
 
 def _free_port():
@@ -30,9 +30,10 @@ def _run(cmd, timeout=900):
 
 def test_single_gpu_modes_share_one_schema():
     base = [sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-realistic-pass"]
-    frames = _run(base)
+    frames = _run(base + ["--windows", "3"])
     patches = _run(base + ["--mode", "patches"])
-    for line in (frames, patches):
+    indep = _run(base + ["--mode", "independent"])
+    for line in (frames, patches, indep):
         assert KEYS <= set(line) and line["n_gpus"] == 1 and line["steps"] == 8 and line["unit"] == "volumes/s"
         assert line["metric"].startswith("volumes/s segment+match") and "workload" in line["config"] and "model" not in line["config"]
         r = line["roofline"]
@@ -44,19 +45,28 @@ def test_single_gpu_modes_share_one_schema():
         assert any("pipe_busy" in ly for ly in line["layers"])                            # SQ digest merged per layer
         assert r["hbm_bound_kernel"]["kernel"].startswith(("conv_first_f16_kernel", "conv_l0l1_fused_kernel"))   # (the first conv runs inside the second's workgroups)
         assert 0 < r["algorithmic_frac"] <= r["frac"] and 0 < r["conv_stack_hbm_frac"] < 1
-        assert line["config"]["headline_excludes"] and line["config"]["rccl_ranks"]["world_size"] == 1
-    assert frames["scaling"] == "weak" and patches["scaling"] == "strong"
-    # at N = 1 the two modes do the same work: same frame rate within noise
-    assert 0.7 < patches["value"] / frames["value"] < 1.4, (frames["value"], patches["value"])      # short runs: generous noise band
+        assert line["config"]["rccl_ranks"]["world_size"] == 1
+    # the contract line is the REAL frame: nothing excluded, every frame chained on its predecessor, several timed windows
+    cfg = frames["config"]
+    assert cfg["headline_excludes"] == [] and cfg["frames_timed"] == 8 and cfg["cells_segmented"][0] > 400 and cfg["prgls_iterations"] <= 30
+    assert {"unet", "regions", "match+correction"} <= set(cfg["stream_spans_ms"])
+    sp = frames["value_spread"]
+    assert sp["windows"] == 3 and sp["min"] <= sp["median"] <= sp["max"] and sp["min"] <= frames["value"] <= sp["max"]
+    assert abs(frames["value"] - 1e3 / frames["ms_per_step"]) < 0.01 * frames["value"]
+    # the lines of rounds 1-4 still say what they leave out
+    assert patches["config"]["headline_excludes"] and indep["config"]["headline_excludes"] and patches["value_spread"] is None
+    assert frames["scaling"] == "weak" and indep["scaling"] == "weak" and patches["scaling"] == "strong"
+    # at N = 1 the patches and independent modes do the same work: same frame rate within noise
+    assert 0.7 < patches["value"] / indep["value"] < 1.4, (indep["value"], patches["value"])      # short runs: generous noise band
     ens = _run(base + ["--mode", "ensemble"])
     assert ens["unit"] == "predictions/s" and ens["value"] > 0 and ens["scaling"] == "strong"
 
 
 def test_lcn_beside_the_match_chains_and_priority_pipeline_run():
-    """The CU-partitioned pipeline (--partition) and the other placement of the LCN (--lcn-stream) do the same work as the default line
-    (priority streams, LCN of frame t+1 on FramePipeline.prep_stream while the U-Net of frame t runs): same PR-GLS iteration count -
-    the check that exposed the co-residency hazard of DESIGN.md section 5."""
-    base = [sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-realistic-pass"]
+    """The CU-partitioned pipeline (--partition) and the other placement of the LCN (--lcn-stream) of the independent-matches mode do the same
+    work as its default (priority streams, LCN of frame t+1 on FramePipeline.prep_stream while the U-Net of frame t runs): same PR-GLS
+    iteration count - the check that exposed the co-residency hazard of DESIGN.md section 5."""
+    base = [sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-realistic-pass", "--mode", "independent"]
     ref = _run(base)
     for extra in (["--lcn-stream", "seg"], ["--partition"], ["--partition", "--lcn-stream", "match"]):
         line = _run(base + extra)
@@ -77,9 +87,10 @@ def test_two_ranks_gloo_same_device_runs_all_sharding_passes():
     assert KEYS <= set(line) and line["n_gpus"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
     cfg = line["config"]
     assert cfg["rccl_ranks"]["world_size"] == 2 and cfg["rccl_ranks"]["backend"] == "gloo"
-    assert cfg["rccl_ranks"]["tracked_sets_gathered"] == 2 * (line["steps"] + line["warmup"])   # every frame (warm-up included) from every rank
+    # every frame of every sequence (warm-up, the priming frames, 5 timed windows) from every rank
+    assert cfg["rccl_ranks"]["tracked_sets_gathered"] == 2 * (line["warmup"] + min(4, line["steps"]) + 5 * line["steps"])
     assert cfg["patches_sharded"]["per_s"] > 0 and cfg["ensemble_sharded"]["per_s"] > 0
-    assert cfg["with_discriminating_ffn"]["prgls_iterations"] <= 30
+    assert cfg["independent_matches"]["with_discriminating_ffn"]["prgls_iterations"] <= 30 and cfg["headline_excludes"] == []
 
 
 def test_two_ranks_without_a_launcher():

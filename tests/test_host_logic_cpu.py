@@ -143,3 +143,23 @@ def test_legacy_match_without_volume_size_flags_no_boundary_cells(monkeypatch):
     trk.cells_on_boundary[2] = 1                            # flags of earlier volumes are kept
     trk._injected = True
     assert trk.match(4)[1][0].tolist() == [0, 0, 1, 0, 0, 0, 0]
+
+
+def test_transform_disps_keeps_integer_arrays_like_the_reference():
+    """tracker.py:553-556 assigns `new[:, 2] = new[:, 2] * factor`: an int array (what _transform_real_to_interpolated returns and the
+    reference feeds back in, :307, :451) keeps its dtype and the scaled z is truncated.  Expected values recorded from the reference's
+    own Tracker._transform_disps (numpy 2.2): an in-place `*=` raises UFuncTypeError instead."""
+    tracker_mod = importlib.import_module("3deecelltracker_amd.tracker")
+    a = np.array([[1, 2, 3], [4, 5, -7], [0, 0, 10]])
+    for factor, want in ((1.9, [[1, 2, 5], [4, 5, -13], [0, 0, 19]]), (0.2, [[1, 2, 0], [4, 5, -1], [0, 0, 2]]),
+                         (5 / 1.9, [[1, 2, 7], [4, 5, -18], [0, 0, 26]])):
+        got = tracker_mod.Tracker._transform_disps(a, factor)
+        assert got.dtype == a.dtype and got.tolist() == want
+    assert a.tolist() == [[1, 2, 3], [4, 5, -7], [0, 0, 10]]                     # a fresh array every time
+    f = tracker_mod.Tracker._transform_disps(a.astype(float), 1.9)
+    assert f.dtype == np.float64 and f.tolist() == [[1.0, 2.0, 5.699999999999999], [4.0, 5.0, -13.299999999999999], [0.0, 0.0, 19.0]]
+    trk = tracker_mod.Tracker.for_matching(None)
+    trk.z_xy_ratio, trk.z_scaling = 1.9, 5
+    i_disp = trk._transform_real_to_interpolated(np.array([[1.0, 2.0, 3.3]]))    # int array ...
+    assert i_disp.dtype.kind == "i"
+    assert trk._transform_interpolated_to_layer(i_disp).dtype.kind == "i"        # ... fed back in, as the reference does
