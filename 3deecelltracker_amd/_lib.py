@@ -114,6 +114,8 @@ SIGNATURES = {
     "ct_watershed_workspace_bytes": (_sz, [_ip, _i]),
     "ct_watershed_read_stage": (_i, [_vp, _ip, _i, _i, _vp, _vp]),
     "ct_watershed_segment": (_i, [_vp, _ip, _d, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ct_watershed_workspace_bytes_ex": (_sz, [_ip, _i, _i, _i]),
+    "ct_watershed_segment_ex": (_i, [_vp, _ip, _d, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -491,8 +491,13 @@ __global__ __launch_bounds__(256) void ws_peak_kernel(SegGeom g, int mode2d, int
         const int grp = mode2d ? z : 0;
         const double a = v[i];
         const bool eq = a == vmax[i];
-        if (eq) atomicAdd(&s_eq[grp & 127], 1u);
-        atomicMin(&s_min[grp & 127], (unsigned long long)__double_as_longlong(a));
+        if (ngroups <= 128) {
+            if (eq) atomicAdd(&s_eq[grp], 1u);
+            atomicMin(&s_min[grp], (unsigned long long)__double_as_longlong(a));
+        } else {                                                                  // more z slices than LDS bins: straight to the tables
+            if (eq) atomicAdd(&eq_count[grp], 1u);
+            atomicMin(&vmin[grp], (unsigned long long)__double_as_longlong(a));
+        }
         const bool inside = x >= border && x < g.X - border && y >= border && y < g.Y - border && (mode2d || (z >= border && z < g.Z - border));
         if (eq && a > 0.0 && inside) {
             const unsigned int pos = atomicAdd(&cand_count[grp], 1u);
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(256) void ws_peak_kernel(SegGeom g, int mode2d, int
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < ngroups && t < 128; t += 256) {
+    for (int t = threadIdx.x; t < ngroups && t < 128 && ngroups <= 128; t += 256) {
         if (s_eq[t]) atomicAdd(&eq_count[t], s_eq[t]);
         if (s_min[t] != ~0ull) atomicMin(&vmin[t], s_min[t]);
     }
@@ -560,11 +565,16 @@ __global__ __launch_bounds__(256) void ws_max_peak_slide_kernel(SegGeom g, int b
                 }
             }
         }
-        if (eqs) atomicAdd(&s_eq[z & 127], eqs);
-        atomicMin(&s_min[z & 127], mn);
+        if (g.Z <= 128) {
+            if (eqs) atomicAdd(&s_eq[z], eqs);
+            atomicMin(&s_min[z], mn);
+        } else {                                                                  // more z slices than LDS bins: one pair of global atomics per line segment
+            if (eqs) atomicAdd(&eq_count[z], eqs);
+            atomicMin(&vmin[z], mn);
+        }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < g.Z && t < 128; t += 256) {
+    for (int t = threadIdx.x; t < g.Z && t < 128 && g.Z <= 128; t += 256) {
         if (s_eq[t]) atomicAdd(&eq_count[t], s_eq[t]);
         if (s_min[t] != ~0ull) atomicMin(&vmin[t], s_min[t]);
     }
@@ -705,15 +715,65 @@ __device__ void ws_aquicksort_block(int* vk, int* ts, int num, int* lists /* LDS
     }
 }
 
+// The whole sort by ONE thread with numpy's own explicit stack (aquicksort_): the form the global-memory mode of ws_peak_select_kernel uses
+// (groups with more candidates than LDS holds: rare, and only reached when equal candidates lie closer than min_distance).
+__device__ void ws_aquicksort_serial(int* vk, int* ts, int num) {
+    if (num < 2) return;
+    int stk[3 * 128];
+    int sp = 0, pl = 0, pr = num - 1, cdepth = 0;
+    for (int n = num >> 1; n; n >>= 1) ++cdepth;
+    cdepth *= 2;
+#define WS_SWAP(a, b) { const int tv_ = vk[a], tt_ = ts[a]; vk[a] = vk[b]; ts[a] = ts[b]; vk[b] = tv_; ts[b] = tt_; }
+    for (;;) {
+        if (cdepth < 0) ws_aheapsort(vk, ts, pl, pr - pl + 1);
+        else {
+            while (pr - pl > 15) {
+                const int pm = pl + ((pr - pl) >> 1);
+                if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
+                if (vk[pr] < vk[pm]) WS_SWAP(pr, pm)
+                if (vk[pm] < vk[pl]) WS_SWAP(pm, pl)
+                const int vp = vk[pm];
+                int pi = pl, pj = pr - 1;
+                WS_SWAP(pm, pj)
+                for (;;) {
+                    do ++pi; while (vk[pi] < vp);
+                    do --pj; while (vp < vk[pj]);
+                    if (pi >= pj) break;
+                    WS_SWAP(pi, pj)
+                }
+                const int pk = pr - 1;
+                WS_SWAP(pi, pk)
+                --cdepth;
+                if (pi - pl < pr - pi) { stk[sp++] = pi + 1; stk[sp++] = pr; stk[sp++] = cdepth; pr = pi - 1; }
+                else { stk[sp++] = pl; stk[sp++] = pi - 1; stk[sp++] = cdepth; pl = pi + 1; }
+            }
+            for (int pi = pl + 1; pi <= pr; ++pi) {
+                const int vv = vk[pi], tt = ts[pi];
+                int pj = pi;
+                while (pj > pl && vv < vk[pj - 1]) { vk[pj] = vk[pj - 1]; ts[pj] = ts[pj - 1]; --pj; }
+                vk[pj] = vv; ts[pj] = tt;
+            }
+        }
+        if (sp == 0) break;
+        cdepth = stk[--sp]; pr = stk[--sp]; pl = stk[--sp];
+    }
+#undef WS_SWAP
+}
+
 // One workgroup per group: final peak test, ensure_spacing among exact ties, raster-order marker labels.
+// GLOBAL = false: the arrays live in LDS (groups of up to 8192 candidates = 128 KB).  GLOBAL = true (peak tables the caller enlarged beyond that:
+// ct_watershed_segment_ex): the same arrays in a global scratch slab of the workspace, 40 B per candidate slot -- the block-wide barriers order
+// global memory inside a workgroup just as they order LDS; slower (every step a memory round trip), same results.
 // Out: labels[idx] = marker number (1-based, raster order within the group), marker list (idx ascending) and count per group.
+template <bool GLOBAL>
 __global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mode2d, int min_distance, const unsigned int* __restrict__ eq_count,
                                                               const unsigned long long* __restrict__ vmin, const unsigned int* __restrict__ cand_count,
                                                               int cap, const unsigned long long* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
                                                               int32_t* __restrict__ labels, int32_t* __restrict__ marker_idx, int32_t* __restrict__ marker_count,
-                                                              int small_elsewhere) {
-    extern __shared__ unsigned long long ws_sm[];
+                                                              int small_elsewhere, unsigned long long* __restrict__ gscratch, size_t gstride /* u64 words per group */) {
+    extern __shared__ unsigned long long ws_sm_lds[];
     const int grp = blockIdx.x;
+    unsigned long long* const ws_sm = GLOBAL ? gscratch + (size_t)grp * gstride : ws_sm_lds;
     const long long gsize = mode2d ? (long long)g.X * g.Y : g.V;
     int n = (int)min(cand_count[grp], (unsigned int)cap);
     if (small_elsewhere && n <= WS_SEL2_CAP) return;                             // ws_peak_select2_kernel's
@@ -796,17 +856,23 @@ __global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mod
         // idx[] <- raveled candidate indices, keep[] <- their ranks (vk); the key region becomes two int arrays: ts | kept flags
         int* ts = (int*)key;
         int* kf = ts + np2;
-        unsigned long long mine[8];
-        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) mine[q] = key[t];
+        unsigned long long mine[8];                                              // (LDS mode: np2 <= 8192 = 8 per thread; global mode: a slab of the scratch)
+        unsigned long long* const stash = GLOBAL ? ws_sm + 2 * (size_t)np2 : nullptr;
+        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) { if constexpr (GLOBAL) stash[t] = key[t]; else mine[q] = key[t]; }
         __syncthreads();
         for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) {
-            idx[t] = (t < nv) ? (int)(mine[q] >> 32) : 0x7fffffff;
-            keep[t] = (t < nv) ? (int)(mine[q] & 0xffffffffu) : 0x7fffffff;
+            const unsigned long long mq = GLOBAL ? stash[t] : mine[q];
+            idx[t] = (t < nv) ? (int)(mq >> 32) : 0x7fffffff;
+            keep[t] = (t < nv) ? (int)(mq & 0xffffffffu) : 0x7fffffff;
             ts[t] = t; kf[t] = (t < nv) ? 1 : 0;
         }
         __syncthreads();
-        __shared__ int qs_lists[2 * 3 * WS_QS_RANGES], qs_counts[2];
-        ws_aquicksort_block(keep, ts, nv, qs_lists, qs_counts);
+        if constexpr (GLOBAL) {
+            if (threadIdx.x == 0) ws_aquicksort_serial(keep, ts, nv);
+        } else {
+            __shared__ int qs_lists[2 * 3 * WS_QS_RANGES], qs_counts[2];
+            ws_aquicksort_block(keep, ts, nv, qs_lists, qs_counts);
+        }
         __syncthreads();
         // greedy spacing inside every run of equal rank, in numpy's order (run starts in parallel)
         for (int t = threadIdx.x; t < nv; t += 1024) {
@@ -824,9 +890,12 @@ __global__ __launch_bounds__(1024) void ws_peak_select_kernel(SegGeom g, int mod
         }
         __syncthreads();
         // back to the common layout: key[t] = kept ? voxel index : ~0  (registers in between: key overlays ts / kf)
-        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) mine[q] = (t < nv && kf[t]) ? (unsigned long long)(unsigned int)idx[ts[t]] : ~0ull;
+        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) {
+            const unsigned long long mq = (t < nv && kf[t]) ? (unsigned long long)(unsigned int)idx[ts[t]] : ~0ull;
+            if constexpr (GLOBAL) stash[t] = mq; else mine[q] = mq;
+        }
         __syncthreads();
-        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) key[t] = mine[q];
+        for (int t = threadIdx.x, q = 0; t < np2; t += 1024, ++q) key[t] = GLOBAL ? stash[t] : mine[q];
         __syncthreads();
     } else {
         for (int t = threadIdx.x; t < np2; t += 1024) key[t] = keep[t] ? (unsigned long long)(unsigned int)idx[t] : ~0ull;
@@ -1735,9 +1804,11 @@ __global__ __launch_bounds__(64) void ws_flood_batch_kernel(SegGeom g, const dou
 __global__ void ws_tie_detect_kernel(SegGeom g, int mode2d, const int32_t* __restrict__ roots, const unsigned int* __restrict__ nroots,
                                      const int32_t* __restrict__ heap_off, const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap,
                                      int32_t* __restrict__ tie_flags, int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox,
-                                     const int* __restrict__ overflow, int32_t* __restrict__ latch) {
+                                     const int* __restrict__ overflow, int32_t* __restrict__ latch, const unsigned int* __restrict__ cand_count, int ngroups) {
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0 && fresh_i32(overflow)) latch[0] = 1;                                       // (the per-stage flag is cleared with the next stage's statistics)
+    // how many candidate slots a group of this stage wanted (the counters keep counting past the table): what the caller sizes its retry from
+    if (t < (unsigned int)ngroups) atomicMax(&latch[mode2d ? 1 : 2], (int32_t)min(fresh_u32(&cand_count[t]), 0x7fffffffu));
     if (t >= fresh_u32(nroots)) return;
     const int root = roots[t];
     slot_of[root] = (int32_t)t;                                                  // (for the bounding boxes ws_fill_single_kernel collects)
@@ -1884,7 +1955,7 @@ __global__ __launch_bounds__(1024) void ws_finish_kernel(long long V, const int3
     __shared__ unsigned long long s_tot;
     const int K = fresh_i32(&marker_count[0]);
     if (fresh_i32(latch)) {                                              // a peak table overflowed in one of the stages: nothing below means anything
-        if (threadIdx.x == 0) { n_out[0] = -2; n_out[1] = min_size; n_out[2] = cell_num; }
+        if (threadIdx.x == 0) { n_out[0] = -2; n_out[1] = fresh_i32(latch + 1); n_out[2] = fresh_i32(latch + 2); }   // (slots the 2-D / 3-D stage wanted)
         for (int l = threadIdx.x; l <= K; l += 1024) newlabel[l] = 0;
         return;
     }
@@ -1955,8 +2026,15 @@ __global__ void ws_clear_kernel(WsClear c) {
 }
 
 struct WsLayout { size_t bn, bn2, gx, d2, dist, tmp, smooth, vmax, labels, parent, size, heap_off, heap_cnt, heap, qlab, roots, cand_val, cand_idx, marker_idx,
-                  stats, sums, weights, bbox, total; int ngroups2d; };
-WsLayout ws_layout(long long V, int Z, int cap) {
+                  stats, sums, weights, bbox, selscratch, total;
+                  // inside `stats` (byte offsets from its start; tables of [ZG] entries, ZG = the z slices rounded up to an even count)
+                  size_t st_eq, st_vmin, st_cand, st_marker, st_misc, st_tie, st_latch, st_counts, st_newlabel, st_zero_words;
+                  int ngroups2d; };
+constexpr int WS_SEL_LDS_CAP = 8192;                 // candidates per group ws_peak_select_kernel sorts inside LDS (16 B each)
+inline int ws_pow2_ceil(int v) { int p2 = 1; while (p2 < v) p2 <<= 1; return p2; }
+// pcap2d / pcap3d: peak-candidate slots per z slice (2-D stage) and in the volume (3-D stage); the volume arrays come first, so their offsets
+// do not depend on the table sizes (ct_watershed_read_stage)
+WsLayout ws_layout(long long V, int Z, int cap, int pcap2d = WS_PEAK_CAP2D, int pcap3d = WS_PEAK_CAP3D) {
     WsLayout L{};
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -1966,12 +2044,32 @@ WsLayout ws_layout(long long V, int Z, int cap) {
     L.labels = take((size_t)V * 4); L.parent = take((size_t)V * 4); L.size = take((size_t)V * 4);
     L.heap_off = take((size_t)V * 4); L.heap_cnt = take((size_t)V * 4);
     L.heap = take((size_t)V * sizeof(WsHeapEntry)); L.qlab = take((size_t)V * 4); L.roots = take((size_t)V * 4);
-    const size_t ncand = (size_t)Z * WS_PEAK_CAP2D > (size_t)WS_PEAK_CAP3D ? (size_t)Z * WS_PEAK_CAP2D : (size_t)WS_PEAK_CAP3D;
+    const size_t ncand = (size_t)Z * pcap2d > (size_t)pcap3d ? (size_t)Z * pcap2d : (size_t)pcap3d;
     L.cand_val = take(ncand * 8); L.cand_idx = take(ncand * 4); L.marker_idx = take(ncand * 4);
-    L.stats = take(4096 + (size_t)(WS_PEAK_CAP3D + 1) * 8);       // eq_count[128] | vmin[128] | cand_count[128] | marker_count[128] | bump, nroots, overflow | counts / newlabel
+    // statistics: eq_count u32[ZG] | vmin u64[ZG] | { cand_count u32[ZG] | marker_count i32[ZG] | bump, nroots, overflow, pad | tie_flags i32[ZG] }
+    //             | latch i32[4] (overflow, slots the 2-D stage wanted, slots the 3-D stage wanted) | counts u32[pcap3d + 1] | newlabel i32[pcap3d + 1]
+    // (the braces: one range the per-stage clear zeroes in 8-byte words)
+    const size_t ZG = ((size_t)Z + 1) & ~(size_t)1;
+    size_t q = 0;
+    L.st_eq = q; q += ZG * 4;
+    L.st_vmin = q; q += ZG * 8;
+    L.st_cand = q; q += ZG * 4;
+    L.st_marker = q; q += ZG * 4;
+    L.st_misc = q; q += 16;
+    L.st_tie = q; q += ZG * 4;
+    L.st_zero_words = (q - L.st_cand) / 8;
+    L.st_latch = q; q += 16;
+    L.st_counts = q; q += (((size_t)pcap3d + 2) & ~(size_t)1) * 4;
+    L.st_newlabel = q; q += ((size_t)pcap3d + 2) * 4;
+    L.stats = take(q);
     L.sums = take((size_t)cap * 4 * 8);
     L.weights = take(64 * 8);
     L.bbox = take((ncand / 2 + 1) * 6 * 4);                       // a listed component holds >= 2 markers
+    // groups beyond the LDS sort's capacity: 24 B per slot (key | idx, rank | stash), padded to a power of two, for every group of the stage
+    size_t sel = 0;
+    if (pcap2d > WS_SEL_LDS_CAP) sel = (size_t)Z * 3 * ws_pow2_ceil(pcap2d);
+    if (pcap3d > WS_SEL_LDS_CAP && (size_t)3 * ws_pow2_ceil(pcap3d) > sel) sel = (size_t)3 * ws_pow2_ceil(pcap3d);
+    L.selscratch = take(sel * 8);
     L.total = o; L.ngroups2d = Z;
     return L;
 }
@@ -2074,27 +2172,45 @@ int ct_segment_centroids(const float* prob, const int dims_xyz[3], float thresho
     return CT_OK;
 }
 
-size_t ct_watershed_workspace_bytes(const int dims_xyz[3], int cap) {
-    if (!dims_xyz || cap <= 0) return 0;
+namespace {
+inline bool ws_caps_ok(int pcap2d, int pcap3d) { return pcap2d >= 16 && pcap3d >= 16 && pcap2d <= (1 << 22) && pcap3d <= (1 << 24); }
+}
+
+size_t ct_watershed_workspace_bytes_ex(const int dims_xyz[3], int cap, int peak_cap_2d, int peak_cap_3d) {
+    if (!dims_xyz || cap <= 0 || !ws_caps_ok(peak_cap_2d, peak_cap_3d)) return 0;
     const long long V = (long long)dims_xyz[0] * dims_xyz[1] * dims_xyz[2];
-    if (V <= 0 || V > 0x7fffffffLL || dims_xyz[2] > 128 || dims_xyz[0] >= WS_INF || dims_xyz[1] >= WS_INF) return 0;
-    return ws_layout(V, dims_xyz[2], cap).total;
+    if (V <= 0 || V > 0x7fffffffLL || dims_xyz[0] >= WS_INF || dims_xyz[1] >= WS_INF || dims_xyz[2] >= WS_INF) return 0;
+    if ((double)dims_xyz[2] * peak_cap_2d > 1e9) return 0;
+    return ws_layout(V, dims_xyz[2], cap, peak_cap_2d, peak_cap_3d).total;
+}
+
+size_t ct_watershed_workspace_bytes(const int dims_xyz[3], int cap) {
+    return ct_watershed_workspace_bytes_ex(dims_xyz, cap, WS_PEAK_CAP2D, WS_PEAK_CAP3D);
 }
 
 int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_ratio, int method, int min_size, int cell_num,
                          int min_distance_2d, int min_distance_3d, const double* gauss_xy, int radius_xy, const double* gauss_z, int radius_z,
                          int cap, int32_t* labels_out, double* centres, int32_t* sizes, int32_t* n_out,
                          void* workspace, size_t workspace_bytes, ct_stream_t stream) {
+    return ct_watershed_segment_ex(prob, dims_xyz, z_xy_ratio, method, min_size, cell_num, min_distance_2d, min_distance_3d, gauss_xy, radius_xy, gauss_z,
+                                   radius_z, cap, WS_PEAK_CAP2D, WS_PEAK_CAP3D, labels_out, centres, sizes, n_out, workspace, workspace_bytes, stream);
+}
+
+int ct_watershed_segment_ex(const float* prob, const int dims_xyz[3], double z_xy_ratio, int method, int min_size, int cell_num,
+                            int min_distance_2d, int min_distance_3d, const double* gauss_xy, int radius_xy, const double* gauss_z, int radius_z,
+                            int cap, int peak_cap_2d, int peak_cap_3d, int32_t* labels_out, double* centres, int32_t* sizes, int32_t* n_out,
+                            void* workspace, size_t workspace_bytes, ct_stream_t stream) {
     if (!prob || !dims_xyz || !centres || !n_out || !workspace || !gauss_xy || !gauss_z) return CT_EINVAL;
     if (dims_xyz[0] <= 0 || dims_xyz[1] <= 0 || dims_xyz[2] <= 0 || cap <= 0 || min_size < 0 || cell_num < 0) return CT_EINVAL;
+    if (!ws_caps_ok(peak_cap_2d, peak_cap_3d) || (double)dims_xyz[2] * peak_cap_2d > 1e9) return CT_EINVAL;
     const int method_in = method;
     method &= 0xff;
     if (method != 0 && method != 1) return CT_EINVAL;
     if (radius_xy < 0 || radius_z < 0 || 2 * radius_xy + 1 > 48 || 2 * radius_z + 1 > 15 || min_distance_2d < 1 || min_distance_3d < 1) return CT_EINVAL;
     const long long V = (long long)dims_xyz[0] * dims_xyz[1] * dims_xyz[2];
-    if (V > 0x7fffffffLL || dims_xyz[2] > 128 || dims_xyz[0] >= WS_INF || dims_xyz[1] >= WS_INF) return CT_ESHAPE;
+    if (V > 0x7fffffffLL || dims_xyz[0] >= WS_INF || dims_xyz[1] >= WS_INF || dims_xyz[2] >= WS_INF) return CT_ESHAPE;
     const int Z = dims_xyz[2];
-    const WsLayout L = ws_layout(V, Z, cap);
+    const WsLayout L = ws_layout(V, Z, cap, peak_cap_2d, peak_cap_3d);
     if (workspace_bytes < L.total) return CT_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
@@ -2106,17 +2222,18 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     WsHeapEntry* heap = (WsHeapEntry*)(ws + L.heap); int32_t* roots = (int32_t*)(ws + L.roots); int32_t* qlab = (int32_t*)(ws + L.qlab);
     unsigned long long* cand_val = (unsigned long long*)(ws + L.cand_val); int32_t* cand_idx = (int32_t*)(ws + L.cand_idx);
     int32_t* marker_idx = (int32_t*)(ws + L.marker_idx);
-    unsigned int* eq_count = (unsigned int*)(ws + L.stats);                       // [128]
-    unsigned long long* vmin = (unsigned long long*)(ws + L.stats + 512);         // [128]
-    unsigned int* cand_count = (unsigned int*)(ws + L.stats + 1536);              // [128]
-    int32_t* marker_count = (int32_t*)(ws + L.stats + 2048);                      // [128]
-    unsigned int* bump = (unsigned int*)(ws + L.stats + 2560);                    // bump | nroots | overflow
+    unsigned int* eq_count = (unsigned int*)(ws + L.stats + L.st_eq);             // [Z]
+    unsigned long long* vmin = (unsigned long long*)(ws + L.stats + L.st_vmin);   // [Z]
+    unsigned int* cand_count = (unsigned int*)(ws + L.stats + L.st_cand);         // [Z]
+    int32_t* marker_count = (int32_t*)(ws + L.stats + L.st_marker);               // [Z]
+    unsigned int* bump = (unsigned int*)(ws + L.stats + L.st_misc);               // bump | nroots | overflow
     unsigned int* nroots = bump + 1; int* overflow = (int*)(bump + 2);
-    int32_t* tie_flags = (int32_t*)(ws + L.stats + 3072);                         // [128] groups whose equal seeds share a component
-    int32_t* latch = (int32_t*)(ws + L.stats + 3584);                             // peak-table overflow of either stage (outside the per-stage clear)
+    int32_t* tie_flags = (int32_t*)(ws + L.stats + L.st_tie);                     // [Z] groups whose equal seeds share a component
+    int32_t* latch = (int32_t*)(ws + L.stats + L.st_latch);                       // peak-table overflow of either stage | slots the 2-D / 3-D stage wanted (outside the per-stage clear)
     int32_t* bbox = (int32_t*)(ws + L.bbox);                                      // [listed component][6] bounding boxes; slot map = gx (free after the EDT)
-    unsigned int* counts = (unsigned int*)(ws + L.stats + 4096);                  // [WS_PEAK_CAP3D + 1]
-    int32_t* newlabel = (int32_t*)(counts + WS_PEAK_CAP3D + 1);
+    unsigned int* counts = (unsigned int*)(ws + L.stats + L.st_counts);           // [peak_cap_3d + 1]
+    int32_t* newlabel = (int32_t*)(ws + L.stats + L.st_newlabel);
+    unsigned long long* selscratch = (unsigned long long*)(ws + L.selscratch);
     unsigned long long* sums = (unsigned long long*)(ws + L.sums);
     WsWeights w_xy{}, w_z{};
     for (int j = 0; j <= 2 * radius_xy; ++j) w_xy.w[j] = gauss_xy[j];
@@ -2124,7 +2241,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     const SegGeom g{dims_xyz[0], dims_xyz[1], dims_xyz[2], V};
     const unsigned nb = (unsigned)((V + 255) / 256);
     // (per call: the attribute belongs to the current device's copy of the kernel, and a process may drive several devices)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_PEAK_CAP3D * 16));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_SEL_LDS_CAP * 16));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_SEL2_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_box_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BOX_LDS));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_flood_box_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_BOX_LDS));
@@ -2160,12 +2277,13 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     // second's the tables of the final bookkeeping, which nothing touches before)
     auto stage_clear = [&](bool first) -> int {
         WsClear c{};
-        c.p[0] = (unsigned long long*)(ws + L.stats); c.n[0] = 512 / 8; c.v[0] = 0ull;                 // eq_count
-        c.p[1] = vmin; c.n[1] = 128; c.v[1] = ~0ull;                                                  // (stats + 512 .. + 1536)
-        c.p[2] = (unsigned long long*)(ws + L.stats + 1536); c.n[2] = (3584 - 1536) / 8; c.v[2] = 0ull;
+        const unsigned int zg = (unsigned int)((Z + 1) / 2);                         // 8-byte words of a u32 [Z] table
+        c.p[0] = (unsigned long long*)eq_count; c.n[0] = zg; c.v[0] = 0ull;
+        c.p[1] = vmin; c.n[1] = 2 * zg; c.v[1] = ~0ull;
+        c.p[2] = (unsigned long long*)cand_count; c.n[2] = (unsigned int)L.st_zero_words; c.v[2] = 0ull;   // cand_count | marker_count | bump, nroots, overflow | tie_flags
         if (first) { c.p[3] = (unsigned long long*)latch; c.n[3] = 2; c.v[3] = 0ull; }
         else {
-            c.p[3] = (unsigned long long*)counts; c.n[3] = (unsigned int)(WS_PEAK_CAP3D + 1); c.v[3] = 0ull;
+            c.p[3] = (unsigned long long*)counts; c.n[3] = (unsigned int)((peak_cap_3d + 2) / 2); c.v[3] = 0ull;
             c.p[4] = sums; c.n[4] = (unsigned int)cap * 4u; c.v[4] = 0ull;
         }
         ws_clear_kernel<<<16, 256, 0, st>>>(c);
@@ -2190,7 +2308,7 @@ int ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_xy_r
     };
 
     auto stage = [&](bool mode2d, const unsigned char* mask, int min_distance, int border) -> int {
-        const int ngroups = mode2d ? Z : 1, pcap = mode2d ? WS_PEAK_CAP2D : WS_PEAK_CAP3D;
+        const int ngroups = mode2d ? Z : 1, pcap = mode2d ? peak_cap_2d : peak_cap_3d;
         // separable window maximum: smooth -> tmp -> (dist ->) [vmax]; the last pass carries the peak test (the maximum itself is only written
         // for the tests' hook)
         double* const vmax_out = (method_in & 0x300) ? vmax : nullptr;
@@ -2222,16 +2340,21 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
                                                                        labels, marker_idx, marker_count);
             LAUNCH_CHECK();
         }
-        if (no_sel2 || pcap > WS_SEL2_CAP)                                       // groups with more candidates than the counting form takes
-            ws_peak_select_kernel<<<ngroups, 1024, (size_t)pcap * 16, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val, cand_idx,
-                                                                        labels, marker_idx, marker_count, no_sel2 ? 0 : 1);
+        if (no_sel2 || pcap > WS_SEL2_CAP) {                                     // groups with more candidates than the counting form takes
+            if (pcap <= WS_SEL_LDS_CAP)
+                ws_peak_select_kernel<false><<<ngroups, 1024, (size_t)ws_pow2_ceil(pcap) * 16, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val,
+                                                                                                   cand_idx, labels, marker_idx, marker_count, no_sel2 ? 0 : 1, nullptr, 0);
+            else                                                                 // enlarged tables: the sort's arrays in the workspace
+                ws_peak_select_kernel<true><<<ngroups, 1024, 0, st>>>(g, mode2d ? 1 : 0, min_distance, eq_count, vmin, cand_count, pcap, cand_val, cand_idx, labels,
+                                                                      marker_idx, marker_count, no_sel2 ? 0 : 1, selscratch, (size_t)3 * ws_pow2_ceil(pcap));
+        }
         LAUNCH_CHECK();
         if (aux) HIPCHK(hipStreamWaitEvent(st, aux->join, 0));                    // the components of the mask (stage_components, helper stream)
-        ws_marker_append_kernel<<<(unsigned)((ngroups * pcap + 255) / 256), 256, 0, st>>>(ngroups, pcap, marker_idx, marker_count, smooth, parent, heap_off,
+        ws_marker_append_kernel<<<(unsigned)(((long long)ngroups * pcap + 255) / 256), 256, 0, st>>>(ngroups, pcap, marker_idx, marker_count, smooth, parent, heap_off,
                                                                                        heap_cnt, heap, roots, nroots, labels);
         LAUNCH_CHECK();
-        ws_tie_detect_kernel<<<(unsigned)((ngroups * pcap / 2 + 255) / 256), 256, 0, st>>>(g, mode2d ? 1 : 0, roots, nroots, heap_off, heap_cnt, heap, tie_flags, gx, bbox,
-                                                                                           overflow, latch);
+        ws_tie_detect_kernel<<<(unsigned)(((long long)ngroups * pcap / 2 + ngroups + 255) / 256), 256, 0, st>>>(g, mode2d ? 1 : 0, roots, nroots, heap_off, heap_cnt, heap, tie_flags,
+                                                                                                              gx, bbox, overflow, latch, cand_count, ngroups);
         LAUNCH_CHECK();
         // No host round trip: the flood kernels walk the device-side list with fixed grids, the groups whose equal seeds share a component are
         // replayed by a kernel that looks at its own flag, and a peak-table overflow is latched and reported through n_out (-2) by ws_finish_kernel.
@@ -2332,7 +2455,7 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
     if (rc) return rc;
 
     // ---- sizes, min_size / cell_num, small objects dropped, sequential labels, centres (watershed.py:88-96, tracker.py:680, :646-647)
-    ws_bincount_kernel<<<nb, 256, 0, st>>>(V, labels, WS_PEAK_CAP3D, counts);
+    ws_bincount_kernel<<<nb, 256, 0, st>>>(V, labels, peak_cap_3d, counts);
     LAUNCH_CHECK();
     ws_finish_kernel<<<1, 1024, 0, st>>>(V, marker_count, method, min_size, cell_num, counts, newlabel, n_out, latch);
     LAUNCH_CHECK();
@@ -2347,8 +2470,8 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
 int ct_watershed_read_stage(const void* workspace, const int dims_xyz[3], int cap, int which, void* dst, ct_stream_t stream) {
     if (!workspace || !dims_xyz || !dst || cap <= 0) return CT_EINVAL;
     const long long V = (long long)dims_xyz[0] * dims_xyz[1] * dims_xyz[2];
-    if (V <= 0 || V > 0x7fffffffLL || dims_xyz[2] > 128) return CT_ESHAPE;
-    const WsLayout L = ws_layout(V, dims_xyz[2], cap);
+    if (V <= 0 || V > 0x7fffffffLL) return CT_ESHAPE;
+    const WsLayout L = ws_layout(V, dims_xyz[2], cap);         // (the volume arrays sit in front of the tables: their offsets do not depend on the peak capacities)
     const char* ws = (const char*)workspace;
     size_t off, bytes;
     switch (which) {

@@ -84,15 +84,21 @@ def gaussian_weights(sigma: float, truncate: float = 4.0):
 
 
 _METHODS = {"min_size": 0, "cell_num": 1}
-# what ct_watershed_workspace_bytes / ct_watershed_segment refuse (csrc/ct_segment.hip: per-slice statistics tables, WS_PEAK_CAP2D / 3D)
-WATERSHED_LIMITS = "z <= 128 slices, x and y < 16384, < 2^31 voxels, <= 2048 peak candidates per z slice and <= 8192 in the volume"
+# what ct_watershed_workspace_bytes_ex / ct_watershed_segment_ex refuse (csrc/ct_segment.hip): the peak tables are sized per call and grown on
+# overflow, the per-slice statistics from the z extent -- what is left is the index arithmetic
+WATERSHED_LIMITS = "x, y and z < 16384 and < 2^31 voxels"
+PEAK_CAP_2D, PEAK_CAP_3D = 2048, 8192          # peak-candidate slots per z slice / in the volume of the first attempt (every stack measured fits)
+PEAK_CAP_MAX_2D, PEAK_CAP_MAX_3D = 1 << 22, 1 << 24
 
 
 class PendingWatershed:
-    """ct_watershed_segment enqueued on a stream (watershed_centroids_enqueue); result() makes the call's only host round trip (the region
-    count), re-running with larger tables in the rare case that `cap` regions were not enough."""
+    """ct_watershed_segment_ex enqueued on a stream (watershed_centroids_enqueue); result() makes the call's only host round trip (the region
+    count), re-running with larger tables in the rare cases that `cap` regions or the peak-candidate tables were not enough (the reference's
+    watershed.py takes any stack: the device's tables grow to what the stack needs)."""
 
     def __init__(self, **kw):
+        self.peak_cap_2d, self.peak_cap_3d = PEAK_CAP_2D, PEAK_CAP_3D
+        self.retries = 0
         self.__dict__.update(kw)
 
     def _enqueue(self):
@@ -102,17 +108,18 @@ class PendingWatershed:
         dims = _lib.ivec(prob.shape)
         self.centres = _dev.empty((cap, 3), t.float64, prob.device)
         self.sizes = _dev.empty((cap,), t.int32, prob.device)
-        nbytes = L.ct_watershed_workspace_bytes(dims, int(cap))
+        nbytes = L.ct_watershed_workspace_bytes_ex(dims, int(cap), int(self.peak_cap_2d), int(self.peak_cap_3d))
         if nbytes == 0:
             raise ValueError(f"volume {tuple(prob.shape)} is outside the device watershed's limits ({WATERSHED_LIMITS}); "
                              "threshold + connected components have none: Tracker.region_method = 'cc' / segment_centroids_device")
         self.ws = _dev.workspace(nbytes, prob.device)
-        rc = L.ct_watershed_segment(prob.data_ptr(), dims, float(self.z_xy_ratio), _METHODS[self.method], int(self.min_size), int(self.cell_num),
-                                    int(self.min_distance_2d), int(self.min_distance_3d), self.w_xy.ctypes.data_as(C.c_void_p), self.r_xy,
-                                    self.w_z.ctypes.data_as(C.c_void_p), self.r_z, int(cap), self.labels.data_ptr() if self.labels is not None else None,
-                                    self.centres.data_ptr(), self.sizes.data_ptr(), self.n_dev.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
-                                    _dev.stream(prob.device))
-        _lib.check(rc, "ct_watershed_segment")
+        rc = L.ct_watershed_segment_ex(prob.data_ptr(), dims, float(self.z_xy_ratio), _METHODS[self.method], int(self.min_size), int(self.cell_num),
+                                       int(self.min_distance_2d), int(self.min_distance_3d), self.w_xy.ctypes.data_as(C.c_void_p), self.r_xy,
+                                       self.w_z.ctypes.data_as(C.c_void_p), self.r_z, int(cap), int(self.peak_cap_2d), int(self.peak_cap_3d),
+                                       self.labels.data_ptr() if self.labels is not None else None,
+                                       self.centres.data_ptr(), self.sizes.data_ptr(), self.n_dev.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                       _dev.stream(prob.device))
+        _lib.check(rc, "ct_watershed_segment_ex")
         self.stream = t.cuda.current_stream(prob.device)
         self.event = t.cuda.Event(); self.event.record(self.stream)
 
@@ -128,9 +135,25 @@ class PendingWatershed:
                     if x is not None:
                         x.record_stream(cur)
             n, ms, cn = (int(v) for v in self.n_dev.cpu().tolist())          # the call's only host round trip
-            if n == -2:                       # a peak table overflowed in one of the stages (latched on the device, nothing was waited for)
-                raise ValueError(f"the probability map has more peak candidates than the device watershed's tables hold ({WATERSHED_LIMITS}): "
-                                 "a map that noisy usually needs a higher noise_level; Tracker.region_method = 'cc' has no such limit")
+            if n == -2:
+                # a peak table overflowed in one of the stages (latched on the device, nothing was waited for); ms / cn = the slots the fullest z
+                # slice / the volume wanted.  The 3-D stage only ran on garbage if the 2-D stage overflowed, so its figure counts only when the
+                # 2-D tables held; a second overflow (the 3-D stage after a 2-D retry) takes one more round.
+                want2, want3 = ms, cn
+                grow2 = want2 > self.peak_cap_2d
+                new2 = max(self.peak_cap_2d, _pow2_ceil(want2)) if grow2 else self.peak_cap_2d
+                new3 = max(self.peak_cap_3d, _pow2_ceil(want3)) if (want3 > self.peak_cap_3d and not grow2) else self.peak_cap_3d
+                if grow2 and want3 > self.peak_cap_3d:
+                    new3 = max(self.peak_cap_3d, _pow2_ceil(min(want3, PEAK_CAP_MAX_3D)))      # (a lower bound taken from the garbage run: saves a round when it holds)
+                if (new2, new3) == (self.peak_cap_2d, self.peak_cap_3d) or new2 > PEAK_CAP_MAX_2D or new3 > PEAK_CAP_MAX_3D or self.retries >= 4:
+                    raise ValueError(f"the probability map has more peak candidates ({want2} in a z slice / {want3} in the volume) than the device "
+                                     f"watershed's tables can be grown to ({PEAK_CAP_MAX_2D} / {PEAK_CAP_MAX_3D}): a map that noisy usually needs a higher "
+                                     "noise_level; Tracker.region_method = 'cc' has no such limit")
+                self.peak_cap_2d, self.peak_cap_3d = new2, new3
+                self.retries += 1
+                with t.cuda.stream(self.stream):
+                    self._enqueue()
+                continue
             if n < 0:                         # watershed.py:92: np.sort(counts)[-cell_num - 1] with fewer than cell_num + 1 bins
                 raise IndexError(f"index {-self.cell_num - 1} is out of bounds: method='cell_num' asks for {self.cell_num} cells, the watershed found fewer regions")
             if n <= self.cap:
@@ -140,8 +163,16 @@ class PendingWatershed:
                 self._enqueue()
 
 
+def _pow2_ceil(v: int) -> int:
+    p = 16
+    while p < v:
+        p <<= 1
+    return p
+
+
 def watershed_centroids_enqueue(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0, cap: int = 4096,
-                                want_labels: bool = True, min_distance_2d: int = 7, min_distance_3d: int = 3) -> PendingWatershed:
+                                want_labels: bool = True, min_distance_2d: int = 7, min_distance_3d: int = 3,
+                                peak_cap_2d: int = PEAK_CAP_2D, peak_cap_3d: int = PEAK_CAP_3D) -> PendingWatershed:
     """watershed_centroids_device without its host round trip: the kernels are enqueued on the current stream, `.result()` waits for them.
     `prob` must stay untouched until result() has returned."""
     t = _dev.torch()
@@ -156,17 +187,19 @@ def watershed_centroids_enqueue(prob, z_xy_ratio: float, method: str = "min_size
     p = PendingWatershed(prob=prob, z_xy_ratio=z_xy_ratio, method=method, min_size=min_size, cell_num=cell_num, cap=cap,
                          min_distance_2d=min_distance_2d, min_distance_3d=min_distance_3d, w_xy=w_xy, r_xy=r_xy, w_z=w_z, r_z=r_z,
                          labels=_dev.empty(tuple(prob.shape), t.int32, prob.device) if want_labels else None,
-                         n_dev=_dev.empty((3,), t.int32, prob.device))
+                         n_dev=_dev.empty((3,), t.int32, prob.device), peak_cap_2d=int(peak_cap_2d), peak_cap_3d=int(peak_cap_3d))
     p._enqueue()
     return p
 
 
 def watershed_centroids_device(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0, cap: int = 4096,
-                               want_labels: bool = True, min_distance_2d: int = 7, min_distance_3d: int = 3):
+                               want_labels: bool = True, min_distance_2d: int = 7, min_distance_3d: int = 3,
+                               peak_cap_2d: int = PEAK_CAP_2D, peak_cap_3d: int = PEAK_CAP_3D):
     """Tracker._watershed (reference tracker.py:671-684 = watershed.py:16-108) + relabel_sequential + center_of_mass on the device.
     prob: contiguous float32 cuda tensor [x, y, z] -> (labels int32 cuda | None, centres fp64 cuda [n, 3], sizes int32 cuda [n],
     min_size in force, cell_num in force)."""
-    return watershed_centroids_enqueue(prob, z_xy_ratio, method, min_size, cell_num, cap, want_labels, min_distance_2d, min_distance_3d).result()
+    return watershed_centroids_enqueue(prob, z_xy_ratio, method, min_size, cell_num, cap, want_labels, min_distance_2d, min_distance_3d,
+                                       peak_cap_2d, peak_cap_3d).result()
 
 
 def watershed_centroids(prob, z_xy_ratio: float, method: str = "min_size", min_size: int = 0, cell_num: int = 0):

@@ -845,6 +845,7 @@ def main():
         # the same window again (5 in all): a 0.14-s sample must not decide the round's number
         wins = [dt] + [timed_window(ctx, lambda: seqm.run(args.steps)) for _ in range(max(0, args.windows - 1))]
         seqm.first_coords = first_coords
+        gathered_main = ctx.gathered_sets                     # (the informative passes below gather their own sets)
         vals = sorted(units / w for w in wins)
         spread = {"windows": len(wins), "frames_per_window": args.steps, "min": round(vals[0], 3), "median": round(float(np.median(vals)), 3), "max": round(vals[-1], 3),
                   "note": "`value` is the FIRST window (the contract's K timed steps after W warm-up steps); every window is one run_sequence of K "
@@ -864,6 +865,7 @@ def main():
             roofline, layers = roofline_from_timing(ctx, args, n_patches, args.steps)
         units = world * args.steps if args.mode == "independent" else args.steps
         spans = None
+        gathered_main = ctx.gathered_sets
 
     # ---- informative passes (never the headline value)
     if not args.no_realistic_pass and args.mode == "frames":
@@ -958,7 +960,7 @@ def main():
                "prgls_iterations": int(np.median(iters_main)) if iters_main else None,
                "headline_excludes": excludes,
                "rccl_ranks": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                               "tracked_sets_gathered": ctx.gathered_sets} if world > 1 else
+                               "tracked_sets_gathered": gathered_main} if world > 1 else
                               {"world_size": 1, "backend": None, "tracked_sets_gathered": 0}),
                "parallelism": parallelism}
         if args.mode == "frames":

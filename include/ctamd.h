@@ -368,8 +368,9 @@ int ct_segment_centroids(const float* prob, const int dims_xyz[3], float thresho
  * caller exactly as scipy does (3deecelltracker_amd/segment.py); labels_out [dev] int32 [x][y][z] or NULL; centres [dev] fp64 [cap][3] raw voxel
  * coordinates; sizes [dev] int32 [cap] or NULL; n_out [dev] int32 [3] = {number of cells, min_size in force, cell_num in force}.
  * More cells than `cap`: only the first `cap` centres are written (the caller retries with a larger table).  Asynchronous: nothing is waited
- * for (component lists and flags stay on the device).  CT_ESHAPE: z > 128 or an axis >= 16384.  More than 2048 peak candidates in a slice /
- * 8192 in the volume are latched on the device and reported as n_out[0] = -2 (labels / centres are meaningless then).
+ * for (component lists and flags stay on the device).  CT_ESHAPE: an axis >= 16384.  More than 2048 peak candidates in a slice /
+ * 8192 in the volume are latched on the device and reported as n_out[0] = -2 (labels / centres are meaningless then; n_out[1], n_out[2] = the
+ * slots the stages wanted: ct_watershed_segment_ex takes larger tables).
  * Ties, as upstream resolves them (pinned against the reference on scikit-image 0.18.3, tests/test_watershed_pin.py): peak candidates of exactly
  * equal height closer than min_distance (strictly) are thinned in the order np.argsort(-values) leaves them -- numpy's generic introsort,
  * replayed on the device; seeds of exactly equal height inside one connected region are popped in the order upstream's image-wide binary heap
@@ -385,6 +386,19 @@ int    ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_x
                             int min_distance_2d, int min_distance_3d, const double* gauss_xy, int radius_xy, const double* gauss_z, int radius_z,
                             int cap, int32_t* labels_out, double* centres, int32_t* sizes, int32_t* n_out,
                             void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
+/* The same call with the peak-candidate tables sized by the caller (the reference's watershed.py:16-108 takes any stack: skimage's peak_local_max
+ * has no table).  peak_cap_2d = candidate slots per z slice of the 2-D stage, peak_cap_3d = slots of the 3-D stage (ct_watershed_segment = 2048 /
+ * 8192, enough for every stack measured; 16 .. 2^22 / 2^24).  A stage that wants more latches the overflow and n_out comes back as
+ * {-2, slots the fullest z slice wanted, slots the volume wanted} (0 for a stage that was not reached with an overflow pending) -- the caller
+ * retries ONCE with tables of that size (3deecelltracker_amd/segment.py does).  Groups of up to 2048 candidates are selected by the counting
+ * kernel, up to 8192 by the LDS bitonic form, beyond that the same algorithm runs on a scratch slab of the workspace (slower, same results).
+ * Any z extent is accepted (per-slice statistics tables are sized from dims_xyz[2]); an axis must stay < 16384.                           */
+size_t ct_watershed_workspace_bytes_ex(const int dims_xyz[3], int cap, int peak_cap_2d, int peak_cap_3d);
+int    ct_watershed_segment_ex(const float* prob, const int dims_xyz[3], double z_xy_ratio, int method, int min_size, int cell_num,
+                               int min_distance_2d, int min_distance_3d, const double* gauss_xy, int radius_xy, const double* gauss_z, int radius_z,
+                               int cap, int peak_cap_2d, int peak_cap_3d, int32_t* labels_out, double* centres, int32_t* sizes, int32_t* n_out,
+                               void* workspace, size_t workspace_bytes, ct_stream_t stream);
 
 
 #ifdef __cplusplus

