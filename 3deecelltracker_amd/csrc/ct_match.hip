@@ -503,6 +503,110 @@ __global__ __launch_bounds__(256) void gd_accept_kernel(int m, int n, float thr,
     keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
 }
 
+// ------------------------------------------------------------------------------------------------
+// All rounds of the greedy assignment in ONE launch (the single-match path, ct_greedy_match): the loop "row / column best -> accept -> anything
+// new?" is sequential anyway, and as 11-19 pairs of launches each of its ~30 tiny kernels waited for a workgroup slot beside the U-Net (the frame
+// loop: gd_best 75-130 us per launch against 8 us alone, ~1 ms of a frame's match stream).  A small persistent grid walks the rounds with a
+// device-side barrier between the two phases; per round exactly gd_best_kernel's and gd_accept_kernel's arithmetic on the same order
+// (max value, lowest index), so the accepted set and the pick order are the same bit for bit.
+//   * the grid is small enough to be co-resident several times over on the CUs the launch stream may use (the host sizes it from the
+//     stream's CU mask: a barrier between workgroups that cannot all be resident would never open);
+//   * what a round writes and the next reads travels through L2: the barrier is a release (__threadfence before the arrival) and an
+//     acquire (after the last arrival), and the wave-uniform reads (flags of a wave's own row, the counters) are agent-scope loads -- plain
+//     loads become scalar loads, and the scalar cache is not covered by the vector L1's invalidate (ct_fresh.h has the history).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gd_fresh_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned char gd_fresh_u8(const unsigned char* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+enum { GD_BAR = 8 };                          // ctr[GD_BAR]: arrivals at the device-side barrier (monotonic)
+__device__ __forceinline__ void gd_grid_barrier(int* bar, int nblk, int& passed) {
+    __syncthreads();
+    ++passed;
+    if (threadIdx.x == 0) {
+        __threadfence();                                                          // release: this workgroup's writes of the phase
+        atomicAdd(bar, 1);
+        while (gd_fresh_i32(bar) < passed * nblk) __builtin_amdgcn_s_sleep(1);
+        __threadfence();                                                          // acquire: the other workgroups' writes
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void gd_persistent_kernel(const float* __restrict__ corr, int m, int n, float thr, unsigned char* row_used,
+                                                            unsigned char* col_used, float* rowval, int* rowcol, int* colrow,
+                                                            unsigned long long* keys, int* ctr, int max_rounds) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int G = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ncb = (n + 63) / 64;
+    int passed = 0;
+    for (int round = 0; round < max_rounds; ++round) {
+        if (round > 0 && gd_fresh_i32(&ctr[GD_NEW + ((round - 1) & 1)]) == 0) break;     // the last round accepted nothing (every workgroup reads the same word)
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctr[GD_NEW + (round & 1)] = 0;            // re-arm this round's counter (last read two barriers ago)
+        // ---- every free row's best free column (a wave per row; gd_best_kernel's row blocks)
+        for (int t = blockIdx.x * 4 + wave; t < m; t += G * 4) {
+            if (gd_fresh_u8(&row_used[t])) { if (lane == 0) rowcol[t] = -1; continue; }
+            const float* row = corr + (size_t)t * n;
+            float best = -1.f; int bi = 0x7fffffff;
+            for (int c0 = lane; c0 < n; c0 += 64 * GD_UN) {
+                float vv[GD_UN]; unsigned char uu[GD_UN];
+#pragma unroll
+                for (int u = 0; u < GD_UN; ++u) { const int c = min(c0 + 64 * u, n - 1); uu[u] = col_used[c]; vv[u] = row[c]; }
+#pragma unroll
+                for (int u = 0; u < GD_UN; ++u) {
+                    const int c = c0 + 64 * u;
+                    if (c < n && !uu[u] && vv[u] > best) { best = vv[u]; bi = c; }   // ascending c => lowest column on ties
+                }
+            }
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) {
+                const float ov = __shfl_xor(best, mk); const int oi = __shfl_xor(bi, mk);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (lane == 0) { rowval[t] = best; rowcol[t] = (bi == 0x7fffffff) ? -1 : bi; }
+        }
+        // ---- every free column's best free row (64 columns x 4 row lanes per workgroup pass; gd_best_kernel's column blocks)
+        for (int cb = blockIdx.x; cb < ncb; cb += G) {
+            const int r = cb * 64 + lane;
+            float best = -1.f; int btg = 0x7fffffff;
+            if (r < n && !col_used[r])
+                for (int t0 = wave; t0 < m; t0 += 4 * GD_UN) {
+                    float vv[GD_UN]; unsigned char uu[GD_UN];
+#pragma unroll
+                    for (int u = 0; u < GD_UN; ++u) { const int t = min(t0 + 4 * u, m - 1); uu[u] = gd_fresh_u8(&row_used[t]); vv[u] = corr[(size_t)t * n + r]; }
+#pragma unroll
+                    for (int u = 0; u < GD_UN; ++u) {
+                        const int t = t0 + 4 * u;
+                        if (t < m && !uu[u] && vv[u] > best) { best = vv[u]; btg = t; }  // ascending t => lowest row on ties
+                    }
+                }
+            sv[wave][lane] = best; si[wave][lane] = btg;
+            __syncthreads();
+            if (wave == 0 && r < n) {
+                for (int q = 1; q < 4; ++q) {
+                    const float ov = sv[q][lane]; const int oi = si[q][lane];
+                    if (ov > best || (ov == best && oi < btg)) { best = ov; btg = oi; }
+                }
+                colrow[r] = (btg == 0x7fffffff) ? -1 : btg;
+            }
+            __syncthreads();
+        }
+        gd_grid_barrier(&ctr[GD_BAR], G, passed);
+        // ---- accept the locally dominant edges (gd_accept_kernel)
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < m; t += G * 256) {
+            if (row_used[t]) continue;
+            const int r = rowcol[t];
+            const float v = rowval[t];
+            if (r < 0 || !(v >= thr) || colrow[r] != t) continue;
+            row_used[t] = 1; col_used[r] = 1;
+            const int k = atomicAdd(&ctr[GD_COUNT], 1);
+            atomicAdd(&ctr[GD_NEW + (round & 1)], 1);
+            const unsigned flat = (unsigned)t * (unsigned)n + (unsigned)r;
+            keys[k] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
+        }
+        gd_grid_barrier(&ctr[GD_BAR], G, passed);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr[GD_DONE] = 1;
+}
+
 // single workgroup: bitonic sort of the accepted keys (descending) -> pairs in the reference's pick order
 __global__ __launch_bounds__(1024) void gd_finalize_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ ctr,
                                                            int n, int32_t* __restrict__ pairs, int32_t* __restrict__ n_pairs,
@@ -2374,6 +2478,39 @@ int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, 
     ENSURE_BIG_LDS(gd_finalize_kernel);
     const int max_rounds = (m < n ? m : n) + 1;
     int hctr[4] = {0, 0, 0, 0};
+    // One persistent launch for all rounds (gd_persistent_kernel) when enough of its workgroups are certain to be co-resident: a quarter of the
+    // 256-thread slots of the CUs `st` may use (8 per CU), so that up to four such chains on one CU partition cannot block each other.
+    // CT_GREEDY_PERSISTENT=0: the launch-per-phase form (A/B; also taken on partitions of fewer than 2 CUs).
+    static const bool no_persist = getenv("CT_GREEDY_PERSISTENT") && atoi(getenv("CT_GREEDY_PERSISTENT")) == 0;
+    int pg = 0;
+    if (!no_persist) {
+        int ncu = 0;
+        uint32_t mask[16] = {0};
+        if (st && hipExtStreamGetCUMask(st, 16, mask) == hipSuccess) { for (int w = 0; w < 16; ++w) ncu += __builtin_popcount(mask[w]); }
+        else (void)hipGetLastError();
+        if (ncu <= 0) {                                                           // (the null stream / no mask: the whole device)
+            int dev = 0; hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+        }
+        const int safe = ncu * 8 / 4;
+        const int want = (m + 15) / 16 < 64 ? ((m + 15) / 16 < 8 ? 8 : (m + 15) / 16) : 64;
+        pg = want < safe ? want : safe;
+        if (pg < 4) pg = 0;
+    }
+    if (pg > 0) {
+        hipLaunchKernelGGL(gd_persistent_kernel, dim3(pg), dim3(256), 0, st, corr, m, n, threshold, row_used, col_used, rowval, rowcol, colrow, keys, ctr,
+                           max_rounds);
+        LAUNCH_CHECK();
+        // the pair count stays on the device: gd_finalize_kernel sizes its sort from it, the host only provides LDS for the largest possible count
+        int p2 = 1; while (p2 < (m < n ? m : n)) p2 <<= 1;
+        hipLaunchKernelGGL(gd_finalize_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, st, keys, ctr, n, pairs, n_pairs);
+        LAUNCH_CHECK();
+        if (getenv("CT_DEBUG")) {
+            HIPCHK(hipMemcpyAsync(hctr, ctr, sizeof(hctr), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            fprintf(stderr, "[ct_greedy_match] m %d n %d pairs %d (persistent, %d workgroups)\n", m, n, hctr[GD_COUNT], pg);
+        }
+    } else {
     for (int done_rounds = 0; done_rounds < max_rounds;) {
         const int chunk = done_rounds == 0 ? 12 : 8;
         const int nrb = (m + GD_ROWLANES - 1) / GD_ROWLANES, ncb = (n + 63) / 64;
@@ -2396,6 +2533,7 @@ int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, 
         int p2 = 1; while (p2 < hctr[GD_COUNT]) p2 <<= 1;
         hipLaunchKernelGGL(gd_finalize_kernel, dim3(1), dim3(1024), (size_t)p2 * 8, st, keys, ctr, n, pairs, n_pairs);
         LAUNCH_CHECK();
+    }
     }
     if (prior) {
         hipLaunchKernelGGL(row_match_kernel, dim3((m + 255) / 256), dim3(256), 0, st, row_match, m);

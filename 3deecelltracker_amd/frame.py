@@ -33,6 +33,9 @@ class FrameChain:
         self.region_method = region_method
         self.prefetch_ref = bool(prefetch_ref)
         self.lcn_beside_unet = True                              # run_sequence: a frame's LCN on the watershed's stream (False: in front of its U-Net)
+        # run_sequence: HIP priorities of the U-Net / watershed / match + correction streams (-1 high, 0 normal, 1 low); CT_SEQ_PRIO="s,w,t" overrides
+        import os
+        self.seq_priorities = tuple(int(v) for v in os.environ.get("CT_SEQ_PRIO", "0,-1,-1").split(","))
         self._side = None
         self._seq = None
         self.unet_model = unet_model
@@ -166,8 +169,9 @@ class FrameChain:
         if any(tuple(r.shape) != key[0] or r.device != dev for r in raws):
             raise ValueError("run_sequence: every volume of a sequence must have the same shape and live on the same device")
         if self._seq is None or self._seq["key"] != key:       # (streams and probability-map buffers belong to one volume shape on one device)
-            self._seq = {"key": key, "S": t.cuda.Stream(device=dev), "W": t.cuda.Stream(device=dev, priority=-1),
-                         "T": t.cuda.Stream(device=dev, priority=-1),
+            ps, pw, pt = self.seq_priorities
+            self._seq = {"key": key, "S": t.cuda.Stream(device=dev, priority=ps), "W": t.cuda.Stream(device=dev, priority=pw),
+                         "T": t.cuda.Stream(device=dev, priority=pt),
                          "prob": [t.empty(key[0], dtype=t.float32, device=dev) for _ in range(NB)],
                          "ready": [t.cuda.Event() for _ in range(NB)]}
         q = self._seq

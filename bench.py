@@ -653,13 +653,16 @@ def measure_other_configs(ctx, args):
         x, y = synth.make_point_pair(n, seed=2000, box=(512, 512, 128), voxel_size=(1.0, 1.0, 1.0))
         xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True)
         a, b = _dev.points_dev(xn, ctx.dev), _dev.points_dev((y - mean) / scale, ctx.dev)
-        out, it = tl.match_device(ffn, a, b, a, 3, 3)
-        torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
-        R = 3
-        for _ in range(R):
+        # (the chip has just idled through a CPU sample: its clocks need tens of ms of work to come back, so warm up and take the median)
+        for _ in range(8):
             out, it = tl.match_device(ffn, a, b, a, 3, 3)
-        torch.cuda.synchronize(ctx.dev)
-        dt = (time.perf_counter() - t0) / R
+        ts = []
+        for _ in range(7):
+            torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
+            out, it = tl.match_device(ffn, a, b, a, 3, 3)
+            torch.cuda.synchronize(ctx.dev)
+            ts.append(time.perf_counter() - t0)
+        dt = float(np.median(ts))
         corr = ffn_mod.initial_matching_device(ffn, a, b, 20)
         torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
         corr = ffn_mod.initial_matching_device(ffn, a, b, 20); torch.cuda.synchronize(ctx.dev)

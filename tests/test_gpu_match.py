@@ -842,3 +842,63 @@ def test_exp_nonpos_is_the_library_exp():
     assert exe.exists(), "scripts/probe/exp_check missing: __graft_entry__.build() compiles it"
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and " 0 mismatches in 268435456 arguments" in r.stdout, r.stdout + r.stderr
+
+
+def test_persistent_greedy_equals_the_launch_per_phase_form():
+    """ct_greedy_match walks all rounds of the assignment in ONE launch (gd_persistent_kernel: device-side barrier between "best" and "accept");
+    CT_GREEDY_PERSISTENT=0 keeps the round-per-launch-pair form.  Same pairs in the same order, same prior -- random scores, scores full of exact
+    ties, rectangular shapes, a threshold nobody passes, 2000 points; also from three host threads at once on streams masked to FOUR CUs (the
+    grid is sized from the stream's CU mask so that concurrent chains cannot starve each other's barrier)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    REPO = Path(__file__).resolve().parent.parent
+    code = r"""
+import sys, importlib, threading, ctypes as C, numpy as np, torch
+sys.path.insert(0, %r)
+_dev = importlib.import_module("3deecelltracker_amd._dev"); _lib = importlib.import_module("3deecelltracker_amd._lib")
+rng = np.random.default_rng(5)
+cases = []
+for m, n in ((600, 600), (540, 600), (113, 90), (25, 21), (2000, 2000)):
+    cases.append(rng.uniform(0, 1, (m, n)).astype(np.float32))
+ties = np.round(rng.uniform(0, 1, (300, 300)) * 8).astype(np.float32) / 8          # nine distinct values: ties everywhere
+cases.append(ties); cases.append(np.full((64, 64), 0.05, np.float32))
+out = []
+for c in cases:
+    d = torch.from_numpy(c).cuda()
+    for mode in (0, 1):
+        pairs, npairs, prior = _dev.greedy_match(d, 0.1 if mode == 0 else 0.5, mode)
+        k = int(npairs.item())
+        out.append((pairs[:k].cpu().numpy().copy(), prior.cpu().numpy().copy()))
+if len(sys.argv) > 1 and sys.argv[1] == "masked":
+    L = _lib.lib()
+    streams = []
+    for _ in range(3):
+        h = C.c_void_p(); _lib.check(L.ct_stream_create_cu_range(0, 0, 4, C.byref(h)), "cu stream"); streams.append(torch.cuda.ExternalStream(h.value, device="cuda:0"))
+    d = torch.from_numpy(cases[0]).cuda(); torch.cuda.synchronize()
+    res = [None] * 3
+    def run(i):
+        with torch.cuda.stream(streams[i]):
+            for _ in range(20):
+                p, k, _ = _dev.greedy_match(d, 0.1, 0)
+            streams[i].synchronize(); res[i] = p[:int(k.item())].cpu().numpy()
+    th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert all(np.array_equal(r, out[0][0]) for r in res)
+np.savez(sys.argv[2], **{f"p{i}": o[0] for i, o in enumerate(out)}, **{f"q{i}": o[1] for i, o in enumerate(out)})
+print("greedy done", len(out))
+""" % str(REPO)
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        files = []
+        for tag, env in (("persistent", {}), ("launches", {"CT_GREEDY_PERSISTENT": "0"})):
+            f = os.path.join(td, tag + ".npz"); files.append(f)
+            r = subprocess.run([sys.executable, "-c", code, "masked" if tag == "persistent" else "plain", f], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, **env), cwd=REPO)
+            assert r.returncode == 0 and "greedy done 14" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+        a, b = np.load(files[0]), np.load(files[1])
+        assert sorted(a.files) == sorted(b.files) and len(a.files) == 28
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), k
+        assert len(a["p0"]) > 300 and len(a["p12"]) == 0                        # many pairs at 600 x 600, none above the threshold in the flat case

@@ -16,7 +16,7 @@ synth = importlib.import_module("3deecelltracker_amd.synth")
 seg = importlib.import_module("3deecelltracker_amd.segment")
 
 
-from _ws_cases import blobs, random_case, tie_case, touching_case  # noqa: E402,F401
+from _ws_cases import blobs, blobs_local, random_case, random_case_large, tie_case, touching_case  # noqa: E402,F401
 
 
 # ------------------------------------------------------------------------------------------------ CPU: the oracle itself
@@ -424,7 +424,7 @@ print("global selection ok")
 def test_device_watershed_notebook_shapes_with_2000_cells(shape, n, zr):
     """The stack shapes of the reference's own notebooks (track_stardist_single_mode.ipynb: 21 x 512 x 1024; -h5.ipynb: 98 x 299 x 499, given
     there as z, x, y) with ~2000 blobs: labels, sizes and centres equal the oracle's, with the default tables (no retry needed)."""
-    prob = random_case(shape, n, seed=shape[2], specks=False)
+    prob = random_case_large(shape, n, seed=shape[2])
     want = wr.segment_centroids(prob, zr, "min_size", 20)
     got = _device_caps(prob, zr, 20, seg.PEAK_CAP_2D, seg.PEAK_CAP_3D)
     assert got[4].retries == 0 and got[2:4] == (want[2], want[3]) and want[3] > 1500
