@@ -59,15 +59,18 @@ struct DeviceGuard {
 // Kernels whose working set lives in LDS need more than the 64 KiB default.  hipFuncSetAttribute is a per-device setting
 // and the match paths run from several host threads (parallel.chain_map / FramePipeline): one bit per device, set after
 // the (idempotent) call has succeeded, so a concurrent first use on the same device merely sets the attribute twice.
-int ensure_big_lds(const void* fn, std::atomic<uint64_t>& done) {
+int ensure_big_lds(const void* fn, std::atomic<uint64_t>& done, int bytes = 150 * 1024) {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     const uint64_t bit = 1ull << (dev & 63);
     if (done.load(std::memory_order_acquire) & bit) return CT_OK;
-    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     done.fetch_or(bit, std::memory_order_release);
     return CT_OK;
 }
+// (a kernel with static LDS of its own asks for what it needs: static + dynamic must stay within the CU's 160 KiB)
+#define ENSURE_LDS(kernel, bytes) do { static std::atomic<uint64_t> done_{0}; int rc_ = ensure_big_lds((const void*)kernel, done_, bytes); \
+                                       if (rc_ != CT_OK) return rc_; } while (0)
 #define ENSURE_BIG_LDS(kernel) do { static std::atomic<uint64_t> done_{0}; int rc_ = ensure_big_lds((const void*)kernel, done_); \
                                     if (rc_ != CT_OK) return rc_; } while (0)
 
@@ -240,11 +243,9 @@ __global__ void denormalize_points_kernel(const double* __restrict__ pts, int n,
 // epilogue (Dense(no bias) + BatchNormalization + LeakyReLU, ffn.py:242-254).
 // 64x64 tile, 256 threads, 4x4 outputs per thread, sequential-k fp32 accumulation.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
-                                                       float* __restrict__ C, int M, int N, int K,
-                                                       const float* __restrict__ bn /* [4][N] gamma,beta,mean,var or null */,
-                                                       Bt bt = Bt{0, nullptr}) {
-    BT_SHIFT(const float*, A); BT_SHIFT(float*, C); BT_DIM_N(M);         // batched: rows = the problem's reference points
+__device__ __forceinline__ void gemm_f32_body(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                              float* __restrict__ C, int M, int N, int K,
+                                              const float* __restrict__ bn /* [4][N] gamma,beta,mean,var or null */) {
     if ((int)blockIdx.y * 64 >= M) return;
     // K in steps of GK = 32 through two LDS buffers: the next step's 64 x 32 | 32 x 64 panels are fetched into registers before the current
     // step's FMAs and parked after them, one barrier per step (the first version waited a full L2 round trip per 16-deep step with nothing
@@ -316,6 +317,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             C[(size_t)gm * N + gn] = v;
         }
     }
+}
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                       float* __restrict__ C, int M, int N, int K,
+                                                       const float* __restrict__ bn /* [4][N] gamma,beta,mean,var or null */,
+                                                       Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const float*, A); BT_SHIFT(float*, C); BT_DIM_N(M);         // batched: rows = the problem's reference points
+    gemm_f32_body(A, lda, B, C, M, N, K, bn);
+}
+// two independent products of one shape family in ONE launch (blockIdx.z picks the operands): the FFN's reference-side and target-side
+// layers.  Beside the U-Net every launch of the match stream waits for workgroup slots (a 600 x 512 x 512 product: 27 us alone, 214 us in
+// the frame loop); the products themselves are unchanged.
+struct GemmPair { const float* A[2]; const float* B[2]; float* C[2]; int M[2]; };
+__global__ __launch_bounds__(256) void gemm_f32_pair_kernel(GemmPair g, int lda, int N, int K, const float* __restrict__ bn) {
+    const int z = blockIdx.z;
+    gemm_f32_body(g.A[z], lda, g.B[z], g.C[z], g.M[z], N, K, bn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -722,12 +738,10 @@ __global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restr
 // finalise scalars from row partials.  mode 0: initial sigma2 = sum / (3 m n)   (both dialects)
 // mode 1 (lite, trackerlite.py:342-350):  gamma = max(1 - sumP/m, 1e-4); sigma2 = sum / (3 sumP)
 // mode 2 (legacy, track.py:103-112):      gamma = 1 - sumP/m;            sigma2 = max(sum / (3 sumP), 1)
-__global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ rowpart, int m, int n, int mode,
-                                                      double* __restrict__ sc, const double* __restrict__ normpart = nullptr,
-                                                      const double* __restrict__ respart = nullptr, int* __restrict__ rank_p = nullptr,
-                                                      Bt bt = Bt{0, nullptr}, const double* __restrict__ tr_tgt = nullptr,
-                                                      const double* __restrict__ tr_arow = nullptr, const double* __restrict__ tr_pred = nullptr,
-                                                      const double* __restrict__ tr_d = nullptr, const double* __restrict__ tr_b = nullptr) {
+// (body of scalars_kernel; also the tail of apply_dual_scalars_kernel, where the last workgroup of the field application runs it)
+__device__ __forceinline__ void scalars_body(const double* rowpart, int m, int n, int mode, double* sc, const double* normpart,
+                                             const double* respart, int* rank_p, Bt bt, const double* tr_tgt,
+                                             const double* tr_arow, const double* tr_pred, const double* tr_d, const double* tr_b) {
     __shared__ double red[4];
     __shared__ double red2[4];
     __shared__ double red3[4], red4[4];
@@ -801,6 +815,37 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__ rowpart, int m, int n, int mode,
+                                                      double* __restrict__ sc, const double* __restrict__ normpart = nullptr,
+                                                      const double* __restrict__ respart = nullptr, int* __restrict__ rank_p = nullptr,
+                                                      Bt bt = Bt{0, nullptr}, const double* __restrict__ tr_tgt = nullptr,
+                                                      const double* __restrict__ tr_arow = nullptr, const double* __restrict__ tr_pred = nullptr,
+                                                      const double* __restrict__ tr_d = nullptr, const double* __restrict__ tr_b = nullptr) {
+    scalars_body(rowpart, m, n, mode, sc, normpart, respart, rank_p, bt, tr_tgt, tr_arow, tr_pred, tr_d, tr_b);
+}
+
+// ---- "last workgroup finishes": the single-workgroup / ten-workgroup kernels that sat between the wide kernels of an EM iteration run as
+// the TAIL of the kernel in front of them, executed by whichever workgroup of that kernel retires last (a counter in the problem's workspace;
+// the last one resets it).  Seven dependent launches per iteration become three -- each launch of the frame loop's match stream waits
+// 10-25 us for a workgroup slot beside the U-Net -- with the arithmetic of every piece unchanged (same device functions, same order):
+// results are bit-identical to the seven-launch form (tests/test_gpu_match.py compares the two).  Opt-in (CT_EM_FUSE=1): it is SLOWER, see em_fuse().
+// Visibility: a workgroup publishes its part with __threadfence() before it takes a ticket; the last one fences again before it reads the
+// others' parts (none of which it has touched earlier in the kernel: nothing stale in its L1), and values the tail itself produces are handed
+// on in registers / LDS, never re-read from global memory through a possibly cached line.
+__device__ __forceinline__ bool em_last_block(int* ticket) {
+    __shared__ int em_is_last;
+    __syncthreads();                                             // (every wave's stores have been issued and counted down: s_waitcnt before the barrier)
+    if (threadIdx.x == 0) {
+        __threadfence();                                         // ONE release per workgroup: the L2 write-back it performs is cache-wide, not per thread
+        const int nblk = (int)gridDim.x;
+        const int t = atomicAdd(ticket, 1);
+        em_is_last = (t == nblk - 1) ? 1 : 0;
+        if (em_is_last) atomicExch(ticket, 0);
+    }
+    __syncthreads();
+    if (em_is_last) __threadfence();
+    return em_is_last != 0;
 }
 
 // E-step: one wave per target row (trackerlite.py:375-382 / track.py:81-88)
@@ -1060,12 +1105,14 @@ __global__ __launch_bounds__(256) void estep_cols_kernel(const double* __restric
 // pair sat in its own `r < n` branch with the library exp: one match's EM iteration 80 -> 71 us; the pipelined benchmark is unchanged,
 // there the kernel's time is the wait for slots between conv workgroups).  MAXT = 512 up to 8 waves (n <= 2560), 1024 beyond (128 VGPRs).
 // The posterior's row sums for the sigma2 trace identity are total * 1 / den (the exact sum of the normalised row up to rounding).
-template <int NQ, int MAXT>
-__global__ __launch_bounds__(MAXT) void estep_rows_kernel(const double* __restrict__ prior, const double* __restrict__ pred, int n,
-                                                          const double* __restrict__ tgt, int m, const double* __restrict__ sc, double vol,
-                                                          double* __restrict__ P /* or null */, double* __restrict__ part, Bt bt,
-                                                          const double* __restrict__ sp, const int* __restrict__ sp_dense, int sp_m,
-                                                          double* __restrict__ arow) {
+__device__ __forceinline__ void colstats_finish_par_body(int vb, const double* part, int n, const double* xref, double* dvec,
+                                                         double* sqd, double* rhs, double* braw, int nseg, double (*red)[64][4]);
+template <int NQ>
+__device__ __forceinline__ void estep_rows_body(const double* __restrict__ prior, const double* pred, int n,
+                                                const double* __restrict__ tgt, int m, const double* sc, double vol,
+                                                double* __restrict__ P /* or null */, double* part, Bt bt,
+                                                const double* __restrict__ sp, const int* __restrict__ sp_dense, int sp_m,
+                                                double* __restrict__ arow) {
     BT_SHIFT(const double*, prior); BT_SHIFT(const double*, pred); BT_SHIFT(const double*, tgt); BT_SHIFT(const double*, sc);
     BT_SHIFT(double*, part);
     if (P) BT_SHIFT(double*, P);
@@ -1143,6 +1190,31 @@ __global__ __launch_bounds__(MAXT) void estep_rows_kernel(const double* __restri
         if (r < n) { o[r] = cs[q]; o[n + r] = cx[q]; o[2 * n + r] = cy[q]; o[3 * n + r] = cz[q]; }
     }
 }
+template <int NQ, int MAXT>
+__global__ __launch_bounds__(MAXT) void estep_rows_kernel(const double* __restrict__ prior, const double* __restrict__ pred, int n,
+                                                          const double* __restrict__ tgt, int m, const double* __restrict__ sc, double vol,
+                                                          double* __restrict__ P /* or null */, double* __restrict__ part, Bt bt,
+                                                          const double* __restrict__ sp, const int* __restrict__ sp_dense, int sp_m,
+                                                          double* __restrict__ arow) {
+    estep_rows_body<NQ>(prior, pred, n, tgt, m, sc, vol, P, part, bt, sp, sp_dense, sp_m, arow);
+}
+// fused E-step + (last workgroup) the column statistics' finish for all columns (colstats_finish_par_kernel's body, one 64-column block after
+// the other): d, sqrt(d), the scaled right-hand sides and P^T Y.  Single problems only.
+struct FinishTail { int* ticket; double* dvec; double* sqd; double* rhs; double* braw; };
+template <int NQ, int MAXT>
+__global__ __launch_bounds__(MAXT) void estep_rows_finish_kernel(const double* __restrict__ prior, const double* pred, int n,
+                                                                 const double* __restrict__ tgt, int m, const double* sc, double vol,
+                                                                 double* __restrict__ P /* or null */, double* part,
+                                                                 double* __restrict__ arow, FinishTail tl) {
+    estep_rows_body<NQ>(prior, pred, n, tgt, m, sc, vol, P, part, Bt{0, nullptr}, nullptr, nullptr, 0, arow);
+    if (!em_last_block(tl.ticket)) return;
+    if (sc[S_DONE] != 0.0) return;
+    __shared__ double red[4][64][4];
+    for (int vb = 0; vb * 64 < n; ++vb) {
+        colstats_finish_par_body(vb, part, n, pred, tl.dvec, tl.sqd, tl.rhs, tl.braw, (int)gridDim.x, red);
+        __syncthreads();                                         // (red is reused by the next block of columns)
+    }
+}
 // CT_ESTEP_FUSED: 0 = posterior + colstats kernels, 1 = estep_cols_kernel (a wave owns whole rows), 2 (default) = estep_rows_kernel
 static int estep_mode() { static const int v = getenv("CT_ESTEP_FUSED") ? atoi(getenv("CT_ESTEP_FUSED")) : 2; return v; }
 // columns per lane: a CONSTANT, so that wave w always owns columns [320 w, 320 (w + 1)) and the row sums of a problem do not depend on the
@@ -1174,6 +1246,29 @@ static bool launch_estep_cols(int n_max, unsigned zB, hipStream_t st, const doub
     if (need <= 1) CT_ESTEP(1); else if (need <= 2) CT_ESTEP(2); else if (need <= 4) CT_ESTEP(4); else if (need <= 6) CT_ESTEP(6);
     else if (need <= 8) CT_ESTEP(8); else if (need <= 10) CT_ESTEP(10); else if (need <= 12) CT_ESTEP(12); else CT_ESTEP(16);
 #undef CT_ESTEP
+    return true;
+}
+
+// CT_EM_FUSE=1: three launches per EM iteration instead of seven (the "last workgroup finishes" form above).  OFF by default -- measured and
+// refuted in round 5: every workgroup has to publish its part with an agent-scope release before it takes its ticket, and on this multi-XCD
+// part such a fence writes the XCD's L2 back: one 600-point PR-GLS iteration 160 us alone -> 295-320 us (fence by every thread / by one thread
+// per workgroup), the frame loop 6.42 -> 7.30-7.88 ms per frame (profiles/r05_conv_experiments.txt).  Round 2 had refuted fence-based fusion
+// of these kernels in another form; kernel boundaries remain the cheapest device-wide release there is.  Bit-identical either way (tested).
+static bool em_fuse() { static const bool v = getenv("CT_EM_FUSE") && getenv("CT_EM_FUSE")[0] == '1'; return v; }
+// the fused E-step with the column statistics' finish as its tail (single problem); false if this shape takes another E-step form
+static bool launch_estep_rows_finish(int n, hipStream_t st, const double* prior, const double* pred, const double* tgt, int m, const double* sc, double* P,
+                                     double* part, double* arow, FinishTail tl) {
+    const int need = (n + 63) / 64;
+    if (estep_mode() < 2) return false;
+    int nq = estep_nq(); if (nq < 1 || nq > 6) nq = 5;
+    const int W = (need + nq - 1) / nq;
+    if (W > 16) return false;
+#define CT_ESTEPF(NQv) do { if (W <= 8) CT_ESTEPF2(NQv, 512); else CT_ESTEPF2(NQv, 1024); } while (0)
+#define CT_ESTEPF2(NQv, MT) hipLaunchKernelGGL((estep_rows_finish_kernel<NQv, MT>), dim3(ES_SEG), dim3(64 * W), 0, st, prior, pred, n, tgt, m, sc, 1.0, P, part, arow, tl)
+    switch (nq) { case 1: CT_ESTEPF(1); break; case 2: CT_ESTEPF(2); break; case 3: CT_ESTEPF(3); break; case 4: CT_ESTEPF(4); break;
+                  case 6: CT_ESTEPF(6); break; default: CT_ESTEPF(5); }
+#undef CT_ESTEPF2
+#undef CT_ESTEPF
     return true;
 }
 
@@ -1265,12 +1360,12 @@ __global__ __launch_bounds__(256) void apply_field_kernel(const double* __restri
 // TrackerLite-dialect field application for both point sets in one launch: waves [0, n) move the ref set
 // (symmetric Gram matrix G, |movement|^2 partials, exact-system residual monitor), waves [n, n+l) the tracked
 // set (kernel stored [l][n]).  Movements are added only from EM iteration 2 on (trackerlite.py:339-341).
-__global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restrict__ C, const double* __restrict__ G, int n,
-                                                         double* __restrict__ predn, const double* __restrict__ Gln, int l,
-                                                         double* __restrict__ predl, double* __restrict__ norm_part,
-                                                         const double* __restrict__ sc, const double* __restrict__ dvec,
-                                                         const double* __restrict__ sqd, const double* __restrict__ rhs,
-                                                         double* __restrict__ res_part, Bt bt = Bt{0, nullptr}, int first_only = 0) {
+__device__ __forceinline__ void apply_dual_body(const double* __restrict__ C, const double* __restrict__ G, int n,
+                                                double* predn, const double* __restrict__ Gln, int l,
+                                                double* __restrict__ predl, double* norm_part,
+                                                const double* sc, const double* dvec,
+                                                const double* __restrict__ sqd, const double* __restrict__ rhs,
+                                                double* res_part, Bt bt, int first_only) {
     BT_SHIFT(const double*, C); BT_SHIFT(const double*, G); BT_SHIFT(double*, predn); BT_SHIFT(const double*, Gln);
     BT_SHIFT(double*, predl); BT_SHIFT(double*, norm_part); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
     BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs);
@@ -1305,6 +1400,27 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
         res_part[n + j] = fmax(fabs(bx), fmax(fabs(by), fabs(bz)));
     }
 }
+__global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restrict__ C, const double* __restrict__ G, int n,
+                                                         double* __restrict__ predn, const double* __restrict__ Gln, int l,
+                                                         double* __restrict__ predl, double* __restrict__ norm_part,
+                                                         const double* __restrict__ sc, const double* __restrict__ dvec,
+                                                         const double* __restrict__ sqd, const double* __restrict__ rhs,
+                                                         double* __restrict__ res_part, Bt bt = Bt{0, nullptr}, int first_only = 0) {
+    apply_dual_body(C, G, n, predn, Gln, l, predl, norm_part, sc, dvec, sqd, rhs, res_part, bt, first_only);
+}
+// field application + (last workgroup) the iteration's scalars: sigma2 by the trace identity, gamma, the iteration counter, convergence and
+// the low-rank residual monitor (scalars_kernel's body).  Single problems only (no batch table).
+struct ScalarsTail { int* ticket; double* sc; int m; int mode; int* rank_p; const double* tgt; const double* arow; const double* trb; const double* rowpart; };
+__global__ __launch_bounds__(256) void apply_dual_scalars_kernel(const double* __restrict__ C, const double* __restrict__ G, int n,
+                                                                 double* predn, const double* __restrict__ Gln, int l,
+                                                                 double* __restrict__ predl, double* norm_part,
+                                                                 const double* sc, const double* dvec,
+                                                                 const double* __restrict__ sqd, const double* __restrict__ rhs,
+                                                                 double* res_part, ScalarsTail tl) {
+    apply_dual_body(C, G, n, predn, Gln, l, predl, norm_part, sc, dvec, sqd, rhs, res_part, Bt{0, nullptr}, 0);
+    if (!em_last_block(tl.ticket)) return;
+    scalars_body(tl.rowpart, tl.m, n, tl.mode, tl.sc, norm_part, res_part, tl.rank_p, Bt{0, nullptr}, tl.tgt, tl.arow, predn, dvec, tl.trb);
+}
 
 
 
@@ -1321,6 +1437,7 @@ __global__ __launch_bounds__(256) void apply_dual_kernel(const double* __restric
 static inline int prgls_chunk(int enq, int total) { const int c = enq < 16 ? 8 : 16; return (total - enq) < c ? (total - enq) : c; }
 
 constexpr int LR_RMAX = 128;
+constexpr int EM_TICKET = 4;                   // w.rank[4..6]: tickets of the three fused EM kernels (em_last_block); zeroed per call
 constexpr int LR_PF = 8;                       // rows of U fetched together in lowrank_factor_kernel's update loop (general path)
 constexpr int LR_REG = 24, LR_PF2 = 16;        // n <= 1024: rows of a thread's column of U kept in registers; rows fetched together beyond them
 
@@ -1443,6 +1560,36 @@ __global__ __launch_bounds__(1024) void lowrank_factor_kernel(const double* __re
 
 // column statistics, stage 2 (parallel): 64 columns per block, the CS_SEG segment partials split over
 // 4 waves; writes d_i, sqrt d_i and the scaled right-hand side b~_i = (Y^T P[:, i] - x_i d_i) / sqrt d_i.
+// body of colstats_finish_par_kernel for the 64 columns of virtual block `vb`, by a workgroup of W waves (the kernel itself: 4; as the tail of the
+// fused E-step: that kernel's 2-16): wave w plays the roles of the original's waves w, w + W, ..., so every partial sum has the same terms in
+// the same order and the four partials are added in the same tree
+__device__ __forceinline__ void colstats_finish_par_body(int vb, const double* part, int n, const double* xref, double* dvec,
+                                                         double* sqd, double* rhs, double* braw, int nseg, double (*red)[64][4]) {
+    const int cl = threadIdx.x & 63, wv0 = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const int i = vb * 64 + cl;
+    for (int wv = wv0; wv < 4; wv += W) {
+        double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
+        if (i < n)
+            for (int seg = wv; seg < nseg; seg += 4) {
+                const double* o = part + (size_t)seg * 4 * n;
+                s += o[i]; sx += o[n + i]; sy += o[2 * n + i]; sz += o[3 * n + i];
+            }
+        red[wv][cl][0] = s; red[wv][cl][1] = sx; red[wv][cl][2] = sy; red[wv][cl][3] = sz;
+    }
+    __syncthreads();
+    if (wv0 == 0 && i < n) {
+        const double s = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+        const double sx = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+        const double sy = (red[0][cl][2] + red[1][cl][2]) + (red[2][cl][2] + red[3][cl][2]);
+        const double sz = (red[0][cl][3] + red[1][cl][3]) + (red[2][cl][3] + red[3][cl][3]);
+        const double q = sqrt(s);
+        const double iq = q > 0.0 ? 1.0 / q : 0.0;
+        dvec[i] = s; sqd[i] = q;
+        rhs[3 * i] = (sx - xref[3 * i] * s) * iq; rhs[3 * i + 1] = (sy - xref[3 * i + 1] * s) * iq;
+        rhs[3 * i + 2] = (sz - xref[3 * i + 2] * s) * iq;
+        if (braw) { braw[3 * i] = sx; braw[3 * i + 1] = sy; braw[3 * i + 2] = sz; }      // P^T Y for the sigma2 trace identity (scalars_kernel)
+    }
+}
 __global__ __launch_bounds__(256) void colstats_finish_par_kernel(const double* __restrict__ part, int n, const double* __restrict__ xref,
                                                                   const double* __restrict__ sc, double* __restrict__ dvec,
                                                                   double* __restrict__ sqd, double* __restrict__ rhs, Bt bt = Bt{0, nullptr},
@@ -1453,28 +1600,7 @@ __global__ __launch_bounds__(256) void colstats_finish_par_kernel(const double* 
     if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
     if (sc[S_DONE] != 0.0) return;
     __shared__ double red[4][64][4];
-    const int cl = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + cl;
-    double s = 0.0, sx = 0.0, sy = 0.0, sz = 0.0;
-    if (i < n)
-        for (int seg = wv; seg < nseg; seg += 4) {
-            const double* o = part + (size_t)seg * 4 * n;
-            s += o[i]; sx += o[n + i]; sy += o[2 * n + i]; sz += o[3 * n + i];
-        }
-    red[wv][cl][0] = s; red[wv][cl][1] = sx; red[wv][cl][2] = sy; red[wv][cl][3] = sz;
-    __syncthreads();
-    if (wv == 0 && i < n) {
-        s = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
-        sx = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
-        sy = (red[0][cl][2] + red[1][cl][2]) + (red[2][cl][2] + red[3][cl][2]);
-        sz = (red[0][cl][3] + red[1][cl][3]) + (red[2][cl][3] + red[3][cl][3]);
-        const double q = sqrt(s);
-        const double iq = q > 0.0 ? 1.0 / q : 0.0;
-        dvec[i] = s; sqd[i] = q;
-        rhs[3 * i] = (sx - xref[3 * i] * s) * iq; rhs[3 * i + 1] = (sy - xref[3 * i + 1] * s) * iq;
-        rhs[3 * i + 2] = (sz - xref[3 * i + 2] * s) * iq;
-        if (braw) { braw[3 * i] = sx; braw[3 * i + 1] = sy; braw[3 * i + 2] = sz; }      // P^T Y for the sigma2 trace identity (scalars_kernel)
-    }
+    colstats_finish_par_body((int)blockIdx.x, part, n, xref, dvec, sqd, rhs, braw, nseg, red);
 }
 
 // S = U D U^T (r x r, lower triangle) and y = U D^1/2 b~ (r x 3): one wave per entry, lanes stride the n rows
@@ -1532,10 +1658,10 @@ __device__ __forceinline__ void wave_sum16_d(double (&acc)[16], int lane) {
     acc[0] += shfl_xor_d(acc[0], 2);
     acc[0] += shfl_xor_d(acc[0], 1);              // lane holds entry q = 8 bit2 + 4 bit3 + 2 bit4 + bit5 (bits of its lane number)
 }
-__global__ __launch_bounds__(256) void lr_gram_tiled_kernel(int n, const double* __restrict__ U, const int* __restrict__ rank_p,
-                                                            const double* __restrict__ sc, const double* __restrict__ dvec,
-                                                            const double* __restrict__ sqd, const double* __restrict__ rhs,
-                                                            double* __restrict__ Sout, double* __restrict__ yout, Bt bt = Bt{0, nullptr}) {
+__device__ __forceinline__ void lr_gram_tiled_body(int n, const double* __restrict__ U, const int* __restrict__ rank_p,
+                                                   const double* sc, const double* dvec,
+                                                   const double* sqd, const double* rhs,
+                                                   double* Sout, double* yout, Bt bt) {
     BT_SHIFT(const double*, U); BT_SHIFT(const int*, rank_p); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
     BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs); BT_SHIFT(double*, Sout); BT_SHIFT(double*, yout);
     if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
@@ -1613,6 +1739,12 @@ __global__ __launch_bounds__(256) void lr_gram_tiled_kernel(int n, const double*
         const int a2 = a0 + q_mine / LG_T, d = q_mine % LG_T;
         if ((lane & 3) == 0 && a2 < r && d < 3) yout[a2 * 3 + d] = acc[0];
     }
+}
+__global__ __launch_bounds__(256) void lr_gram_tiled_kernel(int n, const double* __restrict__ U, const int* __restrict__ rank_p,
+                                                            const double* __restrict__ sc, const double* __restrict__ dvec,
+                                                            const double* __restrict__ sqd, const double* __restrict__ rhs,
+                                                            double* __restrict__ Sout, double* __restrict__ yout, Bt bt = Bt{0, nullptr}) {
+    lr_gram_tiled_body(n, U, rank_p, sc, dvec, sqd, rhs, Sout, yout, bt);
 }
 // CT_GRAM_TILED=0 selects the entry-per-wave kernel (A/B and the bit-identity test)
 static bool gram_tiled() { static const bool v = !(getenv("CT_GRAM_TILED") && getenv("CT_GRAM_TILED")[0] == '0'); return v; }
@@ -2129,14 +2261,10 @@ __global__ __launch_bounds__(256) void chol_backward_kernel(const double* __rest
 // free.  Blocked right-looking factorisation, 8 columns per step, 2 barriers per step: (1) every thread
 // factors the 8 x 8 diagonal block redundantly in registers and solves its own rows of the panel,
 // (2) rank-8 update of the trailing block.  Then a back-substitution, one unknown per thread.
-__global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict__ Sin, const double* __restrict__ yin,
-                                                       int n, const int* __restrict__ rank_p, double lambda,
-                                                       const double* __restrict__ dvec, double* __restrict__ sc,
-                                                       double* __restrict__ qout, Bt bt = Bt{0, nullptr}) {
-    BT_SHIFT(const double*, Sin); BT_SHIFT(const double*, yin); BT_SHIFT(const int*, rank_p); BT_SHIFT(const double*, dvec);
-    BT_SHIFT(double*, sc); BT_SHIFT(double*, qout);
-    if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
-    if (sc[S_DONE] != 0.0) return;
+// body of lr_solve_kernel (256 threads, dynamic LDS = packed triangle + 3 right-hand sides).  qs_out (LDS, [3 r]) and c_out: the solution and
+// c = lambda sigma2 handed to a caller that goes on in the same workgroup (the fused kernel's coefficient pass) without re-reading global memory
+__device__ __forceinline__ void lr_solve_body(const double* Sin, const double* yin, int n, const int* rank_p, double lambda,
+                                              const double* dvec, double* sc, double* qout, double* qs_out, double* c_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int r = *rank_p;
     const int ld = r | 1;                  // (unpacked form: odd leading dimension)
@@ -2179,8 +2307,24 @@ __global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict_
     if (tid == 0) { sc[S_SUMP] = (red[0] + red[1]) + (red[2] + red[3]); sc[S_C] = c; }
     chol_factor_aug_lds_fast<true>(S, idiag, ld, r, 3, tid);
     chol_backsub3_lds_fast<true>(S, idiag, ld, r, tid);
-    for (int e = tid; e < r * 3; e += 256) { const int a2 = e / 3, d = e - a2 * 3; qout[e] = S[PSIX(r + d, a2)]; }
+    for (int e = tid; e < r * 3; e += 256) {
+        const int a2 = e / 3, d = e - a2 * 3;
+        const double qv = S[PSIX(r + d, a2)];
+        qout[e] = qv;
+        if (qs_out) qs_out[e] = qv;
+    }
+    if (c_out) *c_out = c;
 #undef PSIX
+}
+__global__ __launch_bounds__(256) void lr_solve_kernel(const double* __restrict__ Sin, const double* __restrict__ yin,
+                                                       int n, const int* __restrict__ rank_p, double lambda,
+                                                       const double* __restrict__ dvec, double* __restrict__ sc,
+                                                       double* __restrict__ qout, Bt bt = Bt{0, nullptr}) {
+    BT_SHIFT(const double*, Sin); BT_SHIFT(const double*, yin); BT_SHIFT(const int*, rank_p); BT_SHIFT(const double*, dvec);
+    BT_SHIFT(double*, sc); BT_SHIFT(double*, qout);
+    if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
+    if (sc[S_DONE] != 0.0) return;
+    lr_solve_body(Sin, yin, n, rank_p, lambda, dvec, sc, qout, nullptr, nullptr);
 }
 
 // Dense M-step for small n (n + 3 rows of n|1 doubles fit the LDS: n <= DS_MAXN): one workgroup finishes the column
@@ -2242,6 +2386,31 @@ __global__ __launch_bounds__(256) void dense_small_solve_kernel(const double* __
 }
 
 // C[d][i] = sqrt(d_i) (b~_i - sqrt(d_i) sum_a U[a][i] q[a]) / c ; 64 rows i per block, the rank split over 4 waves
+// body of lr_coeff_kernel for the 64 columns of virtual block `vb`: qs = the solution [3 r] in LDS, c = lambda sigma2
+__device__ __forceinline__ void lr_coeff_body(int vb, const double* U, int n, int r, const double* qs, const double* sqd, const double* rhs, double c,
+                                              bool count_it, double* C, double* Csum, double (*ps)[64][3]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = vb * 64 + lane;
+    double ax = 0.0, ay = 0.0, az = 0.0;
+    if (i < n)
+        for (int a = wv; a < r; a += 4) {
+            const double u = U[(size_t)a * n + i];
+            ax = fma(u, qs[3 * a], ax); ay = fma(u, qs[3 * a + 1], ay); az = fma(u, qs[3 * a + 2], az);
+        }
+    ps[wv][lane][0] = ax; ps[wv][lane][1] = ay; ps[wv][lane][2] = az;
+    __syncthreads();
+    if (wv == 0 && i < n) {
+        const double s = sqd[i];
+        ax = (ps[0][lane][0] + ps[1][lane][0]) + (ps[2][lane][0] + ps[3][lane][0]);
+        ay = (ps[0][lane][1] + ps[1][lane][1]) + (ps[2][lane][1] + ps[3][lane][1]);
+        az = (ps[0][lane][2] + ps[1][lane][2]) + (ps[2][lane][2] + ps[3][lane][2]);
+        const double c0 = s * (rhs[3 * i] - s * ax) / c, c1 = s * (rhs[3 * i + 1] - s * ay) / c, c2 = s * (rhs[3 * i + 2] - s * az) / c;
+        C[i] = c0; C[n + i] = c1; C[2 * n + i] = c2;
+        // deferred field application for the tracked set (apply_tracked_kernel): the coefficients of every iteration whose movement
+        // counts (from the second on, trackerlite.py:339-341) are summed; this kernel returns early once the problem has converged
+        if (Csum && count_it) { Csum[i] += c0; Csum[n + i] += c1; Csum[2 * n + i] += c2; }
+    }
+}
 __global__ __launch_bounds__(256) void lr_coeff_kernel(const double* __restrict__ U, int n, const int* __restrict__ rank_p,
                                                        const double* __restrict__ q, const double* __restrict__ sqd,
                                                        const double* __restrict__ rhs, const double* __restrict__ sc,
@@ -2253,29 +2422,31 @@ __global__ __launch_bounds__(256) void lr_coeff_kernel(const double* __restrict_
     if (sc[S_DONE] != 0.0) return;
     __shared__ double ps[4][64][3];
     __shared__ double qs[LR_RMAX * 3];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
     const int r = *rank_p;
     for (int e = threadIdx.x; e < 3 * r; e += 256) qs[e] = q[e];
     __syncthreads();
-    double ax = 0.0, ay = 0.0, az = 0.0;
-    if (i < n)
-        for (int a = wv; a < r; a += 4) {
-            const double u = U[(size_t)a * n + i];
-            ax = fma(u, qs[3 * a], ax); ay = fma(u, qs[3 * a + 1], ay); az = fma(u, qs[3 * a + 2], az);
-        }
-    ps[wv][lane][0] = ax; ps[wv][lane][1] = ay; ps[wv][lane][2] = az;
+    lr_coeff_body((int)blockIdx.x, U, n, r, qs, sqd, rhs, sc[S_C], sc[S_IT] >= 1.0, C, Csum, ps);
+}
+// S = U D U^T and y (lr_gram_tiled_kernel's body) + (last workgroup) the r x r solve and the coefficients C of all columns: lr_solve_kernel's and
+// lr_coeff_kernel's bodies.  Launched with lr_solve_kernel's dynamic LDS.  Single problems only.
+struct SolveTail { int* ticket; double lambda; double* sc; double* q; double* C; };
+__global__ __launch_bounds__(256) void lr_gram_solve_coeff_kernel(int n, const double* __restrict__ U, const int* __restrict__ rank_p,
+                                                                  const double* sc, const double* dvec, const double* sqd, const double* rhs,
+                                                                  double* Sout, double* yout, SolveTail tl) {
+    lr_gram_tiled_body(n, U, rank_p, sc, dvec, sqd, rhs, Sout, yout, Bt{0, nullptr});
+    if (!em_last_block(tl.ticket)) return;
+    if (sc[S_DONE] != 0.0) return;
+    __shared__ double ps[4][64][3];
+    __shared__ double qs[LR_RMAX * 3];
+    __shared__ double c_sh;
+    const bool count_it = sc[S_IT] >= 1.0;
+    lr_solve_body(Sout, yout, n, rank_p, tl.lambda, dvec, tl.sc, tl.q, qs, &c_sh);
     __syncthreads();
-    if (wv == 0 && i < n) {
-        const double c = sc[S_C], s = sqd[i];
-        ax = (ps[0][lane][0] + ps[1][lane][0]) + (ps[2][lane][0] + ps[3][lane][0]);
-        ay = (ps[0][lane][1] + ps[1][lane][1]) + (ps[2][lane][1] + ps[3][lane][1]);
-        az = (ps[0][lane][2] + ps[1][lane][2]) + (ps[2][lane][2] + ps[3][lane][2]);
-        const double c0 = s * (rhs[3 * i] - s * ax) / c, c1 = s * (rhs[3 * i + 1] - s * ay) / c, c2 = s * (rhs[3 * i + 2] - s * az) / c;
-        C[i] = c0; C[n + i] = c1; C[2 * n + i] = c2;
-        // deferred field application for the tracked set (apply_tracked_kernel): the coefficients of every iteration whose movement
-        // counts (from the second on, trackerlite.py:339-341) are summed; this kernel returns early once the problem has converged
-        if (Csum && sc[S_IT] >= 1.0) { Csum[i] += c0; Csum[n + i] += c1; Csum[2 * n + i] += c2; }
+    const int r = *rank_p;
+    const double c = c_sh;
+    for (int vb = 0; vb * 64 < n; ++vb) {
+        lr_coeff_body(vb, U, n, r, qs, sqd, rhs, c, count_it, tl.C, nullptr, ps);
+        __syncthreads();                                         // (ps is reused by the next block of columns)
     }
 }
 
@@ -2419,10 +2590,16 @@ int ct_ffn_pairgrid(ct_ffn_t* h, const float* feat_ref, int n, const float* feat
     float* ws = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     float* Hr = ws; float* Ht = Hr + (size_t)n * HID; float* U = Ht + (size_t)m * HID; float* V = U + (size_t)n * HID;
     int rc;
-    if ((rc = gemm(feat_ref, FEAT, h->d_w + h->o_w1, Hr, n, HID, FEAT, h->d_w + h->o_bn1, st))) return rc;
-    if ((rc = gemm(feat_tgt, FEAT, h->d_w + h->o_w1, Ht, m, HID, FEAT, h->d_w + h->o_bn1, st))) return rc;
-    if ((rc = gemm(Hr, HID, h->d_w + h->o_w2, U, n, HID, HID, nullptr, st))) return rc;                           // ref half: W2[:512]
-    if ((rc = gemm(Ht, HID, h->d_w + h->o_w2 + (size_t)HID * HID, V, m, HID, HID, nullptr, st))) return rc;       // tgt half: W2[512:]
+    (void)rc;
+    {   // layer 1 of both point sets, then layer 2 of both (ref half: W2[:512], tgt half: W2[512:]): two launches instead of four
+        const int mx = n > m ? n : m;
+        hipLaunchKernelGGL(gemm_f32_pair_kernel, dim3((HID + 63) / 64, (mx + 63) / 64, 2), dim3(256), 0, st,
+                           GemmPair{{feat_ref, feat_tgt}, {h->d_w + h->o_w1, h->d_w + h->o_w1}, {Hr, Ht}, {n, m}}, FEAT, HID, FEAT, h->d_w + h->o_bn1);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(gemm_f32_pair_kernel, dim3((HID + 63) / 64, (mx + 63) / 64, 2), dim3(256), 0, st,
+                           GemmPair{{Hr, Ht}, {h->d_w + h->o_w2, h->d_w + h->o_w2 + (size_t)HID * HID}, {U, V}, {n, m}}, HID, HID, HID, (const float*)nullptr);
+        LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(ffn_pair_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, st, U, n, V, m,
                        h->d_w + h->o_bn2, h->d_w + h->o_w3, h->b3, corr);
     LAUNCH_CHECK();
@@ -2596,6 +2773,18 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
     // low-rank iterations of the TrackerLite dialect: fused E-step (the posterior is written only if somebody reads it: the caller, or
     // the direct sigma2 sum when the trace identity is switched off)
     int nseg = CS_SEG;
+    // three launches per iteration (em_last_block): E-step + finish, Gram + solve + coefficients here, field application + scalars in the caller
+    if (rank > 0 && !legacy && vol == 1.0 && trace && em_fuse() && gram_tiled() && xref == w.predn &&
+          launch_estep_rows_finish(n, st, prior, w.predn, tgt, m, w.sc, want_P ? w.P : (double*)nullptr, w.part, w.tra,
+                                   FinishTail{w.rank + EM_TICKET, w.dvec, w.sqd, w.rhs, w.trb})) {
+        LAUNCH_CHECK();
+        const int ntile = (rank + LG_T - 1) / LG_T, nwave = ntile * (ntile + 1) / 2 + ntile;
+        const size_t lds = ((size_t)rank * (rank + 1) / 2 + 3 * (size_t)rank) * sizeof(double);          // packed triangle + 3 right-hand sides
+        hipLaunchKernelGGL(lr_gram_solve_coeff_kernel, dim3((nwave + 3) / 4), dim3(256), lds, st, n, w.U, w.rank, w.sc, w.dvec, w.sqd, w.rhs, w.Spart, w.ypart,
+                           SolveTail{w.rank + EM_TICKET + 1, lambda, w.sc, w.q, w.C});
+        LAUNCH_CHECK();
+        return CT_OK;
+    }
     if (rank > 0 && !legacy && vol == 1.0 &&
           launch_estep_cols(n, 1, st, prior, w.predn, n, tgt, m, w.sc, (want_P || !trace) ? w.P : (double*)nullptr, w.part, Bt{0, nullptr},
                             (const double*)nullptr, (const int*)nullptr, 0, trace ? w.tra : (double*)nullptr)) nseg = ES_SEG;
@@ -2642,6 +2831,7 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
 // pivoted Cholesky of w.G -> w.U; returns the rank (host value; one stream sync), <= 0 => use the dense path
 int lowrank_prepare(const PrglsWs& w, int n, hipStream_t st, int* rank_coarse, int* rank_fine) {
     ENSURE_BIG_LDS(lr_solve_kernel);
+    ENSURE_LDS(lr_gram_solve_coeff_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
     hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1), dim3(1024), 0, st, w.G, n, kLowRankTol, kLowRankTolTight, w.U, w.resid, w.rank);
     LAUNCH_CHECK();
     int r[2] = {0, 0};
@@ -2736,6 +2926,7 @@ int prgls_two_ref_impl(const double* prior, const double* tgt, int m, const doub
     hipStream_t st = (hipStream_t)stream;
     PrglsWs w;
     prgls_layout(m, n, l, (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), &w);
+    HIPCHK(hipMemsetAsync(w.rank + EM_TICKET, 0, 3 * sizeof(int), (hipStream_t)stream));     // tickets of the fused EM kernels (em_last_block)
     PreparedRef prep{};
     const size_t nn = (size_t)n * n;
     // init (trackerlite.py:319-325): gamma 0.05, Gram matrices with beta^2, sigma2 = mean d2 / 3, T(X) = X
@@ -2770,6 +2961,7 @@ int prgls_two_ref_impl(const double* prior, const double* tgt, int m, const doub
         HIPCHK(hipStreamSynchronize(st));
         if (h.magic != PREP_MAGIC || h.n != n || h.beta != beta) return CT_EINVAL;     // not what ct_prgls_prepare_ref wrote for this n / beta
         ENSURE_BIG_LDS(lr_solve_kernel);
+        ENSURE_LDS(lr_gram_solve_coeff_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
         rank_coarse = h.rank[0]; rank = h.rank[1];
     } else if ((rc = lowrank_prepare(w, n, st, &rank_coarse, &rank))) return rc;
     if (rank_coarse <= 0 || getenv("CT_PRGLS_DENSE")) rank = 0;
@@ -2798,6 +2990,13 @@ int prgls_two_ref_impl(const double* prior, const double* tgt, int m, const doub
             // the dense continuation keeps the direct sum
             const bool trace = rank > 0 && sigma_trace();
             if ((rc = em_half(w, prior, tgt, m, n, w.predn, lambda, 0, 1.0, rank, st, trace, posterior != nullptr))) return rc;
+            if (trace && em_fuse()) {                             // field application with the iteration's scalars as its tail
+                hipLaunchKernelGGL(apply_dual_scalars_kernel, dim3((n + l + 3) / 4), dim3(256), 0, st, w.C, w.G, n, w.predn, w.Gln, l, w.predl,
+                                   w.normpart, w.sc, w.dvec, w.sqd, w.rhs, w.respart,
+                                   ScalarsTail{w.rank + EM_TICKET + 2, w.sc, m, 1, w.rank, tgt, w.tra, w.trb, w.rowpart});
+                LAUNCH_CHECK();
+                continue;
+            }
             hipLaunchKernelGGL(apply_dual_kernel, dim3((n + l + 3) / 4), dim3(256), 0, st, w.C, w.G, n, w.predn, w.Gln, l, w.predl,
                                w.normpart, w.sc, w.dvec, w.sqd, w.rhs, rank > 0 ? w.respart : (double*)nullptr);
             LAUNCH_CHECK();
@@ -2953,6 +3152,7 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
                        (const double*)nullptr, (int*)nullptr, bt);
     LAUNCH_CHECK();
     ENSURE_BIG_LDS(lr_solve_kernel);
+    ENSURE_LDS(lr_gram_solve_coeff_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
     hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1, 1, zB), dim3(1024), 0, st, w.G, nn, kLowRankTol, kLowRankTolTight, w.U, w.resid, w.rank, bt);
     LAUNCH_CHECK();
     std::vector<int> hrank(2 * (size_t)B, 0);

@@ -941,7 +941,7 @@ __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)
 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
 #ifndef CT_LB2
-#define CT_LB2 3           // workgroups per CU the NT = 2 instantiations are compiled for (4: 128 VGPRs -- measured slower)
+#define CT_LB2 3           // workgroups per CU the NT = 2 instantiations are compiled for (4: 128 VGPRs -- measured slower, DESIGN App. B.1)
 #endif
 #ifndef CT_WPF1
 #define CT_WPF1 2          // K-blocks of weight fragments in flight ahead of the MFMAs, NT = 1 / 2 / 4

@@ -1,0 +1,7 @@
+set -u
+cd $GRAFT_REPO_ROOT
+timeout 300 python scripts/microbench.py goodprior 600 2>&1 | grep -v amdgpu | tail -1
+CT_EM_FUSE=0 timeout 300 python scripts/microbench.py goodprior 600 2>&1 | grep -v amdgpu | tail -1
+timeout 200 python scripts/probe/seqonly.py 96 2>&1 | tail -1
+CT_EM_FUSE=0 timeout 200 python scripts/probe/seqonly.py 96 2>&1 | tail -1
+timeout 600 python scripts/probe/slow_prior.py 2>&1 | grep -v amdgpu | tail -12

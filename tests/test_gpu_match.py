@@ -902,3 +902,52 @@ print("greedy done", len(out))
         for k in a.files:
             assert np.array_equal(a[k], b[k]), k
         assert len(a["p0"]) > 300 and len(a["p12"]) == 0                        # many pairs at 600 x 600, none above the threshold in the flat case
+
+
+def test_three_launch_em_iteration_equals_the_seven_launch_form(golden_dir):
+    """CT_EM_FUSE=1 runs the single-match EM iteration as three launches -- E-step + column-statistics finish, Gram + r x r solve +
+    coefficients, field application + scalars -- the small kernels being the TAIL of the kernel in front of them (run by its last workgroup,
+    em_last_block).  Built in round 5, measured slower than the seven launches (the per-workgroup release fences) and therefore opt-in;  Same device functions in the same order: moved points, posterior, iteration counts and the
+    batched chain's agreement are bit-identical (prepared and unprepared reference sets, 150 / 600 / 2000 points, a slow noise prior)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from pathlib import Path
+    REPO = Path(__file__).resolve().parent.parent
+    code = r"""
+import sys, importlib, numpy as np, torch
+sys.path.insert(0, %r)
+m = lambda n: importlib.import_module("3deecelltracker_amd." + n)
+synth, ffn_mod, tl, _dev = m("synth"), m("ffn"), m("trackerlite"), m("_dev")
+from pathlib import Path
+trained = ffn_mod.FFN().set_weights_dict(synth.load_ffn_npz(Path(%r) / "ffn_synthetic_trained.npz"))
+noisy = ffn_mod.FFN().set_weights_dict(synth.make_ffn_weights(0))
+out = {}
+for n, ffn, tag in ((150, trained, "a"), (600, trained, "b"), (600, noisy, "c"), (2000, trained, "d")):
+    x, y = synth.make_point_pair(n, seed=300 + n, box=(512, 512, 32))
+    xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True)
+    a, b = _dev.points_dev(xn), _dev.points_dev((y - mean) / scale)
+    corr = ffn_mod.initial_matching_device(ffn, a, b, 20)
+    _, _, prior = _dev.greedy_match(corr, 0.1, 0)
+    for prep in (False, True):
+        p = _dev.prgls_prepare_ref(a, 3.0) if prep else None
+        moved, ref, post, it = _dev.prgls_two_ref(prior, b, a, a, 3.0, 3.0, 2000, want_posterior=True, want_ref=True, prepared=p)
+        out[f"{tag}{int(prep)}_moved"] = moved.cpu().numpy(); out[f"{tag}{int(prep)}_ref"] = ref.cpu().numpy()
+        out[f"{tag}{int(prep)}_post"] = post.cpu().numpy(); out[f"{tag}{int(prep)}_it"] = np.array([it])
+    moved, _, _, it = _dev.prgls_two_ref(prior, b, a, a, 3.0, 3.0, 2000, want_posterior=False)
+    out[f"{tag}_np_moved"] = moved.cpu().numpy(); out[f"{tag}_np_it"] = np.array([it])
+np.savez(sys.argv[1], **out)
+print("em done", len(out))
+""" % (str(REPO), str(golden_dir))
+    with tempfile.TemporaryDirectory() as td:
+        files = []
+        for tag, env in (("fused", {"CT_EM_FUSE": "1"}), ("seven", {"CT_EM_FUSE": "0"})):
+            f = os.path.join(td, tag + ".npz"); files.append(f)
+            r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env), cwd=REPO)
+            assert r.returncode == 0 and "em done 40" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+        a, b = np.load(files[0]), np.load(files[1])
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), k
+        assert 5 <= int(a["b0_it"][0]) <= 30 and int(a["c0_it"][0]) > 100       # a quick and a slow convergence were both covered
