@@ -738,10 +738,20 @@ __global__ __launch_bounds__(256) void dist2_rowsum_kernel(const double* __restr
 // finalise scalars from row partials.  mode 0: initial sigma2 = sum / (3 m n)   (both dialects)
 // mode 1 (lite, trackerlite.py:342-350):  gamma = max(1 - sumP/m, 1e-4); sigma2 = sum / (3 sumP)
 // mode 2 (legacy, track.py:103-112):      gamma = 1 - sumP/m;            sigma2 = max(sum / (3 sumP), 1)
+// em_persistent_kernel calls the bodies of the EM kernels for a VIRTUAL block with the iteration's scalars in registers: inside one launch
+// the scalar block changes between phases, and a wave-uniform plain load of it may come back stale from the scalar cache (ct_fresh.h).
+// ov == nullptr (every other caller): blockIdx / gridDim and the scalar block in memory, as before.
+struct EmOv { int vb, nvb; double s2, gamma, c; int r; bool add; };
+__device__ __forceinline__ double em_fresh_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int em_fresh_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // (body of scalars_kernel; also the tail of apply_dual_scalars_kernel, where the last workgroup of the field application runs it)
+template <bool FRESH = false>
 __device__ __forceinline__ void scalars_body(const double* rowpart, int m, int n, int mode, double* sc, const double* normpart,
                                              const double* respart, int* rank_p, Bt bt, const double* tr_tgt,
                                              const double* tr_arow, const double* tr_pred, const double* tr_d, const double* tr_b) {
+    auto SC = [&](int k) { return FRESH ? em_fresh_f64(sc + k) : sc[k]; };
+    auto RK = [&](int k) { return FRESH ? em_fresh_i32(rank_p + k) : rank_p[k]; };
     __shared__ double red[4];
     __shared__ double red2[4];
     __shared__ double red3[4], red4[4];
@@ -750,7 +760,7 @@ __device__ __forceinline__ void scalars_body(const double* rowpart, int m, int n
     if (respart) BT_SHIFT(const double*, respart);
     if (rank_p) BT_SHIFT(int*, rank_p);
     if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
-    if (mode != 0 && sc[S_DONE] != 0.0) return;
+    if (mode != 0 && SC(S_DONE) != 0.0) return;
     if (respart) {
         double r1 = 0.0, r2 = 0.0;
         for (int i = threadIdx.x; i < n; i += 256) { r1 = fmax(r1, respart[i]); r2 = fmax(r2, respart[n + i]); }
@@ -789,14 +799,14 @@ __device__ __forceinline__ void scalars_body(const double* rowpart, int m, int n
         const double s = (red[0] + red[1]) + (red[2] + red[3]);
         if (mode == 0) { sc[S_SIGMA2] = s / (3.0 * (double)m * (double)n); }
         else {
-            const double sp = sc[S_SUMP];
-            const double s2_prev = sc[S_SIGMA2];              // the sigma2 this iteration's M-step (and its residual) used
+            const double sp = SC(S_SUMP);
+            const double s2_prev = SC(S_SIGMA2);              // the sigma2 this iteration's M-step (and its residual) used
             double g = 1.0 - sp / (double)m;
             double s2 = s / (3.0 * sp);
             if (mode == 1) { if (g < 1e-4) g = 1e-4; }
             else { if (s2 < 1.0) s2 = 1.0; }
             sc[S_GAMMA] = g; sc[S_SIGMA2] = s2;
-            sc[S_IT] = sc[S_IT] + 1.0;
+            sc[S_IT] = SC(S_IT) + 1.0;
             if (normpart) {
                 const double n2 = (red2[0] + red2[1]) + (red2[2] + red2[3]);
                 sc[S_NORM2] = n2;
@@ -806,12 +816,12 @@ __device__ __forceinline__ void scalars_body(const double* rowpart, int m, int n
                 const double r1 = fmax(fmax(red3[0], red3[1]), fmax(red3[2], red3[3]));
                 const double r2 = fmax(fmax(red4[0], red4[1]), fmax(red4[2], red4[3]));
                 const double rel = r2 > 0.0 ? r1 / r2 : (r1 > 0.0 ? INFINITY : 0.0);
-                if (!(rel <= sc[S_RES])) sc[S_RES] = rel;
+                if (!(rel <= SC(S_RES))) sc[S_RES] = rel;
                 // the monitor also steers the rank: well before the residual reaches the rejection level the following
                 // iterations use the finer rows of the (nested) factorisation -- rank_p[0] current, rank_p[1] finest
                 // (the truncation error of the M-step scales with 1 / c = 1 / (lambda sigma2): predict the next iteration's)
                 const double predicted = s2 > 0.0 ? rel * (s2_prev / s2) : INFINITY;
-                if (rank_p && !(fmax(rel, predicted) <= kLowRankSwitchResidual) && rank_p[0] < rank_p[1]) rank_p[0] = rank_p[1];
+                if (rank_p && !(fmax(rel, predicted) <= kLowRankSwitchResidual) && RK(0) < RK(1)) rank_p[0] = RK(1);
             }
         }
     }
@@ -822,7 +832,7 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
                                                       Bt bt = Bt{0, nullptr}, const double* __restrict__ tr_tgt = nullptr,
                                                       const double* __restrict__ tr_arow = nullptr, const double* __restrict__ tr_pred = nullptr,
                                                       const double* __restrict__ tr_d = nullptr, const double* __restrict__ tr_b = nullptr) {
-    scalars_body(rowpart, m, n, mode, sc, normpart, respart, rank_p, bt, tr_tgt, tr_arow, tr_pred, tr_d, tr_b);
+    scalars_body<false>(rowpart, m, n, mode, sc, normpart, respart, rank_p, bt, tr_tgt, tr_arow, tr_pred, tr_d, tr_b);
 }
 
 // ---- "last workgroup finishes": the single-workgroup / ten-workgroup kernels that sat between the wide kernels of an EM iteration run as
@@ -1112,17 +1122,18 @@ __device__ __forceinline__ void estep_rows_body(const double* __restrict__ prior
                                                 const double* __restrict__ tgt, int m, const double* sc, double vol,
                                                 double* __restrict__ P /* or null */, double* part, Bt bt,
                                                 const double* __restrict__ sp, const int* __restrict__ sp_dense, int sp_m,
-                                                double* __restrict__ arow) {
+                                                double* __restrict__ arow, const EmOv* ov = nullptr) {
     BT_SHIFT(const double*, prior); BT_SHIFT(const double*, pred); BT_SHIFT(const double*, tgt); BT_SHIFT(const double*, sc);
     BT_SHIFT(double*, part);
     if (P) BT_SHIFT(double*, P);
     if (sp) BT_SHIFT(const double*, sp);
     if (arow) BT_SHIFT(double*, arow);
     if (bt.dims) { m = bt.dims[4 * blockIdx.z]; n = bt.dims[4 * blockIdx.z + 1]; }
-    if (sc[S_DONE] != 0.0) return;
+    if (!ov && sc[S_DONE] != 0.0) return;
     __shared__ double psum[2][16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, W = blockDim.x >> 6;
-    const double s2 = sc[S_SIGMA2], gamma = sc[S_GAMMA];
+    const int bx = ov ? ov->vb : (int)blockIdx.x, gx = ov ? ov->nvb : (int)gridDim.x;
+    const double s2 = ov ? ov->s2 : sc[S_SIGMA2], gamma = ov ? ov->gamma : sc[S_GAMMA];
     const double two_s2 = 2.0 * s2;
     const double norm = pow(2.0 * M_PI * s2, 1.5);
     const double inv_two_s2 = 1.0 / two_s2, coef = (1.0 - gamma) / norm;
@@ -1141,8 +1152,8 @@ __device__ __forceinline__ void estep_rows_body(const double* __restrict__ prior
         const int rc = ok[q] ? r : 0;
         px[q] = pred[3 * rc]; py[q] = pred[3 * rc + 1]; pz[q] = pred[3 * rc + 2];
     }
-    const int per = (m + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int t0 = blockIdx.x * per, t1 = min(m, t0 + per);
+    const int per = (m + gx - 1) / gx;
+    const int t0 = bx * per, t1 = min(m, t0 + per);
     // (the row loop exists once per prior form, so that no branch sits between the exponentials)
     auto rows = [&](auto structured_c) {
     constexpr bool STRUCT = decltype(structured_c)::value;
@@ -1183,7 +1194,7 @@ __device__ __forceinline__ void estep_rows_body(const double* __restrict__ prior
     }
     };
     if (structured) rows(std::true_type{}); else rows(std::false_type{});
-    double* o = part + (size_t)blockIdx.x * 4 * n;
+    double* o = part + (size_t)bx * 4 * n;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int r = (wave * NQ + q) * 64 + lane;
@@ -1365,17 +1376,17 @@ __device__ __forceinline__ void apply_dual_body(const double* __restrict__ C, co
                                                 double* __restrict__ predl, double* norm_part,
                                                 const double* sc, const double* dvec,
                                                 const double* __restrict__ sqd, const double* __restrict__ rhs,
-                                                double* res_part, Bt bt, int first_only) {
+                                                double* res_part, Bt bt, int first_only, const EmOv* ov = nullptr) {
     BT_SHIFT(const double*, C); BT_SHIFT(const double*, G); BT_SHIFT(double*, predn); BT_SHIFT(const double*, Gln);
     BT_SHIFT(double*, predl); BT_SHIFT(double*, norm_part); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
     BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs);
     if (res_part) BT_SHIFT(double*, res_part);
     if (bt.dims) { n = bt.dims[4 * blockIdx.z + 1]; l = bt.dims[4 * blockIdx.z + 2]; }
     if (first_only) l = 0;
-    if (sc[S_DONE] != 0.0) return;
-    const bool add = sc[S_IT] >= 1.0;
+    if (!ov && sc[S_DONE] != 0.0) return;
+    const bool add = ov ? ov->add : sc[S_IT] >= 1.0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int j = blockIdx.x * 4 + wave;
+    int j = (ov ? ov->vb : (int)blockIdx.x) * 4 + wave;
     if (j >= n + l) return;
     const bool second = j >= n;
     if (second) j -= n;
@@ -1388,13 +1399,16 @@ __device__ __forceinline__ void apply_dual_body(const double* __restrict__ C, co
     ax = wave_sum_d(ax); ay = wave_sum_d(ay); az = wave_sum_d(az);
     if (lane != 0) return;
     double* pts = second ? predl : predn;
-    if (add) { pts[3 * j] += ax; pts[3 * j + 1] += ay; pts[3 * j + 2] += az; }
+    // (j is wave-uniform: under ov -- inside em_persistent_kernel, where these arrays change between phases of ONE launch -- such reads
+    //  must not become scalar loads)
+    auto LD = [&](const double* q) { return ov ? em_fresh_f64(q) : *q; };
+    if (add) { pts[3 * j] = LD(pts + 3 * j) + ax; pts[3 * j + 1] = LD(pts + 3 * j + 1) + ay; pts[3 * j + 2] = LD(pts + 3 * j + 2) + az; }
     if (second) return;
     norm_part[j] = ax * ax + ay * ay + az * az;
     if (res_part) {
-        const double c = sc[S_C], d = dvec[j], q = sqd[j];
-        const double bx = q * rhs[3 * j], by = q * rhs[3 * j + 1], bz = q * rhs[3 * j + 2];
-        const double rx = d * ax + c * C[j] - bx, ry = d * ay + c * C[n + j] - by, rz = d * az + c * C[2 * n + j] - bz;
+        const double c = ov ? ov->c : sc[S_C], d = LD(dvec + j), q = LD(sqd + j);
+        const double bx = q * LD(rhs + 3 * j), by = q * LD(rhs + 3 * j + 1), bz = q * LD(rhs + 3 * j + 2);
+        const double rx = d * ax + c * LD(C + j) - bx, ry = d * ay + c * LD(C + n + j) - by, rz = d * az + c * LD(C + 2 * n + j) - bz;
         const double rr = fabs(rx) + fabs(ry) + fabs(rz);                 // NaN/Inf must not be swallowed by fmax
         res_part[j] = isfinite(rr) ? fmax(fabs(rx), fmax(fabs(ry), fabs(rz))) : INFINITY;
         res_part[n + j] = fmax(fabs(bx), fmax(fabs(by), fabs(bz)));
@@ -1419,7 +1433,7 @@ __global__ __launch_bounds__(256) void apply_dual_scalars_kernel(const double* _
                                                                  double* res_part, ScalarsTail tl) {
     apply_dual_body(C, G, n, predn, Gln, l, predl, norm_part, sc, dvec, sqd, rhs, res_part, Bt{0, nullptr}, 0);
     if (!em_last_block(tl.ticket)) return;
-    scalars_body(tl.rowpart, tl.m, n, tl.mode, tl.sc, norm_part, res_part, tl.rank_p, Bt{0, nullptr}, tl.tgt, tl.arow, predn, dvec, tl.trb);
+    scalars_body<false>(tl.rowpart, tl.m, n, tl.mode, tl.sc, norm_part, res_part, tl.rank_p, Bt{0, nullptr}, tl.tgt, tl.arow, predn, dvec, tl.trb);
 }
 
 
@@ -1433,8 +1447,9 @@ __global__ __launch_bounds__(256) void apply_dual_scalars_kernel(const double* _
 // direct factorisation's).  The truncation |G - U^T U| <= tol perturbs the solution by ~ tol/c.
 // ------------------------------------------------------------------------------------------------
 // EM iterations enqueued before the host looks at the convergence flags again: a first short chunk (matches with a good prior converge in
-// 6-11 iterations; the rest of a 16-iteration chunk would be ~90 launches that return at once): 8, 8, then 16 at a time
-static inline int prgls_chunk(int enq, int total) { const int c = enq < 16 ? 8 : 16; return (total - enq) < c ? (total - enq) : c; }
+// 6-11 iterations; the rest of a 16-iteration chunk would be ~90 launches that return at once): 6, 6, 8, then 16 at a time (8, 8, 16 until round 5:
+// a match that converges in 10 iterations left 42 launches that return at once on the frame loop's match stream, now 14)
+static inline int prgls_chunk(int enq, int total) { const int c = enq < 12 ? 6 : (enq < 20 ? 8 : 16); return (total - enq) < c ? (total - enq) : c; }
 
 constexpr int LR_RMAX = 128;
 constexpr int EM_TICKET = 4;                   // w.rank[4..6]: tickets of the three fused EM kernels (em_last_block); zeroed per call
@@ -1661,14 +1676,14 @@ __device__ __forceinline__ void wave_sum16_d(double (&acc)[16], int lane) {
 __device__ __forceinline__ void lr_gram_tiled_body(int n, const double* __restrict__ U, const int* __restrict__ rank_p,
                                                    const double* sc, const double* dvec,
                                                    const double* sqd, const double* rhs,
-                                                   double* Sout, double* yout, Bt bt) {
+                                                   double* Sout, double* yout, Bt bt, const EmOv* ov = nullptr) {
     BT_SHIFT(const double*, U); BT_SHIFT(const int*, rank_p); BT_SHIFT(const double*, sc); BT_SHIFT(const double*, dvec);
     BT_SHIFT(const double*, sqd); BT_SHIFT(const double*, rhs); BT_SHIFT(double*, Sout); BT_SHIFT(double*, yout);
     if (bt.dims) n = bt.dims[4 * blockIdx.z + 1];
-    if (sc[S_DONE] != 0.0) return;
-    const int r = *rank_p;
+    if (!ov && sc[S_DONE] != 0.0) return;
+    const int r = ov ? ov->r : *rank_p;
     const int T = (r + LG_T - 1) / LG_T, ntri = T * (T + 1) / 2;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int w = (ov ? ov->vb : (int)blockIdx.x) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (w >= ntri + T) return;
     double acc[16];
 #pragma unroll
@@ -2264,16 +2279,16 @@ __global__ __launch_bounds__(256) void chol_backward_kernel(const double* __rest
 // body of lr_solve_kernel (256 threads, dynamic LDS = packed triangle + 3 right-hand sides).  qs_out (LDS, [3 r]) and c_out: the solution and
 // c = lambda sigma2 handed to a caller that goes on in the same workgroup (the fused kernel's coefficient pass) without re-reading global memory
 __device__ __forceinline__ void lr_solve_body(const double* Sin, const double* yin, int n, const int* rank_p, double lambda,
-                                              const double* dvec, double* sc, double* qout, double* qs_out, double* c_out) {
+                                              const double* dvec, double* sc, double* qout, double* qs_out, double* c_out, const EmOv* ov = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int r = *rank_p;
+    const int r = ov ? ov->r : *rank_p;
     const int ld = r | 1;                  // (unpacked form: odd leading dimension)
     double* S = sm;                        // packed: rows of the lower triangle back to back, then the 3 right-hand-side rows (PSIX)
 #define PSIX(row, col) (((row) < r ? (row) * ((row) + 1) / 2 : r * (r + 1) / 2 + ((row) - r) * r) + (col))
     __shared__ double red[4];
     __shared__ double idiag[LR_RMAX];
     const int tid = threadIdx.x;
-    const double c = lambda * sc[S_SIGMA2];
+    const double c = lambda * (ov ? ov->s2 : sc[S_SIGMA2]);
     // loads in batches of 8 per thread, all in flight together (a runtime-bound loop would serialise the L2 round trips)
     const float rinv = 1.0f / (float)r;
     for (int e0 = 0; e0 < r * r; e0 += 256 * 8) {
@@ -2447,6 +2462,81 @@ __global__ __launch_bounds__(256) void lr_gram_solve_coeff_kernel(int n, const d
     for (int vb = 0; vb * 64 < n; ++vb) {
         lr_coeff_body(vb, U, n, r, qs, sqd, rhs, c, count_it, tl.C, nullptr, ps);
         __syncthreads();                                         // (ps is reused by the next block of columns)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A chunk of EM iterations of ONE match in ONE launch (the frame loop's match: beside the U-Net each of an iteration's seven launches
+// waits 10-25 us for a workgroup slot, 175 us per iteration against 72 alone; a prior that needs 48 iterations made the match stream the
+// frame loop's critical path at 11 ms per frame).  A small persistent grid walks the phases -- the SAME device functions the seven kernels
+// are made of, called for virtual blocks -- with gd_grid_barrier between them: E-step | finish | Gram | solve (replicated in every
+// workgroup: the r x r system is tiny, and its solution stays in LDS for the coefficients) + coefficients | field application | scalars
+// (workgroup 0).  Bit-identical to the seven-launch form (tests/test_gpu_match.py).  Between phases of one launch everything travels
+// through L2: the barrier is release + acquire, and what a wave reads at a uniform address (the scalar block, a row's own statistics)
+// goes through agent-scope loads (EmOv / em_fresh_*): plain ones may be served stale by the scalar cache.
+// ------------------------------------------------------------------------------------------------
+struct EmP {
+    const double* prior; const double* tgt; int m, n, l; double lambda;
+    double* predn; double* predl; const double* G; const double* Gln; double* P; double* part; double* dvec; double* sqd; double* rhs;
+    double* trb; double* tra; const double* U; int* rank; double* Spart; double* ypart; double* q; double* C;
+    double* normpart; double* respart; double* rowpart; double* sc; int* bar; int iters;
+};
+constexpr int EMP_NQ = 5, EMP_W = 4;            // E-step columns per lane / waves per workgroup: 1280 columns (launch_estep_cols' own NQ)
+__global__ __launch_bounds__(256) void em_persistent_kernel(const EmP a) {
+    __shared__ double red_ps[4 * 64 * 4];                        // the finish's partials and the coefficients' partials are never live together
+    double (*red)[64][4] = reinterpret_cast<double (*)[64][4]>(red_ps);
+    double (*ps)[64][3] = reinterpret_cast<double (*)[64][3]>(red_ps);
+    __shared__ double qs[LR_RMAX * 3];
+    __shared__ double c_sh;
+    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int n = a.n, m = a.m, l = a.l;
+    int passed = 0;
+    for (int it = 0; it < a.iters; ++it) {
+        if (em_fresh_f64(a.sc + S_DONE) != 0.0) break;           // (every workgroup reads the word after the same barrier: the same value)
+        EmOv ov{};
+        ov.s2 = em_fresh_f64(a.sc + S_SIGMA2); ov.gamma = em_fresh_f64(a.sc + S_GAMMA); ov.add = em_fresh_f64(a.sc + S_IT) >= 1.0;
+        ov.r = em_fresh_i32(a.rank); ov.c = a.lambda * ov.s2;
+        // ---- E-step (estep_rows_kernel<5, .>: ES_SEG row segments)
+        ov.nvb = ES_SEG;
+        for (int vb = bid; vb < ES_SEG; vb += G) {
+            ov.vb = vb;
+            estep_rows_body<EMP_NQ>(a.prior, a.predn, n, a.tgt, m, a.sc, 1.0, a.P, a.part, Bt{0, nullptr}, nullptr, nullptr, 0, a.tra, &ov);
+            __syncthreads();                                     // (the row sums' LDS slots are reused by the next segment)
+        }
+        gd_grid_barrier(a.bar, G, passed);
+        // ---- column statistics' finish (colstats_finish_par_kernel)
+        for (int vb = bid; vb * 64 < n; vb += G) {
+            colstats_finish_par_body(vb, a.part, n, a.predn, a.dvec, a.sqd, a.rhs, a.trb, ES_SEG, red);
+            __syncthreads();
+        }
+        gd_grid_barrier(a.bar, G, passed);
+        // ---- S = U D U^T, y (lr_gram_tiled_kernel)
+        {
+            const int T = (ov.r + LG_T - 1) / LG_T, nwave = T * (T + 1) / 2 + T;
+            for (int vb = bid; vb * 4 < nwave; vb += G) {
+                ov.vb = vb;
+                lr_gram_tiled_body(n, a.U, a.rank, a.sc, a.dvec, a.sqd, a.rhs, a.Spart, a.ypart, Bt{0, nullptr}, &ov);
+            }
+        }
+        gd_grid_barrier(a.bar, G, passed);
+        // ---- the r x r solve in every workgroup (lr_solve_kernel's body; all write the same sumP, c and q), then this workgroup's coefficients
+        lr_solve_body(a.Spart, a.ypart, n, a.rank, a.lambda, a.dvec, a.sc, a.q, qs, &c_sh, &ov);
+        __syncthreads();
+        for (int vb = bid; vb * 64 < n; vb += G) {
+            lr_coeff_body(vb, a.U, n, ov.r, qs, a.sqd, a.rhs, c_sh, ov.add, a.C, nullptr, ps);
+            __syncthreads();
+        }
+        gd_grid_barrier(a.bar, G, passed);
+        // ---- field application (apply_dual_kernel)
+        for (int vb = bid; vb * 4 < n + l; vb += G) {
+            ov.vb = vb;
+            apply_dual_body(a.C, a.G, n, a.predn, a.Gln, l, a.predl, a.normpart, a.sc, a.dvec, a.sqd, a.rhs, a.respart, Bt{0, nullptr}, 0, &ov);
+        }
+        gd_grid_barrier(a.bar, G, passed);
+        // ---- sigma2 (trace identity), gamma, iteration counter, convergence, residual monitor (scalars_kernel), by workgroup 0
+        if (bid == 0)
+            scalars_body<true>(a.rowpart, m, n, 1, a.sc, a.normpart, a.respart, a.rank, Bt{0, nullptr}, a.tgt, a.tra, a.predn, a.dvec, a.trb);
+        gd_grid_barrier(a.bar, G, passed);
     }
 }
 
@@ -2832,6 +2922,7 @@ int em_half(const PrglsWs& w, const double* prior, const double* tgt, int m, int
 int lowrank_prepare(const PrglsWs& w, int n, hipStream_t st, int* rank_coarse, int* rank_fine) {
     ENSURE_BIG_LDS(lr_solve_kernel);
     ENSURE_LDS(lr_gram_solve_coeff_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
+    ENSURE_LDS(em_persistent_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
     hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1), dim3(1024), 0, st, w.G, n, kLowRankTol, kLowRankTolTight, w.U, w.resid, w.rank);
     LAUNCH_CHECK();
     int r[2] = {0, 0};
@@ -2962,6 +3053,8 @@ int prgls_two_ref_impl(const double* prior, const double* tgt, int m, const doub
         if (h.magic != PREP_MAGIC || h.n != n || h.beta != beta) return CT_EINVAL;     // not what ct_prgls_prepare_ref wrote for this n / beta
         ENSURE_BIG_LDS(lr_solve_kernel);
         ENSURE_LDS(lr_gram_solve_coeff_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
+        ENSURE_LDS(em_persistent_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
+    ENSURE_LDS(em_persistent_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
         rank_coarse = h.rank[0]; rank = h.rank[1];
     } else if ((rc = lowrank_prepare(w, n, st, &rank_coarse, &rank))) return rc;
     if (rank_coarse <= 0 || getenv("CT_PRGLS_DENSE")) rank = 0;
@@ -2984,6 +3077,35 @@ int prgls_two_ref_impl(const double* prior, const double* tgt, int m, const doub
             HIPCHK(hipMemcpyAsync(ck_n, w.predn, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
             if (l > 0) HIPCHK(hipMemcpyAsync(ck_l, w.predl, 3 * (size_t)l * sizeof(double), hipMemcpyDeviceToDevice, st));
             HIPCHK(hipMemcpyAsync(ck_sc, w.sc, S_NUM * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        // The chunk as ONE persistent launch (em_persistent_kernel) where its grid is certain to be co-resident several times over on the CUs
+        // `st` may use (as for the greedy: a quarter of their 256-thread slots) and the shape is the one its E-step is built for.
+        // OFF by default (CT_EM_PERSISTENT=1 enables it) -- built in round 5, bit-identical, measured slower: six device-side barriers and the
+        // replicated solve make an iteration 112 us alone against 72 for the seven launches, and beside the U-Net the spinning workgroups cost
+        // the conv stream more than the launches they replace (frame loop 6.86 against 6.47 ms per frame; profiles/r05_conv_experiments.txt).
+        static const bool no_emp = !(getenv("CT_EM_PERSISTENT") && atoi(getenv("CT_EM_PERSISTENT")) == 1);
+        if (rank > 0 && sigma_trace() && !no_emp && !em_fuse() && gram_tiled() && estep_mode() >= 2 && estep_nq() == EMP_NQ && n <= 64 * EMP_NQ * EMP_W) {
+            int ncu = 0;
+            uint32_t mask[16] = {0};
+            if (st && hipExtStreamGetCUMask(st, 16, mask) == hipSuccess) { for (int q = 0; q < 16; ++q) ncu += __builtin_popcount(mask[q]); }
+            else (void)hipGetLastError();
+            if (ncu <= 0) {
+                int dev = 0; hipDeviceProp_t pr;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+            }
+            int pg = ncu * 8 / 4;                                 // (one workgroup per CU in practice: ~90 KB of LDS each)
+            if (pg > ncu / 2) pg = ncu / 2;
+            if (pg > 64) pg = 64;
+            if (pg >= 8) {
+                int* bar = w.rank + EM_TICKET + 3;
+                HIPCHK(hipMemsetAsync(bar, 0, sizeof(int), st));
+                const size_t lds = ((size_t)rank * (rank + 1) / 2 + 3 * (size_t)rank) * sizeof(double);
+                const EmP ea{prior, tgt, m, n, l, lambda, w.predn, w.predl, w.G, w.Gln, posterior != nullptr ? w.P : (double*)nullptr, w.part, w.dvec, w.sqd,
+                             w.rhs, w.trb, w.tra, w.U, w.rank, w.Spart, w.ypart, w.q, w.C, w.normpart, w.respart, w.rowpart, w.sc, bar, chunk};
+                hipLaunchKernelGGL(em_persistent_kernel, dim3(pg), dim3(256), lds, st, ea);
+                LAUNCH_CHECK();
+                goto chunk_done;
+            }
         }
         for (int k = 0; k < chunk; ++k) {
             // low-rank iterations take sigma2 from the trace identity (as the batched chain does: the two stay bit-identical);
@@ -3011,6 +3133,7 @@ int prgls_two_ref_impl(const double* prior, const double* tgt, int m, const doub
             }
             LAUNCH_CHECK();
         }
+    chunk_done:
         HIPCHK(hipMemcpyAsync(hsc, w.sc, sizeof(hsc), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (rank > 0 && !(hsc[S_RES] <= kLowRankMaxResidual)) {
@@ -3153,6 +3276,7 @@ int ct_prgls_two_ref_batched(int B, const double* const* prior, const double* co
     LAUNCH_CHECK();
     ENSURE_BIG_LDS(lr_solve_kernel);
     ENSURE_LDS(lr_gram_solve_coeff_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
+    ENSURE_LDS(em_persistent_kernel, (LR_RMAX * (LR_RMAX + 1) / 2 + 3 * LR_RMAX) * 8);
     hipLaunchKernelGGL(lowrank_factor_kernel, dim3(1, 1, zB), dim3(1024), 0, st, w.G, nn, kLowRankTol, kLowRankTolTight, w.U, w.resid, w.rank, bt);
     LAUNCH_CHECK();
     std::vector<int> hrank(2 * (size_t)B, 0);

@@ -202,13 +202,14 @@ class SequenceMode:
 
     GATHER_EVERY = 8
 
-    def __init__(self, ctx, args, shape=None, cells=None, seed=None):
+    def __init__(self, ctx, args, shape=None, cells=None, seed=None, ffn_weights=None):
         import torch
         frame = mod("frame")
         self.ctx = ctx
         self.shape = tuple(args.shape) if shape is None else tuple(shape)
         self.cells = args.cells if cells is None else cells
-        self.chain = frame.FrameChain.synthetic(shape=self.shape, n_cells=self.cells, seed=ctx.frame_seed if seed is None else seed, device=ctx.local)
+        self.chain = frame.FrameChain.synthetic(shape=self.shape, n_cells=self.cells, seed=ctx.frame_seed if seed is None else seed, device=ctx.local,
+                                                ffn_weights=ffn_weights)
         comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
         self.gatherer = mod("parallel").TrackedSetGather(comm)
         self.comm = comm
@@ -488,6 +489,17 @@ def roofline_from_timing(ctx, args, n_patches, steps, model=None):
     return roofline, layers
 
 
+def mixed_ffn_weights(ctx, a: float):
+    """(1 - a) x the synthetic-trained FFN + a x the seeded random-init one, weight by weight: a prior of adjustable quality (a = 0.7: 25 PR-GLS
+    iterations on the headline frames instead of 10; beyond 0.78 the match no longer finds the cells: scripts/probe/slow_prior.py)."""
+    tr, rnd = ctx.ffn_trained_w, ctx.ffn_w
+    out = {}
+    for k, v in tr.items():
+        out[k] = ({kk: ((1 - a) * vv + a * rnd[k][kk]).astype(np.float32) for kk, vv in v.items()} if isinstance(v, dict)
+                  else ((1 - a) * v + a * rnd[k]).astype(np.float32))
+    return out
+
+
 def cpu_frame(ctx, chain, shape, cells, seed, n_patches_timed=None, cpu_threads=None):
     """One whole frame of the headline workload on the host's cores with the CPU oracle (kind "port": the reference is TensorFlow and cannot
     run here): LCN (numpy) -> unet3_a patches (fp32 torch-CPU conv3d, the chain's pass-through weights) -> stitch -> the reference's marker
@@ -731,6 +743,7 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("frames", "independent", "patches", "ensemble"), default="frames")
+    ap.add_argument("--slow-prior-mix", type=float, default=0.74, help="config.slow_prior: share of random-init weights mixed into the trained FFN")
     ap.add_argument("--windows", type=int, default=5, help="frames mode: timed windows of K frames each (value = the first; value_spread = min / median / max over all)")
     ap.add_argument("--shape", type=int, nargs=3, default=(512, 512, 32))
     ap.add_argument("--cells", type=int, default=600)
@@ -912,7 +925,18 @@ def main():
                                          "both_passes_ms_per_frame": [round(d * 1e3, 3) for d in dts],
                                          "stream_spans_ms": {k: round(v, 3) for k, v in seqm.chain.sequence_spans().items()}}
                 seqm.first_coords = first_coords
-                # the same frames with a prior that needs 40 PR-GLS iterations (a weaker FFN, a denser stack): does the match stream become the critical path?
+                # the same frames with a prior that needs 3-4 x the PR-GLS iterations (a weaker FFN, a denser stack): does the match stream become the critical path?
+                if ctx.ffn_trained_w is not None:
+                    slow = SequenceMode(ctx, args, ffn_weights=mixed_ffn_weights(ctx, args.slow_prior_mix))
+                    slow.run(4)
+                    n_slow = 48
+                    dts = [timed_window(ctx, lambda: slow.run(n_slow)) / n_slow for _ in range(2)]
+                    extra["slow_prior"] = {"frames": n_slow, "volumes_per_s": round(1.0 / min(dts), 2), "ms_per_frame": round(min(dts) * 1e3, 3),
+                                           "prgls_iterations": int(np.median([o["prgls_iterations"] for o in slow.outs])),
+                                           "cells_segmented": slow.outs[0]["n_segmented"],
+                                           "stream_spans_ms": {k: round(v, 3) for k, v in slow.chain.sequence_spans().items()},
+                                           "ffn": f"{1 - args.slow_prior_mix:.2f} x synthetic-trained + {args.slow_prior_mix:.2f} x random-init weights (bench.mixed_ffn_weights)"}
+                    del slow
                 extra["chained"] = measure_chained(ctx, args)
                 extra["pcie_inclusive"] = measure_pcie(ctx)
                 extra["other_configs"] = measure_other_configs(ctx, args)

@@ -16,7 +16,7 @@ def mix(a):
     return out
 def gain(g):
     out = dict(tr); out["w3"] = (tr["w3"] * g).astype(np.float32); out["b3"] = (tr["b3"] * g).astype(np.float32); return out
-for tag, w in [("trained", tr)] + [(f"mix {a}", mix(a)) for a in (0.3, 0.5, 0.6, 0.7, 0.8, 0.9)] + [(f"gain {g}", gain(g)) for g in (0.3, 0.1, 0.03)]:
+for tag, w in [("trained", tr)] + [(f"mix {a}", mix(a)) for a in (0.5, 0.7, 0.72, 0.74, 0.75, 0.76, 0.78, 0.8)]:
     chain = frame.FrameChain.synthetic(shape=(512, 512, 32), n_cells=600, seed=0, ffn_weights=w)
     out = chain.run(); out = chain.run()
     err = float(np.abs(out["coords"].real - chain.true_t2 * np.array([1.0, 1.0, 4.0])).max(axis=1).mean())

@@ -905,7 +905,9 @@ print("greedy done", len(out))
 
 
 def test_three_launch_em_iteration_equals_the_seven_launch_form(golden_dir):
-    """CT_EM_FUSE=1 runs the single-match EM iteration as three launches -- E-step + column-statistics finish, Gram + r x r solve +
+    """CT_EM_PERSISTENT=1 runs a chunk of single-match EM iterations as ONE persistent launch (em_persistent_kernel: the seven kernels' bodies for
+    virtual blocks, a device-side barrier between the phases); built in round 5, measured slower than the seven launches, opt-in.
+    CT_EM_FUSE=1 runs the single-match EM iteration as three launches -- E-step + column-statistics finish, Gram + r x r solve +
     coefficients, field application + scalars -- the small kernels being the TAIL of the kernel in front of them (run by its last workgroup,
     em_last_block).  Built in round 5, measured slower than the seven launches (the per-workgroup release fences) and therefore opt-in;  Same device functions in the same order: moved points, posterior, iteration counts and the
     batched chain's agreement are bit-identical (prepared and unprepared reference sets, 150 / 600 / 2000 points, a slow noise prior)."""
@@ -942,12 +944,13 @@ print("em done", len(out))
 """ % (str(REPO), str(golden_dir))
     with tempfile.TemporaryDirectory() as td:
         files = []
-        for tag, env in (("fused", {"CT_EM_FUSE": "1"}), ("seven", {"CT_EM_FUSE": "0"})):
+        for tag, env in (("persistent", {"CT_EM_PERSISTENT": "1"}), ("fused", {"CT_EM_FUSE": "1"}), ("seven", {})):
             f = os.path.join(td, tag + ".npz"); files.append(f)
             r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env), cwd=REPO)
             assert r.returncode == 0 and "em done 40" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
-        a, b = np.load(files[0]), np.load(files[1])
-        assert sorted(a.files) == sorted(b.files)
+        a, b, c = np.load(files[0]), np.load(files[1]), np.load(files[2])
+        assert sorted(a.files) == sorted(b.files) == sorted(c.files)
         for k in a.files:
-            assert np.array_equal(a[k], b[k]), k
+            assert np.array_equal(a[k], c[k]), ("persistent", k)
+            assert np.array_equal(b[k], c[k]), ("fused", k)
         assert 5 <= int(a["b0_it"][0]) <= 30 and int(a["c0_it"][0]) > 100       # a quick and a slow convergence were both covered
