@@ -2,12 +2,12 @@
 # the U-Net alone, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate PMC passes), SQ counters, the match chain, the bench line.
 #   usage: bash scripts/evidence.sh r02
 set -u
-R=${1:-r04}
+R=${1:-r05}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash scripts/prof.sh bench_$R $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-realistic-pass | head -4
+bash scripts/prof.sh bench_$R $GRAFT_REPO_ROOT/bench.py --steps 64 --windows 1 --no-cpu-baseline --no-realistic-pass | head -4
 bash scripts/prof.sh unet_$R $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -4
 bash scripts/prof_pmc.sh unet_$R FETCH_SIZE $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -3
 bash scripts/prof_pmc.sh unet_$R WRITE_SIZE $GRAFT_REPO_ROOT/scripts/microbench.py unet | head -3
@@ -18,7 +18,9 @@ cd $GRAFT_REPO_ROOT
 python scripts/sq_summary.py gpurun_out/prof/unet_${R}_kernel_stats.csv gpurun_out/prof/${R}_unet_sq_summary.json gpurun_out/prof/unetA_${R}_sq.csv gpurun_out/prof/unetB_${R}_sq.csv gpurun_out/prof/unetC_${R}_sq.csv
 bash scripts/prof.sh watershed_$R $GRAFT_REPO_ROOT/scripts/microbench.py watershed | head -3
 bash scripts/prof.sh lcn_$R $GRAFT_REPO_ROOT/scripts/microbench.py lcn | head -3
-bash scripts/prof.sh frame_$R $GRAFT_REPO_ROOT/scripts/microbench.py frame | head -3
+bash scripts/prof.sh frame_$R $GRAFT_REPO_ROOT/scripts/probe/seqonly.py | head -3      # the frame loop (FrameChain.run_sequence): the contract line's path
+grep "frame sequence" /tmp/prof_frame_$R.log
+bash scripts/prof.sh m2000_$R $GRAFT_REPO_ROOT/scripts/probe/m2000.py | head -3
 bash scripts/prof.sh match600_$R $GRAFT_REPO_ROOT/scripts/microbench.py match 600 | head -3
 bash scripts/prof.sh batched_$R $GRAFT_REPO_ROOT/scripts/microbench.py batched 600 16 | head -3
 cd $GRAFT_REPO_ROOT

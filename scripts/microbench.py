@@ -27,6 +27,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # the frame loop keeps 5-6 streams busy (read when HIP initialises; the package only warns)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
