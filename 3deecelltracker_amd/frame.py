@@ -36,6 +36,10 @@ class FrameChain:
         # run_sequence: HIP priorities of the U-Net / watershed / match + correction streams (-1 high, 0 normal, 1 low); CT_SEQ_PRIO="s,w,t" overrides
         import os
         self.seq_priorities = tuple(int(v) for v in os.environ.get("CT_SEQ_PRIO", "0,-1,-1").split(","))
+        # run_sequence: CUs reserved for the match + correction stream (the U-Net stream is masked off them; 0 = no reservation).  A prior that
+        # needs many PR-GLS iterations makes that stream -- hundreds of dependent small launches, each waiting for a workgroup slot beside the
+        # U-Net -- the loop's critical path; on CUs of its own they start at once.  Costs the U-Net its share of the chip on EVERY frame.
+        self.seq_match_cus = int(os.environ.get("CT_SEQ_MATCH_CUS", "0"))
         self._side = None
         self._seq = None
         self.unet_model = unet_model
@@ -170,8 +174,19 @@ class FrameChain:
             raise ValueError("run_sequence: every volume of a sequence must have the same shape and live on the same device")
         if self._seq is None or self._seq["key"] != key:       # (streams and probability-map buffers belong to one volume shape on one device)
             ps, pw, pt = self.seq_priorities
-            self._seq = {"key": key, "S": t.cuda.Stream(device=dev, priority=ps), "W": t.cuda.Stream(device=dev, priority=pw),
-                         "T": t.cuda.Stream(device=dev, priority=pt),
+            S_, T_ = t.cuda.Stream(device=dev, priority=ps), t.cuda.Stream(device=dev, priority=pt)
+            if self.seq_match_cus > 0:                         # CU-masked streams (library-owned, kept for the chain's lifetime)
+                import ctypes as C
+                L = _lib.lib()
+                n_cu = C.c_int(0)
+                _lib.check(L.ct_device_info(dev.index or 0, C.byref(n_cu), None, None, 0), "ct_device_info")
+                r = max(2, min(self.seq_match_cus, n_cu.value // 2))
+                hs, ht = C.c_void_p(), C.c_void_p()
+                _lib.check(L.ct_stream_create_cu_range(dev.index or 0, r, n_cu.value - r, C.byref(hs)), "ct_stream_create_cu_range")
+                _lib.check(L.ct_stream_create_cu_range(dev.index or 0, 0, r, C.byref(ht)), "ct_stream_create_cu_range")
+                S_, T_ = t.cuda.ExternalStream(hs.value, device=dev), t.cuda.ExternalStream(ht.value, device=dev)
+            self._seq = {"key": key, "S": S_, "W": t.cuda.Stream(device=dev, priority=pw),
+                         "T": T_,
                          "prob": [t.empty(key[0], dtype=t.float32, device=dev) for _ in range(NB)],
                          "ready": [t.cuda.Event() for _ in range(NB)]}
         q = self._seq

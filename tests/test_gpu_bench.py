@@ -200,3 +200,41 @@ def test_frame_sequence_with_overlapped_unet_equals_the_serial_frames(region_met
             assert np.array_equal(g["coords"].real, w["coords"].real)
     assert len({o["n_segmented"] for o in want}) >= 1 and want[0]["n_segmented"] >= 100
     assert list(chain.run_sequence([], seg, conf)) == []
+
+
+@pytest.mark.gpu
+def test_frame_sequence_survives_an_early_stop_and_another_volume_shape():
+    """run_sequence is a generator with streams and probability-map buffers cached on the chain: a consumer that stops after two frames must
+    leave the caller's stream ordered behind the frames already enqueued (try / finally joins the three streams), the next sequence on the
+    same chain gives the values of a fresh one, and a sequence of another volume shape rebuilds the cached buffers instead of handing the
+    U-Net buffers of the wrong shape (round-4 advisor: _seq is keyed on shape and device)."""
+    import importlib
+    import numpy as np
+    import torch
+    frame = importlib.import_module("3deecelltracker_amd.frame")
+    chain = frame.FrameChain.synthetic(shape=(256, 256, 24), n_cells=150, seed=6)
+    raws = [chain.raw_t2, chain.raw_t1, chain.raw_t2, chain.raw_t1]
+    want = list(chain.run_sequence(raws, chain.seg_real_t1, chain.confirmed_real_t1))
+    gen = chain.run_sequence(raws, chain.seg_real_t1, chain.confirmed_real_t1)
+    first = next(gen); next(gen)
+    gen.close()                                                   # GeneratorExit inside the loop: the finally clause joins S / W / T
+    torch.cuda.synchronize()
+    assert np.array_equal(first["coords"].real, want[0]["coords"].real)
+    again = list(chain.run_sequence(raws, chain.seg_real_t1, chain.confirmed_real_t1))
+    for g, w in zip(again, want):
+        assert g["n_segmented"] == w["n_segmented"] and np.array_equal(g["coords"].real, w["coords"].real)
+    assert chain._seq["key"][0] == (256, 256, 24)
+    other = frame.FrameChain.synthetic(shape=(192, 160, 16), n_cells=60, seed=7)
+    small = [other.raw_t2, other.raw_t1]
+    # the same chain fed another geometry: U-Net and watershed run on REBUILT buffers of the new shape; the chain's transformer belongs to the
+    # first volume, so the correction refuses the map (ValueError) -- inside the generator, whose finally clause still joins the streams
+    with pytest.raises(ValueError, match="shape"):
+        list(chain.run_sequence(small, other.seg_real_t1, other.confirmed_real_t1))
+    torch.cuda.synchronize()
+    assert chain._seq["key"][0] == (192, 160, 16)
+    back = list(chain.run_sequence(raws, chain.seg_real_t1, chain.confirmed_real_t1))
+    assert chain._seq["key"][0] == (256, 256, 24)
+    for g, w in zip(back, want):
+        assert g["n_segmented"] == w["n_segmented"] and np.array_equal(g["coords"].real, w["coords"].real)
+    with pytest.raises(ValueError, match="same shape"):
+        list(chain.run_sequence([chain.raw_t2, other.raw_t2], chain.seg_real_t1, chain.confirmed_real_t1))       # mixed shapes in one sequence
