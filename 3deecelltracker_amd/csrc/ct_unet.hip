@@ -756,8 +756,12 @@ __device__ __forceinline__ void amax_publish(float m, uint32_t* slot, int tid, f
 // Tile geometry.  Z8 = false: 4 x 8 columns x 16 z (an MFMA column = one (x, y) column).  Z8 = true (levels with Z <= 8,
 // e.g. every level of unet3_b): 8 x 8 columns x 8 z, an MFMA column = TWO y-adjacent columns x 8 z (lane bit 3 selects the
 // column), so no MFMA lane multiplies padding.
-template <bool Z8> struct BfGeom {
-    static constexpr int TXv = Z8 ? 8 : 4, TYv = 8, ZB = Z8 ? 8 : 16;
+// Y10 (round 5): 4 x 10 columns x 16 z -- every level of unet3_a is a multiple of 10 columns wide (160, 80, 40, 20), the 20 x 20 bottom level is
+// NOT a multiple of 8 (three 8-wide tiles cover 24: a fifth of the bottom convs' MFMAs and weight fetches worked on overhang), and a workgroup that
+// computes 40 instead of 32 columns per weight fragment fetches a fifth less weight stream for the same outputs.  A wave takes a 2 x 5 block.
+template <bool Z8, bool Y10 = false> struct BfGeom {
+    static_assert(!(Z8 && Y10), "one geometry at a time");
+    static constexpr int TXv = Z8 ? 8 : 4, TYv = Y10 ? 10 : 8, ZB = Z8 ? 8 : 16;
     static constexpr int HXv = TXv + 2, HYv = TYv + 2, HZv = ZB + 2;
     static constexpr int POS = HXv * HYv * HZv;               // halo positions
     static constexpr int PLANE = POS * 16;                    // bytes per component plane
@@ -780,7 +784,8 @@ __host__ __device__ constexpr int bf_tap_pos(bool c8, bool folded, int t, int hy
 }
 
 // position offset of the wave's MFMA column mt (relative to the wave / lane base) for the column mappings of the kernel
-__host__ __device__ constexpr int bf_col_pos(bool c8, bool kfold, bool z8, int mt, int hy, int hz, bool low = false) {
+__host__ __device__ constexpr int bf_col_pos(bool c8, bool kfold, bool z8, int mt, int hy, int hz, bool low = false, bool y10 = false) {
+    if (y10) return ((mt / 5) * hy + (mt % 5)) * hz;                      // plain 2 x 5 block of the wave
     if (low) return c8 ? mt * hz : ((mt >> 2) * hy + (mt & 3)) * hz;       // parity class members are neighbours at half resolution
     if (c8) return mt * (kfold ? 2 : 1) * hz;
     if (!z8) return kfold ? (2 * (mt >> 2) * hy + 2 * (mt & 3)) * hz : ((mt >> 2) * hy + (mt & 3)) * hz;
@@ -815,8 +820,8 @@ __device__ __forceinline__ void bf_split4(const f32x4 v, uint2& h, uint2& m, uin
 // = 4 x 6 columns instead of the 6 x 10 full-resolution halo columns that repeat every voxel up to four times (2.5 x fewer loads, splits
 // and LDS stores for half of a decoder conv's chunks); the folded taps then read neighbours (bf_tap_pos / bf_col_pos `low`).
 constexpr int LHX = TX / 2 + 2, LHY = TY / 2 + 2;
-template <bool Z8, bool LOW = false> struct StageGeom {
-    using G = BfGeom<Z8>;
+template <bool Z8, bool LOW = false, bool Y10 = false> struct StageGeom {
+    using G = BfGeom<Z8, Y10>;
     static constexpr int ZS = G::ZB * 2;                      // float4 slots of one column's interior: (z, channel half)
     static constexpr int NCG = 256 / ZS;                      // columns per iteration
     static constexpr int NCOLS = LOW ? LHX * LHY : G::HXv * G::HYv;
@@ -827,9 +832,9 @@ template <bool Z8, bool LOW = false> struct StageGeom {
 
 // Every wave builds its own copy of the table (its lanes write it and read it back: LDS keeps one wave's requests in order, so no
 // workgroup barrier stands between the kernel's entry and its first global loads).
-template <bool Z8, bool LOW = false>
+template <bool Z8, bool LOW = false, bool Y10 = false>
 __device__ __forceinline__ void stage_table(const ConvArgs& a, bool from_a, int x0, int y0, int lane, int* tab) {
-    using G = BfGeom<Z8>;
+    using G = BfGeom<Z8, Y10>;
     const int CQ = from_a ? (a.CA >> 3) : (a.CB >> 3), SY = from_a ? a.AY : a.Y, SZ = from_a ? a.AZ : a.Z;
     const int sux = from_a ? a.ux : 0, suy = from_a ? a.uy : 0;
     if constexpr (LOW) {                                      // columns of the low-resolution source itself (x0, y0 even)
@@ -841,7 +846,7 @@ __device__ __forceinline__ void stage_table(const ConvArgs& a, bool from_a, int 
         return;
     }
 #pragma unroll
-    for (int c = lane; c < StageGeom<Z8>::NCOLS; c += 64) {
+    for (int c = lane; c < StageGeom<Z8, false, Y10>::NCOLS; c += 64) {
         const int hx = c / G::HYv, hy = c - hx * G::HYv;
         const int gx = x0 - 1 + hx, gy = y0 - 1 + hy;
         tab[c] = (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y) ? (((gx >> sux) * SY + (gy >> suy)) * CQ * SZ) * 32 : -1;
@@ -854,10 +859,10 @@ __device__ __forceinline__ const char* stage_base(const ConvArgs& a, int c0, int
     return reinterpret_cast<const char*>(a.srcB + ((size_t)p * a.X * a.Y * (a.CB >> 3) + ((c0 - a.CA) >> 3)) * a.Z * 8);
 }
 
-template <bool Z8, bool LOW = false>
+template <bool Z8, bool LOW = false, bool Y10 = false>
 __device__ __forceinline__ void stage_load(const ConvArgs& a, const char* base, const int* tab, int suz, int z0, int tid, bool with_zhalo,
-                                           f32x4 (&v)[StageGeom<Z8, LOW>::NIT], f32x4 (&vh)[StageGeom<Z8, LOW>::NHIT]) {
-    using S = StageGeom<Z8, LOW>; using G = BfGeom<Z8>;
+                                           f32x4 (&v)[StageGeom<Z8, LOW, Y10>::NIT], f32x4 (&vh)[StageGeom<Z8, LOW, Y10>::NHIT]) {
+    using S = StageGeom<Z8, LOW, Y10>; using G = BfGeom<Z8, Y10>;
     const int zs = tid % S::ZS, cgp = tid / S::ZS;
     const int gz = z0 + (zs >> 1);
     const int zb = gz < a.Z ? ((gz >> suz) * 8 + (zs & 1) * 4) * 4 : -1;
@@ -888,9 +893,9 @@ __device__ __forceinline__ void stage_load(const ConvArgs& a, const char* base, 
     }
 }
 
-template <bool Z8, bool F16>
+template <bool Z8, bool F16, bool Y10 = false>
 __device__ __forceinline__ void stage_put(const f32x4 v, char* d, float in_scale) {
-    using G = BfGeom<Z8>;
+    using G = BfGeom<Z8, Y10>;
     if constexpr (F16) {
         uint2 h, l;
         h_split4(v, in_scale, h, l);
@@ -905,31 +910,31 @@ __device__ __forceinline__ void stage_put(const f32x4 v, char* d, float in_scale
     }
 }
 
-template <bool Z8, bool F16, bool LOW = false>
-__device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8, LOW>::NIT], const f32x4 (&vh)[StageGeom<Z8, LOW>::NHIT], int tid,
+template <bool Z8, bool F16, bool LOW = false, bool Y10 = false>
+__device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8, LOW, Y10>::NIT], const f32x4 (&vh)[StageGeom<Z8, LOW, Y10>::NHIT], int tid,
                                             bool with_zhalo, char* lds, float in_scale) {
-    using S = StageGeom<Z8, LOW>; using G = BfGeom<Z8>;
+    using S = StageGeom<Z8, LOW, Y10>; using G = BfGeom<Z8, Y10>;
     const int zs = tid % S::ZS, cgp = tid / S::ZS;
     char* d0 = lds + ((cgp * G::HZv + 1 + (zs >> 1)) * 2 + (zs & 1)) * 8;
 #pragma unroll
     for (int i = 0; i < S::NIT; ++i)
         if ((i + 1) * S::NCG <= S::NCOLS || cgp + S::NCG * i < S::NCOLS)
-            stage_put<Z8, F16>(v[i], d0 + i * (S::NCG * G::HZv * 16), in_scale);
+            stage_put<Z8, F16, Y10>(v[i], d0 + i * (S::NCG * G::HZv * 16), in_scale);
     if (with_zhalo) {
 #pragma unroll
         for (int i = 0; i < S::NHIT; ++i) {
             const int idx = tid + 256 * i;
             if (idx < S::NHS)
-                stage_put<Z8, F16>(vh[i], lds + (((idx >> 2) * G::HZv + ((idx & 2) ? G::HZv - 1 : 0)) * 2 + (idx & 1)) * 8, in_scale);
+                stage_put<Z8, F16, Y10>(vh[i], lds + (((idx >> 2) * G::HZv + ((idx & 2) ? G::HZv - 1 : 0)) * 2 + (idx & 1)) * 8, in_scale);
         }
     }
 }
 
 // byte offset (inside one component plane) of the lane's B fragment for every K-block of a tap set: lane group g supplies tap slot
 // 4 kb + g.  Built once per kernel -- inside the K loop the four-way select cost a dozen instructions per K-block.
-template <int KB, bool C8, bool FOLDED, bool Z8, bool LOW = false>
+template <int KB, bool C8, bool FOLDED, bool Z8, bool LOW = false, bool Y10 = false>
 __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)[KB]) {
-    using G = BfGeom<Z8>;
+    using G = BfGeom<Z8, Y10>;
     constexpr int HYt = LOW ? LHY : G::HYv;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -952,12 +957,12 @@ __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)
 #ifndef CT_WPF4
 #define CT_WPF4 0
 #endif
-template <bool F16, int NT, int NCOL, int KB, bool C8, bool FOLDED, bool KFOLD, bool Z8, bool LOW = false>
+template <bool F16, int NT, int NCOL, int KB, bool C8, bool FOLDED, bool KFOLD, bool Z8, bool LOW = false, bool Y10 = false>
 __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char* lds, const int (&tapoff)[KB],
                                              const uint4* wp /* uniform */, uint32_t lane16, int nt_total) {   // (no __restrict__: see the prefetch)
     // A K-block is 12-96 MFMAs (200-1600 cycles); the L2 round trip of its weight fragments is 200+ cycles and nothing else in the
     // wave's stream covers it, so the fragments of the next PFD blocks are requested ahead of this block's MFMAs (registers permitting).
-    using G = BfGeom<Z8>;
+    using G = BfGeom<Z8, Y10>;
     constexpr int NC = SplitMath<F16>::NC, NP = SplitMath<F16>::NP;
     constexpr int PFD0 = NT == 1 ? (CT_WPF1) : (NT == 2 ? (CT_WPF2) : (CT_WPF4));
     constexpr int PFD = PFD0 < KB ? PFD0 : KB - 1;
@@ -989,7 +994,8 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int mt = cg + q;
-                const int cpos = bf_col_pos(C8, KFOLD, Z8, mt, LOW ? LHY : G::HYv, G::HZv, LOW);
+                if (mt >= NCOL) continue;                              // (NCOL = 10: column groups of 4, 4, 2; decided at compile time)
+                const int cpos = bf_col_pos(C8, KFOLD, Z8, mt, LOW ? LHY : G::HYv, G::HZv, LOW, Y10);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     if constexpr ((CT_ABL) & 2) av[q][c] = u32x4{lane16, lane16, lane16, lane16};
@@ -1007,6 +1013,7 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
+                        if (cg + q >= NCOL) continue;
                         if constexpr ((CT_ABL) & 1) {           // keep the operands alive, one VALU op instead of the MFMA
                             acc[cg + q][nt][0] += __uint_as_float(wv[nt][WI[pr]][0] ^ av[q][AI[pr]][1]);
                         } else
@@ -1021,16 +1028,17 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
     }
 }
 
-template <bool F16, int NT, bool C8, bool FOLD, bool Z8>
+template <bool F16, int NT, bool C8, bool FOLD, bool Z8, bool Y10 = false>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void conv3_split_kernel(const ConvArgs a_in) {
     static_assert(!C8 || NT == 1, "the Cout = 8 kernel has one row tile");
     static_assert(!(C8 && Z8), "Cout = 8 layers sit at the full-resolution level");
-    using G = BfGeom<Z8>;
-    constexpr int NCOL = C8 ? 4 : 8;
+    static_assert(!Y10 || (!C8 && !FOLD && !Z8), "4 x 10 tiles: plain layers only");
+    using G = BfGeom<Z8, Y10>;
+    constexpr int NCOL = C8 ? 4 : (Y10 ? 10 : 8);
     constexpr int HYg = G::HYv, HZg = G::HZv;
     __shared__ __attribute__((aligned(16))) char lds[SplitMath<F16>::NC * G::PLANE];
     __shared__ float amax_red[4];
-    __shared__ int coltab[4][2][StageGeom<Z8>::NCOLS];       // per wave: column tables of the two source tensors
+    __shared__ int coltab[4][2][StageGeom<Z8, false, Y10>::NCOLS];       // per wave: column tables of the two source tensors
     __shared__ __attribute__((aligned(16))) float epi_s[4 * NT * 16];   // this block's bias | scale | shift | head weights
     // All kernel arguments are fetched in one go: left alone, the compiler loads each where it is first used, and the ~20 dependent
     // scalar-load round trips (200-300 cycles apiece with every workgroup hitting the same lines) were a third of a thin layer's
@@ -1086,13 +1094,14 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
     // wave -> columns.  plain: 2 x 4 block at (wx, wy) (Z8: 2 x 8 at (2 wave, 0), lane bit 3 = y parity);
     // FOLD: parity class (wx, wy) = (px, py), stride 2 (Z8: lane bit 3 = +2 in y); C8: x pair wx
     const int wx = C8 ? 2 * (wave >> 1) : (FOLD ? (wave >> 1) : (Z8 ? 2 * wave : 2 * (wave >> 1)));
-    const int wy = FOLD ? (wave & 1) : (Z8 ? 0 : 4 * (wave & 1));
+    const int wy = FOLD ? (wave & 1) : (Z8 ? 0 : (Y10 ? 5 : 4) * (wave & 1));
     const int lanepos = (wx * HYg + wy + (FOLD ? 2 : 1) * csel) * HZg + zl;
     // folded taps start at halo offset (px, py) (C8: (0, py))
     const int foldpos = lanepos + (C8 ? wy * HZg : (wx * HYg + wy) * HZg);
     // output coordinates of MFMA column mt (relative to the tile origin)
-    auto col_x = [&](int mt) { return C8 ? wx : (FOLD ? (Z8 ? wx + 2 * (mt >> 1) : wx + 2 * (mt >> 2)) : wx + (mt >> 2)); };
+    auto col_x = [&](int mt) { if constexpr (Y10) return wx + mt / 5; else return C8 ? wx : (FOLD ? (Z8 ? wx + 2 * (mt >> 1) : wx + 2 * (mt >> 2)) : wx + (mt >> 2)); };
     auto col_y = [&](int mt) {
+        if constexpr (Y10) return wy + mt % 5; else
         return C8 ? wy + (FOLD ? 2 : 1) * mt
                   : (FOLD ? (Z8 ? wy + 2 * (2 * (mt & 1) + csel) : wy + 2 * (mt & 3)) : (Z8 ? 2 * (mt & 3) + csel : wy + (mt & 3)));
     };
@@ -1132,17 +1141,17 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
     const int cls = C8 ? wy : (wx * 2 + wy);
     const bool lowa = FOLD && !Z8 && a.lowa != 0;
     if constexpr (!((CT_ABL) & 512)) {
-    if (nFromA > 0) { if (lowa) stage_table<Z8, true>(a, true, x0, y0, lane, coltab[wave][0]); else stage_table<Z8>(a, true, x0, y0, lane, coltab[wave][0]); }
-    if (nFromA < a.nchunks) stage_table<Z8>(a, false, x0, y0, lane, coltab[wave][1]);
+    if (nFromA > 0) { if (lowa) stage_table<Z8, true>(a, true, x0, y0, lane, coltab[wave][0]); else stage_table<Z8, false, Y10>(a, true, x0, y0, lane, coltab[wave][0]); }
+    if (nFromA < a.nchunks) stage_table<Z8, false, Y10>(a, false, x0, y0, lane, coltab[wave][1]);
     }
     float in_scale = 1.f, out_mul = 1.f;
     auto stage = [&](int chunk, auto low_tag) {
         constexpr bool LOW = decltype(low_tag)::value;
-        using SL = StageGeom<Z8, LOW>;
+        using SL = StageGeom<Z8, LOW, Y10>;
         f32x4 v[SL::NIT], vh[SL::NHIT];
         const bool from_a = chunk < nFromA;
         const bool zhalo = a.zblocks > 1 || chunk == 0;       // one z block: the z halo is zero padding, written once
-        stage_load<Z8, LOW>(a, stage_base(a, chunk * 8, p), coltab[wave][from_a ? 0 : 1], from_a ? a.uz : 0, z0, tid, zhalo, v, vh);
+        stage_load<Z8, LOW, Y10>(a, stage_base(a, chunk * 8, p), coltab[wave][from_a ? 0 : 1], from_a ? a.uz : 0, z0, tid, zhalo, v, vh);
         if (chunk == 0) CT_TR(1);
         __syncthreads();                                      // every wave is done reading the previous tile
         if (chunk == 0) {
@@ -1153,7 +1162,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                 in_scale = pow2f(-k); out_mul = pow2f(k) * a.wscale_inv;
             }
         }
-        if constexpr (!((CT_ABL) & 4)) stage_store<Z8, F16, LOW>(v, vh, tid, zhalo, lds, in_scale);
+        if constexpr (!((CT_ABL) & 4)) stage_store<Z8, F16, LOW, Y10>(v, vh, tid, zhalo, lds, in_scale);
         else if (v[0][0] == 12345.678f) lds[tid] = 1;        // (keeps the loads alive)
         if constexpr (LOW) {
             // one z block: the z-halo rows are the 'same' padding, written as zeros with the first chunk only -- for ALL 6 x 10 columns the
@@ -1197,11 +1206,11 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
     }
     {
         int tapoff[KBS];
-        bf_tap_offsets<KBS, C8, false, Z8>(lanepos, g, tapoff);
+        bf_tap_offsets<KBS, C8, false, Z8, false, Y10>(lanepos, g, tapoff);
         for (int chunk = nA; chunk < a.nchunks; ++chunk) {
             stage(chunk, NoLow{});
             const uint4* wp = wbase + (((size_t)nA * NCLS * KBF + (size_t)(chunk - nA) * KBS) * a.nt_total + ntb) * NC * 64;
-            bf_chunk_mma<F16, NT, NCOL, KBS, C8, false, FOLD, Z8>(acc, lds, tapoff, wp, lane16, a.nt_total);
+            bf_chunk_mma<F16, NT, NCOL, KBS, C8, false, FOLD, Z8, false, Y10>(acc, lds, tapoff, wp, lane16, a.nt_total);
         }
     }
 
@@ -1269,7 +1278,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
             const f32x4 scale = *reinterpret_cast<const f32x4*>(epi_s + ECH + cbl);
             const f32x4 shift = *reinterpret_cast<const f32x4*>(epi_s + 2 * ECH + cbl);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
+            for (int mt = 0; mt < NCOL; ++mt) {
                 f32x4 r = F16 ? acc[mt][nt] * out_mul + bias : acc[mt][nt] + bias;
                 float cmax = 0.f;
 #pragma unroll
@@ -1289,7 +1298,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
         const int OQ = a.cout >> 3;
         if (a.out && !((CT_ABL) & 2048)) {
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
+            for (int mt = 0; mt < NCOL; ++mt) {
                 const int x = x0 + col_x(mt), y = y0 + col_y(mt);
                 if (x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && z < a.Z) {
 #pragma unroll
@@ -1303,7 +1312,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                 }
             }
         }
-        if constexpr (!FOLD) {
+        if constexpr (!FOLD && !Y10) {
             if (a.pool) {      // MaxPooling3D (2,2,pz)
                 // !Z8: the wave's 2 x 4 columns are two 2 x 2 blocks {2 blk, 2 blk + 1, 4 + 2 blk, 5 + 2 blk};
                 //  Z8: MFMA columns j and j + 4 are x neighbours, the y neighbour sits in lane ^ 8 -> four 2 x 2 blocks
@@ -1342,7 +1351,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
         if (a.head) {      // Conv3D(1, 1, activation='sigmoid') fused: dot over channels, then sigmoid
             const float hb = head_bias;
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
+            for (int mt = 0; mt < NCOL; ++mt) {
                 float part = 0.f;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -2253,8 +2262,12 @@ int launch_conv(const ConvArgs& a, int P, bool fold, hipStream_t st) {
 }
 
 template <bool F16, int NT>
-int launch_conv_bf(const ConvArgs& a, int P, bool fold, bool z8, hipStream_t st) {
+int launch_conv_bf(const ConvArgs& a, int P, bool fold, bool z8, bool y10, hipStream_t st) {
     const int nblk = P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
+    if (y10) {                                                // (the caller offers it for plain split-fp16 layers with NT <= 2 only)
+        if constexpr (F16 && NT <= 2) hipLaunchKernelGGL((conv3_split_kernel<F16, NT, false, false, false, true>), dim3(nblk), dim3(256), 0, st, a);
+        else return CT_ESHAPE;
+    } else
     if (z8) {
         if (fold) hipLaunchKernelGGL((conv3_split_kernel<F16, NT, false, true, true>), dim3(nblk), dim3(256), 0, st, a);
         else      hipLaunchKernelGGL((conv3_split_kernel<F16, NT, false, false, true>), dim3(nblk), dim3(256), 0, st, a);
@@ -2265,7 +2278,7 @@ int launch_conv_bf(const ConvArgs& a, int P, bool fold, bool z8, hipStream_t st)
     return (int)hipGetLastError();
 }
 template <bool F16>
-int launch_conv_split(const ConvArgs& a_in, int P, int NTsel, bool c8, bool fold, bool z8, hipStream_t st) {
+int launch_conv_split(const ConvArgs& a_in, int P, int NTsel, bool c8, bool fold, bool z8, bool y10, hipStream_t st) {
     ConvArgs a = a_in;
     {
         const uint32_t nblk = (uint32_t)P * a.tilesX * a.tilesY * a.zblocks * (c8 ? 1 : a.ngroups);
@@ -2282,9 +2295,9 @@ int launch_conv_split(const ConvArgs& a_in, int P, int NTsel, bool c8, bool fold
         return (int)hipGetLastError();
     }
     switch (NTsel) {
-        case 1: return launch_conv_bf<F16, 1>(a, P, fold, z8, st);
-        case 2: return launch_conv_bf<F16, 2>(a, P, fold, z8, st);
-        case 4: return launch_conv_bf<F16, 4>(a, P, fold, z8, st);
+        case 1: return launch_conv_bf<F16, 1>(a, P, fold, z8, y10, st);
+        case 2: return launch_conv_bf<F16, 2>(a, P, fold, z8, y10, st);
+        case 4: return launch_conv_bf<F16, 4>(a, P, fold, z8, y10, st);
         default: return CT_ESHAPE;
     }
 }
@@ -2785,10 +2798,18 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             // levels with Z <= 8 (all of unet3_b, the bottom of unet3_c): 8 x 8 x 8 tiles whose MFMA columns hold two (x, y)
             // columns x 8 z instead of one x 16 z with half the lanes on padding (split-bf16 kernels, CT_CONV_Z8=0: off)
             const bool z8 = z8_on && c.bf && !c.c8 && d[2] <= 8;
+            // 4 x 10 tiles for plain split-fp16 layers without a fused pool, where they cover strictly fewer columns than 4 x 8 ones (20 wide: 20
+            // instead of 24 -- the bottom convs of unet3_a, measured 10-12 % faster; levels that both shapes tile exactly are 2-20 % SLOWER with
+            // them: profiles/r05_conv_experiments.txt section 7).  CT_CONV_Y10 = 0: never; = a bit mask of conv indices: exactly those layers.
+            static const char* y10_env = getenv("CT_CONV_Y10");
+            static const unsigned y10_mask = y10_env ? (unsigned)strtoul(y10_env, nullptr, 0) : 0u;
+            const int ry = c.region[3] - c.region[2];
+            const bool y10_ok = c.bf && c.f16 && !c.c8 && !c.fold && !z8 && c.pool_dst < 0 && !(i == 1 && fuse01) && (c.NT <= 2 || (c.NT == 4 && !c.head));
+            const bool y10 = y10_ok && (y10_env ? ((y10_mask >> i) & 1u) != 0 : (ry + 9) / 10 * 10 < (ry + TY - 1) / TY * TY);
             {
-                const int tw = z8 ? 8 : TX;
+                const int tw = z8 ? 8 : TX, th = y10 ? 10 : TY;
                 a.tx0 = c.region[0]; a.ty0 = c.region[2];
-                a.tilesX = (c.region[1] - c.region[0] + tw - 1) / tw; a.tilesY = (c.region[3] - c.region[2] + TY - 1) / TY;
+                a.tilesX = (c.region[1] - c.region[0] + tw - 1) / tw; a.tilesY = (c.region[3] - c.region[2] + th - 1) / th;
                 a.nx0 = c.needed[0]; a.nx1 = c.needed[1]; a.ny0 = c.needed[2]; a.ny1 = c.needed[3];
                 a.gx1 = a.gy1 = -1;
                 const bool edges = crop_mode > 0 && vsrc && !layer_dump && c.f16 &&
@@ -2812,7 +2833,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
             {
                 const long nblk4 = (long)P * a.tilesX * a.tilesY * a.zblocks * a.ngroups;
                 static const int thr = getenv("CT_CONV_SPLIT_THR") ? atoi(getenv("CT_CONV_SPLIT_THR")) : 4096;
-                if (!c.c8 && !c.head && c.NT == 4 && nblk4 < thr) { NTsel = 2; a.ngroups = c.nt_total / 2; }   // (the fused head needs all channels in one block)
+                if (!c.c8 && !c.head && c.NT == 4 && (nblk4 < thr || y10)) { NTsel = 2; a.ngroups = c.nt_total / 2; }   // (the fused head needs all channels in one block)
             }
             c.nt_used = NTsel;
             int rc;
@@ -2830,8 +2851,8 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 rc = (int)hipGetLastError();
             } else
             if (c.bf) {
-                rc = c.f16 ? launch_conv_split<true>(a, P, NTsel, c.c8, c.fold, z8, st)
-                           : launch_conv_split<false>(a, P, NTsel, c.c8, c.fold, z8, st);
+                rc = c.f16 ? launch_conv_split<true>(a, P, NTsel, c.c8, c.fold, z8, y10, st)
+                           : launch_conv_split<false>(a, P, NTsel, c.c8, c.fold, z8, false, st);
             } else if (c.c8) {
                 const int nblk = P * a.tilesX * a.tilesY * a.zblocks;
                 if (c.fold) hipLaunchKernelGGL(conv3_mfma_c8_fold_kernel, dim3(nblk), dim3(256), 0, st, a);

@@ -1,5 +1,5 @@
 """The conv kernel families must agree with each other: f32-input MFMA vs split-bf16 (bf16x6) vs split-fp16 (f16x3, the default),
-decoder tap folding on/off, Z8 tiles on/off.
+decoder tap folding on/off, Z8 tiles on/off, 4 x 10 tiles never / where they fit better (default) / on every layer that can take them.
 
 The family is chosen when the model is created (CT_CONV_MATH / CT_CONV_FOLD, read once per process), so every mode runs in
 its own child process on the same seeded patches (CT_CONV_MATH / CT_CONV_FOLD / CT_CONV_Z8); the default mode is additionally held to the oracle in test_gpu_unet.py."""
@@ -34,15 +34,19 @@ np.savez(out, prob=both.cpu().numpy(), dump=dump.cpu().numpy())
 @pytest.mark.parametrize("name", ["unet3_a", "unet3_b", "unet3_c"])
 def test_kernel_families_agree(name, tmp_path):
     res = {}
-    # (math, fold, z8): z8 = the 8 x 8 x 8 tile geometry of levels with Z <= 8 (split-bf16 kernels only)
-    for math, fold, z8 in (("f32", "0", "1"), ("f32", "1", "1"), ("bf16x6", "0", "1"), ("bf16x6", "1", "1"), ("bf16x6", "1", "0"),
-                           ("f16x3", "0", "1"), ("f16x3", "1", "1"), ("f16x3", "1", "0")):
-        out = tmp_path / f"{name}_{math}_{fold}_{z8}.npz"
+    # (math, fold, z8[, y10]): z8 = the 8 x 8 x 8 tile geometry of levels with Z <= 8 (split-bf16 kernels only); y10 = CT_CONV_Y10
+    for math, fold, z8, *y10 in (("f32", "0", "1"), ("f32", "1", "1"), ("bf16x6", "0", "1"), ("bf16x6", "1", "1"), ("bf16x6", "1", "0"),
+                                 ("f16x3", "0", "1"), ("f16x3", "1", "1"), ("f16x3", "1", "0"), ("f16x3", "1", "1", "0"),
+                                 ("f16x3", "1", "1", "0xffff"), ("f16x3", "0", "0", "0xffff")):
+        out = tmp_path / f"{name}_{math}_{fold}_{z8}_{''.join(y10)}.npz"
         env = dict(os.environ, CT_CONV_MATH=math, CT_CONV_FOLD=fold, CT_CONV_Z8=z8)
+        env.pop("CT_CONV_Y10", None)
+        if y10:
+            env["CT_CONV_Y10"] = y10[0]
         r = subprocess.run([sys.executable, "-c", CHILD, str(REPO), name, str(out)], env=env, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        res[(math, fold, z8)] = np.load(out)
+        res[(math, fold, z8) + tuple(y10)] = np.load(out)
     ref = res[("f32", "0", "1")]                      # the exact-fp32 fmaf-chain kernels without any tap folding
     scale = max(1.0, float(np.abs(ref["dump"]).max()))
     for key, z in res.items():
