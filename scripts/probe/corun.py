@@ -6,6 +6,8 @@ that a subset can run without the others; pacing is the real loop's (W and T wai
 whole loop, the U-Net span on its own stream (HIP events), and package power / shader clock sampled through amdsmi every 10 ms.
 
     python scripts/probe/corun.py [--frames 48] [--mask-cus N]      (--mask-cus: W and T on a CU-masked stream of the first N CUs, S on the rest)
+    python scripts/probe/corun.py --delays                           (the watershed / the match started D ms after the U-Net they run beside: does it
+                                                                      matter WHICH conv layers a co-runner overlaps?  a spinning one-wave kernel is the delay)
 """
 import importlib
 import os
@@ -102,8 +104,22 @@ def main():
     probs = [t.empty_like(prob_fixed) for _ in range(3)]
     smp = Sampler()
 
+    # device-side delay: torch.cuda._sleep spins one wave for a number of counter ticks; calibrated here
+    def sleep_ms_per_tick():
+        e0 = t.cuda.Event(enable_timing=True); e1 = t.cuda.Event(enable_timing=True)
+        t.cuda._sleep(1000); t.cuda.synchronize()
+        e0.record(); t.cuda._sleep(2_000_000); e1.record(); t.cuda.synchronize()
+        return e0.elapsed_time(e1) / 2_000_000
+    tick_ms = sleep_ms_per_tick()
+    delay = {"ws": 0.0, "match": 0.0}
+
+    def spin(ms):
+        if ms > 0:
+            t.cuda._sleep(int(ms / tick_ms))
+
     def loop(parts, n):
         ev_u = [None] * n
+        ev_s = [None] * n                                    # start of U-Net j on S (what a delayed co-runner counts from)
         pend = {}
 
         def enq_unet(j):
@@ -111,6 +127,7 @@ def main():
                 with t.cuda.stream(W):
                     chain.normalized(raw)
             with t.cuda.stream(S):
+                ev_s[j] = t.cuda.Event(); ev_s[j].record(S)
                 if "unet" in parts:
                     chain.unet_model.predict_volume_device(norm, chain.shrink, out=probs[j % 3])
                 ev_u[j] = t.cuda.Event(); ev_u[j].record(S)
@@ -119,6 +136,8 @@ def main():
             if "ws" in parts:
                 with t.cuda.stream(W):
                     W.wait_event(ev_u[j])
+                    if delay["ws"] > 0 and j + 1 < n and ev_s[j + 1] is not None:
+                        W.wait_event(ev_s[j + 1]); spin(delay["ws"])
                     pend[j] = chain.regions_enqueue(prob_fixed)
         e0 = t.cuda.Event(enable_timing=True); e1 = t.cuda.Event(enable_timing=True)
         t.cuda.synchronize(); t0 = time.perf_counter()
@@ -132,6 +151,8 @@ def main():
             if "match" in parts:
                 with t.cuda.stream(T):
                     T.wait_event(ev_u[i])
+                    if delay["match"] > 0 and i + 1 < n and ev_s[i + 1] is not None:
+                        T.wait_event(ev_s[i + 1]); spin(delay["match"])
                     if i in pend:
                         pend.pop(i).result()
                     chain.track(prob_fixed, seg1, conf1, centres=centres_fixed)
@@ -144,6 +165,16 @@ def main():
         dt = (time.perf_counter() - t0) / n
         return dt * 1e3, e0.elapsed_time(e1) / n
 
+    if "--delays" in sys.argv:
+        print(f"device-side delay: {tick_ms * 1e6:.3f} ns per tick; frames per configuration {frames}")
+        for parts, key in ((("unet", "ws"), "ws"), (("unet", "match"), "match"), (("unet", "lcn", "ws", "match"), "ws"), (("unet", "lcn", "ws", "match"), "match")):
+            for d in (0.0, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0):
+                delay["ws"] = delay["match"] = 0.0
+                delay[key] = d
+                loop(parts, 6)
+                ms, span = loop(parts, frames)
+                print(f"{'+'.join(parts):22s} {key} delayed by {d:3.1f} ms after the U-Net's start: loop {ms:6.2f} ms/frame   S-stream span {span:6.2f} ms/frame", flush=True)
+        return
     configs = [("unet",), ("unet", "lcn"), ("unet", "ws"), ("unet", "lcn", "ws"), ("unet", "match"), ("unet", "lcn", "ws", "match"),
                ("lcn", "ws", "match"), ("ws",), ("match",), ("lcn",)]
     print(f"frames per configuration {frames}; mask {mask} CUs for W/T{' (U-Net on the rest)' if '--mask-unet' in sys.argv else ''}")
