@@ -50,6 +50,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   2048 epilogue arithmetic kept, global stores (output, pool) skipped   4096 no per-patch maximum (reduction, barrier, atomic)
 //   512 no per-wave column tables (no barrier-free LDS write -> read)   1024 the per-patch maxima are not fetched (no threadIdx.y)
 //   (conv_l0l1_fused_kernel honours 8, 2048 and 16384 = no L0 MFMAs: profiles/r03_fuse01_ablation.txt)
+#ifndef CT_TAP_TABLE
+#define CT_TAP_TABLE 1     // tap-slot offsets from a constant table (0: the four-way select per K-block)
+#endif
+#ifndef CT_EPI_SBASE
+#define CT_EPI_SBASE 1     // epilogue stores addressed as scalar column base + 32-bit lane offset (0: the size_t index expression per store)
+#endif
 #ifndef CT_ABL
 #define CT_ABL 0
 #endif
@@ -932,8 +938,25 @@ __device__ __forceinline__ void stage_store(const f32x4 (&v)[StageGeom<Z8, LOW, 
 
 // byte offset (inside one component plane) of the lane's B fragment for every K-block of a tap set: lane group g supplies tap slot
 // 4 kb + g.  Built once per kernel -- inside the K loop the four-way select cost a dozen instructions per K-block.
+// The slot positions are a compile-time table in constant memory, one vector load per K-block issued at kernel entry (round 5: written as
+// `g == 0 ? t0 : g == 1 ? t1 : ...` the compiler produced ~14 instructions of exec-mask branching per K-block -- VOP3 takes no literals).
+template <int KB, bool C8, bool FOLDED, bool Z8, bool LOW, bool Y10> struct TapTable {
+    int v[KB * 4];
+    constexpr TapTable() : v{} {
+        using G = BfGeom<Z8, Y10>;
+        constexpr int HYt = LOW ? LHY : G::HYv;
+        for (int t = 0; t < KB * 4; ++t) v[t] = bf_tap_pos(C8, FOLDED, t, HYt, G::HZv, LOW) * 16;
+    }
+};
+template <int KB, bool C8, bool FOLDED, bool Z8, bool LOW, bool Y10> __device__ const TapTable<KB, C8, FOLDED, Z8, LOW, Y10> kTapTable{};
+
 template <int KB, bool C8, bool FOLDED, bool Z8, bool LOW = false, bool Y10 = false>
 __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)[KB]) {
+#if CT_TAP_TABLE
+    const int* tab = kTapTable<KB, C8, FOLDED, Z8, LOW, Y10>.v + g;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) tapoff[kb] = lanepos * 16 + tab[4 * kb];
+#else
     using G = BfGeom<Z8, Y10>;
     constexpr int HYt = LOW ? LHY : G::HYv;
 #pragma unroll
@@ -942,6 +965,7 @@ __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)
                   t2 = bf_tap_pos(C8, FOLDED, 4 * kb + 2, HYt, G::HZv, LOW), t3 = bf_tap_pos(C8, FOLDED, 4 * kb + 3, HYt, G::HZv, LOW);
         tapoff[kb] = (lanepos + (g == 0 ? t0 : (g == 1 ? t1 : (g == 2 ? t2 : t3)))) * 16;
     }
+#endif
 }
 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
@@ -1029,7 +1053,7 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 }
 
 template <bool F16, int NT, bool C8, bool FOLD, bool Z8, bool Y10 = false>
-__global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void conv3_split_kernel(const ConvArgs a_in) {
+__global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10 ? 4 : 3))) void conv3_split_kernel(const ConvArgs a_in) {
     static_assert(!C8 || NT == 1, "the Cout = 8 kernel has one row tile");
     static_assert(!(C8 && Z8), "Cout = 8 layers sit at the full-resolution level");
     static_assert(!Y10 || (!C8 && !FOLD && !Z8), "4 x 10 tiles: plain layers only");
@@ -1246,6 +1270,13 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
         const f32x4 scale = *reinterpret_cast<const f32x4*>(epi_s + ECH + cb);
         const f32x4 shift = *reinterpret_cast<const f32x4*>(epi_s + 2 * ECH + cb);
         const int x = x0 + wx + (g >> 1);
+#if CT_EPI_SBASE
+        // Cout = 8: one channel octet per voxel; the lane's x (through g >> 1), z and channel half are the lane offset, the column y is scalar
+        const size_t patch_bytes8 = (size_t)a.X * a.Y * a.Z * 32;
+        const __amdgpu_buffer_rsrc_t rs8 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + (a.out ? (size_t)p * patch_bytes8 : 0), 0,
+                                                                             a.out ? (int)patch_bytes8 : 0, 0x00020000);   // (head layer: no tensor, never used)
+        const uint32_t lane_off8 = (uint32_t)(((x * a.Y * a.Z + z) * 8 + cb) * 4);
+#endif
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             f32x4 r = F16 ? acc[mt][0] * out_mul + bias : acc[mt][0] + bias;
@@ -1259,8 +1290,13 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
             const int y = y0 + col_y(mt);
             if constexpr (F16) { if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax); }
             const bool ok = x < a.X && y < a.Y && z < a.Z;
+#if CT_EPI_SBASE
+            if (a.out && ok && x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && !((CT_ABL) & 2048))
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), rs8, lane_off8, y * a.Z * 32, 0);
+#else
             if (a.out && ok && x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && !((CT_ABL) & 2048))
                 *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
+#endif
             if (a.head) {
                 const f32x4 hw = *reinterpret_cast<const f32x4*>(epi_s + 3 * ECH + cb);
                 float part = r[0] * hw[0] + r[1] * hw[1] + r[2] * hw[2] + r[3] * hw[3];
@@ -1296,6 +1332,36 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
         }
         if constexpr (F16 && !((CT_ABL) & 4096)) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
         const int OQ = a.cout >> 3;
+#if CT_EPI_SBASE
+        // stores through a buffer descriptor of this patch's output tensor: scalar column / cout-tile offset + one 32-bit lane offset for
+        // all columns (no vector instruction per store; the size_t index expression cost 8 VALU + 10 SALU apiece)
+        const int col_bytes = OQ * a.Z * 32;
+        if (a.out && !((CT_ABL) & 2048)) {
+            const size_t patch_bytes = (size_t)a.X * a.Y * col_bytes;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + (size_t)p * patch_bytes, 0,
+                                                                                (int)patch_bytes, 0x00020000);
+            const uint32_t lane_off = (uint32_t)((((g >> 1) * a.Z + z) * 8 + 4 * (g & 1)) * 4);
+            const int nt_bytes = a.Z * 64;                                 // one 16-channel tile = two channel octets
+            constexpr bool ZX = Z8;                                        // (Z8: x / y depend on the lane through csel)
+#pragma unroll
+            for (int mt = 0; mt < NCOL; ++mt) {
+                const int x = x0 + col_x(mt), y = y0 + col_y(mt);
+                if (x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && z < a.Z) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (16 * (ntb + nt) + 4 * g < a.cout) {
+                            if constexpr (ZX) {
+                                const uint32_t voff = lane_off + (uint32_t)((x * a.Y + y) * col_bytes);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), rs, voff, (ntb + nt) * nt_bytes, 0);
+                            } else
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), rs, lane_off,
+                                                                       (x * a.Y + y) * col_bytes + (ntb + nt) * nt_bytes, 0);
+                        }
+                    }
+                }
+            }
+        }
+#else
         if (a.out && !((CT_ABL) & 2048)) {
 #pragma unroll
             for (int mt = 0; mt < NCOL; ++mt) {
@@ -1312,11 +1378,19 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                 }
             }
         }
+#endif
         if constexpr (!FOLD && !Y10) {
             if (a.pool) {      // MaxPooling3D (2,2,pz)
                 // !Z8: the wave's 2 x 4 columns are two 2 x 2 blocks {2 blk, 2 blk + 1, 4 + 2 blk, 5 + 2 blk};
                 //  Z8: MFMA columns j and j + 4 are x neighbours, the y neighbour sits in lane ^ 8 -> four 2 x 2 blocks
                 constexpr int NBLK = Z8 ? 4 : 2;
+#if CT_EPI_SBASE
+                const int pcol_bytes = OQ * a.PZ * 32;
+                const size_t ppatch_bytes = (size_t)a.PX * a.PY * pcol_bytes;
+                const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.pool) + (size_t)p * ppatch_bytes, 0,
+                                                                                     (int)ppatch_bytes, 0x00020000);
+                const uint32_t plane_off = (uint32_t)((((g >> 1) * a.PZ + (a.pz == 2 ? (z >> 1) : z)) * 8 + 4 * (g & 1)) * 4);
+#endif
 #pragma unroll
                 for (int blk = 0; blk < NBLK; ++blk) {
                     const int x = x0 + wx, y = y0 + (Z8 ? 2 * blk : wy + 2 * blk);
@@ -1340,9 +1414,14 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : 3)) void con
                         const int cb = 16 * (ntb + nt) + 4 * g;
                         const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
                         if (ok && zok && cb < a.cout && !((CT_ABL) & 2048)) {
+#if CT_EPI_SBASE
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), prs, plane_off,
+                                                                   ((x >> 1) * a.PY + (y >> 1)) * pcol_bytes + (ntb + nt) * (a.PZ * 64), 0);
+#else
                             const int pzc = a.pz == 2 ? (z >> 1) : z;
                             const size_t idx = ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7);
                             *reinterpret_cast<f32x4*>(a.pool + idx) = m;
+#endif
                         }
                     }
                 }
@@ -1899,6 +1978,26 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red);
     const int OQ = a.cout >> 3;
     const int cb = 4 * g;
+#if CT_EPI_SBASE
+    // stores through a buffer descriptor of this PATCH's output tensor: scalar column offset (SALU) + a 32-bit lane offset that is the same
+    // for all eight columns -- no vector instruction per store (round 5: 8 VALU incl. three v_mad_u64_u32 and ten SALU of 64-bit index
+    // arithmetic per store before)
+    const uint32_t lane_off = (uint32_t)((((cb >> 3) * a.Z + z) * 8 + (cb & 7)) * 4);
+    const int col_bytes = OQ * a.Z * 32;
+    if (a.out && !((CT_ABL) & 2048)) {
+        const size_t patch_bytes = (size_t)a.X * a.Y * col_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + (size_t)p * patch_bytes, 0,
+                                                                            (int)patch_bytes, 0x00020000);
+        const bool lane_ok = z < a.Z && cb < a.cout;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int x = x0 + wx + (mt >> 2), y = y0 + wy + (mt & 3);
+            if (x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1) {      // (wave-uniform)
+                if (lane_ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][0]), rs, lane_off, (x * a.Y + y) * col_bytes, 0);
+            }
+        }
+    }
+#else
     if (a.out && !((CT_ABL) & 2048)) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
@@ -1907,7 +2006,16 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
                 *reinterpret_cast<f32x4*>(a.out + ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7)) = acc[mt][0];
         }
     }
+#endif
     if (a.pool) {      // MaxPooling3D (2, 2, pz): the wave's 2 x 4 columns are two 2 x 2 blocks
+#if CT_EPI_SBASE
+        const int pcol_bytes = OQ * a.PZ * 32;
+        const size_t ppatch_bytes = (size_t)a.PX * a.PY * pcol_bytes;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.pool) + (size_t)p * ppatch_bytes, 0,
+                                                                             (int)ppatch_bytes, 0x00020000);
+        const int pzc0 = a.pz == 2 ? (z >> 1) : z;
+        const uint32_t plane_off = (uint32_t)((((cb >> 3) * a.PZ + pzc0) * 8 + (cb & 7)) * 4);
+#endif
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             const int x = x0 + wx, y = y0 + wy + 2 * blk;
@@ -1921,8 +2029,12 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
             }
             const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
             if (ok && zok && cb < a.cout && !((CT_ABL) & 2048)) {
+#if CT_EPI_SBASE
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), prs, plane_off, ((x >> 1) * a.PY + (y >> 1)) * pcol_bytes, 0);
+#else
                 const int pzc = a.pz == 2 ? (z >> 1) : z;
                 *reinterpret_cast<f32x4*>(a.pool + ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7)) = m;
+#endif
             }
         }
     }
