@@ -62,6 +62,7 @@ SIGNATURES = {
     "ct_unet_layer_info": (_i, [_vp, _i, _ip, _ip, _ip, _ip]),
     "ct_unet_layer_fold_channels": (_i, [_vp, _i]),
     "ct_unet_layer_region": (_i, [_vp, _i, _vp]),
+    "ct_unet_layer_tile": (_i, [_vp, _i, _vp]),
     "ct_unet_set_timing": (_i, [_vp, _i]),
     "ct_unet_get_timing": (_i, [_vp, C.POINTER(C.c_float), _ip, _i]),
     "ct_tile_plan": (_i, [_ip, _ip, _ip, _ip, _ip]),

@@ -2079,6 +2079,7 @@ struct ConvPlan {
     bool f16;             // the split kernel's f16x3 variant (2 fp16 components, 3 products, per-patch power-of-two scaling)
     float wscale_inv;     // f16x3: 1 / power-of-two scale of the packed weights
     int nt_used;          // instantiation launched by the last run (small grids split NT = 4 into 2 x NT = 2)
+    int tile[3];          // workgroup tile of the last run
     int region[4];        // x0, x1, y0, y1 computed by the last run (volume path: the part the centre crops depend on)
     int needed[4];        // the part of it some kept voxel really depends on (region = needed rounded out to whole tiles)
     int region_e[4], needed_e[4];   // the same for patches on the volume's far faces (their kept crop is shorter)
@@ -2454,6 +2455,12 @@ int ct_unet_layer_info(const ct_unet_t* h, int layer, int* cin, int* cout, int d
 int ct_unet_layer_region(const ct_unet_t* h, int layer, int region[4]) {
     if (!h || !region || layer < 0 || layer >= (int)h->convs.size()) return CT_EINVAL;
     for (int i = 0; i < 4; ++i) region[i] = h->convs[layer].region[i];
+    return CT_OK;
+}
+
+int ct_unet_layer_tile(const ct_unet_t* h, int layer, int tile_xyz[3]) {
+    if (!h || !tile_xyz || layer < 0 || layer >= (int)h->convs.size()) return CT_EINVAL;
+    for (int i = 0; i < 3; ++i) tile_xyz[i] = h->convs[layer].tile[i];
     return CT_OK;
 }
 
@@ -2948,6 +2955,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 if (!c.c8 && !c.head && c.NT == 4 && (nblk4 < thr || y10)) { NTsel = 2; a.ngroups = c.nt_total / 2; }   // (the fused head needs all channels in one block)
             }
             c.nt_used = NTsel;
+            c.tile[0] = z8 ? 8 : TX; c.tile[1] = y10 ? 10 : TY; c.tile[2] = z8 ? 8 : 16;
             int rc;
             if (i == 1 && fuse01) {
                 ConvArgs af = a;

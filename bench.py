@@ -385,10 +385,13 @@ def roofline_from_timing(ctx, args, n_patches, steps, model=None):
         elif code == 0:
             name = "conv_first_kernel"                 # resolved below (depends on the arithmetic family of the other layers)
         elif bf:
-            z8 = "true" if (code > 0 and d[2] <= 8 and os.environ.get("CT_CONV_Z8", "1") != "0") else "false"   # 8 x 8 x 8 tiles
+            tile = (C.c_int * 3)()
+            L.ct_unet_layer_tile(model._handle, i, tile)
+            z8 = "true" if tile[0] == 8 else "false"          # 8 x 8 x 8 tiles (levels with Z <= 8)
+            y10 = "true" if tile[1] == 10 else "false"        # 4 x 10 x 16 tiles (20-wide levels)
             fl = "true" if f16 else "false"
-            name = (f"conv3_split_kernel<{fl}, 1, true, {'true' if code == -9 else 'false'}, false>" if code < 0 else
-                    f"conv3_split_kernel<{fl}, {code % 100}, false, {'true' if code > 100 else 'false'}, {z8}>")
+            name = (f"conv3_split_kernel<{fl}, 1, true, {'true' if code == -9 else 'false'}, false, false>" if code < 0 else
+                    f"conv3_split_kernel<{fl}, {code % 100}, false, {'true' if code > 100 else 'false'}, {z8}, {y10}>")
         elif code in (-8, -9):
             name = "conv3_mfma_c8_kernel" if code == -8 else "conv3_mfma_c8_fold_kernel"
         elif code > 100:
@@ -420,8 +423,12 @@ def roofline_from_timing(ctx, args, n_patches, steps, model=None):
             break
         except Exception:
             pass
+    def by_name(table, name):
+        """digests recorded before the sixth template argument (the 4 x 10 tile flag) existed carry five-argument names"""
+        return table.get(name) or table.get(name.replace(", false>", ">", 1) if name.endswith(", false>") else name)
+
     for ly in layers:
-        kk = sq.get(ly.get("kernel", ""))
+        kk = by_name(sq, ly.get("kernel", ""))
         if not kk or not ly.get("ms"):
             continue
         ly["pipe_busy"] = kk.get("mfma_pipe_busy"); ly["clock_GHz"] = kk.get("effective_clock_GHz")
@@ -448,7 +455,7 @@ def roofline_from_timing(ctx, args, n_patches, steps, model=None):
     traffic = None
     for cand in sorted((ROOT / "profiles").glob("r*_unet_hbm_traffic.json"), reverse=True):
         try:
-            kk = json.loads(cand.read_text())["kernels"].get(dom_name)
+            kk = by_name(json.loads(cand.read_text())["kernels"], dom_name)
             if kk:
                 traffic = {"hbm_bytes_per_launch": round(kk["hbm_bytes_per_launch"]), "source": f"profiles/{cand.name}",
                            "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1))}

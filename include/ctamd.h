@@ -106,6 +106,10 @@ int ct_unet_layer_fold_channels(const ct_unet_t* h, int layer);
  * entry point computes every layer in full; ct_unet_predict_volume keeps only the centre crop of every patch (unet3d.py:246-254),
  * so its decoder convs compute only the tiles some kept voxel depends on (CT_CONV_CROP=0: everything, as the reference does).  */
 int ct_unet_layer_region(const ct_unet_t* h, int layer, int region[4]);
+/* Tile {x, y, z} a workgroup of `layer` computed in the last run: 4 x 8 x 16 by default, 8 x 8 x 8 on levels with Z <= 8 (CT_CONV_Z8),
+ * 4 x 10 x 16 where that covers the level with fewer columns than 4 x 8 does (20-wide levels; CT_CONV_Y10).  Diagnostics
+ * (bench.py names the kernel instantiation of every layer with it).                                                             */
+int ct_unet_layer_tile(const ct_unet_t* h, int layer, int tile_xyz[3]);
 int ct_unet_set_timing(ct_unet_t* h, int enable);
 int ct_unet_get_timing(ct_unet_t* h, float* ms_per_layer, int* launches_per_layer, int n_layers);
 
