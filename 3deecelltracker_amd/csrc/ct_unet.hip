@@ -2580,6 +2580,11 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
     int t1 = add_conv(0, lowA, lowCA, cur, h->tensors[cur].C, ad.outw[0], false, false);
     add_conv(0, -1, 0, t1, ad.outw[0], ad.outw[1], false, true);
     h->floats_per_patch = off;
+    // the epilogues address a patch's tensor through a buffer descriptor with 32-bit offsets (CT_EPI_SBASE)
+    for (const TensorPlan& tp : h->tensors) {
+        const int* dd = h->dims[tp.level];
+        if ((size_t)dd[0] * dd[1] * dd[2] * (size_t)tp.C * sizeof(float) >= (size_t)1 << 31) { delete h; return CT_ESHAPE; }
+    }
 
     // ---- device weight arena: first conv [27][C0] + epi, then packed convs, then head
     std::vector<float> arena;
