@@ -2372,7 +2372,9 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
         }
         {
             static const bool thread_flood = getenv("CT_WS_FLOOD") && atoi(getenv("CT_WS_FLOOD")) == 0;      // (A/B: one thread per component, binary heap)
-            constexpr unsigned FLOOD_GRID = 512;
+            // every workgroup of the LDS floods holds ~150 KB of LDS, i.e. a whole CU: beside other work a CU has to drain before one can start
+            // (CT_WS_FLOOD_GRID: probe of what that costs a co-running U-Net)
+            static const unsigned FLOOD_GRID = getenv("CT_WS_FLOOD_GRID") ? (unsigned)std::max(1, atoi(getenv("CT_WS_FLOOD_GRID"))) : 512u;
             if (thread_flood) {
                 if (mode2d) ws_flood_kernel<true><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels, size, -1, nullptr);
                 else ws_flood_kernel<false><<<64, 64, 0, st>>>(g, mask, smooth, roots, nroots, heap_off, heap_cnt, heap, labels, size, -1, nullptr);

@@ -177,6 +177,9 @@ def main():
         return
     configs = [("unet",), ("unet", "lcn"), ("unet", "ws"), ("unet", "lcn", "ws"), ("unet", "match"), ("unet", "lcn", "ws", "match"),
                ("lcn", "ws", "match"), ("ws",), ("match",), ("lcn",)]
+    if "--only" in sys.argv:
+        want = [tuple(c.split("+")) for c in sys.argv[sys.argv.index("--only") + 1].split(",")]
+        configs = [c for c in configs if c in want] + [c for c in want if c not in configs]
     print(f"frames per configuration {frames}; mask {mask} CUs for W/T{' (U-Net on the rest)' if '--mask-unet' in sys.argv else ''}")
     for parts in configs:
         loop(parts, 6)
