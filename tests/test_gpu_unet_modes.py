@@ -55,3 +55,38 @@ def test_kernel_families_agree(name, tmp_path):
         perr = float(np.abs(z["prob"] - ref["prob"]).max())
         assert derr <= 1e-5 * scale, f"{name} {key}: conv blocks differ from the f32 kernels by {derr} (scale {scale})"
         assert perr <= 5e-6, f"{name} {key}: probability maps differ by {perr}"
+
+
+VOLUME_CHILD = r"""
+import importlib, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+out = sys.argv[2]
+synth = importlib.import_module("3deecelltracker_amd.synth")
+unet3d = importlib.import_module("3deecelltracker_amd.unet3d")
+model = unet3d.unet3_a().set_weights_dict(synth.make_unet_weights("unet3_a", seed=3))
+vol = torch.from_numpy(np.random.default_rng(5).normal(size=(200, 330, 21)).astype(np.float32)).cuda()
+pv = model.predict_volume_device(vol)
+torch.cuda.synchronize()
+np.save(out, pv.cpu().numpy())
+"""
+
+
+@pytest.mark.gpu
+def test_tile_shapes_agree_bitwise_on_a_volume_with_far_face_patches(tmp_path):
+    """The 4 x 10 x 16 tiles (CT_CONV_Y10: never / where they cover a level with fewer columns -- the default / every layer that can take them)
+    change which workgroup computes a voxel, never how: the volume path (decoder windows, shorter kept crops on the volume's far faces, store
+    windows) must give the same bits in all three settings."""
+    res = {}
+    for y10 in ("0", None, "0xffff"):
+        out = tmp_path / f"vol_{y10}.npy"
+        env = dict(os.environ)
+        env.pop("CT_CONV_Y10", None)
+        if y10 is not None:
+            env["CT_CONV_Y10"] = y10
+        r = subprocess.run([sys.executable, "-c", VOLUME_CHILD, str(REPO), str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[y10] = np.load(out)
+    assert np.isfinite(res["0"]).all() and res["0"].std() > 0
+    assert np.array_equal(res["0"], res[None]), "default tile selection differs from the 4 x 8 tiles"
+    assert np.array_equal(res["0"], res["0xffff"]), "4 x 10 tiles on every eligible layer differ from the 4 x 8 tiles"
