@@ -7,6 +7,7 @@ are gathers of results: centre crops / probability volumes, centroid sets, ensem
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Sequence
 
 
@@ -18,6 +19,17 @@ def dist_info():
     except Exception:
         pass
     return 0, 1
+
+
+def _solo(world: int) -> bool:
+    """One rank: the sharded entry points take their single-process shortcuts.  CT_FORCE_COLLECTIVES=1 with a process group of ONE rank
+    (tests): every collective is issued for real -- the way to execute the RCCL calls, with their stream and event ordering, on a one-GPU box."""
+    if world != 1:
+        return False
+    if os.environ.get("CT_FORCE_COLLECTIVES") != "1":
+        return True
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized())
 
 
 def shard_range(n_items: int, rank: int, world: int):
@@ -38,7 +50,7 @@ def all_gather_varlen(local, counts: Sequence[int]):
     import torch
     import torch.distributed as dist
     rank, world = dist_info()
-    if world == 1:
+    if _solo(world):
         return local
     mx = max(counts)
     tail = tuple(local.shape[1:])
@@ -160,7 +172,7 @@ def sharded_map_gather(fn: Callable, items: Sequence, tail_shape=None, dtype=Non
     # batch_fn(list of items) -> list of tensors: the rank's whole share at once (e.g. one batched chain of launches)
     mine = (batch_fn(items[b:e]) if e > b else []) if batch_fn is not None else chain_map(fn, items[b:e], chains)
     local = torch.stack(mine) if mine else None
-    if world == 1:
+    if _solo(world):
         if local is None:
             if tail_shape is None:
                 raise ValueError("no items and no tail_shape: cannot build an empty result")
@@ -191,7 +203,7 @@ def predict_volume_sharded(model, vol, shrink=(24, 24, 2), src: int | None = 0, 
     centre, grid = tile_plan(tuple(vol.shape), model.arch.input_shape, shrink)
     total = grid[0] * grid[1] * grid[2]
     out = torch.empty_like(vol)
-    if world == 1:
+    if _solo(world):
         return model.predict_volume_device(vol, shrink, out=out)
     L = _lib.lib()
     cur = torch.cuda.current_stream(vol.device)
@@ -229,7 +241,7 @@ def gather_centroids(local_coords, cap: int = 4096):
     import torch
     import torch.distributed as dist
     rank, world = dist_info()
-    if world == 1:
+    if _solo(world):
         return [local_coords]
     n = local_coords.shape[0]
     if n > cap:
@@ -267,7 +279,7 @@ class TrackedSetGather:
         import torch.distributed as dist
         rank, world = dist_info()
         tracked = list(tracked)
-        if world == 1 or not tracked:
+        if _solo(world) or not tracked:
             return None
         cuda = tracked[0].is_cuda
         side = cuda and self.comm is not None

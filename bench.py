@@ -67,6 +67,15 @@ class Ctx:
     pass
 
 
+def flush_c_stdio():
+    """RCCL writes a version banner to the C library's stdout when its first communicator is created; with stdout on a pipe it would sit in
+    that buffer until the process exits -- AFTER the JSON line.  Everything buffered goes out now, so that the JSON line is the last line."""
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def timed(ctx, step, finish, steps, warmup):
     """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks."""
     import torch
@@ -210,7 +219,7 @@ class SequenceMode:
         self.cells = args.cells if cells is None else cells
         self.chain = frame.FrameChain.synthetic(shape=self.shape, n_cells=self.cells, seed=ctx.frame_seed if seed is None else seed, device=ctx.local,
                                                 ffn_weights=ffn_weights)
-        comm = torch.cuda.Stream(device=ctx.dev) if ctx.world > 1 else None
+        comm = torch.cuda.Stream(device=ctx.dev) if (ctx.world > 1 or getattr(ctx, "force_collectives", False)) else None
         self.gatherer = mod("parallel").TrackedSetGather(comm)
         self.comm = comm
         self.outs = []
@@ -228,7 +237,7 @@ class SequenceMode:
             outs.append({k: out[k] for k in ("n_segmented", "prgls_iterations", "correction_rounds")})
             if keep:
                 outs[-1]["coords"] = out["coords"].real
-            if self.ctx.world > 1:
+            if self.comm is not None:
                 batch.append(torch.from_numpy(np.ascontiguousarray(out["coords"].real, dtype=np.float64)).to(self.ctx.dev))
                 if len(batch) == self.GATHER_EVERY:
                     self.gatherer(batch); batch = []
@@ -239,6 +248,40 @@ class SequenceMode:
         self.ctx.gathered_sets = self.gatherer.gathered
         self.outs = outs
         return outs
+
+
+def measure_rccl_single_rank(ctx, args, frames=32):
+    """--rccl-selftest (N = 1 only): RCCL refuses two ranks on one device, so on a one-GPU box the nccl backend is driven with a process group
+    of ONE rank and CT_FORCE_COLLECTIVES=1 (parallel._solo): the frames mode's gather of corrected centroid sets every 8 frames and the
+    patches mode's broadcast + all_gather_into_tensor really go through RCCL kernels on their communication streams, inside the frame loop."""
+    import socket
+    from datetime import timedelta
+    import torch
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port); os.environ["CT_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group("nccl", rank=0, world_size=1, timeout=timedelta(seconds=120))
+    try:
+        ctx.force_collectives = True
+        seq = SequenceMode(ctx, args)
+        seq.run(8)
+        g0 = seq.gatherer.gathered
+        dt = timed_window(ctx, lambda: seq.run(frames)) / frames
+        pre = mod("preprocess"); par = mod("parallel")
+        norm = pre.normalize_image_device(ctx.raw, NOISE_LEVEL, (27, 27, 1), mode=0, subtract_median=True)
+        whole = ctx.model.predict_volume_device(norm).clone()
+        sharded = par.predict_volume_sharded(ctx.model, norm)
+        torch.cuda.synchronize(ctx.dev)
+        return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "frames": frames, "volumes_per_s": round(1.0 / dt, 2), "ms_per_frame": round(dt * 1e3, 3),
+                "tracked_sets_gathered": seq.gatherer.gathered - g0, "gather_every_frames": SequenceMode.GATHER_EVERY,
+                "patches_sharded_equals_single_process": bool(torch.equal(sharded, whole)),
+                "what": "the frame loop with its all_gather_into_tensor of corrected centroid sets issued through RCCL on a one-rank group (CT_FORCE_COLLECTIVES=1); "
+                        "predict_volume_sharded (broadcast + all_gather_into_tensor of centre-crop slabs) checked against the single-process volume"}
+    finally:
+        ctx.force_collectives = False
+        os.environ.pop("CT_FORCE_COLLECTIVES", None)
+        dist.destroy_process_group()
+        flush_c_stdio()
 
 
 def make_patches_mode(ctx, args):
@@ -771,6 +814,7 @@ def main():
     ap.add_argument("--realistic-partition", action="store_true", help="discriminating-FFN pass on a CU partition (--realistic-match-cus) instead of priority streams (116 vs 121 volumes/s)")
     ap.add_argument("--match-batch", type=int, default=None, help="frames whose matches share one chain of launches (ct_prgls_two_ref_batched); capped at ceil(steps / chains) so that a short run does not end on queued match batches")
     ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
+    ap.add_argument("--rccl-selftest", action="store_true", help="N = 1 only: an extra pass that runs the frame loop's gather and the patches mode's collectives through RCCL on a one-rank group")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous only: every rank joins the process group, rank 0 prints {world_size, backend}; no GPU work (CPU test of the self-launch)")
     ap.add_argument("--cpu-patches", type=int, default=75, help="U-Net patches timed by the CPU baseline sample (default: the whole 75-patch volume, ~6 s on 32 threads: nothing is extrapolated)")
     args = ap.parse_args()
@@ -803,6 +847,9 @@ def main():
     if ctx.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=ctx.rank, world_size=ctx.world)
+        dist.barrier()                                   # creates the communicator (and its banner) now, on every rank
+        torch.cuda.synchronize()
+        sys.stdout.flush(); flush_c_stdio()
     if ctx.world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={ctx.world} ranks")
     ctx.dev = f"cuda:{ctx.local}"
@@ -988,6 +1035,11 @@ def main():
                             f"beta=lambda=3), seeded random-init weights")
                 parallelism = (f"frames sharded, {world} rank(s), all-gather of tracked centroids" if args.mode == "independent" else
                                f"patches of one frame sharded over {world} rank(s), input broadcast + all-gather of centre-crop slabs, match on rank 0")
+        if world == 1 and args.rccl_selftest and args.mode == "frames":
+            try:
+                extra["rccl_single_rank"] = measure_rccl_single_rank(ctx, args)
+            except Exception as e:  # noqa: BLE001  (reported, not swallowed)
+                extra["rccl_single_rank"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         excludes = ([] if args.mode in ("frames", "ensemble") else
                     ["regions->centres (ct_watershed_segment, the reference's marker watershed)", "accurate correction"])
         cfg = {"workload": workload, "mode": args.mode, "patches_per_volume": n_patches, "cells": args.cells,
@@ -1024,10 +1076,18 @@ def main():
             "cpu_baseline": cpu,
             "layers": layers,
         }
-        print(json.dumps(out))
+        final_line = json.dumps(out)
     ctx.pipe.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    # the ONE JSON line is the last thing on stdout: whatever the collectives library buffered in C stdio goes out first, and rank 0 lets the
+    # other ranks' processes finish their teardown before it prints
+    sys.stdout.flush(); flush_c_stdio()
+    if rank == 0:
+        if world > 1:
+            time.sleep(1.0)
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":

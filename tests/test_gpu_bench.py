@@ -238,3 +238,15 @@ def test_frame_sequence_survives_an_early_stop_and_another_volume_shape():
         assert g["n_segmented"] == w["n_segmented"] and np.array_equal(g["coords"].real, w["coords"].real)
     with pytest.raises(ValueError, match="same shape"):
         list(chain.run_sequence([chain.raw_t2, other.raw_t2], chain.seg_real_t1, chain.confirmed_real_t1))       # mixed shapes in one sequence
+
+
+def test_rccl_selftest_runs_the_frame_loops_gather_through_rccl_on_one_rank():
+    """--rccl-selftest: a one-rank nccl process group inside the bench process; the frame loop's gather of corrected centroid sets (every 8
+    frames, on its communication stream) and predict_volume_sharded's collectives go through RCCL; the contract line itself is unchanged."""
+    line = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "2", "--windows", "1", "--no-cpu-baseline", "--no-realistic-pass",
+                 "--rccl-selftest"])
+    assert KEYS <= set(line) and line["config"]["rccl_ranks"]["world_size"] == 1
+    r = line["config"]["rccl_single_rank"]
+    assert "error" not in r, r
+    assert r["backend"] == "nccl" and r["world_size"] == 1 and r["patches_sharded_equals_single_process"] is True
+    assert r["tracked_sets_gathered"] == r["frames"] == 32 and r["volumes_per_s"] > 0.5 * line["value"]
