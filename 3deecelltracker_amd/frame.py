@@ -15,6 +15,8 @@ probability map has cell-like regions, the synthetic-trained FFN) for the benchm
 """
 from __future__ import annotations
 
+import collections
+
 import numpy as np
 
 from . import _dev
@@ -191,7 +193,7 @@ class FrameChain:
                          "ready": [t.cuda.Event() for _ in range(NB)]}
         q = self._seq
         q["free"] = [None] * NB
-        q["spans"] = []                                          # (stream-local spans of the last sequence: sequence_spans())
+        q["spans"] = collections.deque(maxlen=3 * 512)           # (stream-local spans of the last sequence's last 512 frames: sequence_spans())
         S, W, T = q["S"], q["W"], q["T"]
         entry = t.cuda.current_stream(dev)
         for st in (S, W, T):
