@@ -20,4 +20,5 @@ cp gpurun_out/microbench_${R}.txt      profiles/${R}_microbench.txt
 cp gpurun_out/evidence_${R}.log        profiles/${R}_evidence_log.txt
 tail -n 1 gpurun_out/bench_${R}.json > profiles/${R}_bench_line.json
 tail -n 1 gpurun_out/bench_${R}_steps20.json > profiles/${R}_bench_line_steps20.json
+[ -s gpurun_out/bench_${R}_rccl_selftest.json ] && cp gpurun_out/bench_${R}_rccl_selftest.json profiles/${R}_bench_rccl_selftest.json
 ls -la profiles/${R}_* | wc -l

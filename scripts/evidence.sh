@@ -28,4 +28,5 @@ python scripts/hbm_traffic.py gpurun_out/prof/unet_${R}_FETCH_SIZE.csv gpurun_ou
 for s in unet "unet --layers" lcn segment watershed correction "match 600" "goodprior 600" legacy ensemble frame pcie; do timeout 300 python scripts/microbench.py $s 2>&1 | grep -v amdgpu.ids | tail -16; done > gpurun_out/microbench_$R.txt 2>&1
 tail -60 gpurun_out/microbench_$R.txt
 timeout 900 python bench.py > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err; tail -c 400 gpurun_out/bench_$R.err; head -c 1500 gpurun_out/bench_$R.json
+timeout 600 python bench.py --steps 20 --warmup 5 --windows 2 --no-cpu-baseline --no-realistic-pass --rccl-selftest 2>/dev/null | tail -n 1 > gpurun_out/bench_${R}_rccl_selftest.json; head -c 200 gpurun_out/bench_${R}_rccl_selftest.json; echo
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${R}_steps20.json 2>> gpurun_out/bench_$R.err; head -c 300 gpurun_out/bench_${R}_steps20.json
