@@ -250,3 +250,14 @@ def test_rccl_selftest_runs_the_frame_loops_gather_through_rccl_on_one_rank():
     assert "error" not in r, r
     assert r["backend"] == "nccl" and r["world_size"] == 1 and r["patches_sharded_equals_single_process"] is True
     assert r["tracked_sets_gathered"] == r["frames"] == 32 and r["volumes_per_s"] > 0.5 * line["value"]
+
+
+def test_the_json_line_is_the_last_line_on_stdout_when_rccl_has_printed_its_banner():
+    """RCCL writes a version banner to the C library's stdout when its first communicator is created; with stdout on a pipe it used to come out at
+    process exit, after the JSON line.  bench.py flushes C stdio and prints its line last."""
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--windows", "1", "--no-cpu-baseline",
+                          "--no-realistic-pass", "--rccl-selftest"], cwd=REPO, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith("{") and json.loads(lines[-1])["config"]["rccl_single_rank"]["backend"] == "nccl", lines[-3:]
