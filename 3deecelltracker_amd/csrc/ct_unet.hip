@@ -969,6 +969,9 @@ __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)
 }
 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
+#ifndef CT_LB1
+#define CT_LB1 4           // workgroups per CU the NT = 1 split-fp16 instantiations are compiled for (<= 128 VGPRs; 3: round 4's bound)
+#endif
 #ifndef CT_LB2
 #define CT_LB2 3           // workgroups per CU the NT = 2 instantiations are compiled for (4: 128 VGPRs -- measured slower, DESIGN App. B.1)
 #endif
@@ -1053,7 +1056,7 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
 }
 
 template <bool F16, int NT, bool C8, bool FOLD, bool Z8, bool Y10 = false>
-__global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10 ? 4 : 3))) void conv3_split_kernel(const ConvArgs a_in) {
+__global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10 ? CT_LB1 : 3))) void conv3_split_kernel(const ConvArgs a_in) {
     static_assert(!C8 || NT == 1, "the Cout = 8 kernel has one row tile");
     static_assert(!(C8 && Z8), "Cout = 8 layers sit at the full-resolution level");
     static_assert(!Y10 || (!C8 && !FOLD && !Z8), "4 x 10 tiles: plain layers only");
