@@ -969,6 +969,9 @@ __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)
 }
 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
+#ifndef CT_PREFETCH
+#define CT_PREFETCH 0      // 1: touch the next channel chunk's tile lines (one dummy load per 128-B line) before the current chunk's MFMAs --
+#endif                     //    measured 3-12 % SLOWER on every multi-chunk layer (profiles/r05_conv_experiments.txt section 15): experiment, off
 #ifndef CT_LB1
 #define CT_LB1 4           // workgroups per CU the NT = 1 split-fp16 instantiations are compiled for (<= 128 VGPRs; 3: round 4's bound)
 #endif
@@ -1172,6 +1175,28 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
     if (nFromA < a.nchunks) stage_table<Z8, false, Y10>(a, false, x0, y0, lane, coltab[wave][1]);
     }
     float in_scale = 1.f, out_mul = 1.f;
+#if CT_PREFETCH
+    // The next chunk's tile is requested only after this chunk's MFMAs (registers for a real prefetch cost a workgroup per CU, round 2); a dummy
+    // load per 128-B line -- one instruction per thread into ONE register that nobody reads -- brings the lines into L2 / MALL meanwhile, so that
+    // the real loads find them there.  (inline asm: the compiler must not wait for it; its own vmcnt waits only become conservative)
+    float pf_sink = 0.f;
+    auto prefetch = [&](int chunk) {
+        const bool from_a = chunk < nFromA;
+        const bool low = lowa && chunk < nA;
+        const int ncols = low ? LHX * LHY : StageGeom<Z8, false, Y10>::NCOLS;
+        const int* tab = coltab[wave][from_a ? 0 : 1];
+        const int suz = from_a ? a.uz : 0;
+        const char* base = stage_base(a, chunk * 8, p);
+        const uint32_t zoff = (uint32_t)((z0 >> suz) * 32 + (tid & 3) * 128);
+        for (int c = tid >> 2; c < ncols; c += 64) {
+            const int t = tab[c];
+            if (t >= 0 && ((tid & 3) * 4 + (z0 >> suz)) < (a.Z >> suz)) {
+                const uint32_t voff = (uint32_t)t + zoff;
+                asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(voff), "s"(base) : "memory");
+            }
+        }
+    };
+#endif
     auto stage = [&](int chunk, auto low_tag) {
         constexpr bool LOW = decltype(low_tag)::value;
         using SL = StageGeom<Z8, LOW, Y10>;
@@ -1204,6 +1229,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
         }
         __syncthreads();
         if (chunk == 0) CT_TR(3);
+#if CT_PREFETCH
+        if constexpr (!(Y10 && NT == 2)) { if (chunk + 1 < a.nchunks) prefetch(chunk + 1); }      // (that instantiation has no register to spare)
+#endif
     };
     using NoLow = std::integral_constant<bool, false>;
     if constexpr (FOLD) {
@@ -1450,6 +1478,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
         }
     }
     CT_TR(5);
+#if CT_PREFETCH
+    asm volatile("" :: "v"(pf_sink));                        // (the register stays reserved until the last dummy load has landed)
+#endif
 #ifdef CT_TRACE
     __builtin_amdgcn_s_waitcnt(0); CT_TR(6);
 #endif
