@@ -969,6 +969,9 @@ __device__ __forceinline__ void bf_tap_offsets(int lanepos, int g, int (&tapoff)
 }
 
 // K-blocks of one chunk: KB blocks of 4 tap slots; weights at wp[((kb * nt_total + nt) * NC + comp) * 64]
+#ifndef CT_STORE_FIRST
+#define CT_STORE_FIRST 1   // output stores issued before the per-patch maximum is reduced and published (0: after)
+#endif
 #ifndef CT_PREFETCH
 #define CT_PREFETCH 0      // 1: touch the next channel chunk's tile lines (one dummy load per 128-B line) before the current chunk's MFMAs --
 #endif                     //    measured 3-12 % SLOWER on every multi-chunk layer (profiles/r05_conv_experiments.txt section 15): experiment, off
@@ -1361,7 +1364,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
                 acc[mt][nt] = r;
             }
         }
+#if !CT_STORE_FIRST
         if constexpr (F16 && !((CT_ABL) & 4096)) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
+#endif
         const int OQ = a.cout >> 3;
 #if CT_EPI_SBASE
         // stores through a buffer descriptor of this patch's output tensor: scalar column / cout-tile offset + one 32-bit lane offset for
@@ -1409,6 +1414,10 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
                 }
             }
         }
+#endif
+#if CT_STORE_FIRST
+        // (the per-patch maximum -- wave reduction, barrier, one atomic -- after the output stores have been issued: they drain meanwhile)
+        if constexpr (F16 && !((CT_ABL) & 4096)) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
 #endif
         if constexpr (!FOLD && !Y10) {
             if (a.pool) {      // MaxPooling3D (2,2,pz)
@@ -2009,7 +2018,9 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
             acc[mt][0] = r;
         }
     }
+#if !CT_STORE_FIRST
     if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red);
+#endif
     const int OQ = a.cout >> 3;
     const int cb = 4 * g;
 #if CT_EPI_SBASE
@@ -2040,6 +2051,9 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
                 *reinterpret_cast<f32x4*>(a.out + ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7)) = acc[mt][0];
         }
     }
+#endif
+#if CT_STORE_FIRST
+    if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red);
 #endif
     if (a.pool) {      // MaxPooling3D (2, 2, pz): the wave's 2 x 4 columns are two 2 x 2 blocks
 #if CT_EPI_SBASE
