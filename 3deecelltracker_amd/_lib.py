@@ -20,10 +20,11 @@ _warned_queues = False
 
 def check_hw_queues(what: str = "the frame loop") -> bool:
     """HIP streams share 4 hardware queues per process unless GPU_MAX_HW_QUEUES (a ROCm runtime variable, read when the runtime
-    initialises) says otherwise; the frame loop keeps five to six streams busy, and two of them on one queue serialise (measured:
-    6.6-9.3 ms per frame depending on the order in which the process created its streams, 6.8 ms every time with 16 queues:
-    INTEGRATION.md).  The package does NOT touch the host application's environment: this warns, once, when the variable is missing
-    or below 8, and returns whether it was fine.  bench.py, the tests and the probes export it themselves."""
+    initialises) says otherwise.  The MULTI-CHAIN modes (FramePipeline: one U-Net stream + `workers` match streams, each driven by its own
+    host thread) are where aliasing was measured: 6.6-9.3 ms per frame depending on the order in which the process created its streams,
+    6.8 ms every time with 16 queues.  FrameChain.run_sequence (the contract loop, three streams) showed no dependence
+    from 4 to 32 queues (profiles/r05_conv_experiments.txt section 16) and therefore does not call this.  The package does NOT touch the host
+    application's environment: this warns, once, when the variable is missing or below 8, and returns whether it was fine."""
     global _warned_queues
     try:
         ok = int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8

@@ -527,15 +527,22 @@ __global__ __launch_bounds__(256) void gd_accept_kernel(int m, int n, float thr,
 // (max value, lowest index), so the accepted set and the pick order are the same bit for bit.
 //   * the grid is small enough to be co-resident several times over on the CUs the launch stream may use (the host sizes it from the
 //     stream's CU mask: a barrier between workgroups that cannot all be resident would never open);
-//   * what a round writes and the next reads travels through L2: the barrier is a release (__threadfence before the arrival) and an
+//   * what a round writes and the next reads travels through L2: the barrier is a release (__threadfence in EVERY wave before the arrival) and an
 //     acquire (after the last arrival), and the wave-uniform reads (flags of a wave's own row, the counters) are agent-scope loads -- plain
 //     loads become scalar loads, and the scalar cache is not covered by the vector L1's invalidate (ct_fresh.h has the history).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int gd_fresh_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned char gd_fresh_u8(const unsigned char* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// How many workgroups of `kernel` the runtime will keep resident per CU (registers, LDS and wave slots considered); 1 if it cannot say.
+template <class K> static int coresident_per_cu(K kernel, int threads, size_t dyn_lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, dyn_lds) != hipSuccess) { (void)hipGetLastError(); nb = 1; }
+    return nb < 1 ? 1 : nb;
+}
 enum { GD_BAR = 8 };                          // ctr[GD_BAR]: arrivals at the device-side barrier (monotonic)
 __device__ __forceinline__ void gd_grid_barrier(int* bar, int nblk, int& passed) {
-    __syncthreads();
+    __threadfence();                                                              // EVERY wave releases its own stores / no-return atomics of the phase: the
+    __syncthreads();                                                              // workgroup barrier alone does not wait for vmcnt (round-5 advisor finding)
     ++passed;
     if (threadIdx.x == 0) {
         __threadfence();                                                          // release: this workgroup's writes of the phase
@@ -845,7 +852,8 @@ __global__ __launch_bounds__(256) void scalars_kernel(const double* __restrict__
 // on in registers / LDS, never re-read from global memory through a possibly cached line.
 __device__ __forceinline__ bool em_last_block(int* ticket) {
     __shared__ int em_is_last;
-    __syncthreads();                                             // (every wave's stores have been issued and counted down: s_waitcnt before the barrier)
+    __threadfence();                                             // every wave: its own stores are complete and written back before the workgroup takes its
+    __syncthreads();                                             // ticket (s_barrier does not imply s_waitcnt vmcnt(0) on this target)
     if (threadIdx.x == 0) {
         __threadfence();                                         // ONE release per workgroup: the L2 write-back it performs is cache-wide, not per thread
         const int nblk = (int)gridDim.x;
@@ -2759,7 +2767,10 @@ int ct_greedy_match(const float* corr, int m, int n, float threshold, int mode, 
             int dev = 0; hipDeviceProp_t pr;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
         }
-        const int safe = ncu * 8 / 4;
+        // co-resident 256-thread workgroups per CU: asked from the runtime (register allocation decides: 72 VGPRs -> 7, not 8), a quarter of them
+        // per chain so that up to four chains sharing the partition cannot block each other at the device-side barrier
+        static const int occ = coresident_per_cu(gd_persistent_kernel, 256, 0);
+        const int safe = ncu * occ / 4;
         const int want = (m + 15) / 16 < 64 ? ((m + 15) / 16 < 8 ? 8 : (m + 15) / 16) : 64;
         pg = want < safe ? want : safe;
         if (pg < 4) pg = 0;
@@ -3093,7 +3104,8 @@ int prgls_two_ref_impl(const double* prior, const double* tgt, int m, const doub
                 int dev = 0; hipDeviceProp_t pr;
                 if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
             }
-            int pg = ncu * 8 / 4;                                 // (one workgroup per CU in practice: ~90 KB of LDS each)
+            const size_t lds_need = ((size_t)rank * (rank + 1) / 2 + 3 * (size_t)rank) * sizeof(double);
+            int pg = ncu * coresident_per_cu(em_persistent_kernel, 256, lds_need) / 4;      // (a quarter of what the runtime says fits, LDS included)
             if (pg > ncu / 2) pg = ncu / 2;
             if (pg > 64) pg = 64;
             if (pg >= 8) {

@@ -37,7 +37,13 @@ class FrameChain:
         self.lcn_beside_unet = True                              # run_sequence: a frame's LCN on the watershed's stream (False: in front of its U-Net)
         # run_sequence: HIP priorities of the U-Net / watershed / match + correction streams (-1 high, 0 normal, 1 low); CT_SEQ_PRIO="s,w,t" overrides
         import os
-        self.seq_priorities = tuple(int(v) for v in os.environ.get("CT_SEQ_PRIO", "0,-1,-1").split(","))
+        try:
+            self.seq_priorities = tuple(int(v) for v in os.environ.get("CT_SEQ_PRIO", "0,-1,-1").split(","))
+        except ValueError:
+            self.seq_priorities = ()
+        if len(self.seq_priorities) != 3 or any(v not in (-1, 0, 1) for v in self.seq_priorities):
+            raise ValueError(f"CT_SEQ_PRIO must be three comma-separated stream priorities out of -1, 0, 1 (U-Net, watershed, match); got "
+                             f"{os.environ.get('CT_SEQ_PRIO')!r}")
         # run_sequence: CUs reserved for the match + correction stream (the U-Net stream is masked off them; 0 = no reservation).  A prior that
         # needs many PR-GLS iterations makes that stream -- hundreds of dependent small launches, each waiting for a workgroup slot beside the
         # U-Net -- the loop's critical path; on CUs of its own they start at once.  Costs the U-Net its share of the chip on EVERY frame.
@@ -168,13 +174,13 @@ class FrameChain:
         if not raws:
             return
         from . import _lib
-        _lib.check_hw_queues("FrameChain.run_sequence")
         dev = raws[0].device
         NB = 3
         key = (tuple(raws[0].shape), str(dev))
         if any(tuple(r.shape) != key[0] or r.device != dev for r in raws):
             raise ValueError("run_sequence: every volume of a sequence must have the same shape and live on the same device")
         if self._seq is None or self._seq["key"] != key:       # (streams and probability-map buffers belong to one volume shape on one device)
+            self._release_seq_streams()
             ps, pw, pt = self.seq_priorities
             S_, T_ = t.cuda.Stream(device=dev, priority=ps), t.cuda.Stream(device=dev, priority=pt)
             if self.seq_match_cus > 0:                         # CU-masked streams (library-owned, kept for the chain's lifetime)
@@ -187,6 +193,7 @@ class FrameChain:
                 _lib.check(L.ct_stream_create_cu_range(dev.index or 0, r, n_cu.value - r, C.byref(hs)), "ct_stream_create_cu_range")
                 _lib.check(L.ct_stream_create_cu_range(dev.index or 0, 0, r, C.byref(ht)), "ct_stream_create_cu_range")
                 S_, T_ = t.cuda.ExternalStream(hs.value, device=dev), t.cuda.ExternalStream(ht.value, device=dev)
+                self._seq_handles = [hs, ht]
             self._seq = {"key": key, "S": S_, "W": t.cuda.Stream(device=dev, priority=pw),
                          "T": T_,
                          "prob": [t.empty(key[0], dtype=t.float32, device=dev) for _ in range(NB)],
@@ -258,6 +265,29 @@ class FrameChain:
             for st in (S, W, T):
                 entry.wait_stream(st)
 
+    def _release_seq_streams(self):
+        """The CU-masked streams of run_sequence are library-owned (ct_stream_create_cu_range): give them back when the sequence key changes
+        or the chain goes away, after whatever they still hold has finished."""
+        handles, self._seq_handles = getattr(self, "_seq_handles", []), []
+        if handles:
+            from . import _lib
+            L = _lib.lib()
+            if self._seq is not None:
+                for k in ("S", "T"):
+                    self._seq[k].synchronize()
+            self._seq = None
+            for h in handles:
+                L.ct_stream_destroy(h)
+
+    def close(self):
+        self._release_seq_streams()
+
+    def __del__(self):
+        try:
+            self._release_seq_streams()
+        except Exception:
+            pass
+
     def sequence_spans(self):
         """Mean ms of the LCN + U-Net spans (stream S) and of the regions/match/correction spans (stream T) of the last run_sequence."""
         _dev.torch().cuda.synchronize()
@@ -318,8 +348,7 @@ class FrameChain:
         tr = CoordsToImageTransformer(shape, vs, factor, subregions, vol1)
         model = unet3d.unet3_a(device=device).set_weights_dict(synth.make_passthrough_unet_weights("unet3_a", seed))
         if ffn_weights is None:
-            trained = Path(__file__).resolve().parent.parent / "tests" / "golden" / "ffn_synthetic_trained.npz"
-            ffn_weights = synth.load_ffn_npz(trained) if trained.exists() else synth.make_ffn_weights(0, 6.0, -3.0)
+            ffn_weights = synth.load_trained_ffn()                  # package data (3deecelltracker_amd/data/)
         ffn = FFN(device=device).set_weights_dict(ffn_weights)
         chain = cls(model, ffn, tr, noise_level=100.0, region_method=region_method, prefetch_ref=prefetch_ref)
         dev = "cuda" if device is None else f"cuda:{device}"

@@ -337,6 +337,7 @@ class FramePipeline:
         self.match_cus = max(4, min(int(match_cus), self.n_cu // 2))
         self.workers = max(1, int(workers))
         self._handles = []
+        _lib.check_hw_queues(f"FramePipeline with {self.workers} match workers")   # the multi-chain mode is where stream aliasing was measured
 
         def cu_stream(first, count):
             h = C.c_void_p()

@@ -19,6 +19,8 @@ Weight container (plain dict of numpy arrays, Keras layouts):
 """
 from __future__ import annotations
 
+from pathlib import Path
+
 import numpy as np
 
 from .arch import ARCHS, FFN_FEAT, FFN_HID
@@ -175,11 +177,20 @@ def make_prob_map(seed: int, shape, n_cells: int, radius=(4.0, 4.0, 1.5), speckl
 
 def load_ffn_npz(path) -> dict:
     """FFN weights stored flat (w1, w2, w3, b3, bn{1,2}_{gamma,beta,mean,var}; any float dtype) -> the nested float32 dict of
-    make_ffn_weights.  tests/golden/ffn_synthetic_trained.npz (made by tests/golden/train_synthetic_ffn.py) is such a file."""
+    make_ffn_weights.  The package's data/ffn_synthetic_trained.npz (made by tests/golden/train_synthetic_ffn.py) is such a file."""
     z = np.load(path)
     f = lambda k: np.asarray(z[k], dtype=np.float32)
     bn = lambda p: {k: f(f"{p}_{k}") for k in ("gamma", "beta", "mean", "var")}
     return {"w1": f("w1"), "bn1": bn("bn1"), "w2": f("w2"), "bn2": bn("bn2"), "w3": f("w3").reshape(FFN_HID, 1), "b3": f("b3").reshape(1)}
+
+
+TRAINED_FFN_PATH = Path(__file__).resolve().parent / "data" / "ffn_synthetic_trained.npz"
+
+
+def load_trained_ffn() -> dict:
+    """The FFN trained on the reference's synthetic-pair recipe (ffn.py:18-53) that ships with the package (package data, not a test
+    fixture: FrameChain.synthetic and bench.py use it as the default discriminating matcher)."""
+    return load_ffn_npz(TRAINED_FFN_PATH)
 
 
 def make_passthrough_unet_weights(arch_name: str = "unet3_a", seed: int = 0, gain: float = 4.0, bias: float = -3.0,

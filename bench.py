@@ -866,8 +866,7 @@ def main():
     ctx.ffn_w = synth.make_ffn_weights(seed=0)
     ctx.model = unet3d.unet3_a(device=ctx.local).set_weights_dict(ctx.unet_w)
     ctx.ffn = ffn_mod.FFN(device=ctx.local).set_weights_dict(ctx.ffn_w)
-    trained_path = ROOT / "tests" / "golden" / "ffn_synthetic_trained.npz"
-    ctx.ffn_trained = ffn_mod.FFN(device=ctx.local).set_weights_dict(synth.load_ffn_npz(trained_path)) if trained_path.exists() else None
+    ctx.ffn_trained = ffn_mod.FFN(device=ctx.local).set_weights_dict(synth.load_trained_ffn())     # package data
     frame_seed = rank if args.mode in ("frames", "independent") else 0
     stack, _ = synth.make_stack(shape, n_cells=args.cells, seed=frame_seed)
     ctx.raw = torch.from_numpy(stack).to(dev)                                   # uint16, LCN runs inside the step
@@ -891,7 +890,7 @@ def main():
     makers = {"independent": make_frames_mode, "patches": make_patches_mode, "ensemble": make_ensemble_mode}
 
     ctx.frame_seed = frame_seed
-    ctx.ffn_trained_w = synth.load_ffn_npz(trained_path) if trained_path.exists() else None
+    ctx.ffn_trained_w = synth.load_trained_ffn()
     L.ct_unet_set_timing.restype = C.c_int
     extra = {}
     spread = None
@@ -966,7 +965,7 @@ def main():
                 # converges in ~10 iterations as with the reference's trained weights
                 ind["with_discriminating_ffn"] = independent(ctx.ffn_trained, dict(match_cus=args.realistic_match_cus, workers=args.match_workers,
                                                                                    priority=not args.realistic_partition))
-                ind["with_discriminating_ffn"]["ffn"] = "tests/golden/ffn_synthetic_trained.npz (synthetic-pair training, 84 % of the true pairs found at 600 cells)"
+                ind["with_discriminating_ffn"]["ffn"] = "3deecelltracker_amd/data/ffn_synthetic_trained.npz (synthetic-pair training, 84 % of the true pairs found at 600 cells)"
             extra["independent_matches"] = ind
         except Exception as e:  # noqa: BLE001  (reported, not swallowed)
             extra["independent_matches"] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -394,8 +394,10 @@ int    ct_watershed_segment(const float* prob, const int dims_xyz[3], double z_x
 /* The same call with the peak-candidate tables sized by the caller (the reference's watershed.py:16-108 takes any stack: skimage's peak_local_max
  * has no table).  peak_cap_2d = candidate slots per z slice of the 2-D stage, peak_cap_3d = slots of the 3-D stage (ct_watershed_segment = 2048 /
  * 8192, enough for every stack measured; 16 .. 2^22 / 2^24).  A stage that wants more latches the overflow and n_out comes back as
- * {-2, slots the fullest z slice wanted, slots the volume wanted} (0 for a stage that was not reached with an overflow pending) -- the caller
- * retries ONCE with tables of that size (3deecelltracker_amd/segment.py does).  Groups of up to 2048 candidates are selected by the counting
+ * {-2, slots the fullest z slice wanted, slots the volume wanted} (0 for a stage that was not reached with an overflow pending).  Retry protocol:
+ * n_out[1] is exact; n_out[2] is meaningful ONLY when n_out[1] <= peak_cap_2d (after a 2-D overflow the 3-D stage ran on a truncated candidate set,
+ * so its figure is a hint).  The caller therefore LOOPS -- grow each table to max(own cap, reported want), call again -- until n_out[0] != -2 or the
+ * caps above are exceeded; two rounds are the common case (2-D grows, then 3-D), 3deecelltracker_amd/segment.py allows four.  Groups of up to 2048 candidates are selected by the counting
  * kernel, up to 8192 by the LDS bitonic form, beyond that the same algorithm runs on a scratch slab of the workspace (slower, same results).
  * Any z extent is accepted (per-slice statistics tables are sized from dims_xyz[2]); an axis must stay < 16384.                           */
 size_t ct_watershed_workspace_bytes_ex(const int dims_xyz[3], int cap, int peak_cap_2d, int peak_cap_3d);

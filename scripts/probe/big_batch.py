@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 tl = importlib.import_module("3deecelltracker_amd.trackerlite"); synth = importlib.import_module("3deecelltracker_amd.synth"); ffn_mod = importlib.import_module("3deecelltracker_amd.ffn"); dev = importlib.import_module("3deecelltracker_amd._dev")
 from pathlib import Path
-ffn = ffn_mod.FFN().set_weights_dict(synth.load_ffn_npz(Path("/root/repo/tests/golden/ffn_synthetic_trained.npz")))
+ffn = ffn_mod.FFN().set_weights_dict(synth.load_ffn_npz(synth.TRAINED_FFN_PATH))
 problems = []
 for b, n in enumerate((2000, 1500, 1800)):
     x, y = synth.make_point_pair(n, seed=70 + b, box=(1024, 1024, 64))

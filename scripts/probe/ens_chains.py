@@ -11,7 +11,7 @@ for _ in range(nvol):
     a = np.eye(3) + (rng.uniform(0, 1, (3, 3)) - 0.5) * 0.04
     pts = (base - base.mean(0)) @ a + base.mean(0) + rng.normal(0, 0.5, base.shape)
     segs.append(pts[rng.permutation(n)]); trks.append(pts + rng.normal(0, 0.3, base.shape))
-ffn = ffn_mod.FFN().set_weights_dict(synth.load_ffn_npz(Path("/root/repo/tests/golden/ffn_synthetic_trained.npz")))
+ffn = ffn_mod.FFN().set_weights_dict(synth.load_ffn_npz(synth.TRAINED_FFN_PATH))
 for chains in (1, 2, 4, 8, 12, 20):
     trk = tracker_mod.Tracker.for_matching(ffn, beta_tk=1000.0, lambda_tk=1e-5, maxiter_tk=10, ensemble=20)
     trk.ensemble_chains = chains

@@ -5,7 +5,7 @@ import numpy as np, torch
 m = lambda n: importlib.import_module("3deecelltracker_amd." + n)
 synth, ffn_mod, tl, _dev = m("synth"), m("ffn"), m("trackerlite"), m("_dev")
 from pathlib import Path
-w = synth.load_ffn_npz(Path(__file__).resolve().parents[2] / "tests" / "golden" / "ffn_synthetic_trained.npz")
+w = synth.load_ffn_npz(synth.TRAINED_FFN_PATH)
 ffn = ffn_mod.FFN().set_weights_dict(w)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 x, y = synth.make_point_pair(n, seed=2000, box=(512, 512, 128), voxel_size=(1.0, 1.0, 1.0))

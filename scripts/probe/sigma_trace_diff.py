@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     synth, ffn_mod, tl, _dev = mod("synth"), mod("ffn"), mod("trackerlite"), mod("_dev")
     out = {}
     for name, ffn in (("noise", ffn_mod.FFN().set_weights_dict(synth.make_ffn_weights(0))),
-                      ("trained", ffn_mod.FFN().set_weights_dict(synth.load_ffn_npz(os.path.join(REPO, "tests", "golden", "ffn_synthetic_trained.npz"))))):
+                      ("trained", ffn_mod.FFN().set_weights_dict(synth.load_ffn_npz(synth.TRAINED_FFN_PATH)))):
         for n in (113, 600):
             x, y = synth.make_point_pair(n, seed=100 + n)
             xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True); yn = (y - mean) / scale

@@ -7,7 +7,7 @@ import numpy as np, torch
 from pathlib import Path
 m = lambda n: importlib.import_module("3deecelltracker_amd." + n)
 synth, frame = m("synth"), m("frame")
-tr = synth.load_ffn_npz(Path(__file__).resolve().parents[2] / "tests" / "golden" / "ffn_synthetic_trained.npz")
+tr = synth.load_ffn_npz(synth.TRAINED_FFN_PATH)
 rnd = synth.make_ffn_weights(0)
 def mix(a):
     out = {}

@@ -334,7 +334,7 @@ def gen_legacy_tracker():
     from oracle import segment_ref as sr
     from oracle.match_ref import FFNRef as _FFN
     out = {}
-    ffn_w = ct_synth.load_ffn_npz(HERE / "ffn_synthetic_trained.npz")
+    ffn_w = ct_synth.load_ffn_npz(ct_synth.TRAINED_FFN_PATH)
     for ci, (seed, siz, zs, ratio, ncell, ens, margin) in enumerate(((0, (120, 136, 14), 5, 4.0, 40, False, 6.5), (1, (96, 110, 12), 3, 2.5, 30, 5, 10.0))):
         case = ct_synth.make_legacy_frame_case(seed, siz, zs, ratio, ncell, margin=margin, edge_cells=2 if margin < 10 else 0)
         tmp = tempfile.mkdtemp()

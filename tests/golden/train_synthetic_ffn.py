@@ -3,7 +3,7 @@
 Why: the repository cannot ship the reference's trained weights (no network, none in the reference tree), and a random-init
 FFN gives a noise prior -- PR-GLS then runs 364 iterations instead of the 6-9 a real model needs.  This script follows the
 reference's training-data recipe (ffn.py:18-53: normalised points, affine_level 0.2, random_movement_level 0.001, 15 %
-segmentation errors, k = 20 neighbour features) with a short Adam schedule and writes tests/golden/ffn_synthetic_trained.npz
+segmentation errors, k = 20 neighbour features) with a short Adam schedule and writes 3deecelltracker_amd/data/ffn_synthetic_trained.npz
 in the layout of 3deecelltracker_amd.synth.make_ffn_weights (fp16 storage).  It is test/bench data, not a port of the
 reference's training loop."""
 import os, sys, time
@@ -85,7 +85,7 @@ def main(steps=int(os.environ.get("FFN_STEPS", 9000))):
     for name, bn in (("bn1", net.b1), ("bn2", net.b2)):
         out[f"{name}_gamma"] = f16(bn.weight); out[f"{name}_beta"] = f16(bn.bias)
         out[f"{name}_mean"] = f16(bn.running_mean); out[f"{name}_var"] = f16(bn.running_var)
-    np.savez_compressed(ROOT / "tests" / "golden" / "ffn_synthetic_trained.npz", **out)
+    np.savez_compressed(ROOT / "3deecelltracker_amd" / "data" / "ffn_synthetic_trained.npz", **out)
     print("saved", sum(v.size for v in out.values()), "values")
 
 

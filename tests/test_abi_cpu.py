@@ -103,9 +103,9 @@ def test_no_packed_fp32_outside_the_conv_kernels(L):
 
 
 def test_package_leaves_the_environment_alone_and_warns_about_hardware_queues():
-    """The frame loop keeps five to six HIP streams busy; on the runtime's default of four hardware queues they alias.  The package
+    """FramePipeline keeps five to six HIP streams busy; on the runtime's default of four hardware queues they alias.  The package
     must not set GPU_MAX_HW_QUEUES behind the host application's back (a process-global side effect that is silently ineffective once HIP is
-    initialised): importing it leaves the environment alone, and _lib.check_hw_queues() -- what FrameChain.run_sequence calls -- warns once
+    initialised): importing it leaves the environment alone, and _lib.check_hw_queues() -- what FramePipeline (the multi-chain mode) calls -- warns once
     when the variable is missing or too small."""
     import os
     import subprocess

@@ -29,3 +29,9 @@ def test_gpus_2_without_a_launcher_starts_two_ranks():
 def test_gpus_1_does_not_relaunch():
     line = _line([sys.executable, "bench.py", "--gpus", "1", "--launch-check"])
     assert line["world_size"] == 1 and line["backend"] is None
+
+
+def test_gpus_8_rendezvous_of_a_whole_node():
+    """The driver's N = 8 command line (one rank per GPU of one node): the rendezvous, the rank -> device mapping and the line's shape."""
+    line = _line([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--same-device", "--steps", "1", "--launch-check"])
+    assert line["world_size"] == 8 and line["gpus"] == 8 and line["ranks"] == list(range(8))

@@ -257,8 +257,10 @@ def test_trackerlite_end_to_end(tmp_path, ffn_w):
     want_n, _ = mr.prgls_with_two_ref(prior, s2, s1, conf_n, beta=3, lambda_=3)
     want = cit.Coordinates(want_n * scale + mean, 4, vs, "real")
     got_pairs = trk.match_by_ffn(1, 2)
-    if np.array_equal(got_pairs, pairs):          # identical correspondences -> coordinates within 1e-4
-        np.testing.assert_allclose(out.real, want.real, rtol=0, atol=1e-4)
+    why = check_pairs(got_pairs, corr, pairs, SCORE_TOL, "TrackerLite end to end")   # raises unless an oracle decision was within the score tolerance
+    if why:
+        pytest.xfail(why)
+    np.testing.assert_allclose(out.real, want.real, rtol=0, atol=1e-4)                # identical correspondences -> coordinates within 1e-4
     # ensemble: frames 1..3 tracked, predict 5 skipping the missing frame 4
     for t in (1, 2, 3):
         np.save(tmp_path / "track_results" / "coords_real" / f"coords{str(t).zfill(6)}.npy",
@@ -361,9 +363,9 @@ def test_prgls_with_a_prepared_reference_set_is_bit_identical(n, rep):
 @pytest.mark.parametrize("n", (150, 400))
 def test_end_to_end_with_a_discriminating_ffn(golden_dir, n):
     """Whole match (features -> FFN -> greedy -> PR-GLS) with the small FFN trained on synthetic pairs
-    (tests/golden/ffn_synthetic_trained.npz): most true pairs are recovered, PR-GLS converges in a handful of iterations as with
+    (3deecelltracker_amd/data/ffn_synthetic_trained.npz): most true pairs are recovered, PR-GLS converges in a handful of iterations as with
     the reference's trained weights, and scores / correspondence indices / coordinates equal the oracle's."""
-    w = synth.load_ffn_npz(golden_dir / "ffn_synthetic_trained.npz")
+    w = synth.load_ffn_npz(synth.TRAINED_FFN_PATH)
     model = ffn_mod.FFN().set_weights_dict(w)
     rng = np.random.default_rng(11 + n)
     xn = mr.normalize_points(rng.uniform(0, 1, (n, 3)) * np.array([512.0, 512.0, 128.0]))
@@ -923,7 +925,7 @@ sys.path.insert(0, %r)
 m = lambda n: importlib.import_module("3deecelltracker_amd." + n)
 synth, ffn_mod, tl, _dev = m("synth"), m("ffn"), m("trackerlite"), m("_dev")
 from pathlib import Path
-trained = ffn_mod.FFN().set_weights_dict(synth.load_ffn_npz(Path(%r) / "ffn_synthetic_trained.npz"))
+trained = ffn_mod.FFN().set_weights_dict(synth.load_trained_ffn())
 noisy = ffn_mod.FFN().set_weights_dict(synth.make_ffn_weights(0))
 out = {}
 for n, ffn, tag in ((150, trained, "a"), (600, trained, "b"), (600, noisy, "c"), (2000, trained, "d")):
@@ -941,7 +943,7 @@ for n, ffn, tag in ((150, trained, "a"), (600, trained, "b"), (600, noisy, "c"),
     out[f"{tag}_np_moved"] = moved.cpu().numpy(); out[f"{tag}_np_it"] = np.array([it])
 np.savez(sys.argv[1], **out)
 print("em done", len(out))
-""" % (str(REPO), str(golden_dir))
+""" % (str(REPO),)
     with tempfile.TemporaryDirectory() as td:
         files = []
         for tag, env in (("persistent", {"CT_EM_PERSISTENT": "1"}), ("fused", {"CT_EM_FUSE": "1"}), ("seven", {})):

@@ -23,7 +23,7 @@ def g(golden_dir):
 
 @pytest.fixture(scope="module")
 def ffn_w(golden_dir):
-    return synth.load_ffn_npz(golden_dir / "ffn_synthetic_trained.npz")
+    return synth.load_ffn_npz(synth.TRAINED_FFN_PATH)
 
 
 def _case(g, ci):
