@@ -53,9 +53,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CT_TAP_TABLE
 #define CT_TAP_TABLE 1     // tap-slot offsets from a constant table (0: the four-way select per K-block)
 #endif
-#ifndef CT_EPI_SBASE
-#define CT_EPI_SBASE 1     // epilogue stores addressed as scalar column base + 32-bit lane offset (0: the size_t index expression per store)
-#endif
 #ifndef CT_ABL
 #define CT_ABL 0
 #endif
@@ -1061,6 +1058,29 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
     }
 }
 
+// Shared epilogue arithmetic of the split kernels: (accumulator * out_mul + bias) -> LeakyReLU / ReLU -> BatchNorm affine on one MFMA result
+// quad, written on register PAIRS so that the three affine steps are packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: half the issue
+// slots of the scalar form -- the thin layers are VALU-issue bound, round-5 verdict).  Bit-identical to the scalar chain fma, mul, max, fma.
+// |max| of the four results is folded into `amax` (v_max3_f32 with |.| modifiers).
+struct EpiQuad { f32x2 b01, b23, s01, s23, h01, h23; };
+__device__ __forceinline__ EpiQuad epi_quad_load(const float* epi_s, int stride, int cb) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(epi_s + cb), s = *reinterpret_cast<const f32x4*>(epi_s + stride + cb),
+                h = *reinterpret_cast<const f32x4*>(epi_s + 2 * stride + cb);
+    return EpiQuad{f32x2{b[0], b[1]}, f32x2{b[2], b[3]}, f32x2{s[0], s[1]}, f32x2{s[2], s[3]}, f32x2{h[0], h[1]}, f32x2{h[2], h[3]}};
+}
+__device__ __forceinline__ f32x4 epi_quad_apply(const f32x4 acc, const f32x2 om2, const f32x2 al2, const EpiQuad& k, float& amax) {
+    f32x2 t01 = __builtin_elementwise_fma(f32x2{acc[0], acc[1]}, om2, k.b01);
+    f32x2 t23 = __builtin_elementwise_fma(f32x2{acc[2], acc[3]}, om2, k.b23);
+    const f32x2 u01 = t01 * al2, u23 = t23 * al2;
+    t01 = f32x2{fmaxf(t01[0], u01[0]), fmaxf(t01[1], u01[1])};            // LeakyReLU / ReLU (0 <= alpha < 1) without a select
+    t23 = f32x2{fmaxf(t23[0], u23[0]), fmaxf(t23[1], u23[1])};
+    t01 = __builtin_elementwise_fma(t01, k.s01, k.h01);
+    t23 = __builtin_elementwise_fma(t23, k.s23, k.h23);
+    amax = fmaxf(amax, fmaxf(fabsf(t01[0]), fabsf(t01[1])));
+    amax = fmaxf(amax, fmaxf(fabsf(t23[0]), fabsf(t23[1])));
+    return f32x4{t01[0], t01[1], t23[0], t23[1]};
+}
+
 template <bool F16, int NT, bool C8, bool FOLD, bool Z8, bool Y10 = false>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10 ? CT_LB1 : 3))) void conv3_split_kernel(const ConvArgs a_in) {
     static_assert(!C8 || NT == 1, "the Cout = 8 kernel has one row tile");
@@ -1297,45 +1317,58 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
         } else a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + zz] = v;
     };
     float vmax = 0.f;                                         // |max| of what this wave writes (split-fp16 consumers scale by it)
+    const f32x2 al2 = f32x2{alpha, alpha};
+    const f32x2 om2 = F16 ? f32x2{out_mul, out_mul} : f32x2{1.f, 1.f};   // (x * 1 + bias == x + bias exactly: one code path for both families)
+    // Wave-uniform shortcuts (round 6): a tile that lies inside the window whose voxels enter the tensor's maximum / inside the stored window / inside the
+    // tensor needs no per-column compare chain and no select -- that is every tile but the ones on the windows' borders.
+    const bool tile_needed = x0 >= a.nx0 && x0 + G::TXv <= nx1 && y0 >= a.ny0 && y0 + G::TYv <= ny1;
+    const bool tile_stored = x0 >= a.sx0 && x0 + G::TXv <= a.sx1 && y0 >= a.sy0 && y0 + G::TYv <= a.sy1 && x0 + G::TXv <= a.X && y0 + G::TYv <= a.Y &&
+                             z0 + G::ZB <= a.Z;
     if constexpr (C8) {
         // lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx + (g>>1), y = y0 + col_y(mt)
         const int cb = 4 * (g & 1);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(epi_s + cb);
-        const f32x4 scale = *reinterpret_cast<const f32x4*>(epi_s + ECH + cb);
-        const f32x4 shift = *reinterpret_cast<const f32x4*>(epi_s + 2 * ECH + cb);
+        const EpiQuad kq = epi_quad_load(epi_s, ECH, cb);
         const int x = x0 + wx + (g >> 1);
-#if CT_EPI_SBASE
         // Cout = 8: one channel octet per voxel; the lane's x (through g >> 1), z and channel half are the lane offset, the column y is scalar
         const size_t patch_bytes8 = (size_t)a.X * a.Y * a.Z * 32;
         const __amdgpu_buffer_rsrc_t rs8 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + (a.out ? (size_t)p * patch_bytes8 : 0), 0,
                                                                              a.out ? (int)patch_bytes8 : 0, 0x00020000);   // (head layer: no tensor, never used)
         const uint32_t lane_off8 = (uint32_t)(((x * a.Y * a.Z + z) * 8 + cb) * 4);
-#endif
+        f32x4 r[4];
+        if (tile_needed) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            f32x4 r = F16 ? acc[mt][0] * out_mul + bias : acc[mt][0] + bias;
-            float cmax = 0.f;
+            for (int mt = 0; mt < 4; ++mt) r[mt] = epi_quad_apply(acc[mt][0], om2, al2, kq, vmax);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = r[e];
-                r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e];       // LeakyReLU / ReLU (0 <= alpha < 1) without a select
-                if constexpr (F16) cmax = fmaxf(cmax, fabsf(r[e]));
+            for (int mt = 0; mt < 4; ++mt) {
+                float cmax = 0.f;
+                r[mt] = epi_quad_apply(acc[mt][0], om2, al2, kq, cmax);
+                const int y = y0 + col_y(mt);
+                if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax);
             }
-            const int y = y0 + col_y(mt);
-            if constexpr (F16) { if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax); }
-            const bool ok = x < a.X && y < a.Y && z < a.Z;
-#if CT_EPI_SBASE
-            if (a.out && ok && x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && !((CT_ABL) & 2048))
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), rs8, lane_off8, y * a.Z * 32, 0);
-#else
-            if (a.out && ok && x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && !((CT_ABL) & 2048))
-                *reinterpret_cast<f32x4*>(a.out + (((size_t)(p * a.X + x) * a.Y + y) * a.Z + z) * 8 + cb) = r;
-#endif
-            if (a.head) {
-                const f32x4 hw = *reinterpret_cast<const f32x4*>(epi_s + 3 * ECH + cb);
-                float part = r[0] * hw[0] + r[1] * hw[1] + r[2] * hw[2] + r[3] * hw[3];
+        }
+        if (a.out && !((CT_ABL) & 2048)) {
+            if (tile_stored) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r[mt]), rs8, lane_off8, (y0 + col_y(mt)) * a.Z * 32, 0);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int y = y0 + col_y(mt);
+                    if (x < a.X && y < a.Y && z < a.Z && x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r[mt]), rs8, lane_off8, y * a.Z * 32, 0);
+                }
+            }
+        }
+        if (a.head) {
+            const f32x4 hw = *reinterpret_cast<const f32x4*>(epi_s + 3 * ECH + cb);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int y = y0 + col_y(mt);
+                float part = r[mt][0] * hw[0] + r[mt][1] * hw[1] + r[mt][2] * hw[2] + r[mt][3] * hw[3];
                 part += __shfl_xor(part, 16);                    // the other channel half of the same voxel
-                if ((g & 1) == 0 && ok)
+                if ((g & 1) == 0 && x < a.X && y < a.Y && z < a.Z)
                     stitch(x, y, z, 1.f / (1.f + expf(-(part + head_bias))));
             }
         }
@@ -1343,32 +1376,24 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
     } else {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int cbl = 16 * nt + 4 * g;
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(epi_s + cbl);
-            const f32x4 scale = *reinterpret_cast<const f32x4*>(epi_s + ECH + cbl);
-            const f32x4 shift = *reinterpret_cast<const f32x4*>(epi_s + 2 * ECH + cbl);
+            const EpiQuad kq = epi_quad_load(epi_s, ECH, 16 * nt + 4 * g);
+            if (!F16 || tile_needed) {                         // (the maximum only serves the split-fp16 consumers)
 #pragma unroll
-            for (int mt = 0; mt < NCOL; ++mt) {
-                f32x4 r = F16 ? acc[mt][nt] * out_mul + bias : acc[mt][nt] + bias;
-                float cmax = 0.f;
+                for (int mt = 0; mt < NCOL; ++mt) acc[mt][nt] = epi_quad_apply(acc[mt][nt], om2, al2, kq, vmax);
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = r[e];
-                    r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e];       // LeakyReLU / ReLU (0 <= alpha < 1) without a select
-                    if constexpr (F16) cmax = fmaxf(cmax, fabsf(r[e]));
-                }
-                if constexpr (F16) {
+                for (int mt = 0; mt < NCOL; ++mt) {
+                    float cmax = 0.f;
+                    acc[mt][nt] = epi_quad_apply(acc[mt][nt], om2, al2, kq, cmax);
                     const int x = x0 + col_x(mt), y = y0 + col_y(mt);
                     if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax);
                 }
-                acc[mt][nt] = r;
             }
         }
 #if !CT_STORE_FIRST
         if constexpr (F16 && !((CT_ABL) & 4096)) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
 #endif
         const int OQ = a.cout >> 3;
-#if CT_EPI_SBASE
         // stores through a buffer descriptor of this patch's output tensor: scalar column / cout-tile offset + one 32-bit lane offset for
         // all columns (no vector instruction per store; the size_t index expression cost 8 VALU + 10 SALU apiece)
         const int col_bytes = OQ * a.Z * 32;
@@ -1379,6 +1404,21 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
             const uint32_t lane_off = (uint32_t)((((g >> 1) * a.Z + z) * 8 + 4 * (g & 1)) * 4);
             const int nt_bytes = a.Z * 64;                                 // one 16-channel tile = two channel octets
             constexpr bool ZX = Z8;                                        // (Z8: x / y depend on the lane through csel)
+            if (tile_stored && 16 * (ntb + NT) <= a.cout) {                 // (wave-uniform) every lane of every column stores
+#pragma unroll
+                for (int mt = 0; mt < NCOL; ++mt) {
+                    const int x = x0 + col_x(mt), y = y0 + col_y(mt);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (ZX) {
+                            const uint32_t voff = lane_off + (uint32_t)((x * a.Y + y) * col_bytes);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), rs, voff, (ntb + nt) * nt_bytes, 0);
+                        } else
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][nt]), rs, lane_off,
+                                                                   (x * a.Y + y) * col_bytes + (ntb + nt) * nt_bytes, 0);
+                    }
+                }
+            } else
 #pragma unroll
             for (int mt = 0; mt < NCOL; ++mt) {
                 const int x = x0 + col_x(mt), y = y0 + col_y(mt);
@@ -1397,24 +1437,6 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
                 }
             }
         }
-#else
-        if (a.out && !((CT_ABL) & 2048)) {
-#pragma unroll
-            for (int mt = 0; mt < NCOL; ++mt) {
-                const int x = x0 + col_x(mt), y = y0 + col_y(mt);
-                if (x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && z < a.Z) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int cb = 16 * (ntb + nt) + 4 * g;
-                        if (cb < a.cout) {
-                            const size_t idx = ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7);
-                            *reinterpret_cast<f32x4*>(a.out + idx) = acc[mt][nt];
-                        }
-                    }
-                }
-            }
-        }
-#endif
 #if CT_STORE_FIRST
         // (the per-patch maximum -- wave reduction, barrier, one atomic -- after the output stores have been issued: they drain meanwhile)
         if constexpr (F16 && !((CT_ABL) & 4096)) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
@@ -1424,13 +1446,11 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
                 // !Z8: the wave's 2 x 4 columns are two 2 x 2 blocks {2 blk, 2 blk + 1, 4 + 2 blk, 5 + 2 blk};
                 //  Z8: MFMA columns j and j + 4 are x neighbours, the y neighbour sits in lane ^ 8 -> four 2 x 2 blocks
                 constexpr int NBLK = Z8 ? 4 : 2;
-#if CT_EPI_SBASE
                 const int pcol_bytes = OQ * a.PZ * 32;
                 const size_t ppatch_bytes = (size_t)a.PX * a.PY * pcol_bytes;
                 const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.pool) + (size_t)p * ppatch_bytes, 0,
                                                                                      (int)ppatch_bytes, 0x00020000);
                 const uint32_t plane_off = (uint32_t)((((g >> 1) * a.PZ + (a.pz == 2 ? (z >> 1) : z)) * 8 + 4 * (g & 1)) * 4);
-#endif
 #pragma unroll
                 for (int blk = 0; blk < NBLK; ++blk) {
                     const int x = x0 + wx, y = y0 + (Z8 ? 2 * blk : wy + 2 * blk);
@@ -1448,20 +1468,17 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
                                 t = fmaxf(fmaxf(acc[2 * blk][nt][e], acc[2 * blk + 1][nt][e]),
                                           fmaxf(acc[4 + 2 * blk][nt][e], acc[5 + 2 * blk][nt][e]));
                             }
-                            if (a.pz == 2) t = fmaxf(t, __shfl_xor(t, 1));
                             m[e] = t;
+                        }
+                        if (a.pz == 2) {                                       // (uniform; one branch per quad) z neighbours sit in adjacent lanes
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], __shfl_xor(m[e], 1));
                         }
                         const int cb = 16 * (ntb + nt) + 4 * g;
                         const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
                         if (ok && zok && cb < a.cout && !((CT_ABL) & 2048)) {
-#if CT_EPI_SBASE
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), prs, plane_off,
                                                                    ((x >> 1) * a.PY + (y >> 1)) * pcol_bytes + (ntb + nt) * (a.PZ * 64), 0);
-#else
-                            const int pzc = a.pz == 2 ? (z >> 1) : z;
-                            const size_t idx = ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7);
-                            *reinterpret_cast<f32x4*>(a.pool + idx) = m;
-#endif
                         }
                     }
                 }
@@ -1825,21 +1842,41 @@ __global__ __launch_bounds__(256, OCC) void conv_first_f16_kernel(const float* _
 // ------------------------------------------------------------------------------------------------
 struct FirstArgs { const float* vol; TileGeom q; int p_begin; const u32x4* wf16; float wscale_inv; const float* epi; };
 
-__global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs a_in, const FirstArgs f) {
+// (dy, dz) combination `idx` (0 .. 8; 9 = the zero-weight pad slot) of the fused kernel's L0 tap order -> entry offset inside the input tile
+// (the pad slot reads the entry after (2, 2): one ds_read2_b64 with adjacent offsets; for the tile's last column that is the zeroed entry behind the tile)
+__host__ __device__ constexpr int l0_tap_entry(int idx, int iz) { return idx < 9 ? (idx / 3) * iz + idx % 3 : 2 * iz + 3; }
+
+// Round 6: the kernel was VALU-issue bound (1307 vector + 764 scalar instructions around 208 MFMAs per wave and tile; profiles/r05_conv_experiments.txt
+// section 4, round-5 verdict).  What changed, in the order of the phases:
+//   * L0's K order is (lane group g = x offset dx' of the output PAIR, K-block j = (dy, dz) combinations 2j, 2j + 1): the lane part of a B-fragment
+//     address is dx' alone, the tap part is a compile-time immediate -- one ds_read2_b64 per MFMA and no vector instruction (before: two ds_read_b32, two
+//     adds, two ands, and a wave-uniform branch around every MFMA that kept the LDS reads of a column from overlapping the previous MFMA).  The input
+//     tile holds 8 B per voxel {hi | lo << 16, hi}, the second word precomputed by the gather;
+//   * every wave runs eight pair columns (the two spare slots of waves 2 and 3 recompute pair 29 and write the same values): straight-line code;
+//   * tiles whose L0 halo lies inside the patch (85 % of them) skip the zero-padding selects, tiles inside the needed / stored windows skip the per-column
+//     compare chains (one wave-uniform test each);
+//   * both epilogues on register pairs (epi_quad_apply); the staging offsets of L0's outputs are scalar column + lane constant.
+__global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs a_in, const FirstArgs f_in) {
     using G = BfGeom<false>;
     constexpr int HYg = G::HYv, HZg = G::HZv;                                 // L1 halo tile: 6 x 10 columns x 18 z
     constexpr int IX = G::HXv + 2, IY = G::HYv + 2, IZ = G::ZB + 2;           // L0's input tile: 8 x 12 x 18
     constexpr int NPAIR = (G::HXv / 2) * G::HYv;                              // 30 x-pairs of L0 outputs
     __shared__ __attribute__((aligned(16))) char lds[2 * G::PLANE];
-    // L0's packed input tile lives in the first 6.9 KB of L1's planes: nobody writes the planes before every wave has finished its L0
-    // MFMAs (the barrier of the output-maximum reduction), and 35 KB instead of 42 keep FOUR workgroups on a CU like the plain L1 kernel
-    uint32_t* const itile = reinterpret_cast<uint32_t*>(lds);
-    static_assert(IX * IY * IZ * 4 <= G::PLANE, "input tile must fit into the first plane");
+    // L0's packed input tile (8 B per voxel) lives in the first 13.8 KB of L1's planes: nobody writes the planes before every wave has finished its L0
+    // MFMAs (the barrier of the output-maximum reduction), and 35 KB instead of 49 keep FOUR workgroups on a CU like the plain L1 kernel
+    uint2* const itile = reinterpret_cast<uint2*>(lds);
+    static_assert((IX * IY * IZ + 1) * 8 <= G::PLANE, "input tile (+ the pad entry) must fit into the first plane");
     __shared__ int mapx[IX], mapy[IY], mapz[IZ];
     __shared__ float amax_red[4], tmax_red[4], omax_red[4];
     __shared__ __attribute__((aligned(16))) float epi_s[3 * 16];
     __shared__ __attribute__((aligned(16))) float epi0_s[3 * 8];
-    const ConvArgs& a = a_in;
+    ConvArgs a = a_in;
+    FirstArgs f = f_in;
+    // every argument the kernel uses in ONE batch of scalar loads (as conv3_split_kernel does: left alone, each is fetched where it is first needed)
+    asm volatile("" : "+s"(a.X), "+s"(a.Y), "+s"(a.Z), "+s"(a.tilesX), "+s"(a.tilesY), "+s"(a.nxcd), "+s"(a.xper), "+s"(a.xrem), "+s"(a.mdiv[2]), "+s"(a.mdiv[3]),
+                      "+s"(a.mdiv[4]), "+s"(a.nx0), "+s"(a.nx1), "+s"(a.ny0), "+s"(a.ny1), "+s"(a.sx0), "+s"(a.sx1), "+s"(a.sy0), "+s"(a.sy1), "+s"(a.pz), "+s"(a.PX),
+                      "+s"(a.PY), "+s"(a.PZ), "+s"(a.act), "+s"(a.pg_yz), "+s"(a.pg_z), "+s"(a.mdivp[0]), "+s"(a.mdivp[1]), "+s"(a.p_first)
+                    : "s"(a_in.out), "s"(a_in.pool), "s"(a_in.epi), "s"(a_in.amax_out), "s"(a_in.wpack), "s"(f_in.vol), "s"(f_in.wf16), "s"(f_in.epi));
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t b = blockIdx.x;
     auto divmod = [](uint32_t& n, uint32_t d, uint32_t m) { uint32_t q = __umulhi(n, m), r = n - q * d; if (r >= d) { ++q; r -= d; }
@@ -1860,8 +1897,12 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     u32x4 w_pre1 = u32x4{0u, 0u, 0u, 0u};
     if (tid < 64) w_pre1 = f.wf16[256 + tid];
     {
-        const int pg = f.p_begin + p;
-        const int pk = pg % q.gz, pj = (pg / q.gz) % q.gy, pi = pg / (q.gz * q.gy);
+        // the patch's place in the volume's patch grid: scalar, by the host's reciprocals (a.p_first = f.p_begin, a.pg_yz = gy * gz, a.pg_z = gz)
+        uint32_t pgq = (uint32_t)(a.p_first + p);
+        const int rem = divmod(pgq, (uint32_t)a.pg_yz, a.mdivp[0]);
+        uint32_t jq = (uint32_t)rem;
+        const int pk = divmod(jq, (uint32_t)a.pg_z, a.mdivp[1]);
+        const int pi = (int)pgq, pj = (int)jq;
         if (tid < IX) { const int l = x0 - 2 + tid; mapx[tid] = (l >= 0 && l < q.nx) ? reflect_idx(pi * q.cx + l - q.bx, q.vx) : -1; }
         else if (tid >= 64 && tid < 64 + IY) { const int t = tid - 64, l = y0 - 2 + t; mapy[t] = (l >= 0 && l < q.ny) ? reflect_idx(pj * q.cy + l - q.by, q.vy) : -1; }
         else if (tid >= 128 && tid < 128 + IZ) { const int t = tid - 128, l = t - 1; mapz[t] = (l >= 0 && l < q.nz) ? reflect_idx(pk * q.cz + l - q.bz, q.vz) : -1; }
@@ -1904,60 +1945,68 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
             for (int i = 0; i < HALF; ++i) {
                 const float x = vals[i] * in_scale0;
                 const float hi = __uint_as_float(__float_as_uint(x) & 0xffffe000u);
-                itile[gcol * IZ + gz0 + i] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(hi, x - hi));
+                const uint32_t pk = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(hi, x - hi));   // [15:0] hi, [31:16] lo
+                itile[gcol * IZ + gz0 + i] = uint2{pk, pk & 0xffffu};          // the B fragment's (a_hi, a_lo, a_hi, 0) as it is read
             }
         }
+        if (tid == 255) itile[IX * IY * IZ] = uint2{0u, 0u};                  // what the pad slot of the tile's last column reads (weight 0: must be finite)
     }
     __syncthreads();
-    // ---- L0 on the halo: pair column c = wave + 4 m (x pair c / 10, y c % 10), rows (x-select, cout) as in conv_first_f16_kernel
+    // ---- L0 on the halo: pair column c = wave + 4 m (x pair c / 10, y c % 10; slots 30, 31 repeat pair 29), rows (x-select, cout), lane group g = dx'
     f32x4 acc0[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc0[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int cbase[8];
+    int pxi_[8], hy_[8];                                                      // (scalar: wave is uniform)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int c = min(wave + 4 * m, NPAIR - 1);
-        const int pxi = c / G::HYv, hy = c - pxi * G::HYv;
-        cbase[m] = ((2 * pxi) * IY + hy) * IZ + zl;
+        pxi_[m] = (c * 205) >> 11;                                            // c / 10 for c < 69
+        hy_[m] = c - pxi_[m] * G::HYv;
     }
-    {
+    if constexpr (!((CT_ABL) & 16384)) {
+        const int lane_l0 = ((g * IY) * IZ + zl) * 8;
+        int cbl[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) cbl[m] = lane_l0 + ((2 * pxi_[m]) * IY + hy_[m]) * (IZ * 8);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const u32x4 wj = wlds[j * 64 + lane];
-            const int k0 = 8 * j + 2 * g, k1 = k0 + 1;
-            const int o0 = k0 < 36 ? ((k0 / 9) * IY + (k0 / 3) % 3) * IZ + k0 % 3 : 0;
-            const int o1 = k1 < 36 ? ((k1 / 9) * IY + (k1 / 3) % 3) * IZ + k1 % 3 : 0;
+            // (a compiler fence per K-block: left alone, the load-merging pass pairs tap reads of DIFFERENT K-blocks into one ds_read2_b64 and pays
+            //  six v_mov per column to sort the halves out again)
+            asm volatile("" ::: "memory");
+            u32x4 av[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                if (wave + 4 * m < NPAIR && !((CT_ABL) & 16384)) {                     // (wave-uniform)
-                    const uint32_t a0 = itile[cbase[m] + o0], a1 = itile[cbase[m] + o1];
-                    const u32x4 av = u32x4{a0, a0 & 0xffffu, a1, a1 & 0xffffu};
-                    acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wj), __builtin_bit_cast(f16x8, av), acc0[m], 0, 0, 0);
-                }
+                const char* ib = lds + cbl[m];
+                const uint2 t0 = *reinterpret_cast<const uint2*>(ib + l0_tap_entry(2 * j, IZ) * 8);
+                const uint2 t1 = *reinterpret_cast<const uint2*>(ib + l0_tap_entry(2 * j + 1, IZ) * 8);
+                av[m] = u32x4{t0.x, t0.y, t1.x, t1.y};
             }
+            // all eight fragment reads go out before the first MFMA (left alone, the scheduler issues each just in time and every MFMA eats an LDS round trip)
+            asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wj), __builtin_bit_cast(f16x8, av[m]), acc0[m], 0, 0, 0);
         }
     }
     const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
+    const f32x2 al2 = f32x2{alpha, alpha};
     float omax = 0.f;
     {
-        const int cb = 4 * (g & 1);
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(epi0_s + cb);
-        const f32x4 scale = *reinterpret_cast<const f32x4*>(epi0_s + 8 + cb);
-        const f32x4 shift = *reinterpret_cast<const f32x4*>(epi0_s + 16 + cb);
+        const EpiQuad k0 = epi_quad_load(epi0_s, 8, 4 * (g & 1));
+        const f32x2 om0 = f32x2{out_mul0, out_mul0};
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int c = wave + 4 * m;
-            const int pxi = c / G::HYv, hy = c - pxi * G::HYv;
-            const int px = x0 - 1 + 2 * pxi + (g >> 1), py = y0 - 1 + hy;
-            const bool inside = c < NPAIR && px >= 0 && px < a.X && py >= 0 && py < a.Y;       // outside the patch: L1's zero padding
-            f32x4 r = acc0[m] * out_mul0 + bias;
+        for (int m = 0; m < 8; ++m) acc0[m] = epi_quad_apply(acc0[m], om0, al2, k0, omax);
+        // outside the patch the tile holds L1's zero padding: only tiles on the patch border have such voxels (wave-uniform test)
+        if (!(x0 >= 1 && x0 + G::HXv - 1 <= a.X && y0 >= 1 && y0 + G::HYv - 1 <= a.Y)) {
+            omax = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = r[e];
-                r[e] = inside ? fmaxf(t, t * alpha) * scale[e] + shift[e] : 0.f;
-                omax = fmaxf(omax, fabsf(r[e]));
+            for (int m = 0; m < 8; ++m) {
+                const int px = x0 - 1 + 2 * pxi_[m] + (g >> 1), py = y0 - 1 + hy_[m];
+                const bool inside = px >= 0 && px < a.X && py >= 0 && py < a.Y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc0[m][e] = inside ? acc0[m][e] : 0.f; omax = fmaxf(omax, fabsf(acc0[m][e])); }
             }
-            acc0[m] = r;
         }
     }
     omax = wave_max_nonneg_l63(omax);
@@ -1972,19 +2021,13 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
             const int col = tid >> 2, row = (tid & 2) ? HZg - 1 : 0, plane = tid & 1;
             *reinterpret_cast<uint4*>(lds + plane * G::PLANE + (col * HZg + row) * 16) = uint4{0u, 0u, 0u, 0u};
         }
+        const int lane_st = ((((g >> 1) * HYg) * HZg + 1 + zl) * 2 + (g & 1)) * 8;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int c = wave + 4 * m;
-            if (c < NPAIR) {
-                const int pxi = c / G::HYv, hy = c - pxi * G::HYv;
-                const int hx = 2 * pxi + (g >> 1);
-                char* d = lds + (((hx * HYg + hy) * HZg + 1 + zl) * 2 + (g & 1)) * 8;
-                stage_put<false, true>(acc0[m], d, in_scale);
-            }
-        }
+        for (int m = 0; m < 8; ++m)
+            stage_put<false, true>(acc0[m], lds + lane_st + ((2 * pxi_[m]) * HYg + hy_[m]) * (HZg * 16), in_scale);
     }
     __syncthreads();
-    // ---- L1: the ordinary single-chunk MFMA phase and epilogue of conv3_split_kernel<true, 1, false, false, false>
+    // ---- L1: the ordinary single-chunk MFMA phase of conv3_split_kernel<true, 1, false, false, false>
     constexpr int NT = 1;
     const int wx = 2 * (wave >> 1), wy = 4 * (wave & 1);
     const int lanepos = (wx * HYg + wy) * HZg + zl;
@@ -1996,94 +2039,77 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
         bf_tap_offsets<KB_STD, false, false, false>(lanepos, g, tapoff);
         bf_chunk_mma<true, NT, 8, KB_STD, false, false, false, false>(acc, lds, tapoff, reinterpret_cast<const uint4*>(a.wpack), (uint32_t)lane * 16u, a.nt_total);
     }
+    // ---- L1 epilogue.  Preconditions of the launch (run_network): X % 4 == 0, Y % 8 == 0, Z == 16, Cout == 16 -- every lane holds a valid output.
     const int z = zl;
+    const int xw = x0 + wx, yw = y0 + wy;                                     // the wave's 2 x 4 block of columns
     float vmax = 0.f;
     {
-        const int cbl = 4 * g;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(epi_s + cbl);
-        const f32x4 scale = *reinterpret_cast<const f32x4*>(epi_s + 16 + cbl);
-        const f32x4 shift = *reinterpret_cast<const f32x4*>(epi_s + 32 + cbl);
+        const EpiQuad k1 = epi_quad_load(epi_s, 16, 4 * g);
+        const f32x2 om1 = f32x2{out_mul, out_mul};
+        if (xw >= a.nx0 && xw + 2 <= a.nx1 && yw >= a.ny0 && yw + 4 <= a.ny1) {           // (wave-uniform) every column enters the tensor's maximum
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            f32x4 r = acc[mt][0] * out_mul + bias;
-            float cmax = 0.f;
+            for (int mt = 0; mt < 8; ++mt) acc[mt][0] = epi_quad_apply(acc[mt][0], om1, al2, k1, vmax);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = r[e];
-                r[e] = fmaxf(t, t * alpha) * scale[e] + shift[e];
-                cmax = fmaxf(cmax, fabsf(r[e]));
+            for (int mt = 0; mt < 8; ++mt) {
+                float cmax = 0.f;
+                acc[mt][0] = epi_quad_apply(acc[mt][0], om1, al2, k1, cmax);
+                const int x = xw + (mt >> 2), y = yw + (mt & 3);
+                if (x >= a.nx0 && x < a.nx1 && y >= a.ny0 && y < a.ny1) vmax = fmaxf(vmax, cmax);
             }
-            const int x = x0 + wx + (mt >> 2), y = y0 + wy + (mt & 3);
-            if (x >= a.nx0 && x < a.nx1 && y >= a.ny0 && y < a.ny1) vmax = fmaxf(vmax, cmax);
-            acc[mt][0] = r;
         }
     }
-#if !CT_STORE_FIRST
-    if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red);
-#endif
     const int OQ = a.cout >> 3;
-    const int cb = 4 * g;
-#if CT_EPI_SBASE
     // stores through a buffer descriptor of this PATCH's output tensor: scalar column offset (SALU) + a 32-bit lane offset that is the same
-    // for all eight columns -- no vector instruction per store (round 5: 8 VALU incl. three v_mad_u64_u32 and ten SALU of 64-bit index
-    // arithmetic per store before)
-    const uint32_t lane_off = (uint32_t)((((cb >> 3) * a.Z + z) * 8 + (cb & 7)) * 4);
+    // for all eight columns -- no vector instruction per store
+    const uint32_t lane_off = (uint32_t)((((g >> 1) * a.Z + z) * 8 + 4 * (g & 1)) * 4);
     const int col_bytes = OQ * a.Z * 32;
     if (a.out && !((CT_ABL) & 2048)) {
         const size_t patch_bytes = (size_t)a.X * a.Y * col_bytes;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + (size_t)p * patch_bytes, 0,
                                                                             (int)patch_bytes, 0x00020000);
-        const bool lane_ok = z < a.Z && cb < a.cout;
+        const int row0 = (xw * a.Y + yw) * col_bytes, row1 = row0 + a.Y * col_bytes;
+        if (xw >= a.sx0 && xw + 2 <= a.sx1 && yw >= a.sy0 && yw + 4 <= a.sy1) {           // (wave-uniform) the whole block lies inside the stored window
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int x = x0 + wx + (mt >> 2), y = y0 + wy + (mt & 3);
-            if (x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1) {      // (wave-uniform)
-                if (lane_ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][0]), rs, lane_off, (x * a.Y + y) * col_bytes, 0);
+            for (int mt = 0; mt < 8; ++mt)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][0]), rs, lane_off, (mt >> 2 ? row1 : row0) + (mt & 3) * col_bytes, 0);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int x = xw + (mt >> 2), y = yw + (mt & 3);
+                if (x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1)     // (wave-uniform)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mt][0]), rs, lane_off, (mt >> 2 ? row1 : row0) + (mt & 3) * col_bytes, 0);
             }
         }
     }
-#else
-    if (a.out && !((CT_ABL) & 2048)) {
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int x = x0 + wx + (mt >> 2), y = y0 + wy + (mt & 3);
-            if (x >= a.sx0 && x < a.sx1 && y >= a.sy0 && y < a.sy1 && z < a.Z && cb < a.cout)
-                *reinterpret_cast<f32x4*>(a.out + ((((size_t)(p * a.X + x) * a.Y + y) * OQ + (cb >> 3)) * a.Z + z) * 8 + (cb & 7)) = acc[mt][0];
-        }
-    }
-#endif
-#if CT_STORE_FIRST
+    // (the per-patch maximum -- wave reduction, barrier, one atomic -- after the output stores have been issued: they drain meanwhile)
     if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red);
-#endif
-    if (a.pool) {      // MaxPooling3D (2, 2, pz): the wave's 2 x 4 columns are two 2 x 2 blocks
-#if CT_EPI_SBASE
+    if (a.pool && !((CT_ABL) & 2048)) {      // MaxPooling3D (2, 2, pz): the wave's 2 x 4 columns are two 2 x 2 blocks
         const int pcol_bytes = OQ * a.PZ * 32;
         const size_t ppatch_bytes = (size_t)a.PX * a.PY * pcol_bytes;
         const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.pool) + (size_t)p * ppatch_bytes, 0,
                                                                              (int)ppatch_bytes, 0x00020000);
-        const int pzc0 = a.pz == 2 ? (z >> 1) : z;
-        const uint32_t plane_off = (uint32_t)((((cb >> 3) * a.PZ + pzc0) * 8 + (cb & 7)) * 4);
-#endif
+        const int prow = ((xw >> 1) * a.PY + (yw >> 1)) * pcol_bytes;
+        f32x4 m[2];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const int x = x0 + wx, y = y0 + wy + 2 * blk;
-            const bool ok = (x + 1 < a.X) && (y + 1 < a.Y) && (z < a.Z);
-            f32x4 m;
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = fmaxf(fmaxf(acc[2 * blk][0][e], acc[2 * blk + 1][0][e]), fmaxf(acc[4 + 2 * blk][0][e], acc[5 + 2 * blk][0][e]));
-                if (a.pz == 2) t = fmaxf(t, __shfl_xor(t, 1));
-                m[e] = t;
+            for (int e = 0; e < 4; ++e)
+                m[blk][e] = fmaxf(fmaxf(acc[2 * blk][0][e], acc[2 * blk + 1][0][e]), fmaxf(acc[4 + 2 * blk][0][e], acc[5 + 2 * blk][0][e]));
+        if (a.pz == 2) {                                                      // (uniform) z neighbours sit in adjacent lanes
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[blk][e] = fmaxf(m[blk][e], __shfl_xor(m[blk][e], 1));
+            const uint32_t plane_off = (uint32_t)((((g >> 1) * a.PZ + (z >> 1)) * 8 + 4 * (g & 1)) * 4);
+            if ((zl & 1) == 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m[0]), prs, plane_off, prow, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m[1]), prs, plane_off, prow + pcol_bytes, 0);
             }
-            const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
-            if (ok && zok && cb < a.cout && !((CT_ABL) & 2048)) {
-#if CT_EPI_SBASE
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), prs, plane_off, ((x >> 1) * a.PY + (y >> 1)) * pcol_bytes, 0);
-#else
-                const int pzc = a.pz == 2 ? (z >> 1) : z;
-                *reinterpret_cast<f32x4*>(a.pool + ((((size_t)(p * a.PX + (x >> 1)) * a.PY + (y >> 1)) * OQ + (cb >> 3)) * a.PZ + pzc) * 8 + (cb & 7)) = m;
-#endif
-            }
+        } else {
+            const uint32_t plane_off = (uint32_t)((((g >> 1) * a.PZ + z) * 8 + 4 * (g & 1)) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m[0]), prs, plane_off, prow, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m[1]), prs, plane_off, prow + pcol_bytes, 0);
         }
     }
 }
@@ -2162,6 +2188,7 @@ struct ct_unet {
     size_t first_w_off, head_off;    // float offsets
     size_t first_mfma_off;           // packed weights of conv_first_mfma_kernel (Cout == 8)
     size_t first_f16_off;            // packed (hi, hi, lo, 0) fp16 weights of conv_first_f16_kernel
+    size_t first_f16b_off;           // the same weights in conv_l0l1_fused_kernel's K order
     float first_wscale_inv;          // 1 / their power-of-two scale
     bool first_f16;                  // the split-fp16 first conv is in use
     bool fused01 = false;            // the last run evaluated the first conv inside the second one's workgroups (conv_l0l1_fused_kernel)
@@ -2575,7 +2602,7 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
     ct_unet* h = new (std::nothrow) ct_unet();
     if (!h) return CT_EINVAL;
     h->timing = false;
-    h->first_f16 = false; h->first_f16_off = 0; h->first_wscale_inv = 1.f;
+    h->first_f16 = false; h->first_f16_off = 0; h->first_f16b_off = 0; h->first_wscale_inv = 1.f;
     h->arch_id = arch_id; h->device = device; h->ad = kArch[arch_id];
     const ArchDesc& ad = h->ad;
     h->nlevels = ad.ndown + 1;
@@ -2687,6 +2714,22 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
                             uint16_t hl[2] = {0, 0};
                             if (kk < 36 && dx >= 0 && dx <= 2) h_split_host(kern[((dx * 3 + dy) * 3 + dz) * 8 + co] * wscale, hl);
                             uint16_t* d = wf + ((size_t)(j * 64 + lane) * 4 + 2 * s2) * 2;      // two dwords per sub-slot
+                            d[0] = hl[0]; d[1] = hl[0]; d[2] = hl[1]; d[3] = 0;
+                        }
+                    }
+                // the fused first pair (conv_l0l1_fused_kernel) orders L0's K differently: lane group g = dx' (x offset inside the output pair), K-block j
+                // holds the (dy, dz) combinations 2j, 2j + 1 of the nine (slot 9: zero weights) -- the lane part of a B-fragment address is then dx' alone
+                h->first_f16b_off = arena.size();
+                arena.resize(arena.size() + 5 * 64 * 4, 0.f);
+                uint16_t* wfb = reinterpret_cast<uint16_t*>(arena.data() + h->first_f16b_off);
+                for (int j = 0; j < 5; ++j)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int g = lane >> 4, n = lane & 15, xs = n >> 3, co = n & 7;
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int idx = 2 * j + s2, dy = idx / 3, dz = idx % 3, dx = g - xs;
+                            uint16_t hl[2] = {0, 0};
+                            if (idx < 9 && dx >= 0 && dx <= 2) h_split_host(kern[((dx * 3 + dy) * 3 + dz) * 8 + co] * wscale, hl);
+                            uint16_t* d = wfb + ((size_t)(j * 64 + lane) * 4 + 2 * s2) * 2;     // two dwords per sub-slot
                             d[0] = hl[0]; d[1] = hl[0]; d[2] = hl[1]; d[3] = 0;
                         }
                     }
@@ -3018,7 +3061,10 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 af.xper = nblk / (uint32_t)af.nxcd; af.xrem = nblk - af.xper * (uint32_t)af.nxcd;
                 const int dd[5] = {1, 1, af.tilesY, af.tilesX, af.nxcd};
                 for (int k = 0; k < 5; ++k) af.mdiv[k] = dd[k] <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)dd[k]);
-                FirstArgs fa{vsrc->vol, vsrc->q, vsrc->p_begin, reinterpret_cast<const u32x4*>(h->d_weights + h->first_f16_off), h->first_wscale_inv,
+                af.p_first = vsrc->p_begin; af.pg_yz = vsrc->q.gy * vsrc->q.gz; af.pg_z = vsrc->q.gz;     // (the kernel decodes the patch's grid place itself)
+                { const int dp[2] = {af.pg_yz, af.pg_z};
+                  for (int k = 0; k < 2; ++k) af.mdivp[k] = dp[k] <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)dp[k]); }
+                FirstArgs fa{vsrc->vol, vsrc->q, vsrc->p_begin, reinterpret_cast<const u32x4*>(h->d_weights + h->first_f16b_off), h->first_wscale_inv,
                              h->d_weights + h->convs[0].epi_off};
                 hipLaunchKernelGGL(conv_l0l1_fused_kernel, dim3(nblk), dim3(256), 0, st, af, fa);
                 rc = (int)hipGetLastError();
