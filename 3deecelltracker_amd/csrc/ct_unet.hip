@@ -705,9 +705,17 @@ template <bool F16> struct SplitMath { static constexpr int NC = F16 ? 2 : 3, NP
 
 __device__ __forceinline__ void h_split4(const f32x4 v, float s, uint2& h, uint2& l) {
     // hi = the scaled value cut to fp16 (round toward zero: its top 11 significant bits), lo = fp16(x - hi); x - hi is exact in fp32
+#if CT_PK
+    const f32x2 s2 = f32x2{s, s};
+    const f32x2 x01 = f32x2{v[0], v[1]} * s2, x23 = f32x2{v[2], v[3]} * s2;      // (v_pk_mul_f32: the scale is a power of two, the products are exact)
+    const float x0 = x01[0], x1 = x01[1], x2 = x23[0], x3 = x23[1];
+#else
     const float x0 = v[0] * s, x1 = v[1] * s, x2 = v[2] * s, x3 = v[3] * s;
+#endif
     const auto h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
-    const float l0 = x0 - (float)h01[0], l1 = x1 - (float)h01[1], l2 = x2 - (float)h23[0], l3 = x3 - (float)h23[1];
+    // (the difference as ONE v_fma_mix_f32 per value -- v * s - hi with the fp16 operand read in place; the same number as x - hi, the product being exact)
+    const float l0 = __builtin_fmaf(v[0], s, -(float)h01[0]), l1 = __builtin_fmaf(v[1], s, -(float)h01[1]),
+                l2 = __builtin_fmaf(v[2], s, -(float)h23[0]), l3 = __builtin_fmaf(v[3], s, -(float)h23[1]);
     h = uint2{__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
     l = uint2{__builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l0, l1)),
               __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l2, l3))};
@@ -1058,27 +1066,46 @@ __device__ __forceinline__ void bf_chunk_mma(f32x4 (&acc)[NCOL][NT], const char*
     }
 }
 
+// max of three / four finite values in one / two instructions.  (fmaxf on values that reached the pool through a two-way branch compiles to a
+// canonicalising v_max_f32 x, x, x per operand in front of every maximum: 51 instructions for the 24 maxima of the fused pair's pool.)
+__device__ __forceinline__ float max3_nc(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float max2_nc(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max4_nc(float a, float b, float c, float d) { return max2_nc(max3_nc(a, b, c), d); }
+
 // Shared epilogue arithmetic of the split kernels: (accumulator * out_mul + bias) -> LeakyReLU / ReLU -> BatchNorm affine on one MFMA result
-// quad, written on register PAIRS so that the three affine steps are packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: half the issue
-// slots of the scalar form -- the thin layers are VALU-issue bound, round-5 verdict).  Bit-identical to the scalar chain fma, mul, max, fma.
-// |max| of the four results is folded into `amax` (v_max3_f32 with |.| modifiers).
-struct EpiQuad { f32x2 b01, b23, s01, s23, h01, h23; };
+// quad: fma, mul, max, fma per value, |max| of the four results folded into `amax` (v_max3_f32 with |.| modifiers).  Deliberately NOT packed
+// fp32 (CT_PK): v_pk_fma_f32 / v_pk_mul_f32 halve the instruction count and are bit-identical, but beside MFMAs they cost more than the two scalar
+// instructions they replace (round 6 A/B: profiles/r06_conv_experiments.txt; the whole translation unit is built with -fno-slp-vectorize for that).
+#ifndef CT_PK
+#define CT_PK 0            // 1: the affine steps of the epilogues and the staging scale as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32) -- measured SLOWER
+#endif                     //    beside MFMAs (MI355X_MICROARCH: +22 cycles per v_pk_fma_f32 against two v_fma_f32 in an MFMA gap); A/B switch, off
+struct EpiQuad { f32x4 b, s, h; };
 __device__ __forceinline__ EpiQuad epi_quad_load(const float* epi_s, int stride, int cb) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(epi_s + cb), s = *reinterpret_cast<const f32x4*>(epi_s + stride + cb),
-                h = *reinterpret_cast<const f32x4*>(epi_s + 2 * stride + cb);
-    return EpiQuad{f32x2{b[0], b[1]}, f32x2{b[2], b[3]}, f32x2{s[0], s[1]}, f32x2{s[2], s[3]}, f32x2{h[0], h[1]}, f32x2{h[2], h[3]}};
+    return EpiQuad{*reinterpret_cast<const f32x4*>(epi_s + cb), *reinterpret_cast<const f32x4*>(epi_s + stride + cb),
+                   *reinterpret_cast<const f32x4*>(epi_s + 2 * stride + cb)};
 }
-__device__ __forceinline__ f32x4 epi_quad_apply(const f32x4 acc, const f32x2 om2, const f32x2 al2, const EpiQuad& k, float& amax) {
-    f32x2 t01 = __builtin_elementwise_fma(f32x2{acc[0], acc[1]}, om2, k.b01);
-    f32x2 t23 = __builtin_elementwise_fma(f32x2{acc[2], acc[3]}, om2, k.b23);
+__device__ __forceinline__ f32x4 epi_quad_apply(const f32x4 acc, const float om, const float alpha, const EpiQuad& k, float& amax) {
+#if CT_PK
+    const f32x2 om2 = f32x2{om, om}, al2 = f32x2{alpha, alpha};
+    f32x2 t01 = __builtin_elementwise_fma(f32x2{acc[0], acc[1]}, om2, f32x2{k.b[0], k.b[1]});
+    f32x2 t23 = __builtin_elementwise_fma(f32x2{acc[2], acc[3]}, om2, f32x2{k.b[2], k.b[3]});
     const f32x2 u01 = t01 * al2, u23 = t23 * al2;
-    t01 = f32x2{fmaxf(t01[0], u01[0]), fmaxf(t01[1], u01[1])};            // LeakyReLU / ReLU (0 <= alpha < 1) without a select
+    t01 = f32x2{fmaxf(t01[0], u01[0]), fmaxf(t01[1], u01[1])};
     t23 = f32x2{fmaxf(t23[0], u23[0]), fmaxf(t23[1], u23[1])};
-    t01 = __builtin_elementwise_fma(t01, k.s01, k.h01);
-    t23 = __builtin_elementwise_fma(t23, k.s23, k.h23);
-    amax = fmaxf(amax, fmaxf(fabsf(t01[0]), fabsf(t01[1])));
-    amax = fmaxf(amax, fmaxf(fabsf(t23[0]), fabsf(t23[1])));
-    return f32x4{t01[0], t01[1], t23[0], t23[1]};
+    t01 = __builtin_elementwise_fma(t01, f32x2{k.s[0], k.s[1]}, f32x2{k.h[0], k.h[1]});
+    t23 = __builtin_elementwise_fma(t23, f32x2{k.s[2], k.s[3]}, f32x2{k.h[2], k.h[3]});
+    f32x4 r = f32x4{t01[0], t01[1], t23[0], t23[1]};
+#else
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = __builtin_fmaf(acc[e], om, k.b[e]);
+        r[e] = __builtin_fmaf(fmaxf(t, t * alpha), k.s[e], k.h[e]);           // LeakyReLU / ReLU (0 <= alpha < 1) without a select
+    }
+#endif
+    amax = fmaxf(amax, fmaxf(fabsf(r[0]), fabsf(r[1])));
+    amax = fmaxf(amax, fmaxf(fabsf(r[2]), fabsf(r[3])));
+    return r;
 }
 
 template <bool F16, int NT, bool C8, bool FOLD, bool Z8, bool Y10 = false>
@@ -1317,8 +1344,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
         } else a.head_out[((size_t)(p * a.X + x) * a.Y + y) * a.Z + zz] = v;
     };
     float vmax = 0.f;                                         // |max| of what this wave writes (split-fp16 consumers scale by it)
-    const f32x2 al2 = f32x2{alpha, alpha};
-    const f32x2 om2 = F16 ? f32x2{out_mul, out_mul} : f32x2{1.f, 1.f};   // (x * 1 + bias == x + bias exactly: one code path for both families)
+    const float al2 = alpha;
+    const float om2 = F16 ? out_mul : 1.f;                    // (x * 1 + bias == x + bias exactly: one code path for both families)
     // Wave-uniform shortcuts (round 6): a tile that lies inside the window whose voxels enter the tensor's maximum / inside the stored window / inside the
     // tensor needs no per-column compare chain and no select -- that is every tile but the ones on the windows' borders.
     const bool tile_needed = x0 >= a.nx0 && x0 + G::TXv <= nx1 && y0 >= a.ny0 && y0 + G::TYv <= ny1;
@@ -1462,17 +1489,16 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
                         for (int e = 0; e < 4; ++e) {
                             float t;
                             if constexpr (Z8) {
-                                t = fmaxf(acc[blk][nt][e], acc[blk + 4][nt][e]);
-                                t = fmaxf(t, __shfl_xor(t, 8));
+                                t = max2_nc(acc[blk][nt][e], acc[blk + 4][nt][e]);
+                                t = max2_nc(t, __shfl_xor(t, 8));
                             } else {
-                                t = fmaxf(fmaxf(acc[2 * blk][nt][e], acc[2 * blk + 1][nt][e]),
-                                          fmaxf(acc[4 + 2 * blk][nt][e], acc[5 + 2 * blk][nt][e]));
+                                t = max4_nc(acc[2 * blk][nt][e], acc[2 * blk + 1][nt][e], acc[4 + 2 * blk][nt][e], acc[5 + 2 * blk][nt][e]);
                             }
                             m[e] = t;
                         }
                         if (a.pz == 2) {                                       // (uniform; one branch per quad) z neighbours sit in adjacent lanes
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], __shfl_xor(m[e], 1));
+                            for (int e = 0; e < 4; ++e) m[e] = max2_nc(m[e], __shfl_xor(m[e], 1));
                         }
                         const int cb = 16 * (ntb + nt) + 4 * g;
                         const bool zok = (a.pz == 1) || ((zl & 1) == 0 && z + 1 < a.Z);
@@ -1587,8 +1613,8 @@ struct TileGeom {
 __device__ __forceinline__ int reflect_idx(int i, int n) {   // numpy 'reflect' for any pad width
     if (n == 1) return 0;
     const int period = 2 * (n - 1);
-    int t = i % period;
-    if (t < 0) t += period;
+    int t = i < 0 ? -i : i;                                   // the index map is even about 0 and periodic with 2 (n - 1) ...
+    if (t >= period) t %= period;                             // ... and only pads wider than the volume ever take the division
     return t >= n ? period - t : t;
 }
 
@@ -1905,7 +1931,8 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
         const int pi = (int)pgq, pj = (int)jq;
         if (tid < IX) { const int l = x0 - 2 + tid; mapx[tid] = (l >= 0 && l < q.nx) ? reflect_idx(pi * q.cx + l - q.bx, q.vx) : -1; }
         else if (tid >= 64 && tid < 64 + IY) { const int t = tid - 64, l = y0 - 2 + t; mapy[t] = (l >= 0 && l < q.ny) ? reflect_idx(pj * q.cy + l - q.by, q.vy) : -1; }
-        else if (tid >= 128 && tid < 128 + IZ) { const int t = tid - 128, l = t - 1; mapz[t] = (l >= 0 && l < q.nz) ? reflect_idx(pk * q.cz + l - q.bz, q.vz) : -1; }
+        // (z: BYTE offsets; 'outside the patch' = an offset beyond the volume -- the gather reads through a buffer descriptor, which returns 0 there)
+        else if (tid >= 128 && tid < 128 + IZ) { const int t = tid - 128, l = t - 1; mapz[t] = (l >= 0 && l < q.nz) ? reflect_idx(pk * q.cz + l - q.bz, q.vz) * 4 : 0x40000000; }
         else if (tid >= 192 && tid < 192 + 48) { const int t = tid - 192; epi_s[t] = a.epi[(t >> 4) * (a.nt_total * 16) + (t & 15)]; }
         if (tid >= 32 && tid < 32 + 24) epi0_s[tid - 32] = f.epi[tid - 32];
     }
@@ -1917,14 +1944,17 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     const int gcol = tid >> 1, gz0 = (tid & 1) * HALF;
     const bool gact = tid < 2 * IX * IY;
     {
+        // one 32-bit offset per element on a buffer descriptor of the volume: row offset + z offset, either of them beyond the volume where the
+        // voxel is L0's zero padding (0x80000000 + 0x40000000 does not wrap into range; the launch requires a volume below 1 GiB) -- the
+        // hardware's range check supplies the zero: no select, no 64-bit address arithmetic
         const int hx = gcol / IY, hy = gcol - hx * IY;
         const int sx = gact ? mapx[hx] : -1, sy = gact ? mapy[hy] : -1;
-        const float* rowp = f.vol + ((size_t)(sx < 0 ? 0 : sx) * q.vy + (sy < 0 ? 0 : sy)) * q.vz;
-        const bool rowok = sx >= 0 && sy >= 0;
+        const uint32_t rowoff = (sx >= 0 && sy >= 0) ? (uint32_t)((sx * q.vy + sy) * q.vz) * 4u : 0x80000000u;
+        const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f.vol), 0, q.vx * q.vy * q.vz * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < HALF; ++i) {
-            const int sz = mapz[gz0 + i];
-            const float v = ((CT_ABL) & 8) ? (float)(sz & 7) : ((rowok && sz >= 0) ? rowp[sz] : 0.f);
+            const uint32_t off = rowoff + (uint32_t)mapz[gz0 + i];
+            const float v = ((CT_ABL) & 8) ? (float)(off & 7) : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vrs, off, 0, 0));
             vals[i] = v; tmax = fmaxf(tmax, fabsf(v));
         }
     }
@@ -1990,11 +2020,11 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
         }
     }
     const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
-    const f32x2 al2 = f32x2{alpha, alpha};
+    const float al2 = alpha;
     float omax = 0.f;
     {
         const EpiQuad k0 = epi_quad_load(epi0_s, 8, 4 * (g & 1));
-        const f32x2 om0 = f32x2{out_mul0, out_mul0};
+        const float om0 = out_mul0;
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc0[m] = epi_quad_apply(acc0[m], om0, al2, k0, omax);
         // outside the patch the tile holds L1's zero padding: only tiles on the patch border have such voxels (wave-uniform test)
@@ -2045,7 +2075,7 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     float vmax = 0.f;
     {
         const EpiQuad k1 = epi_quad_load(epi_s, 16, 4 * g);
-        const f32x2 om1 = f32x2{out_mul, out_mul};
+        const float om1 = out_mul;
         if (xw >= a.nx0 && xw + 2 <= a.nx1 && yw >= a.ny0 && yw + 4 <= a.ny1) {           // (wave-uniform) every column enters the tensor's maximum
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) acc[mt][0] = epi_quad_apply(acc[mt][0], om1, al2, k1, vmax);
@@ -2095,12 +2125,12 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                m[blk][e] = fmaxf(fmaxf(acc[2 * blk][0][e], acc[2 * blk + 1][0][e]), fmaxf(acc[4 + 2 * blk][0][e], acc[5 + 2 * blk][0][e]));
+                m[blk][e] = max4_nc(acc[2 * blk][0][e], acc[2 * blk + 1][0][e], acc[4 + 2 * blk][0][e], acc[5 + 2 * blk][0][e]);
         if (a.pz == 2) {                                                      // (uniform) z neighbours sit in adjacent lanes
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) m[blk][e] = fmaxf(m[blk][e], __shfl_xor(m[blk][e], 1));
+                for (int e = 0; e < 4; ++e) m[blk][e] = max2_nc(m[blk][e], __shfl_xor(m[blk][e], 1));
             const uint32_t plane_off = (uint32_t)((((g >> 1) * a.PZ + (z >> 1)) * 8 + 4 * (g & 1)) * 4);
             if ((zl & 1) == 0) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m[0]), prs, plane_off, prow, 0);
@@ -2933,7 +2963,8 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
         const int* d1 = h->dims[c1.level];
         fuse01 = c0.cout == 8 && c1.cin == 8 && c1.bf && c1.f16 && !c1.c8 && !c1.fold && !c1.head && c1.nt_total == 1 && c1.NT == 1 && c1.srcA < 0 &&
                  c1.level == c0.level && d1[2] == 16 && d1[0] % TX == 0 && d1[1] % TY == 0 &&
-                 c1.region[0] == 0 && c1.region[2] == 0 && c1.region[1] == d1[0] && c1.region[3] == d1[1];
+                 c1.region[0] == 0 && c1.region[2] == 0 && c1.region[1] == d1[0] && c1.region[3] == d1[1] &&
+                 (size_t)vsrc->q.vx * vsrc->q.vy * vsrc->q.vz * 4 < ((size_t)1 << 30);            // (its gather addresses the volume with 32-bit offsets)
     }
     h->fused01 = fuse01;
     for (size_t i = 0; i < h->convs.size(); ++i) {
