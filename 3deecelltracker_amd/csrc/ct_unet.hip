@@ -1072,10 +1072,10 @@ __device__ __forceinline__ float max3_nc(float a, float b, float c) { float r; a
 __device__ __forceinline__ float max2_nc(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float max4_nc(float a, float b, float c, float d) { return max2_nc(max3_nc(a, b, c), d); }
 
-// Shared epilogue arithmetic of the split kernels: (accumulator * out_mul + bias) -> LeakyReLU / ReLU -> BatchNorm affine on one MFMA result
-// quad: fma, mul, max, fma per value, |max| of the four results folded into `amax` (v_max3_f32 with |.| modifiers).  Deliberately NOT packed
-// fp32 (CT_PK): v_pk_fma_f32 / v_pk_mul_f32 halve the instruction count and are bit-identical, but beside MFMAs they cost more than the two scalar
-// instructions they replace (round 6 A/B: profiles/r06_conv_experiments.txt; the whole translation unit is built with -fno-slp-vectorize for that).
+// Shared epilogue arithmetic of the split kernels: bias -> LeakyReLU / ReLU -> BatchNorm affine on one MFMA result quad, |max| of the four results folded
+// into `amax` (v_max3_f32 with |.| modifiers).  Deliberately NOT packed fp32 (CT_PK): v_pk_fma_f32 / v_pk_mul_f32 halve the instruction count and are
+// bit-identical, but beside MFMAs they cost more than the two scalar instructions they replace (round 6 A/B: profiles/r06_conv_experiments.txt; the whole
+// translation unit is built with -fno-slp-vectorize for that).
 #ifndef CT_PK
 #define CT_PK 0            // 1: the affine steps of the epilogues and the staging scale as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32) -- measured SLOWER
 #endif                     //    beside MFMAs (MI355X_MICROARCH: +22 cycles per v_pk_fma_f32 against two v_fma_f32 in an MFMA gap); A/B switch, off
@@ -1084,28 +1084,36 @@ __device__ __forceinline__ EpiQuad epi_quad_load(const float* epi_s, int stride,
     return EpiQuad{*reinterpret_cast<const f32x4*>(epi_s + cb), *reinterpret_cast<const f32x4*>(epi_s + stride + cb),
                    *reinterpret_cast<const f32x4*>(epi_s + 2 * stride + cb)};
 }
-__device__ __forceinline__ f32x4 epi_quad_apply(const f32x4 acc, const float om, const float alpha, const EpiQuad& k, float& amax) {
-#if CT_PK
-    const f32x2 om2 = f32x2{om, om}, al2 = f32x2{alpha, alpha};
-    f32x2 t01 = __builtin_elementwise_fma(f32x2{acc[0], acc[1]}, om2, f32x2{k.b[0], k.b[1]});
-    f32x2 t23 = __builtin_elementwise_fma(f32x2{acc[2], acc[3]}, om2, f32x2{k.b[2], k.b[3]});
-    const f32x2 u01 = t01 * al2, u23 = t23 * al2;
-    t01 = f32x2{fmaxf(t01[0], u01[0]), fmaxf(t01[1], u01[1])};
-    t23 = f32x2{fmaxf(t23[0], u23[0]), fmaxf(t23[1], u23[1])};
-    t01 = __builtin_elementwise_fma(t01, f32x2{k.s[0], k.s[1]}, f32x2{k.h[0], k.h[1]});
-    t23 = __builtin_elementwise_fma(t23, f32x2{k.s[2], k.s[3]}, f32x2{k.h[2], k.h[3]});
-    f32x4 r = f32x4{t01[0], t01[1], t23[0], t23[1]};
-#else
+// The bias enters the accumulator as its INITIAL value (bias / out_mul: out_mul is a power of two, the quotient exact) and out_mul is folded into the
+// BatchNorm scale (LeakyReLU commutes with a positive power-of-two factor): mul, max, fma per value -- one instruction fewer than the round-5 chain
+// fma (un-scale + bias), mul, max, fma.  k.s holds scale * out_mul, k.h the shift; equal to that chain up to the position of the bias in the fp32 accumulation.
+__device__ __forceinline__ f32x4 epi_quad_apply_c(const f32x4 acc, const float alpha, const EpiQuad& k, float& amax) {
     f32x4 r;
+#if CT_PK
+    const f32x2 al2 = f32x2{alpha, alpha};
+    const f32x2 u01 = f32x2{acc[0], acc[1]} * al2, u23 = f32x2{acc[2], acc[3]} * al2;
+    const f32x2 t01 = __builtin_elementwise_fma(f32x2{fmaxf(acc[0], u01[0]), fmaxf(acc[1], u01[1])}, f32x2{k.s[0], k.s[1]}, f32x2{k.h[0], k.h[1]});
+    const f32x2 t23 = __builtin_elementwise_fma(f32x2{fmaxf(acc[2], u23[0]), fmaxf(acc[3], u23[1])}, f32x2{k.s[2], k.s[3]}, f32x2{k.h[2], k.h[3]});
+    r = f32x4{t01[0], t01[1], t23[0], t23[1]};
+#else
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float t = __builtin_fmaf(acc[e], om, k.b[e]);
-        r[e] = __builtin_fmaf(fmaxf(t, t * alpha), k.s[e], k.h[e]);           // LeakyReLU / ReLU (0 <= alpha < 1) without a select
-    }
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(fmaxf(acc[e], acc[e] * alpha), k.s[e], k.h[e]);      // LeakyReLU / ReLU (0 <= alpha < 1) without a select
 #endif
     amax = fmaxf(amax, fmaxf(fabsf(r[0]), fabsf(r[1])));
     amax = fmaxf(amax, fmaxf(fabsf(r[2]), fabsf(r[3])));
     return r;
+}
+__device__ __forceinline__ float rcp_pow2(float x) { return __uint_as_float(0x7f000000u - __float_as_uint(x)); }   // exact 1 / x for a normal power of two
+
+// hi / lo fp16 split of four values that are ALREADY scaled (the fused pair's L0 outputs: the scale sits in their BatchNorm constants).
+// `one` must be an opaque 1.0f (the compiler folds fma(x, 1, c) into an add and the difference then takes a conversion + a subtraction instead of one v_fma_mix_f32).
+__device__ __forceinline__ void h_split4_scaled(const f32x4 v, float one, uint2& h, uint2& l) {
+    const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+    const float l0 = __builtin_fmaf(v[0], one, -(float)h01[0]), l1 = __builtin_fmaf(v[1], one, -(float)h01[1]),
+                l2 = __builtin_fmaf(v[2], one, -(float)h23[0]), l3 = __builtin_fmaf(v[3], one, -(float)h23[1]);
+    h = uint2{__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+    l = uint2{__builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l0, l1)),
+              __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l2, l3))};
 }
 
 template <bool F16, int NT, bool C8, bool FOLD, bool Z8, bool Y10 = false>
@@ -1278,7 +1286,18 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
             }
         }
         __syncthreads();
-        if (chunk == 0) CT_TR(3);
+        if (chunk == 0) {
+            CT_TR(3);
+            // the bias enters the accumulators as their initial value (bias / out_mul, exact: out_mul is a power of two): the epilogue saves its first fma per
+            // value (epi_quad_apply_c).  Read from epi_s, which the barrier above has just published; the first MFMA of every column takes the quad as its C operand.
+            const float rom = F16 ? rcp_pow2(out_mul) : 1.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(epi_s + (C8 ? 4 * (g & 1) : 16 * nt + 4 * g)) * rom;
+#pragma unroll
+                for (int mt = 0; mt < NCOL; ++mt) acc[mt][nt] = bq;
+            }
+        }
 #if CT_PREFETCH
         if constexpr (!(Y10 && NT == 2)) { if (chunk + 1 < a.nchunks) prefetch(chunk + 1); }      // (that instantiation has no register to spare)
 #endif
@@ -1345,7 +1364,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
     };
     float vmax = 0.f;                                         // |max| of what this wave writes (split-fp16 consumers scale by it)
     const float al2 = alpha;
-    const float om2 = F16 ? out_mul : 1.f;                    // (x * 1 + bias == x + bias exactly: one code path for both families)
+    const float om2 = F16 ? out_mul : 1.f;                    // (folded into the BatchNorm scale: epi_quad_apply_c)
     // Wave-uniform shortcuts (round 6): a tile that lies inside the window whose voxels enter the tensor's maximum / inside the stored window / inside the
     // tensor needs no per-column compare chain and no select -- that is every tile but the ones on the windows' borders.
     const bool tile_needed = x0 >= a.nx0 && x0 + G::TXv <= nx1 && y0 >= a.ny0 && y0 + G::TYv <= ny1;
@@ -1354,7 +1373,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
     if constexpr (C8) {
         // lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx + (g>>1), y = y0 + col_y(mt)
         const int cb = 4 * (g & 1);
-        const EpiQuad kq = epi_quad_load(epi_s, ECH, cb);
+        EpiQuad kq = epi_quad_load(epi_s, ECH, cb);
+        kq.s *= om2;
         const int x = x0 + wx + (g >> 1);
         // Cout = 8: one channel octet per voxel; the lane's x (through g >> 1), z and channel half are the lane offset, the column y is scalar
         const size_t patch_bytes8 = (size_t)a.X * a.Y * a.Z * 32;
@@ -1364,12 +1384,12 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
         f32x4 r[4];
         if (tile_needed) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) r[mt] = epi_quad_apply(acc[mt][0], om2, al2, kq, vmax);
+            for (int mt = 0; mt < 4; ++mt) r[mt] = epi_quad_apply_c(acc[mt][0], al2, kq, vmax);
         } else {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 float cmax = 0.f;
-                r[mt] = epi_quad_apply(acc[mt][0], om2, al2, kq, cmax);
+                r[mt] = epi_quad_apply_c(acc[mt][0], al2, kq, cmax);
                 const int y = y0 + col_y(mt);
                 if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax);
             }
@@ -1403,15 +1423,16 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
     } else {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const EpiQuad kq = epi_quad_load(epi_s, ECH, 16 * nt + 4 * g);
+            EpiQuad kq = epi_quad_load(epi_s, ECH, 16 * nt + 4 * g);
+            kq.s *= om2;
             if (!F16 || tile_needed) {                         // (the maximum only serves the split-fp16 consumers)
 #pragma unroll
-                for (int mt = 0; mt < NCOL; ++mt) acc[mt][nt] = epi_quad_apply(acc[mt][nt], om2, al2, kq, vmax);
+                for (int mt = 0; mt < NCOL; ++mt) acc[mt][nt] = epi_quad_apply_c(acc[mt][nt], al2, kq, vmax);
             } else {
 #pragma unroll
                 for (int mt = 0; mt < NCOL; ++mt) {
                     float cmax = 0.f;
-                    acc[mt][nt] = epi_quad_apply(acc[mt][nt], om2, al2, kq, cmax);
+                    acc[mt][nt] = epi_quad_apply_c(acc[mt][nt], al2, kq, cmax);
                     const int x = x0 + col_x(mt), y = y0 + col_y(mt);
                     if (x >= a.nx0 && x < nx1 && y >= a.ny0 && y < ny1) vmax = fmaxf(vmax, cmax);
                 }
@@ -1866,7 +1887,8 @@ __global__ __launch_bounds__(256, OCC) void conv_first_f16_kernel(const float* _
 // its 1-channel input.  Values differ from the two-kernel path only through those scale exponents (both are exact splits of fp32 data).
 // Preconditions (run_network): one z block (Z = 16), Cout(L1) = 16, plain (not folded, not 8 x 8 x 8) tiles, whole-patch region.
 // ------------------------------------------------------------------------------------------------
-struct FirstArgs { const float* vol; TileGeom q; int p_begin; const u32x4* wf16; float wscale_inv; const float* epi; };
+// bound_a, bound_b: |L0 output| <= bound_a * max|input| + bound_b for every channel (host: max_c |scale_c| * sum |w_c|, max_c (|scale_c| |bias_c| + |shift_c|))
+struct FirstArgs { const float* vol; TileGeom q; int p_begin; const u32x4* wf16; float wscale_inv; const float* epi; float bound_a, bound_b; };
 
 // (dy, dz) combination `idx` (0 .. 8; 9 = the zero-weight pad slot) of the fused kernel's L0 tap order -> entry offset inside the input tile
 // (the pad slot reads the entry after (2, 2): one ds_read2_b64 with adjacent offsets; for the tile's last column that is the zeroed entry behind the tile)
@@ -1881,7 +1903,11 @@ __host__ __device__ constexpr int l0_tap_entry(int idx, int iz) { return idx < 9
 //   * every wave runs eight pair columns (the two spare slots of waves 2 and 3 recompute pair 29 and write the same values): straight-line code;
 //   * tiles whose L0 halo lies inside the patch (85 % of them) skip the zero-padding selects, tiles inside the needed / stored windows skip the per-column
 //     compare chains (one wave-uniform test each);
-//   * both epilogues on register pairs (epi_quad_apply); the staging offsets of L0's outputs are scalar column + lane constant.
+//   * the staging offsets of L0's outputs are scalar column + lane constant;
+//   * L1's input scale comes from a BOUND of L0's outputs (bound_a * max|input tile| + bound_b, known before L0 runs) instead of their measured maximum: no second
+//     reduction, and the scale folds into L0's BatchNorm constants, so the staged values leave the epilogue ready to split (the bound exceeds the true maximum by
+//     the slack of the triangle inequality, a few bits of the 2^17 of head-room the split has below the maximum);
+//   * both biases enter their accumulators as initial values and out_mul folds into the BatchNorm scale (epi_quad_apply_c): three instructions per value.
 __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs a_in, const FirstArgs f_in) {
     using G = BfGeom<false>;
     constexpr int HYg = G::HYv, HZg = G::HZv;                                 // L1 halo tile: 6 x 10 columns x 18 z
@@ -1893,7 +1919,7 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     uint2* const itile = reinterpret_cast<uint2*>(lds);
     static_assert((IX * IY * IZ + 1) * 8 <= G::PLANE, "input tile (+ the pad entry) must fit into the first plane");
     __shared__ int mapx[IX], mapy[IY], mapz[IZ];
-    __shared__ float amax_red[4], tmax_red[4], omax_red[4];
+    __shared__ float amax_red[4], tmax_red[4];
     __shared__ __attribute__((aligned(16))) float epi_s[3 * 16];
     __shared__ __attribute__((aligned(16))) float epi0_s[3 * 8];
     ConvArgs a = a_in;
@@ -1965,11 +1991,15 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     wlds[tid] = w_pre0;
     if (tid < 64) wlds[256 + tid] = w_pre1;
     __syncthreads();
-    float out_mul0;
+    float out_mul0, out_mul, in_scale;
     {
-        const int kexp = amax_exponent(__float_as_uint(fmaxf(fmaxf(tmax_red[0], tmax_red[1]), fmaxf(tmax_red[2], tmax_red[3]))));
+        const float tmaxv = fmaxf(fmaxf(tmax_red[0], tmax_red[1]), fmaxf(tmax_red[2], tmax_red[3]));
+        const int kexp = amax_exponent(__float_as_uint(tmaxv));
         const float in_scale0 = pow2f(-kexp);
         out_mul0 = pow2f(kexp) * f.wscale_inv;
+        const int k1e = amax_exponent(__float_as_uint(__builtin_fmaf(f.bound_a, tmaxv, f.bound_b)));    // L1's input scale from the bound of L0's outputs
+        in_scale = pow2f(-k1e);
+        out_mul = pow2f(k1e) * a.wscale_inv;
         if (gact) {
 #pragma unroll
             for (int i = 0; i < HALF; ++i) {
@@ -1984,8 +2014,11 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     __syncthreads();
     // ---- L0 on the halo: pair column c = wave + 4 m (x pair c / 10, y c % 10; slots 30, 31 repeat pair 29), rows (x-select, cout), lane group g = dx'
     f32x4 acc0[8];
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(epi0_s + 4 * (g & 1)) * rcp_pow2(out_mul0);      // the bias as the accumulators' initial value
 #pragma unroll
-    for (int m = 0; m < 8; ++m) acc0[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 8; ++m) acc0[m] = b0;
+    }
     int pxi_[8], hy_[8];                                                      // (scalar: wave is uniform)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -2021,40 +2054,40 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     }
     const float alpha = a.act == 0 ? kLeakyAlpha : 0.f;
     const float al2 = alpha;
-    float omax = 0.f;
     {
-        const EpiQuad k0 = epi_quad_load(epi0_s, 8, 4 * (g & 1));
-        const float om0 = out_mul0;
+        EpiQuad k0 = epi_quad_load(epi0_s, 8, 4 * (g & 1));
+        k0.s *= out_mul0 * in_scale; k0.h *= in_scale;                        // values leave the epilogue in L1's scaled units (powers of two: exact)
+        float unused = 0.f;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) acc0[m] = epi_quad_apply(acc0[m], om0, al2, k0, omax);
+        for (int m = 0; m < 8; ++m) acc0[m] = epi_quad_apply_c(acc0[m], al2, k0, unused);
         // outside the patch the tile holds L1's zero padding: only tiles on the patch border have such voxels (wave-uniform test)
         if (!(x0 >= 1 && x0 + G::HXv - 1 <= a.X && y0 >= 1 && y0 + G::HYv - 1 <= a.Y)) {
-            omax = 0.f;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int px = x0 - 1 + 2 * pxi_[m] + (g >> 1), py = y0 - 1 + hy_[m];
                 const bool inside = px >= 0 && px < a.X && py >= 0 && py < a.Y;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { acc0[m][e] = inside ? acc0[m][e] : 0.f; omax = fmaxf(omax, fabsf(acc0[m][e])); }
+                for (int e = 0; e < 4; ++e) acc0[m][e] = inside ? acc0[m][e] : 0.f;
             }
         }
     }
-    omax = wave_max_nonneg_l63(omax);
-    if (lane == 63) omax_red[wave] = omax;
-    __syncthreads();
-    float out_mul;
+    __syncthreads();                                                          // every wave is done with the input tile and L0's weights: the planes are free
     {
-        const int k1e = amax_exponent(__float_as_uint(fmaxf(fmaxf(omax_red[0], omax_red[1]), fmaxf(omax_red[2], omax_red[3]))));
-        const float in_scale = pow2f(-k1e);
-        out_mul = pow2f(k1e) * a.wscale_inv;
         if (tid < 4 * G::HXv * G::HYv) {          // the z-halo rows of L1's tile are its 'same' padding (one z block): zeros in both planes
             const int col = tid >> 2, row = (tid & 2) ? HZg - 1 : 0, plane = tid & 1;
             *reinterpret_cast<uint4*>(lds + plane * G::PLANE + (col * HZg + row) * 16) = uint4{0u, 0u, 0u, 0u};
         }
         const int lane_st = ((((g >> 1) * HYg) * HZg + 1 + zl) * 2 + (g & 1)) * 8;
+        float one = 1.f;
+        asm volatile("" : "+v"(one));                                         // (opaque: see h_split4_scaled)
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
-            stage_put<false, true>(acc0[m], lds + lane_st + ((2 * pxi_[m]) * HYg + hy_[m]) * (HZg * 16), in_scale);
+        for (int m = 0; m < 8; ++m) {
+            uint2 hh, ll;
+            h_split4_scaled(acc0[m], one, hh, ll);
+            char* d = lds + lane_st + ((2 * pxi_[m]) * HYg + hy_[m]) * (HZg * 16);
+            *reinterpret_cast<uint2*>(d) = hh;
+            *reinterpret_cast<uint2*>(d + G::PLANE) = ll;
+        }
     }
     __syncthreads();
     // ---- L1: the ordinary single-chunk MFMA phase of conv3_split_kernel<true, 1, false, false, false>
@@ -2062,8 +2095,11 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     const int wx = 2 * (wave >> 1), wy = 4 * (wave & 1);
     const int lanepos = (wx * HYg + wy) * HZg + zl;
     f32x4 acc[8][NT];
+    {
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(epi_s + 4 * g) * rcp_pow2(out_mul);
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < 8; ++mt) acc[mt][0] = b1;
+    }
     {
         int tapoff[KB_STD];
         bf_tap_offsets<KB_STD, false, false, false>(lanepos, g, tapoff);
@@ -2074,16 +2110,16 @@ __global__ __launch_bounds__(256, 3) void conv_l0l1_fused_kernel(const ConvArgs 
     const int xw = x0 + wx, yw = y0 + wy;                                     // the wave's 2 x 4 block of columns
     float vmax = 0.f;
     {
-        const EpiQuad k1 = epi_quad_load(epi_s, 16, 4 * g);
-        const float om1 = out_mul;
+        EpiQuad k1 = epi_quad_load(epi_s, 16, 4 * g);
+        k1.s *= out_mul;
         if (xw >= a.nx0 && xw + 2 <= a.nx1 && yw >= a.ny0 && yw + 4 <= a.ny1) {           // (wave-uniform) every column enters the tensor's maximum
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) acc[mt][0] = epi_quad_apply(acc[mt][0], om1, al2, k1, vmax);
+            for (int mt = 0; mt < 8; ++mt) acc[mt][0] = epi_quad_apply_c(acc[mt][0], al2, k1, vmax);
         } else {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 float cmax = 0.f;
-                acc[mt][0] = epi_quad_apply(acc[mt][0], om1, al2, k1, cmax);
+                acc[mt][0] = epi_quad_apply_c(acc[mt][0], al2, k1, cmax);
                 const int x = xw + (mt >> 2), y = yw + (mt & 3);
                 if (x >= a.nx0 && x < a.nx1 && y >= a.ny0 && y < a.ny1) vmax = fmaxf(vmax, cmax);
             }
@@ -2219,6 +2255,7 @@ struct ct_unet {
     size_t first_mfma_off;           // packed weights of conv_first_mfma_kernel (Cout == 8)
     size_t first_f16_off;            // packed (hi, hi, lo, 0) fp16 weights of conv_first_f16_kernel
     size_t first_f16b_off;           // the same weights in conv_l0l1_fused_kernel's K order
+    float first_bound_a, first_bound_b;   // |first conv's output| <= a * max|input| + b (conv_l0l1_fused_kernel scales the second conv's input by it)
     float first_wscale_inv;          // 1 / their power-of-two scale
     bool first_f16;                  // the split-fp16 first conv is in use
     bool fused01 = false;            // the last run evaluated the first conv inside the second one's workgroups (conv_l0l1_fused_kernel)
@@ -2632,7 +2669,7 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
     ct_unet* h = new (std::nothrow) ct_unet();
     if (!h) return CT_EINVAL;
     h->timing = false;
-    h->first_f16 = false; h->first_f16_off = 0; h->first_f16b_off = 0; h->first_wscale_inv = 1.f;
+    h->first_f16 = false; h->first_f16_off = 0; h->first_f16b_off = 0; h->first_wscale_inv = 1.f; h->first_bound_a = h->first_bound_b = 0.f;
     h->arch_id = arch_id; h->device = device; h->ad = kArch[arch_id];
     const ArchDesc& ad = h->ad;
     h->nlevels = ad.ndown + 1;
@@ -2766,6 +2803,16 @@ int ct_unet_create(int arch_id, const float* w, size_t n_floats, int device, ct_
                 static const bool first_f16_on = !(getenv("CT_FIRST_F16") && atoi(getenv("CT_FIRST_F16")) == 0);
                 const char* mathenv = getenv("CT_CONV_MATH");
                 h->first_f16 = first_f16_on && !(mathenv && (strcmp(mathenv, "f32") == 0 || strcmp(mathenv, "bf16x6") == 0));
+            }
+            {   // bound of this layer's outputs: |LeakyReLU / ReLU (t)| <= |t|, so |out_c| <= |scale_c| (sum |w_c| max|in| + |bias_c|) + |shift_c|
+                float ba = 0.f, bb = 0.f;
+                for (int co = 0; co < c.cout; ++co) {
+                    const float sc = gamma[co] / sqrtf(var[co] + kBnEps), sh = beta[co] - mean[co] * sc;
+                    float sw = 0.f;
+                    for (int t = 0; t < 27; ++t) sw += fabsf(kern[t * c.cout + co]);
+                    ba = fmaxf(ba, fabsf(sc) * sw); bb = fmaxf(bb, fabsf(sc) * fabsf(bias[co]) + fabsf(sh));
+                }
+                h->first_bound_a = ba * 1.001f; h->first_bound_b = bb * 1.001f;      // (a margin for the fp32 rounding of the sums)
             }
             c.epi_off = push_epi(bias, gamma, beta, mean, var, c.cout, c.cout);
             arena.resize(align_up(arena.size(), 4), 0.f);
@@ -3096,7 +3143,7 @@ static int run_network(ct_unet_t* h, float* ws, int P, float* prob_out, float* l
                 { const int dp[2] = {af.pg_yz, af.pg_z};
                   for (int k = 0; k < 2; ++k) af.mdivp[k] = dp[k] <= 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint32_t)dp[k]); }
                 FirstArgs fa{vsrc->vol, vsrc->q, vsrc->p_begin, reinterpret_cast<const u32x4*>(h->d_weights + h->first_f16b_off), h->first_wscale_inv,
-                             h->d_weights + h->convs[0].epi_off};
+                             h->d_weights + h->convs[0].epi_off, h->first_bound_a, h->first_bound_b};
                 hipLaunchKernelGGL(conv_l0l1_fused_kernel, dim3(nblk), dim3(256), 0, st, af, fa);
                 rc = (int)hipGetLastError();
             } else

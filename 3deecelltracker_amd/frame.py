@@ -167,18 +167,29 @@ class FrameChain:
         chain with ITS OWN predecessor's results -- frame i is matched against frame i-1's segmentation and moves frame i-1's corrected
         cells.  Three streams, one host thread: the LCN + U-Net of frame i+2 (stream S) and the marker watershed of frame i+1 (stream W,
         enqueued without its host round trip) run beside the match + correction of frame i (stream T, whose steps the host synchronises
-        with); three probability-map buffers.  `raws`: device uint16 stacks.  Yields run()'s dict per frame; same values as calling
-        run(raw_i, seg_{i-1}, corrected_{i-1}) frame after frame."""
+        with); three probability-map buffers.  `raws`: the stacks as the reference's loop finds them -- on the HOST (tracker.py:605-650 reads every volume
+        from disk): numpy arrays or CPU tensors (pinned ones copy asynchronously), uploaded inside the loop on a copy stream of their own, frame i+3's
+        upload beside everything else (a ring of four device buffers) -- or device uint16 / float stacks that are already resident.  Yields run()'s
+        dict per frame; same values as calling run(raw_i, seg_{i-1}, corrected_{i-1}) frame after frame."""
         t = _dev.torch()
-        raws = list(raws)
+        raws = [t.from_numpy(np.ascontiguousarray(r)) if isinstance(r, np.ndarray) else r for r in raws]
         if not raws:
             return
         from . import _lib
-        dev = raws[0].device
-        NB = 3
+        on_host = [not r.is_cuda for r in raws]
+        if any(on_host):
+            dev = next((r.device for r in raws if r.is_cuda), None)
+            if dev is None:
+                m = self.unet_model
+                dev = t.device("cuda", m._device if getattr(m, "_device", None) is not None else t.cuda.current_device())
+        else:
+            dev = raws[0].device
+        NB, NR = 3, 4
         key = (tuple(raws[0].shape), str(dev))
-        if any(tuple(r.shape) != key[0] or r.device != dev for r in raws):
-            raise ValueError("run_sequence: every volume of a sequence must have the same shape and live on the same device")
+        if any(tuple(r.shape) != key[0] or (r.is_cuda and r.device != dev) for r in raws):
+            raise ValueError("run_sequence: every volume of a sequence must have the same shape and live on the host or on the same device")
+        if any(h and r.dtype != raws[0].dtype for h, r in zip(on_host, raws)):
+            raise ValueError("run_sequence: host volumes of one sequence must share a dtype")
         if self._seq is None or self._seq["key"] != key:       # (streams and probability-map buffers belong to one volume shape on one device)
             self._release_seq_streams()
             ps, pw, pt = self.seq_priorities
@@ -199,6 +210,15 @@ class FrameChain:
                          "prob": [t.empty(key[0], dtype=t.float32, device=dev) for _ in range(NB)],
                          "ready": [t.cuda.Event() for _ in range(NB)]}
         q = self._seq
+        if any(on_host):
+            hdt = next(r.dtype for h, r in zip(on_host, raws) if h)
+            if q.get("raw_dtype") != hdt:                        # upload ring + copy stream: made once per (shape, device, dtype)
+                q["raw"] = [t.empty(key[0], dtype=hdt, device=dev) for _ in range(NR)]
+                q["raw_dtype"] = hdt
+                q["C"] = t.cuda.Stream(device=dev)
+            q["raw_free"] = [None] * NR
+            q["raw_up"] = [None] * NR
+        uploaded = [-1]
         q["free"] = [None] * NB
         q["spans"] = collections.deque(maxlen=3 * 512)           # (stream-local spans of the last sequence's last 512 frames: sequence_spans())
         S, W, T = q["S"], q["W"], q["T"]
@@ -216,21 +236,52 @@ class FrameChain:
 
         lcn_on_w = self.lcn_beside_unet and self.region_method == "watershed"
 
+        def upload_through(k_last):
+            # host stacks: frame k's copy goes out on the copy stream as soon as the ring slot's previous tenant (frame k - NR) has been normalised
+            for k in range(uploaded[0] + 1, min(k_last, len(raws) - 1) + 1):
+                uploaded[0] = k
+                if not on_host[k]:
+                    continue
+                rb = k % NR
+                Cs = q["C"]
+                if q["raw_free"][rb] is not None:
+                    Cs.wait_event(q["raw_free"][rb])
+                else:
+                    Cs.wait_stream(entry)
+                with t.cuda.stream(Cs):
+                    q["raw"][rb].copy_(raws[k], non_blocking=True)
+                    q["raw_up"][rb] = t.cuda.Event(); q["raw_up"][rb].record(Cs)
+
+        def raw_of(j, stream):
+            """Frame j's stack on the device, `stream` ordered behind its upload."""
+            if not on_host[j]:
+                return raws[j]
+            stream.wait_event(q["raw_up"][j % NR])
+            return q["raw"][j % NR]
+
+        def raw_done(j, stream):
+            if on_host[j]:
+                q["raw_free"][j % NR] = t.cuda.Event(); q["raw_free"][j % NR].record(stream)
+
         def enqueue_unet(j):
             b = j % NB
+            upload_through(j + 1)                                # (frame j's own upload was queued one enqueue_unet ago: it runs a frame ahead)
             norm = None
             if lcn_on_w:
                 # the LCN (bandwidth-bound sweeps) of frame j on the watershed's stream, which has ~3 ms of slack per frame, beside the
                 # power-bound U-Net of the frame before: the U-Net stream is the pipeline's bottleneck and loses 0.25 ms per frame
                 with t.cuda.stream(W):
-                    norm = self.normalized(raws[j])
+                    norm = self.normalized(raw_of(j, W))
                     ev = t.cuda.Event(); ev.record(W)
+                    raw_done(j, W)
                 S.wait_event(ev)
                 norm.record_stream(S)
             if q["free"][b] is not None:
                 S.wait_event(q["free"][b])                       # frame j-3's correction has read this buffer
             with t.cuda.stream(S):
-                span("unet", S, lambda: self.probability_map(raws[j], out=q["prob"][b], norm=norm))
+                span("unet", S, lambda: self.probability_map(None if norm is not None else raw_of(j, S), out=q["prob"][b], norm=norm))
+                if norm is None:
+                    raw_done(j, S)
                 q["ready"][b].record(S)
 
         def enqueue_regions(j):
@@ -262,7 +313,7 @@ class FrameChain:
         finally:
             # also when the consumer stops early or a frame raises (GeneratorExit / the exception passes through here): the U-Nets and
             # watersheds already enqueued keep writing the cached buffers, so the caller's stream is ordered behind all three streams
-            for st in (S, W, T):
+            for st in (S, W, T) + ((q["C"],) if any(on_host) else ()):
                 entry.wait_stream(st)
 
     def _release_seq_streams(self):

@@ -224,11 +224,19 @@ class SequenceMode:
         self.comm = comm
         self.outs = []
         self.first_coords = None                                 # corrected cells (real units) of the first frame of the last run()
+        # The contract's `value` takes inputs that are resident in HBM when the timed region starts.  The reference's loop reads every volume from the
+        # host (tracker.py:605-650): with host_inputs the stacks start in pinned host memory and run_sequence uploads them inside the timed loop
+        # (--host-inputs for the headline; config.host_inputs is that pass beside the default headline).
+        self.resident = not bool(getattr(args, "host_inputs", False))
+        self.host_raws = None
 
     def run(self, n, keep=False):
         import torch
         ch = self.chain
-        raws = ([ch.raw_t2, ch.raw_t1] * ((n + 1) // 2))[:n]
+        if not self.resident and self.host_raws is None:
+            self.host_raws = [ch.raw_t2.cpu().pin_memory(), ch.raw_t1.cpu().pin_memory()]
+        pair = [ch.raw_t2, ch.raw_t1] if self.resident else self.host_raws
+        raws = (pair * ((n + 1) // 2))[:n]
         batch = []
         outs = []
         for out in ch.run_sequence(raws, ch.seg_real_t1, ch.confirmed_real_t1):
@@ -328,6 +336,25 @@ def make_ensemble_mode(ctx, args):
         ctx.ensemble_out = trk.predict_ensemble(nvol)        # get_reference_vols(20, 21) = volumes 1..20
 
     return step, (lambda: None)
+
+
+def measure_unet_alone(ctx, args, seqm, n_patches, reps=12):
+    """The U-Net of the headline volume with nothing beside it (LCN output resident, one stream): what the conv stack costs without the co-runners
+    of the frame loop.  hbm_contract_frac = SURVEY 8(d)'s 285.1 MB per patch x patches over this time, against 8 TB/s."""
+    import torch
+    ch = seqm.chain
+    norm = ch.normalized(ch.raw_t2)
+    out = torch.empty_like(norm)
+    for _ in range(3):
+        ch.unet_model.predict_volume_device(norm, ch.shrink, out=out)
+    torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
+    for _ in range(reps):
+        ch.unet_model.predict_volume_device(norm, ch.shrink, out=out)
+    torch.cuda.synchronize(ctx.dev)
+    dt = (time.perf_counter() - t0) / reps
+    gb = n_patches * mod("arch").UNET3_A.algorithmic_bytes_per_patch() / 1e9
+    return {"ms_per_volume": round(dt * 1e3, 3), "volumes": reps, "hbm_contract_frac": round(gb / dt / 1e3 / HBM_PEAK_TBS, 4),
+            "what": "ct_unet_predict_volume alone, back to back (the frame loop's U-Net weights and volume)"}
 
 
 def measure_pcie(ctx):
@@ -756,6 +783,27 @@ def measure_other_configs(ctx, args):
                                  "sample": f"3 PR-GLS iterations of the CPU oracle at N = 2000 ({t_cpu_it:.2f} s each, numpy + LAPACK threads as configured), x {iters} iterations; "
                                            "FFN and greedy not timed on the CPU (the reference's materialised pair grid is 1.9 GB at this size)"}}
     guarded("cfg5_match_2000cells", match2000)
+
+    def other_net(name, n_patch):
+        # rows a2 / a3 of SURVEY 8(a): the other two architectures through the patch entry point (ct_unet_predict_patches), Glorot weights
+        arch = mod("arch").ARCHS[name]
+        model = getattr(unet3d, name)(device=ctx.local).set_weights_dict(synth.make_unet_weights(name, seed=0))
+        x = torch.randn((n_patch, *arch.input_shape), dtype=torch.float32, device=ctx.dev)
+        for _ in range(3):
+            model.predict_device(x)
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize(ctx.dev); t0 = time.perf_counter()
+            model.predict_device(x)
+            torch.cuda.synchronize(ctx.dev)
+            ts.append(time.perf_counter() - t0)
+        dt = float(np.median(ts))
+        gf = n_patch * arch.flops_per_patch() / 1e9
+        return {"what": f"{name}: {n_patch} patches of {'x'.join(str(v) for v in arch.input_shape)} through ct_unet_predict_patches (split-fp16 family, Glorot weights)",
+                "ms": round(dt * 1e3, 3), "ms_per_patch": round(dt * 1e3 / n_patch, 4), "fp32_equivalent_tflops": round(gf / dt / 1e3, 1),
+                "executed_f16_frac_of_peak": round(3.0 * gf / dt / 1e3 / BF16_MFMA_PEAK_TF, 4)}
+    guarded("unet3_b_24_patches", lambda: other_net("unet3_b", 24))
+    guarded("unet3_c_150_patches", lambda: other_net("unet3_c", 150))
     return res
 
 
@@ -813,6 +861,8 @@ def main():
     ap.add_argument("--priority-streams", action="store_true", help="(the default now; kept for old command lines)")
     ap.add_argument("--realistic-partition", action="store_true", help="discriminating-FFN pass on a CU partition (--realistic-match-cus) instead of priority streams (116 vs 121 volumes/s)")
     ap.add_argument("--match-batch", type=int, default=None, help="frames whose matches share one chain of launches (ct_prgls_two_ref_batched); capped at ceil(steps / chains) so that a short run does not end on queued match batches")
+    ap.add_argument("--host-inputs", action="store_true", help="frames mode: the raw stacks start in pinned HOST memory and are uploaded inside the timed loop (default: resident in HBM, "
+                                                               "as the contract's `value` requires; config.host_inputs reports this variant either way)")
     ap.add_argument("--no-realistic-pass", action="store_true", help="skip the informative passes (discriminating FFN, chained frame, PCIe, sharding modes)")
     ap.add_argument("--rccl-selftest", action="store_true", help="N = 1 only: an extra pass that runs the frame loop's gather and the patches mode's collectives through RCCL on a one-rank group")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous only: every rank joins the process group, rank 0 prints {world_size, backend}; no GPU work (CPU test of the self-launch)")
@@ -990,6 +1040,19 @@ def main():
                                            "stream_spans_ms": {k: round(v, 3) for k, v in slow.chain.sequence_spans().items()},
                                            "ffn": f"{1 - args.slow_prior_mix:.2f} x synthetic-trained + {args.slow_prior_mix:.2f} x random-init weights (bench.mixed_ffn_weights)"}
                     del slow
+                # the same K-frame window with the stacks in pinned host memory, uploaded inside the loop (what the reference's loop over files sees)
+                keep_res = seqm.resident
+                seqm.resident = False
+                seqm.run(min(4, args.steps))
+                hw = [timed_window(ctx, lambda: seqm.run(args.steps)) for _ in range(3)]
+                same = bool(seqm.first_coords is not None and first_coords is not None and np.array_equal(seqm.first_coords, first_coords))
+                seqm.resident = keep_res
+                seqm.first_coords = first_coords
+                extra["host_inputs"] = {"volumes_per_s": round(args.steps / float(np.median(hw)), 3), "windows": len(hw), "frames_per_window": args.steps,
+                                        "ms_per_frame": round(float(np.median(hw)) / args.steps * 1e3, 3), "first_frame_coordinates_identical": same,
+                                        "what": "the headline's window with pinned HOST uint16 stacks: run_sequence uploads frame i+3 on a copy stream inside the loop "
+                                                "(33.5 MB per frame); never `value` (the contract takes resident inputs)"}
+                extra["unet_alone"] = measure_unet_alone(ctx, args, seqm, n_patches)
                 extra["chained"] = measure_chained(ctx, args)
                 extra["pcie_inclusive"] = measure_pcie(ctx)
                 extra["other_configs"] = measure_other_configs(ctx, args)
@@ -1050,6 +1113,9 @@ def main():
                "parallelism": parallelism}
         if args.mode == "frames":
             cfg.update({"frames_timed": args.steps, "cells_segmented": [o["n_segmented"] for o in outs_main[:2]],
+                        "inputs": ("pinned host uint16 stacks, uploaded in the loop (copy stream, frame i+3's upload beside the U-Net of i+2, the watershed of i+1 and the match of i)"
+                                   if args.host_inputs else "uint16 stacks resident in HBM when the timed region starts (the contract); config.host_inputs = the same window with "
+                                                            "pinned host stacks uploaded inside the loop"),
                         "correction_rounds": int(np.median([o["correction_rounds"] for o in outs_main])),
                         "stream_spans_ms": spans,
                         "headline_note": "value = K real frames (nothing excluded, each matched against ITS predecessor) as one software-pipelined run_sequence "
@@ -1061,6 +1127,28 @@ def main():
                                          {"unet": ctx.pipe.n_cu, "match": "no partition: match chains on high-priority streams"}),
                         "match_chains_in_flight": args.match_workers, "frames_per_match_chain": args.match_batch})
         cfg.update(extra)
+        # flat scalars: the driver's record keeps scalar `config` fields only, so every number a reader should find there is repeated as one
+        def _dig(d, *keys):
+            for k in keys:
+                if not isinstance(d, dict) or k not in d:
+                    return None
+                d = d[k]
+            return d if isinstance(d, (int, float)) else None
+        oc = extra.get("other_configs", {}) if isinstance(extra.get("other_configs"), dict) else {}
+        flat = {"value_median": _dig(spread or {}, "median"), "value_min": _dig(spread or {}, "min"), "value_max": _dig(spread or {}, "max"),
+                "steady_state_volumes_per_s": _dig(extra, "steady_state", "volumes_per_s"), "steady_state_ms_per_frame": _dig(extra, "steady_state", "ms_per_frame"),
+                "conv_stack_ms_in_loop": _dig(roofline or {}, "conv_stack_ms_per_volume"), "unet_alone_ms": _dig(extra, "unet_alone", "ms_per_volume"),
+                "hbm_contract_frac_in_loop": _dig(roofline or {}, "hbm_contract_frac"), "hbm_contract_frac_alone": _dig(extra, "unet_alone", "hbm_contract_frac"),
+                "slow_prior_volumes_per_s": _dig(extra, "slow_prior", "volumes_per_s"), "chained_ms_per_frame": _dig(extra, "chained", "ms_per_frame"),
+                "independent_matches_volumes_per_s": _dig(extra, "independent_matches", "volumes_per_s"),
+                "host_inputs_volumes_per_s": _dig(extra, "host_inputs", "volumes_per_s"),
+                "pcie_inclusive_volumes_per_s": _dig(extra, "pcie_inclusive", "volumes_per_s"),
+                "cfg1_volumes_per_s": _dig(oc, "cfg1_64x64x16_50cells", "volumes_per_s"), "cfg2_volumes_per_s": _dig(oc, "cfg2_256x256x24_150cells", "volumes_per_s"),
+                "cfg4_predictions_per_s": _dig(oc, "cfg4_ensemble_20x113", "predictions_per_s"), "cfg5_match_ms": _dig(oc, "cfg5_match_2000cells", "match_ms"),
+                "unet3_b_24_patches_ms": _dig(oc, "unet3_b_24_patches", "ms"), "unet3_b_f16_frac_of_peak": _dig(oc, "unet3_b_24_patches", "executed_f16_frac_of_peak"),
+                "unet3_c_150_patches_ms": _dig(oc, "unet3_c_150_patches", "ms"), "unet3_c_f16_frac_of_peak": _dig(oc, "unet3_c_150_patches", "executed_f16_frac_of_peak"),
+                "cpu_baseline_volumes_per_s": _dig(cpu or {}, "value")}
+        cfg.update({k: v for k, v in flat.items() if v is not None})
         out = {
             "metric": metric,
             "value": round(value, 3), "unit": "volumes/s" if args.mode != "ensemble" else "predictions/s", "n_gpus": world, "steps": args.steps,

@@ -200,6 +200,22 @@ def test_frame_sequence_with_overlapped_unet_equals_the_serial_frames(region_met
             assert np.array_equal(g["coords"].real, w["coords"].real)
     assert len({o["n_segmented"] for o in want}) >= 1 and want[0]["n_segmented"] >= 100
     assert list(chain.run_sequence([], seg, conf)) == []
+    # the stacks as the reference's loop finds them: on the HOST (numpy, pinned tensors, or a mix with resident ones) -- uploaded inside the
+    # loop on the sequence's copy stream through a ring of four device buffers (more frames than ring slots: every slot is reused); same values
+    import torch
+    long_raws = raws + raws[:4]                                   # 9 frames
+    want9 = list(chain.run_sequence(long_raws, chain.seg_real_t1, chain.confirmed_real_t1))
+    pinned = [r.cpu().pin_memory() for r in long_raws]
+    as_numpy = [r.cpu().numpy() for r in long_raws]
+    mixed = [p if i % 3 else r for i, (p, r) in enumerate(zip(pinned, long_raws))]
+    for variant in (pinned, as_numpy, mixed, pinned):
+        got = list(chain.run_sequence(variant, chain.seg_real_t1, chain.confirmed_real_t1))
+        assert len(got) == len(want9)
+        for g, w in zip(got, want9):
+            assert g["n_segmented"] == w["n_segmented"] and g["prgls_iterations"] == w["prgls_iterations"]
+            assert np.array_equal(g["coords"].real, w["coords"].real)
+    with pytest.raises(ValueError):
+        list(chain.run_sequence([pinned[0], pinned[1][:, :, :8]], chain.seg_real_t1, chain.confirmed_real_t1))
 
 
 @pytest.mark.gpu
