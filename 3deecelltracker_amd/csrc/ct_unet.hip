@@ -713,12 +713,14 @@ __device__ __forceinline__ void h_split4(const f32x4 v, float s, uint2& h, uint2
     const float x0 = v[0] * s, x1 = v[1] * s, x2 = v[2] * s, x3 = v[3] * s;
 #endif
     const auto h01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), h23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
-    // (the difference as ONE v_fma_mix_f32 per value -- v * s - hi with the fp16 operand read in place; the same number as x - hi, the product being exact)
-    const float l0 = __builtin_fmaf(v[0], s, -(float)h01[0]), l1 = __builtin_fmaf(v[1], s, -(float)h01[1]),
-                l2 = __builtin_fmaf(v[2], s, -(float)h23[0]), l3 = __builtin_fmaf(v[3], s, -(float)h23[1]);
+    // lo = fp16(v * s - hi) as ONE v_fma_mixlo_f16 / v_fma_mixhi_f16 per value: the fp16 operand is read in place, the difference (exact in fp32, the product
+    // being exact) is rounded to nearest and lands in its half of the packed word -- no separate conversion (round 5: v_fma_mix_f32 + v_cvt_pkrtz, lo cut
+    // toward zero; nearest halves lo's error)
+    f16x2 l01, l23;
+    l01[0] = (_Float16)__builtin_fmaf(v[0], s, -(float)h01[0]); l01[1] = (_Float16)__builtin_fmaf(v[1], s, -(float)h01[1]);
+    l23[0] = (_Float16)__builtin_fmaf(v[2], s, -(float)h23[0]); l23[1] = (_Float16)__builtin_fmaf(v[3], s, -(float)h23[1]);
     h = uint2{__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
-    l = uint2{__builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l0, l1)),
-              __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l2, l3))};
+    l = uint2{__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
 }
 
 // exponent k such that m * 2^-k lies in [2^13, 2^14); 0 for m == 0 / inf / nan; clamped so that 2^+-k stay normal floats
@@ -1106,14 +1108,14 @@ __device__ __forceinline__ f32x4 epi_quad_apply_c(const f32x4 acc, const float a
 __device__ __forceinline__ float rcp_pow2(float x) { return __uint_as_float(0x7f000000u - __float_as_uint(x)); }   // exact 1 / x for a normal power of two
 
 // hi / lo fp16 split of four values that are ALREADY scaled (the fused pair's L0 outputs: the scale sits in their BatchNorm constants).
-// `one` must be an opaque 1.0f (the compiler folds fma(x, 1, c) into an add and the difference then takes a conversion + a subtraction instead of one v_fma_mix_f32).
+// `one` must be an opaque 1.0f (the compiler folds fma(x, 1, c) into an add and the difference then takes a conversion + a subtraction instead of one v_fma_mixlo_f16).
 __device__ __forceinline__ void h_split4_scaled(const f32x4 v, float one, uint2& h, uint2& l) {
     const auto h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-    const float l0 = __builtin_fmaf(v[0], one, -(float)h01[0]), l1 = __builtin_fmaf(v[1], one, -(float)h01[1]),
-                l2 = __builtin_fmaf(v[2], one, -(float)h23[0]), l3 = __builtin_fmaf(v[3], one, -(float)h23[1]);
+    f16x2 l01, l23;
+    l01[0] = (_Float16)__builtin_fmaf(v[0], one, -(float)h01[0]); l01[1] = (_Float16)__builtin_fmaf(v[1], one, -(float)h01[1]);
+    l23[0] = (_Float16)__builtin_fmaf(v[2], one, -(float)h23[0]); l23[1] = (_Float16)__builtin_fmaf(v[3], one, -(float)h23[1]);
     h = uint2{__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
-    l = uint2{__builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l0, l1)),
-              __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(l2, l3))};
+    l = uint2{__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
 }
 
 template <bool F16, int NT, bool C8, bool FOLD, bool Z8, bool Y10 = false>
@@ -1409,14 +1411,23 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
             }
         }
         if (a.head) {
+            // Conv3D(1, 1, activation='sigmoid') fused.  The two channel halves of a voxel sit in lanes 16 apart; after the exchange BOTH hold the voxel's
+            // sum, so each half finishes two of the four columns (sigmoid + stitch: ~60 vector instructions per column, and this layer is bound by
+            // them) instead of one half doing all four while the other idles.  Same arithmetic per voxel as before.
             const f32x4 hw = *reinterpret_cast<const f32x4*>(epi_s + 3 * ECH + cb);
+            float part[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const int y = y0 + col_y(mt);
-                float part = r[mt][0] * hw[0] + r[mt][1] * hw[1] + r[mt][2] * hw[2] + r[mt][3] * hw[3];
-                part += __shfl_xor(part, 16);                    // the other channel half of the same voxel
-                if ((g & 1) == 0 && x < a.X && y < a.Y && z < a.Z)
-                    stitch(x, y, z, 1.f / (1.f + expf(-(part + head_bias))));
+                part[mt] = r[mt][0] * hw[0] + r[mt][1] * hw[1] + r[mt][2] * hw[2] + r[mt][3] * hw[3];
+                part[mt] += __shfl_xor(part[mt], 16);            // the other channel half of the same voxel
+            }
+            const bool upper = (g & 1) != 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float pv = upper ? part[2 + k] : part[k];
+                const int y = y0 + (upper ? col_y(2 + k) : col_y(k));
+                if (x < a.X && y < a.Y && z < a.Z)
+                    stitch(x, y, z, 1.f / (1.f + expf(-(pv + head_bias))));
             }
         }
         if constexpr (F16 && !((CT_ABL) & 4096)) { if (a.amax_out) amax_publish(vmax, a.amax_out + p * AMAX_STRIDE, tid, amax_red); }
