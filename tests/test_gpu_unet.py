@@ -296,6 +296,33 @@ def test_split_fp16_with_batchnorm_statistics_that_amplify_one_channel(amp_log2)
     assert float((m_amp.predict_volume_device(vol) - m_ref.predict_volume_device(vol)).abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("case", ("x1e-4", "x1", "x1e4", "amplified_first_conv"))
+def test_fused_first_pair_scales_by_a_bound_of_the_first_convs_outputs(case):
+    """Volume path (conv_l0l1_fused_kernel, round 6): the second conv's input scale is taken from a BOUND of the first conv's outputs
+    (bound_a * max|input tile| + bound_b, host constants) instead of their measured maximum.  The bound exceeds the true maximum by the slack of
+    the triangle inequality; the split keeps full precision 2^17 below its scale, so a few bits of slack must not show: one-patch volumes whose
+    input is scaled by 1e-4 / 1 / 1e4, and a net whose first conv has one channel amplified by 2^12 through its BatchNorm (the consumer's
+    weights divided by the same power of two: the same function, a bound 2^12 above every other channel), against the fp64 oracle."""
+    import copy
+    import torch
+    arch = arch_mod.UNET3_A
+    w = synth.make_unet_weights("unet3_a", seed=21)
+    scale = {"x1e-4": 1e-4, "x1": 1.0, "x1e4": 1e4}.get(case, 1.0)
+    if case == "amplified_first_conv":
+        w = copy.deepcopy(w)
+        amp = np.float32(2.0 ** 12)
+        w["convs"][0]["gamma"][3] *= amp; w["convs"][0]["beta"][3] *= amp
+        w["convs"][1]["kernel"][:, :, :, 3, :] /= amp
+    rng = np.random.default_rng(22)
+    vol = (scale * rng.normal(size=(112, 112, 12))).astype(np.float32)          # one 160 x 160 x 16 patch after padding by (24, 24, 2)
+    model = unet3d.unet3_a().set_weights_dict(w)
+    got = model.predict_volume_device(torch.from_numpy(vol).cuda()).cpu().numpy()
+    want = ur.unet3_prediction_ref(vol[None, :, :, :, None], lambda p: ur.unet_forward_torch(p, w, arch, dtype=np.float64), arch.input_shape)[0, :, :, :, 0]
+    assert np.isfinite(got).all()
+    err = float(np.abs(got - want).max())
+    assert err <= 1e-4, (case, err)
+
+
 def test_volume_path_computes_only_what_the_centre_crops_need():
     """ct_unet_predict_volume evaluates decoder tiles only where a kept (centre-crop) voxel depends on them; the rest of its
     workspace is never read by a kept voxel.  (1) The stitched map equals -- within the arithmetic's own noise -- the one
