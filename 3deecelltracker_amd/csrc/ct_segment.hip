@@ -37,6 +37,11 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Per-voxel sweeps walk the volume with a grid-stride loop: with one pass per thread (grid = V / block) it is the plain one-voxel-per-thread kernel; a smaller grid
+// (CT_WS_GRID) makes every workgroup walk several slabs.  The bound is V rounded up to whole workgroups, so all lanes of a wave make the same number of trips (the
+// kernels that use ballots / shuffles test `i < V` themselves; block sizes are powers of two: no 64-bit division per thread).
+#define WS_FOR_VOXELS(i, V) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, i##_end = ((V) + blockDim.x - 1) & ~((long long)blockDim.x - 1); i < i##_end; \
+                                 i += (long long)gridDim.x * blockDim.x)
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;                       // elements per thread in the prefix-sum passes
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 4096 voxels per workgroup
@@ -101,20 +106,21 @@ __global__ void cc_merge_kernel(SegGeom g, int32_t* __restrict__ parent) {
 
 // Path compression to depth 1 plus component sizes.  Lanes of a wave that share a root add once.
 __global__ void cc_flatten_kernel(long long V, int32_t* __restrict__ parent, int32_t* __restrict__ size) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int root = -1;
-    if (i < V && parent[i] >= 0) root = find_root(parent, (int)i);
-    unsigned long long todo = __ballot(root >= 0);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lr = __shfl(root, leader);
-        const unsigned long long same = __ballot(root == lr) & todo;
-        if (lane == leader) atomicAdd(size + lr, (int)__popcll(same));
-        todo &= ~same;
+    WS_FOR_VOXELS(i, V) {
+        int root = -1;
+        if (i < V && parent[i] >= 0) root = find_root(parent, (int)i);
+        unsigned long long todo = __ballot(root >= 0);
+        const int lane = threadIdx.x & 63;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lr = __shfl(root, leader);
+            const unsigned long long same = __ballot(root == lr) & todo;
+            if (lane == leader) atomicAdd(size + lr, (int)__popcll(same));
+            todo &= ~same;
+        }
+        // Written after the wave's finds; other waves may still walk through i, which stays valid: root is an ancestor of i.
+        if (root >= 0) __atomic_store_n(parent + i, root, __ATOMIC_RELAXED);
     }
-    // Written after the wave's finds; other waves may still walk through i, which stays valid: root is an ancestor of i.
-    if (root >= 0) __atomic_store_n(parent + i, root, __ATOMIC_RELAXED);
 }
 
 __device__ __forceinline__ int kept_root(const int32_t* parent, const int32_t* size, long long i, long long V,
@@ -200,35 +206,36 @@ __global__ void cc_assign_kernel(long long V, const int32_t* __restrict__ parent
 // labels + per-label {count, sum x, sum y, sum z}.  Lanes of a wave carrying the same label are reduced first.
 __global__ void cc_label_kernel(SegGeom g, const int32_t* __restrict__ parent, const int32_t* __restrict__ newlabel,
                                 int32_t* __restrict__ labels, int cap, unsigned long long* __restrict__ sums) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int lab = 0;
-    if (i < g.V) {
-        const int p = parent[i];
-        if (p >= 0) lab = newlabel[p];
-        if (labels) labels[i] = lab;
-    }
-    const int z = (int)(i % g.Z);
-    const int y = (int)((i / g.Z) % g.Y);
-    const int x = (int)(i / ((long long)g.Z * g.Y));
-    const bool active = lab > 0 && lab <= cap;
-    unsigned long long todo = __ballot(active);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int ll = __shfl(lab, leader);
-        const bool mine = active && lab == ll;
-        const unsigned long long same = __ballot(mine) & todo;
-        int sx = mine ? x : 0, sy = mine ? y : 0, sz = mine ? z : 0;   // <= 64 * 2^20: fits int
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { sx += __shfl_xor(sx, m); sy += __shfl_xor(sy, m); sz += __shfl_xor(sz, m); }
-        if (lane == leader) {
-            unsigned long long* s = sums + (size_t)(ll - 1) * 4;
-            atomicAdd(s + 0, (unsigned long long)__popcll(same));
-            atomicAdd(s + 1, (unsigned long long)sx);
-            atomicAdd(s + 2, (unsigned long long)sy);
-            atomicAdd(s + 3, (unsigned long long)sz);
+    WS_FOR_VOXELS(i, g.V) {
+        int lab = 0;
+        if (i < g.V) {
+            const int p = parent[i];
+            if (p >= 0) lab = newlabel[p];
+            if (labels) labels[i] = lab;
         }
-        todo &= ~same;
+        const int z = (int)(i % g.Z);
+        const int y = (int)((i / g.Z) % g.Y);
+        const int x = (int)(i / ((long long)g.Z * g.Y));
+        const bool active = lab > 0 && lab <= cap;
+        unsigned long long todo = __ballot(active);
+        const int lane = threadIdx.x & 63;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int ll = __shfl(lab, leader);
+            const bool mine = active && lab == ll;
+            const unsigned long long same = __ballot(mine) & todo;
+            int sx = mine ? x : 0, sy = mine ? y : 0, sz = mine ? z : 0;   // <= 64 * 2^20: fits int
+    #pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { sx += __shfl_xor(sx, m); sy += __shfl_xor(sy, m); sz += __shfl_xor(sz, m); }
+            if (lane == leader) {
+                unsigned long long* s = sums + (size_t)(ll - 1) * 4;
+                atomicAdd(s + 0, (unsigned long long)__popcll(same));
+                atomicAdd(s + 1, (unsigned long long)sx);
+                atomicAdd(s + 2, (unsigned long long)sy);
+                atomicAdd(s + 3, (unsigned long long)sz);
+            }
+            todo &= ~same;
+        }
     }
 }
 
@@ -291,6 +298,12 @@ SegLayout seg_layout(long long V, int cap) {
 // All volume arrays are [x][y][z] like the probability map; threads run over z fastest so that every 1-D pass along x or y is a
 // coalesced sweep.
 // ================================================================================================
+#ifndef CT_WS_BLOCK_DEFAULT
+#define CT_WS_BLOCK_DEFAULT 512
+#endif
+#ifndef CT_WS_GRID_DEFAULT
+#define CT_WS_GRID_DEFAULT 1024
+#endif
 constexpr int WS_INF = 1 << 14;                       // "no background on this line" (volumes are < 2^14 voxels per axis)
 constexpr int WS_PEAK_CAP2D = 2048, WS_PEAK_CAP3D = 8192;
 constexpr int WS_SEL2_CAP = 2048;                  // groups of at most this many candidates take ws_peak_select2_kernel
@@ -304,85 +317,90 @@ __device__ __forceinline__ void ws_xyz(long long i, const SegGeom& g, int& x, in
 // (every kernel that produces a mask also prepares the union-find of its components: parent = own index / -1, size = 0)
 __global__ void ws_threshold_kernel(const float* __restrict__ prob, long long V, unsigned char* __restrict__ bn, int32_t* __restrict__ parent,
                                     int32_t* __restrict__ size) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V) return;
-    const bool fg = prob[i] > 0.5f;
-    bn[i] = fg ? 1 : 0; parent[i] = fg ? (int32_t)i : -1; size[i] = 0;
+    WS_FOR_VOXELS(i, V) {
+        if (i >= V) continue;
+        const bool fg = prob[i] > 0.5f;
+        bn[i] = fg ? 1 : 0; parent[i] = fg ? (int32_t)i : -1; size[i] = 0;
+    }
 }
 
 // distance (voxels) to the nearest background voxel along x, WS_INF if the line has none.  One thread per VOXEL searching outwards
 // (cells are a few voxels thick: a handful of byte loads per foreground voxel; a thread per line walking 2 x 512 dependent steps left the
 // chip idle for 0.29 ms per pass)
 __global__ void ws_edt_x_kernel(SegGeom g, const unsigned char* __restrict__ bn, int32_t* __restrict__ gx) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.V) return;
-    int d = 0;
-    if (bn[i]) {
-        const long long YZ = (long long)g.Y * g.Z;
-        const int x = (int)(i / YZ);
-        d = WS_INF;
-        const int kmax = max(x, g.X - 1 - x);
-        for (int k = 1; k <= kmax; ++k) {
-            const bool lo = x - k >= 0 && !bn[i - k * YZ], hi = x + k < g.X && !bn[i + k * YZ];
-            if (lo || hi) { d = k; break; }
+    WS_FOR_VOXELS(i, g.V) {
+        if (i >= g.V) continue;
+        int d = 0;
+        if (bn[i]) {
+            const long long YZ = (long long)g.Y * g.Z;
+            const int x = (int)(i / YZ);
+            d = WS_INF;
+            const int kmax = max(x, g.X - 1 - x);
+            for (int k = 1; k <= kmax; ++k) {
+                const bool lo = x - k >= 0 && !bn[i - k * YZ], hi = x + k < g.X && !bn[i + k * YZ];
+                if (lo || hi) { d = k; break; }
+            }
         }
+        gx[i] = d;
     }
-    gx[i] = d;
 }
 
 // exact squared distance in the (x, y) plane: min_j gx(x, j)^2 + (y - j)^2, searched outwards from j = y until (y - j)^2 >= best
 // (INT_MAX if the slice has no background).  MODE2D: dist = sqrt(d2) is written directly (fp64).
 template <bool MODE2D>
 __global__ void ws_edt_y_kernel(SegGeom g, const int32_t* __restrict__ gx, int32_t* __restrict__ d2, double* __restrict__ dist) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.V) return;
-    int x, y, z; ws_xyz(i, g, x, y, z);
-    const int g0 = gx[i];
-    long long best = g0 >= WS_INF ? 0x7fffffffLL : (long long)g0 * g0;
-    if (g0 != 0) {
-        for (int k = 1; k < g.Y && (long long)k * k < best; ++k) {
-            if (y - k >= 0) { const int v = gx[i - (long long)k * g.Z]; if (v < WS_INF) { const long long c = (long long)v * v + (long long)k * k; if (c < best) best = c; } }
-            if (y + k < g.Y) { const int v = gx[i + (long long)k * g.Z]; if (v < WS_INF) { const long long c = (long long)v * v + (long long)k * k; if (c < best) best = c; } }
+    WS_FOR_VOXELS(i, g.V) {
+        if (i >= g.V) continue;
+        int x, y, z; ws_xyz(i, g, x, y, z);
+        const int g0 = gx[i];
+        long long best = g0 >= WS_INF ? 0x7fffffffLL : (long long)g0 * g0;
+        if (g0 != 0) {
+            for (int k = 1; k < g.Y && (long long)k * k < best; ++k) {
+                if (y - k >= 0) { const int v = gx[i - (long long)k * g.Z]; if (v < WS_INF) { const long long c = (long long)v * v + (long long)k * k; if (c < best) best = c; } }
+                if (y + k < g.Y) { const int v = gx[i + (long long)k * g.Z]; if (v < WS_INF) { const long long c = (long long)v * v + (long long)k * k; if (c < best) best = c; } }
+            }
         }
+        if (MODE2D) dist[i] = best >= 0x7fffffffLL ? 0.0 : sqrt((double)best);
+        else d2[i] = (int32_t)best;
     }
-    if (MODE2D) dist[i] = best >= 0x7fffffffLL ? 0.0 : sqrt((double)best);
-    else d2[i] = (int32_t)best;
 }
 
 // anisotropic third axis: dist = sqrt(min_k ((dx^2 + dy^2)(k) + (sz (z - k))^2)) in scipy's operand order
 __global__ void ws_edt_z_kernel(SegGeom g, const int32_t* __restrict__ d2, double sz, double* __restrict__ dist) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.V) return;
-    const int z = (int)(i % g.Z);
-    const long long base = i - z;
-    if (d2[i] == 0) { dist[i] = 0.0; return; }
-    double best = INFINITY;
-    for (int k = 0; k < g.Z; ++k) {
-        const int v = d2[base + k];
-        if (v == 0x7fffffff) continue;
-        const double dz = (double)(k - z) * sz;
-        const double c = (double)v + dz * dz;
-        if (c < best) best = c;
+    WS_FOR_VOXELS(i, g.V) {
+        if (i >= g.V) continue;
+        const int z = (int)(i % g.Z);
+        const long long base = i - z;
+        if (d2[i] == 0) { dist[i] = 0.0; continue; }
+        double best = INFINITY;
+        for (int k = 0; k < g.Z; ++k) {
+            const int v = d2[base + k];
+            if (v == 0x7fffffff) continue;
+            const double dz = (double)(k - z) * sz;
+            const double c = (double)v + dz * dz;
+            if (c < best) best = c;
+        }
+        dist[i] = isfinite(best) ? sqrt(best) : 0.0;
     }
-    dist[i] = isfinite(best) ? sqrt(best) : 0.0;
 }
 
 // scipy.ndimage correlate1d, symmetric kernel w[0..2r], 'constant' (0) borders, along the axis with element stride `stride`
 struct WsWeights { double w[48]; };                   // a kernel argument (384 bytes): no device copy of the host's weights per call
 __global__ void ws_gauss_kernel(SegGeom g, int axis, const double* __restrict__ in, double* __restrict__ out, const WsWeights ww, int r) {
     const double* w = ww.w;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.V) return;
-    int x, y, z; ws_xyz(i, g, x, y, z);
-    const int pos = axis == 0 ? x : (axis == 1 ? y : z), len = axis == 0 ? g.X : (axis == 1 ? g.Y : g.Z);
-    const long long stride = axis == 0 ? (long long)g.Y * g.Z : (axis == 1 ? g.Z : 1);
-    double acc = in[i] * w[r];
-    for (int j = r; j >= 1; --j) {
-        const double a = pos - j >= 0 ? in[i - j * stride] : 0.0;
-        const double b = pos + j < len ? in[i + j * stride] : 0.0;
-        acc += (a + b) * w[r - j];
+    WS_FOR_VOXELS(i, g.V) {
+        if (i >= g.V) continue;
+        int x, y, z; ws_xyz(i, g, x, y, z);
+        const int pos = axis == 0 ? x : (axis == 1 ? y : z), len = axis == 0 ? g.X : (axis == 1 ? g.Y : g.Z);
+        const long long stride = axis == 0 ? (long long)g.Y * g.Z : (axis == 1 ? g.Z : 1);
+        double acc = in[i] * w[r];
+        for (int j = r; j >= 1; --j) {
+            const double a = pos - j >= 0 ? in[i - j * stride] : 0.0;
+            const double b = pos + j < len ? in[i + j * stride] : 0.0;
+            acc += (a + b) * w[r - j];
+        }
+        out[i] = acc;
     }
-    out[i] = acc;
 }
 
 // maximum over [pos - r, pos + r] along one axis, 'constant' 0 outside the image
@@ -1118,22 +1136,24 @@ __global__ __launch_bounds__(1024) void ws_peak_select2_kernel(SegGeom g, int mo
 // connectivity-1 components of the mask (2-D mode: inside every z slice) with the union-find of the connected-components path
 template <bool MODE2D>
 __global__ void ws_cc_init_merge_kernel(SegGeom g, const unsigned char* __restrict__ bn, int32_t* __restrict__ parent, int phase) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.V) return;
-    if (phase == 0) { parent[i] = bn[i] ? (int32_t)i : -1; return; }
-    if (!bn[i]) return;
-    int x, y, z; ws_xyz(i, g, x, y, z);
-    if (x + 1 < g.X && bn[i + (long long)g.Y * g.Z]) unite(parent, (int)i, (int)(i + (long long)g.Y * g.Z));
-    if (y + 1 < g.Y && bn[i + g.Z]) unite(parent, (int)i, (int)(i + g.Z));
-    if (!MODE2D && z + 1 < g.Z && bn[i + 1]) unite(parent, (int)i, (int)(i + 1));
+    WS_FOR_VOXELS(i, g.V) {
+        if (i >= g.V) continue;
+        if (phase == 0) { parent[i] = bn[i] ? (int32_t)i : -1; continue; }
+        if (!bn[i]) continue;
+        int x, y, z; ws_xyz(i, g, x, y, z);
+        if (x + 1 < g.X && bn[i + (long long)g.Y * g.Z]) unite(parent, (int)i, (int)(i + (long long)g.Y * g.Z));
+        if (y + 1 < g.Y && bn[i + g.Z]) unite(parent, (int)i, (int)(i + g.Z));
+        if (!MODE2D && z + 1 < g.Z && bn[i + 1]) unite(parent, (int)i, (int)(i + 1));
+    }
 }
 
 // heap space for every component (a bump allocation of `size` entries per root), marker counters cleared
 __global__ void ws_heap_alloc_kernel(long long V, const int32_t* __restrict__ parent, const int32_t* __restrict__ size,
                                      int32_t* __restrict__ heap_off, int32_t* __restrict__ heap_cnt, unsigned int* __restrict__ bump) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V) return;
-    if (parent[i] == (int32_t)i) { heap_off[i] = (int32_t)atomicAdd(bump, (unsigned int)size[i]); heap_cnt[i] = 0; }
+    WS_FOR_VOXELS(i, V) {
+        if (i >= V) continue;
+        if (parent[i] == (int32_t)i) { heap_off[i] = (int32_t)atomicAdd(bump, (unsigned int)size[i]); heap_cnt[i] = 0; }
+    }
 }
 
 // every marker joins its component's queue (value = -smooth, age 0); components with two or more markers are listed for the flood
@@ -1251,35 +1271,36 @@ __device__ __forceinline__ unsigned int ws_wave_max_u32(unsigned int v) {
 __global__ void ws_fill_single_kernel(SegGeom g, const int32_t* __restrict__ parent, const int32_t* __restrict__ heap_off,
                                       const int32_t* __restrict__ heap_cnt, const WsHeapEntry* __restrict__ heap, int32_t* __restrict__ labels,
                                       const int32_t* __restrict__ slot_of, int32_t* __restrict__ bbox, int what /* 1 fill | 2 boxes */) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int root = -1, cnt = 0;
-    if (i < g.V) { root = parent[i]; if (root >= 0) cnt = heap_cnt[root]; }
-    if (cnt == 1 && (what & 1)) {
-        const int m = heap[heap_off[root]].idx;
-        if (m != (int)i) labels[i] = labels[m];
-    }
-    if (!(what & 2)) return;
-    // bounding boxes: the lanes of a wave that belong to one component are reduced first (one atomic per coordinate bound, wave and component:
-    // a thread-per-voxel version spent 0.2 ms on the same-address atomics of the largest component)
-    unsigned long long todo = __ballot(cnt >= 2);
-    if (!todo) return;
-    int x = 0, y = 0, z = 0;
-    if (cnt >= 2) ws_xyz(i, g, x, y, z);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lr = __shfl(root, leader);
-        const bool mine = cnt >= 2 && root == lr;
-        const unsigned long long same = __ballot(mine) & todo;
-        const unsigned int nx = ws_wave_max_u32(mine ? 0x7fffffffu - (unsigned int)x : 0u), mx = ws_wave_max_u32(mine ? (unsigned int)x + 1u : 0u);
-        const unsigned int ny = ws_wave_max_u32(mine ? 0x7fffffffu - (unsigned int)y : 0u), my = ws_wave_max_u32(mine ? (unsigned int)y + 1u : 0u);
-        const unsigned int nz = ws_wave_max_u32(mine ? 0x7fffffffu - (unsigned int)z : 0u), mz = ws_wave_max_u32(mine ? (unsigned int)z + 1u : 0u);
-        if (lane == leader) {
-            int32_t* bb = bbox + 6 * (size_t)slot_of[lr];
-            atomicMin(bb + 0, (int)(0x7fffffffu - nx)); atomicMin(bb + 1, (int)(0x7fffffffu - ny)); atomicMin(bb + 2, (int)(0x7fffffffu - nz));
-            atomicMax(bb + 3, (int)mx - 1); atomicMax(bb + 4, (int)my - 1); atomicMax(bb + 5, (int)mz - 1);
+    WS_FOR_VOXELS(i, g.V) {
+        int root = -1, cnt = 0;
+        if (i < g.V) { root = parent[i]; if (root >= 0) cnt = heap_cnt[root]; }
+        if (cnt == 1 && (what & 1)) {
+            const int m = heap[heap_off[root]].idx;
+            if (m != (int)i) labels[i] = labels[m];
         }
-        todo &= ~same;
+        if (!(what & 2)) continue;
+        // bounding boxes: the lanes of a wave that belong to one component are reduced first (one atomic per coordinate bound, wave and component:
+        // a thread-per-voxel version spent 0.2 ms on the same-address atomics of the largest component)
+        unsigned long long todo = __ballot(cnt >= 2);
+        if (!todo) continue;
+        int x = 0, y = 0, z = 0;
+        if (cnt >= 2) ws_xyz(i, g, x, y, z);
+        const int lane = threadIdx.x & 63;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lr = __shfl(root, leader);
+            const bool mine = cnt >= 2 && root == lr;
+            const unsigned long long same = __ballot(mine) & todo;
+            const unsigned int nx = ws_wave_max_u32(mine ? 0x7fffffffu - (unsigned int)x : 0u), mx = ws_wave_max_u32(mine ? (unsigned int)x + 1u : 0u);
+            const unsigned int ny = ws_wave_max_u32(mine ? 0x7fffffffu - (unsigned int)y : 0u), my = ws_wave_max_u32(mine ? (unsigned int)y + 1u : 0u);
+            const unsigned int nz = ws_wave_max_u32(mine ? 0x7fffffffu - (unsigned int)z : 0u), mz = ws_wave_max_u32(mine ? (unsigned int)z + 1u : 0u);
+            if (lane == leader) {
+                int32_t* bb = bbox + 6 * (size_t)slot_of[lr];
+                atomicMin(bb + 0, (int)(0x7fffffffu - nx)); atomicMin(bb + 1, (int)(0x7fffffffu - ny)); atomicMin(bb + 2, (int)(0x7fffffffu - nz));
+                atomicMax(bb + 3, (int)mx - 1); atomicMax(bb + 4, (int)my - 1); atomicMax(bb + 5, (int)mz - 1);
+            }
+            todo &= ~same;
+        }
     }
 }
 
@@ -1906,41 +1927,43 @@ __global__ __launch_bounds__(64) void ws_flood_upstream_kernel(SegGeom g, const 
 // find_boundaries(labels, connectivity 2, mode 'outer') inside every z slice, removed from the mask (watershed.py:45-51)
 __global__ void ws_boundary2d_kernel(SegGeom g, const unsigned char* __restrict__ bn, const int32_t* __restrict__ labels, unsigned char* __restrict__ bn_out,
                                      int32_t* __restrict__ parent, int32_t* __restrict__ size) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.V) return;
-    bool keep = false;
-    if (bn[i]) {                                           // background stays background: only the 2 % foreground voxels look at their 3 x 3
-        int x, y, z; ws_xyz(i, g, x, y, z);
-        const int own = labels[i];
-        int mx = own, mn = own, mn_obj = own ? own : 0x7fffffff;
-        for (int dx = -1; dx <= 1; ++dx)
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int xx = x + dx, yy = y + dy;
-                if (xx < 0 || xx >= g.X || yy < 0 || yy >= g.Y) continue;
-                const int l = labels[((long long)xx * g.Y + yy) * g.Z + z];
-                mx = max(mx, l); mn = min(mn, l);
-                if (l) mn_obj = min(mn_obj, l);
-            }
-        const bool boundary = (mx != mn) && (own == 0 || mx != mn_obj);
-        keep = !boundary;
+    WS_FOR_VOXELS(i, g.V) {
+        if (i >= g.V) continue;
+        bool keep = false;
+        if (bn[i]) {                                           // background stays background: only the 2 % foreground voxels look at their 3 x 3
+            int x, y, z; ws_xyz(i, g, x, y, z);
+            const int own = labels[i];
+            int mx = own, mn = own, mn_obj = own ? own : 0x7fffffff;
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int xx = x + dx, yy = y + dy;
+                    if (xx < 0 || xx >= g.X || yy < 0 || yy >= g.Y) continue;
+                    const int l = labels[((long long)xx * g.Y + yy) * g.Z + z];
+                    mx = max(mx, l); mn = min(mn, l);
+                    if (l) mn_obj = min(mn_obj, l);
+                }
+            const bool boundary = (mx != mn) && (own == 0 || mx != mn_obj);
+            keep = !boundary;
+        }
+        bn_out[i] = keep ? 1 : 0; parent[i] = keep ? (int32_t)i : -1; size[i] = 0;     // + the union-find of the 3-D stage's components
     }
-    bn_out[i] = keep ? 1 : 0; parent[i] = keep ? (int32_t)i : -1; size[i] = 0;     // + the union-find of the 3-D stage's components
 }
 
 // bincount of the watershed labels (bins 1..K; bin 0 = V - the rest), wave-aggregated
 __global__ void ws_bincount_kernel(long long V, const int32_t* __restrict__ labels, int K, unsigned int* __restrict__ counts) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int lab = 0;
-    if (i < V) lab = labels[i];
-    const bool active = lab > 0 && lab <= K;
-    unsigned long long todo = __ballot(active);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int ll = __shfl(lab, leader);
-        const unsigned long long same = __ballot(active && lab == ll) & todo;
-        if (lane == leader) atomicAdd(&counts[ll], (unsigned int)__popcll(same));
-        todo &= ~same;
+    WS_FOR_VOXELS(i, V) {
+        int lab = 0;
+        if (i < V) lab = labels[i];
+        const bool active = lab > 0 && lab <= K;
+        unsigned long long todo = __ballot(active);
+        const int lane = threadIdx.x & 63;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int ll = __shfl(lab, leader);
+            const unsigned long long same = __ballot(active && lab == ll) & todo;
+            if (lane == leader) atomicAdd(&counts[ll], (unsigned int)__popcll(same));
+            todo &= ~same;
+        }
     }
 }
 
@@ -2239,7 +2262,13 @@ int ct_watershed_segment_ex(const float* prob, const int dims_xyz[3], double z_x
     for (int j = 0; j <= 2 * radius_xy; ++j) w_xy.w[j] = gauss_xy[j];
     for (int j = 0; j <= 2 * radius_z; ++j) w_z.w[j] = gauss_z[j];
     const SegGeom g{dims_xyz[0], dims_xyz[1], dims_xyz[2], V};
-    const unsigned nb = (unsigned)((V + 255) / 256);
+    // threads per workgroup of the per-voxel sweeps (threshold, EDT, z filters, union-find, fills, histogram, relabel: ~25 launches per call, none uses LDS or
+    // assumes a block size).  CT_WS_BLOCK = 256 | 512 | 1024: fewer, larger workgroups ask less of the dispatcher the U-Net's 60 000-workgroup layers share.
+    static const unsigned WSB = [] { const char* e = getenv("CT_WS_BLOCK"); const int v = e ? atoi(e) : CT_WS_BLOCK_DEFAULT; return (unsigned)(v == 512 || v == 1024 ? v : 256); }();
+    // CT_WS_GRID = n: at most n workgroups per sweep, each walking several slabs (WS_FOR_VOXELS); 0 = one slab per workgroup
+    static const unsigned WSG = [] { const char* e = getenv("CT_WS_GRID"); const int v = e ? atoi(e) : CT_WS_GRID_DEFAULT; return (unsigned)(v > 0 ? v : 0); }();
+    const unsigned nb_full = (unsigned)((V + WSB - 1) / WSB);
+    const unsigned nb = WSG && WSG < nb_full ? WSG : nb_full;
     // (per call: the attribute belongs to the current device's copy of the kernel, and a process may drive several devices)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_SEL_LDS_CAP * 16));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ws_peak_select2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_SEL2_LDS));
@@ -2256,14 +2285,14 @@ int ct_watershed_segment_ex(const float* prob, const int dims_xyz[3], double z_x
     auto gauss_pass = [&](int axis, const double* in, double* out) {
         if (!no_slide && radius_xy == 8) {
             if (axis == 0) ws_gauss_slide_kernel<0, 8><<<nbx, 256, 0, st>>>(g, in, out, w_xy); else ws_gauss_slide_kernel<1, 8><<<nby, 256, 0, st>>>(g, in, out, w_xy);
-        } else ws_gauss_kernel<<<nb, 256, 0, st>>>(g, axis, in, out, w_xy, radius_xy);
+        } else ws_gauss_kernel<<<nb, WSB, 0, st>>>(g, axis, in, out, w_xy, radius_xy);
     };
     auto max_pass = [&](int axis, const double* in, double* out, int r) {
         if (!no_slide && r == 7) {
             if (axis == 0) ws_max_slide_kernel<0, 7><<<nbx, 256, 0, st>>>(g, in, out); else ws_max_slide_kernel<1, 7><<<nby, 256, 0, st>>>(g, in, out);
         } else if (!no_slide && r == 3) {
             if (axis == 0) ws_max_slide_kernel<0, 3><<<nbx, 256, 0, st>>>(g, in, out); else ws_max_slide_kernel<1, 3><<<nby, 256, 0, st>>>(g, in, out);
-        } else ws_maxfilt_kernel<<<nb, 256, 0, st>>>(g, axis, in, out, r);
+        } else ws_maxfilt_kernel<<<nb, WSB, 0, st>>>(g, axis, in, out, r);
     };
 
     // Serial form (CT_WS_FORK=0) or the helper stream; the lock is held while this call enqueues.
@@ -2296,12 +2325,12 @@ int ct_watershed_segment_ex(const float* prob, const int dims_xyz[3], double z_x
     auto stage_components = [&](bool mode2d, const unsigned char* mask) -> int {
         hipStream_t sc = aux ? aux->stream : st;
         if (aux) { HIPCHK(hipEventRecord(aux->fork, st)); HIPCHK(hipStreamWaitEvent(sc, aux->fork, 0)); }
-        if (mode2d) ws_cc_init_merge_kernel<true><<<nb, 256, 0, sc>>>(g, mask, parent, 1);
-        else ws_cc_init_merge_kernel<false><<<nb, 256, 0, sc>>>(g, mask, parent, 1);
+        if (mode2d) ws_cc_init_merge_kernel<true><<<nb, WSB, 0, sc>>>(g, mask, parent, 1);
+        else ws_cc_init_merge_kernel<false><<<nb, WSB, 0, sc>>>(g, mask, parent, 1);
         LAUNCH_CHECK();
-        cc_flatten_kernel<<<nb, 256, 0, sc>>>(V, parent, size);
+        cc_flatten_kernel<<<nb, WSB, 0, sc>>>(V, parent, size);
         LAUNCH_CHECK();
-        ws_heap_alloc_kernel<<<nb, 256, 0, sc>>>(V, parent, size, heap_off, heap_cnt, bump);
+        ws_heap_alloc_kernel<<<nb, WSB, 0, sc>>>(V, parent, size, heap_off, heap_cnt, bump);
         LAUNCH_CHECK();
         if (aux) HIPCHK(hipEventRecord(aux->join, sc));
         return CT_OK;
@@ -2362,11 +2391,11 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
         static const bool no_upstream = getenv("CT_WS_UPSTREAM_TIES") && atoi(getenv("CT_WS_UPSTREAM_TIES")) == 0;   // (A/B: raveled order among equal seeds)
         // the boxes first (the LDS flood needs them); the fill of the single-marker components touches no voxel of a listed component and runs
         // on the helper stream beside the floods (a handful of waves walking sequentially for 70-310 us)
-        ws_fill_single_kernel<<<nb, 256, 0, st>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, aux ? 2 : 3);
+        ws_fill_single_kernel<<<nb, WSB, 0, st>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, aux ? 2 : 3);
         LAUNCH_CHECK();
         if (aux) {
             HIPCHK(hipEventRecord(aux->fork, st)); HIPCHK(hipStreamWaitEvent(aux->stream, aux->fork, 0));
-            ws_fill_single_kernel<<<nb, 256, 0, aux->stream>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, 1);
+            ws_fill_single_kernel<<<nb, WSB, 0, aux->stream>>>(g, parent, heap_off, heap_cnt, heap, labels, gx, bbox, 1);
             LAUNCH_CHECK();
             HIPCHK(hipEventRecord(aux->join, aux->stream));
         }
@@ -2416,11 +2445,11 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
     };
 
     // ---- watershed_2d (watershed.py:16-53), all z slices at once
-    ws_threshold_kernel<<<nb, 256, 0, st>>>(prob, V, bn, parent, size);
+    ws_threshold_kernel<<<nb, WSB, 0, st>>>(prob, V, bn, parent, size);
     LAUNCH_CHECK();
-    ws_edt_x_kernel<<<nb, 256, 0, st>>>(g, bn, gx);
+    ws_edt_x_kernel<<<nb, WSB, 0, st>>>(g, bn, gx);
     LAUNCH_CHECK();
-    ws_edt_y_kernel<true><<<nb, 256, 0, st>>>(g, gx, d2, dist);
+    ws_edt_y_kernel<true><<<nb, WSB, 0, st>>>(g, gx, d2, dist);
     LAUNCH_CHECK();
     gauss_pass(0, dist, tmp);
     LAUNCH_CHECK();
@@ -2428,7 +2457,7 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
     LAUNCH_CHECK();
     int rc = stage(true, bn, min_distance_2d, min_distance_2d);
     if (rc) return rc;
-    ws_boundary2d_kernel<<<nb, 256, 0, st>>>(g, bn, labels, bn2, parent, size);
+    ws_boundary2d_kernel<<<nb, WSB, 0, st>>>(g, bn, labels, bn2, parent, size);
     LAUNCH_CHECK();
     if (method_in & 0x100) {                                                      // (tests: stop after watershed_2d, see ct_watershed_read_stage)
         int32_t h_latch = 0;
@@ -2441,27 +2470,27 @@ static const bool no_sel2 = getenv("CT_WS_SELECT") && atoi(getenv("CT_WS_SELECT"
     }
 
     // ---- watershed_3d (watershed.py:55-108)
-    ws_edt_x_kernel<<<nb, 256, 0, st>>>(g, bn2, gx);
+    ws_edt_x_kernel<<<nb, WSB, 0, st>>>(g, bn2, gx);
     LAUNCH_CHECK();
-    ws_edt_y_kernel<false><<<nb, 256, 0, st>>>(g, gx, d2, dist);
+    ws_edt_y_kernel<false><<<nb, WSB, 0, st>>>(g, gx, d2, dist);
     LAUNCH_CHECK();
-    ws_edt_z_kernel<<<nb, 256, 0, st>>>(g, d2, z_xy_ratio, dist);
+    ws_edt_z_kernel<<<nb, WSB, 0, st>>>(g, d2, z_xy_ratio, dist);
     LAUNCH_CHECK();
     gauss_pass(0, dist, tmp);
     LAUNCH_CHECK();
     gauss_pass(1, tmp, dist);
     LAUNCH_CHECK();
-    ws_gauss_kernel<<<nb, 256, 0, st>>>(g, 2, dist, smooth, w_z, radius_z);
+    ws_gauss_kernel<<<nb, WSB, 0, st>>>(g, 2, dist, smooth, w_z, radius_z);
     LAUNCH_CHECK();
     rc = stage(false, bn2, min_distance_3d, 0);
     if (rc) return rc;
 
     // ---- sizes, min_size / cell_num, small objects dropped, sequential labels, centres (watershed.py:88-96, tracker.py:680, :646-647)
-    ws_bincount_kernel<<<nb, 256, 0, st>>>(V, labels, peak_cap_3d, counts);
+    ws_bincount_kernel<<<nb, WSB, 0, st>>>(V, labels, peak_cap_3d, counts);
     LAUNCH_CHECK();
     ws_finish_kernel<<<1, 1024, 0, st>>>(V, marker_count, method, min_size, cell_num, counts, newlabel, n_out, latch);
     LAUNCH_CHECK();
-    cc_label_kernel<<<nb, 256, 0, st>>>(g, labels, newlabel, labels_out, cap, sums);
+    cc_label_kernel<<<nb, WSB, 0, st>>>(g, labels, newlabel, labels_out, cap, sums);
     LAUNCH_CHECK();
     cc_centroid_kernel<<<(cap + 255) / 256, 256, 0, st>>>(n_out, cap, sums, centres, sizes);
     LAUNCH_CHECK();
