@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -29,7 +30,8 @@ inline hipError_t ct_fill_async(void* p, int byte_value, size_t bytes, hipStream
     const uint32_t b = (uint32_t)(byte_value & 0xFF), word = b | (b << 8) | (b << 16) | (b << 24);
     size_t blocks = (bytes / 16 + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 4096) blocks = 4096;
+    static const size_t cap = [] { const char* e = getenv("CT_FILL_BLOCKS"); const long v = e ? atol(e) : 4096; return (size_t)(v >= 1 ? v : 4096); }();   // (grid-stride: any cap works)
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(ct_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned char*)p, bytes, word);
     return hipGetLastError();
 }

@@ -29,6 +29,7 @@
 
 #include "../../include/ctamd.h"
 #include "ct_fresh.h"
+#include "ct_fill.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -2304,6 +2305,7 @@ int ct_watershed_segment_ex(const float* prob, const int dims_xyz[3], double z_x
     // the per-stage clears
     // (the small clears of a stage are one launch: five memsets of a few KB each were 25 us of a call; the first stage's carries the latch, the
     // second's the tables of the final bookkeeping, which nothing touches before)
+    static const bool ws_labels_memset = getenv("CT_WS_MEMSET") && atoi(getenv("CT_WS_MEMSET")) == 1;      // (A/B: the runtime's memset for the label volume)
     auto stage_clear = [&](bool first) -> int {
         WsClear c{};
         const unsigned int zg = (unsigned int)((Z + 1) / 2);                         // 8-byte words of a u32 [Z] table
@@ -2317,7 +2319,7 @@ int ct_watershed_segment_ex(const float* prob, const int dims_xyz[3], double z_x
         }
         ws_clear_kernel<<<16, 256, 0, st>>>(c);
         LAUNCH_CHECK();
-        HIPCHK(hipMemsetAsync(labels, 0, (size_t)V * 4, st));
+        HIPCHK(ws_labels_memset ? hipMemsetAsync(labels, 0, (size_t)V * 4, st) : ct_fill_async(labels, 0, (size_t)V * 4, st));   // (a fill kernel of this library: its grid is ours to size)
         return CT_OK;
     };
     // connectivity-1 components of `mask` (whose producer initialised parent / size), flattened, with queue space per component: everything
