@@ -1078,6 +1078,9 @@ __device__ __forceinline__ float max4_nc(float a, float b, float c, float d) { r
 // into `amax` (v_max3_f32 with |.| modifiers).  Deliberately NOT packed fp32 (CT_PK): v_pk_fma_f32 / v_pk_mul_f32 halve the instruction count and are
 // bit-identical, but beside MFMAs they cost more than the two scalar instructions they replace (round 6 A/B: profiles/r06_conv_experiments.txt; the whole
 // translation unit is built with -fno-slp-vectorize for that).
+#ifndef CT_EPI_DUAL4
+#define CT_EPI_DUAL4 0
+#endif
 #ifndef CT_PK
 #define CT_PK 0            // 1: the affine steps of the epilogues and the staging scale as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32) -- measured SLOWER
 #endif                     //    beside MFMAs (MI355X_MICROARCH: +22 cycles per v_pk_fma_f32 against two v_fma_f32 in an MFMA gap); A/B switch, off
@@ -1369,8 +1372,10 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : (NT == 2 ? CT_LB2 : (F16 && !Y10
     const float om2 = F16 ? out_mul : 1.f;                    // (folded into the BatchNorm scale: epi_quad_apply_c)
     // Wave-uniform shortcuts (round 6): a tile that lies inside the window whose voxels enter the tensor's maximum / inside the stored window / inside the
     // tensor needs no per-column compare chain and no select -- that is every tile but the ones on the windows' borders.
-    const bool tile_needed = x0 >= a.nx0 && x0 + G::TXv <= nx1 && y0 >= a.ny0 && y0 + G::TYv <= ny1;
-    const bool tile_stored = x0 >= a.sx0 && x0 + G::TXv <= a.sx1 && y0 >= a.sy0 && y0 + G::TYv <= a.sy1 && x0 + G::TXv <= a.X && y0 + G::TYv <= a.Y &&
+    // (NT = 4: one path only -- CT_EPI_DUAL4: the second copy of a four-row-tile epilogue is ~30 % more code for kernels that are not bound by their epilogue)
+    constexpr bool DUAL = NT <= 2 || (CT_EPI_DUAL4);
+    const bool tile_needed = DUAL && x0 >= a.nx0 && x0 + G::TXv <= nx1 && y0 >= a.ny0 && y0 + G::TYv <= ny1;
+    const bool tile_stored = DUAL && x0 >= a.sx0 && x0 + G::TXv <= a.sx1 && y0 >= a.sy0 && y0 + G::TYv <= a.sy1 && x0 + G::TXv <= a.X && y0 + G::TYv <= a.Y &&
                              z0 + G::ZB <= a.Z;
     if constexpr (C8) {
         // lane (zl, g) holds channels 4(g&1)..+3 of the voxel at x = x0 + wx + (g>>1), y = y0 + col_y(mt)
