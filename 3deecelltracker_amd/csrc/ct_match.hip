@@ -243,6 +243,12 @@ __global__ void denormalize_points_kernel(const double* __restrict__ pts, int n,
 // epilogue (Dense(no bias) + BatchNormalization + LeakyReLU, ffn.py:242-254).
 // 64x64 tile, 256 threads, 4x4 outputs per thread, sequential-k fp32 accumulation.
 // ------------------------------------------------------------------------------------------------
+static bool gemm_valu() { static const bool v = getenv("CT_GEMM_VALU") && getenv("CT_GEMM_VALU")[0] == '1'; return v; }   // (A/B + the bit-identity test: the vector-fma form)
+// MFMA = true (round 6, the default): the 64 x 64 block's inner products on the matrix cores' exact-fp32 instruction -- v_mfma_f32_16x16x4_f32 is an fmaf chain over its
+// four k in ascending order, so every output still accumulates fmaf(a, b, acc) over k = 0, 1, 2, ...: the SAME bits as the vector form (tests/test_gpu_match.py compares the
+// two), at a sixteenth of the vector-issue slots (one MFMA per 2048 flop instead of 16 v_fma: the match stream runs beside the U-Net's issue-bound thin layers) and twice the
+// rate of un-packed v_fma.  A wave takes a 32 x 32 quarter of the block as 2 x 2 MFMA tiles; the panels, their staging and the epilogue arithmetic are unchanged.
+template <bool MFMA>
 __device__ __forceinline__ void gemm_f32_body(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                               float* __restrict__ C, int M, int N, int K,
                                               const float* __restrict__ bn /* [4][N] gamma,beta,mean,var or null */) {
@@ -257,6 +263,9 @@ __device__ __forceinline__ void gemm_f32_body(const float* __restrict__ A, int l
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     float acc[4][4] = {};
+    typedef float gf32x4 __attribute__((ext_vector_type(4)));
+    gf32x4 macc[2][2] = {{gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}}, {gf32x4{0.f, 0.f, 0.f, 0.f}, gf32x4{0.f, 0.f, 0.f, 0.f}}};
+    const int lane = tid & 63, wv = tid >> 6, wr = 32 * (wv >> 1), wc = 32 * (wv & 1), l16 = lane & 15, lk = lane >> 4;
     float ra[8], rb[8];
     auto fetch = [&](int k0) {
 #pragma unroll
@@ -284,6 +293,17 @@ __device__ __forceinline__ void gemm_f32_body(const float* __restrict__ A, int l
     for (int k0 = 0; k0 < K; k0 += GK) {
         const bool more = k0 + GK < K;
         if (more) fetch(k0 + GK);
+        if constexpr (MFMA) {
+#pragma unroll
+            for (int k4 = 0; k4 < GK; k4 += 4) {                  // lane (l16, lk): A[row l16][k4 + lk], B[k4 + lk][col l16]; D rows 4 lk + e
+                const float a0 = As[buf][k4 + lk][wr + l16], a1 = As[buf][k4 + lk][wr + 16 + l16];
+                const float b0 = Bs[buf][k4 + lk][wc + l16], b1 = Bs[buf][k4 + lk][wc + 16 + l16];
+                macc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, macc[0][0], 0, 0, 0);
+                macc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, macc[0][1], 0, 0, 0);
+                macc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, macc[1][0], 0, 0, 0);
+                macc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, macc[1][1], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < GK; ++kk) {
             float a[4], b[4];
@@ -296,42 +316,47 @@ __device__ __forceinline__ void gemm_f32_body(const float* __restrict__ A, int l
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
         }
+        }
         if (more) park(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
+    // the lane's 16 outputs: vector form rows ty * 4 + i, columns tx * 4 + j; MFMA form tile (i >> 1, j >> 1) ... written as one loop over (i, j) in 0..3
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + ty * 4 + i;
-        if (gm >= M) continue;
+        const int gm = MFMA ? m0 + wr + 16 * (i >> 1) + 4 * lk + 2 * (i & 1) : m0 + ty * 4 + i;     // MFMA: (i, j) -> tile i >> 1, element e = 2 (i & 1) + (j & 1), column tile j >> 1
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int gn = n0 + tx * 4 + j;
-            if (gn >= N) continue;
-            float v = acc[i][j];
+            const int e = 2 * (i & 1) + (j & 1);
+            const int gmm = MFMA ? m0 + wr + 16 * (i >> 1) + 4 * lk + e : gm;
+            const int gn = MFMA ? n0 + wc + 16 * (j >> 1) + l16 : n0 + tx * 4 + j;
+            if (gmm >= M || gn >= N) continue;
+            float v = MFMA ? macc[i >> 1][j >> 1][e] : acc[i][j];
             if (bn) {
                 const float inv = bn[gn] / sqrtf(bn[3 * N + gn] + kBnEps);
                 v = (v - bn[2 * N + gn]) * inv + bn[N + gn];
                 v = v >= 0.f ? v : v * kLeakyAlpha;
             }
-            C[(size_t)gm * N + gn] = v;
+            C[(size_t)gmm * N + gn] = v;
         }
     }
 }
+template <bool MFMA>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                        float* __restrict__ C, int M, int N, int K,
                                                        const float* __restrict__ bn /* [4][N] gamma,beta,mean,var or null */,
                                                        Bt bt = Bt{0, nullptr}) {
     BT_SHIFT(const float*, A); BT_SHIFT(float*, C); BT_DIM_N(M);         // batched: rows = the problem's reference points
-    gemm_f32_body(A, lda, B, C, M, N, K, bn);
+    gemm_f32_body<MFMA>(A, lda, B, C, M, N, K, bn);
 }
 // two independent products of one shape family in ONE launch (blockIdx.z picks the operands): the FFN's reference-side and target-side
 // layers.  Beside the U-Net every launch of the match stream waits for workgroup slots (a 600 x 512 x 512 product: 27 us alone, 214 us in
 // the frame loop); the products themselves are unchanged.
 struct GemmPair { const float* A[2]; const float* B[2]; float* C[2]; int M[2]; };
+template <bool MFMA>
 __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(GemmPair g, int lda, int N, int K, const float* __restrict__ bn) {
     const int z = blockIdx.z;
-    gemm_f32_body(g.A[z], lda, g.B[z], g.C[z], g.M[z], N, K, bn);
+    gemm_f32_body<MFMA>(g.A[z], lda, g.B[z], g.C[z], g.M[z], N, K, bn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2673,7 +2698,7 @@ size_t ct_ffn_workspace_bytes(int n_ref, int n_tgt) {
 }
 
 static int gemm(const float* A, int lda, const float* B, float* Cm, int M, int N, int K, const float* bn, hipStream_t st) {
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, lda, B, Cm, M, N, K, bn);
+    { if (gemm_valu()) hipLaunchKernelGGL((gemm_f32_kernel<false>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, lda, B, Cm, M, N, K, bn); else hipLaunchKernelGGL((gemm_f32_kernel<true>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, A, lda, B, Cm, M, N, K, bn); }
     LAUNCH_CHECK();
     return CT_OK;
 }
@@ -2691,11 +2716,13 @@ int ct_ffn_pairgrid(ct_ffn_t* h, const float* feat_ref, int n, const float* feat
     (void)rc;
     {   // layer 1 of both point sets, then layer 2 of both (ref half: W2[:512], tgt half: W2[512:]): two launches instead of four
         const int mx = n > m ? n : m;
-        hipLaunchKernelGGL(gemm_f32_pair_kernel, dim3((HID + 63) / 64, (mx + 63) / 64, 2), dim3(256), 0, st,
-                           GemmPair{{feat_ref, feat_tgt}, {h->d_w + h->o_w1, h->d_w + h->o_w1}, {Hr, Ht}, {n, m}}, FEAT, HID, FEAT, h->d_w + h->o_bn1);
+        { if (gemm_valu()) hipLaunchKernelGGL((gemm_f32_pair_kernel<false>), dim3((HID + 63) / 64, (mx + 63) / 64, 2), dim3(256), 0, st,
+                           GemmPair{{feat_ref, feat_tgt}, {h->d_w + h->o_w1, h->d_w + h->o_w1}, {Hr, Ht}, {n, m}}, FEAT, HID, FEAT, h->d_w + h->o_bn1); else hipLaunchKernelGGL((gemm_f32_pair_kernel<true>), dim3((HID + 63) / 64, (mx + 63) / 64, 2), dim3(256), 0, st,
+                           GemmPair{{feat_ref, feat_tgt}, {h->d_w + h->o_w1, h->d_w + h->o_w1}, {Hr, Ht}, {n, m}}, FEAT, HID, FEAT, h->d_w + h->o_bn1); }
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(gemm_f32_pair_kernel, dim3((HID + 63) / 64, (mx + 63) / 64, 2), dim3(256), 0, st,
-                           GemmPair{{Hr, Ht}, {h->d_w + h->o_w2, h->d_w + h->o_w2 + (size_t)HID * HID}, {U, V}, {n, m}}, HID, HID, HID, (const float*)nullptr);
+        { if (gemm_valu()) hipLaunchKernelGGL((gemm_f32_pair_kernel<false>), dim3((HID + 63) / 64, (mx + 63) / 64, 2), dim3(256), 0, st,
+                           GemmPair{{Hr, Ht}, {h->d_w + h->o_w2, h->d_w + h->o_w2 + (size_t)HID * HID}, {U, V}, {n, m}}, HID, HID, HID, (const float*)nullptr); else hipLaunchKernelGGL((gemm_f32_pair_kernel<true>), dim3((HID + 63) / 64, (mx + 63) / 64, 2), dim3(256), 0, st,
+                           GemmPair{{Hr, Ht}, {h->d_w + h->o_w2, h->d_w + h->o_w2 + (size_t)HID * HID}, {U, V}, {n, m}}, HID, HID, HID, (const float*)nullptr); }
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(ffn_pair_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, st, U, n, V, m,
@@ -3642,14 +3669,15 @@ int ct_match_front_batched(ct_ffn_t* ffn, int B, const double* const* ref, const
     LAUNCH_CHECK();
     hipLaunchKernelGGL(knn_features_kernel, dim3(mmax, 1, zB), dim3(64), 0, st, (const double*)at(L.tgt), mmax, k_ptrs, featt, btT);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, featr, FEAT, W + ffn->o_w1, Hr, nmax, HID, FEAT, W + ffn->o_bn1, bt);
+    { if (gemm_valu()) hipLaunchKernelGGL((gemm_f32_kernel<false>), dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, featr, FEAT, W + ffn->o_w1, Hr, nmax, HID, FEAT, W + ffn->o_bn1, bt); else hipLaunchKernelGGL((gemm_f32_kernel<true>), dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, featr, FEAT, W + ffn->o_w1, Hr, nmax, HID, FEAT, W + ffn->o_bn1, bt); }
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (mmax + 63) / 64, zB), dim3(256), 0, st, featt, FEAT, W + ffn->o_w1, Ht, mmax, HID, FEAT, W + ffn->o_bn1, btT);
+    { if (gemm_valu()) hipLaunchKernelGGL((gemm_f32_kernel<false>), dim3((HID + 63) / 64, (mmax + 63) / 64, zB), dim3(256), 0, st, featt, FEAT, W + ffn->o_w1, Ht, mmax, HID, FEAT, W + ffn->o_bn1, btT); else hipLaunchKernelGGL((gemm_f32_kernel<true>), dim3((HID + 63) / 64, (mmax + 63) / 64, zB), dim3(256), 0, st, featt, FEAT, W + ffn->o_w1, Ht, mmax, HID, FEAT, W + ffn->o_bn1, btT); }
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, Hr, HID, W + ffn->o_w2, U, nmax, HID, HID, (const float*)nullptr, bt);
+    { if (gemm_valu()) hipLaunchKernelGGL((gemm_f32_kernel<false>), dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, Hr, HID, W + ffn->o_w2, U, nmax, HID, HID, (const float*)nullptr, bt); else hipLaunchKernelGGL((gemm_f32_kernel<true>), dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, Hr, HID, W + ffn->o_w2, U, nmax, HID, HID, (const float*)nullptr, bt); }
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (mmax + 63) / 64, zB), dim3(256), 0, st, Ht, HID, W + ffn->o_w2 + (size_t)HID * HID, V, mmax, HID, HID,
-                       (const float*)nullptr, btT);
+    { if (gemm_valu()) hipLaunchKernelGGL((gemm_f32_kernel<false>), dim3((HID + 63) / 64, (mmax + 63) / 64, zB), dim3(256), 0, st, Ht, HID, W + ffn->o_w2 + (size_t)HID * HID, V, mmax, HID, HID,
+                       (const float*)nullptr, btT); else hipLaunchKernelGGL((gemm_f32_kernel<true>), dim3((HID + 63) / 64, (mmax + 63) / 64, zB), dim3(256), 0, st, Ht, HID, W + ffn->o_w2 + (size_t)HID * HID, V, mmax, HID, HID,
+                       (const float*)nullptr, btT); }
     LAUNCH_CHECK();
     hipLaunchKernelGGL(ffn_pair_kernel, dim3((nmax + 31) / 32, (mmax + 31) / 32, zB), dim3(256), 0, st, U, nmax, V, mmax, W + ffn->o_bn2, W + ffn->o_w3, ffn->b3, corr, bt);
     LAUNCH_CHECK();
@@ -3792,11 +3820,13 @@ int ct_legacy_predict_pos_batched(ct_ffn_t* ffn, int B, const double* const* seg
         // initial_matching_quick (track.py:117-178): features -> FFN on all pairs
         hipLaunchKernelGGL(knn_features_kernel, dim3(nmax, 1, zB), dim3(64), 0, st, X, nmax, k_ptrs, feat, bt);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, feat, FEAT, W + ffn->o_w1, Hr, nmax, HID, FEAT,
-                           W + ffn->o_bn1, bt);
+        { if (gemm_valu()) hipLaunchKernelGGL((gemm_f32_kernel<false>), dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, feat, FEAT, W + ffn->o_w1, Hr, nmax, HID, FEAT,
+                           W + ffn->o_bn1, bt); else hipLaunchKernelGGL((gemm_f32_kernel<true>), dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, feat, FEAT, W + ffn->o_w1, Hr, nmax, HID, FEAT,
+                           W + ffn->o_bn1, bt); }
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(gemm_f32_kernel, dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, Hr, HID, W + ffn->o_w2, U, nmax, HID, HID,
-                           (const float*)nullptr, bt);
+        { if (gemm_valu()) hipLaunchKernelGGL((gemm_f32_kernel<false>), dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, Hr, HID, W + ffn->o_w2, U, nmax, HID, HID,
+                           (const float*)nullptr, bt); else hipLaunchKernelGGL((gemm_f32_kernel<true>), dim3((HID + 63) / 64, (nmax + 63) / 64, zB), dim3(256), 0, st, Hr, HID, W + ffn->o_w2, U, nmax, HID, HID,
+                           (const float*)nullptr, bt); }
         LAUNCH_CHECK();
         hipLaunchKernelGGL(ffn_pair_kernel, dim3((nmax + 31) / 32, (m + 31) / 32, zB), dim3(256), 0, st, U, nmax, V, m, W + ffn->o_bn2, W + ffn->o_w3,
                            ffn->b3, corr, bt);

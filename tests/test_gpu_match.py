@@ -956,3 +956,42 @@ print("em done", len(out))
             assert np.array_equal(a[k], c[k]), ("persistent", k)
             assert np.array_equal(b[k], c[k]), ("fused", k)
         assert 5 <= int(a["b0_it"][0]) <= 30 and int(a["c0_it"][0]) > 100       # a quick and a slow convergence were both covered
+
+
+def test_ffn_gemm_on_the_matrix_cores_equals_the_vector_form_bit_for_bit():
+    """The FFN's dense layers (ffn.py:242-258) run as v_mfma_f32_16x16x4_f32 products since round 6: an fmaf chain over k in ascending order, i.e. the SAME bits as the
+    vector-fma kernel they replace (CT_GEMM_VALU=1 keeps that form).  Scores of single and batched matches at 50 / 113 / 600 points (row counts that are not multiples of 16
+    or 64), both prior dialects' inputs, compared bit for bit between the two forms; and against the oracle within the score tolerance."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from pathlib import Path
+    REPO = Path(__file__).resolve().parent.parent
+    code = r"""
+import sys, importlib, numpy as np, torch
+sys.path.insert(0, %r)
+m = lambda n: importlib.import_module("3deecelltracker_amd." + n)
+synth, ffn_mod, _dev = m("synth"), m("ffn"), m("_dev")
+out = {}
+for tag, w in (("t", synth.load_trained_ffn()), ("r", synth.make_ffn_weights(0))):
+    ffn = ffn_mod.FFN().set_weights_dict(w)
+    for n in (50, 113, 600):
+        x, y = synth.make_point_pair(n, seed=700 + n, box=(512, 512, 32))
+        xn, (mean, scale) = ffn_mod.normalize_points(x, return_para=True)
+        a, b = _dev.points_dev(xn), _dev.points_dev(((y - mean) / scale)[: n - 7])
+        out[f"{tag}{n}"] = ffn_mod.initial_matching_device(ffn, a, b, 20).cpu().numpy()
+    q = np.random.default_rng(5).normal(size=(333, 122)).astype(np.float32)
+    out[f"{tag}_predict"] = ffn.predict(q)
+np.savez(sys.argv[1], **out)
+print("gemm done", len(out))
+""" % (str(REPO),)
+    with tempfile.TemporaryDirectory() as td:
+        files = []
+        for tag, env in (("mfma", {}), ("valu", {"CT_GEMM_VALU": "1"})):
+            f = os.path.join(td, tag + ".npz"); files.append(f)
+            r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env), cwd=REPO)
+            assert r.returncode == 0 and "gemm done 8" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+        a, b = np.load(files[0]), np.load(files[1])
+        for k in a.files:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
